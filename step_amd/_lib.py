@@ -1,0 +1,96 @@
+"""ctypes binding of libstep_hip.so (the C ABI declared in include/step_hip.h).
+
+The library is the product path: if it is missing or a call fails, this module raises --
+there is no eager/PyTorch fallback anywhere in step_amd.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstep_hip.so")
+
+_vp, _i, _l, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
+
+
+class StepGemm(ctypes.Structure):
+    _fields_ = [("M", _i), ("N", _i), ("K", _i), ("batch", _i),
+                ("A", _vp), ("sam", _l), ("sak", _l), ("sab", _l), ("a_bf16", _i),
+                ("B", _vp), ("sbk", _l), ("sbn", _l), ("sbb", _l), ("b_bf16", _i),
+                ("C", _vp), ("ldc", _l), ("scn", _l), ("scb", _l),
+                ("alpha", _f), ("accumulate", _i), ("bias", _vp), ("relu", _i), ("splitk", _i)]
+
+
+_SIGS = {
+    "step_last_error": (ctypes.c_char_p, []),
+    "step_abi_version": (_i, []),
+    "step_gemm": (_i, [ctypes.POINTER(StepGemm), _vp]),
+    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _u64, _vp]),
+    "step_pack_long_history": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "step_knn_workspace_bytes": (_l, [_i, _i, _i]),
+    "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
+    "step_topk_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp]),
+    "step_selftest_mfma": (_i, [_vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libstep_hip.so not found at {LIB_PATH}: build it with `python -m step_amd.build` "
+                "(step_amd has no fallback path)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().step_last_error().decode(errors="replace")
+        raise RuntimeError(f"libstep_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libstep_hip takes contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0, scn=1, alpha=1.0,
+         accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0):
+    """Thin descriptor builder around step_gemm; a/b/c are device tensors (f32 or bf16 for a, b),
+    offsets are in elements."""
+    g = StepGemm()
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.A = a.data_ptr() + a_off * a.element_size()
+    g.sam, g.sak, g.sab, g.a_bf16 = sam, sak, sab, int(a.dtype == torch.bfloat16)
+    g.B = b.data_ptr() + b_off * b.element_size()
+    g.sbk, g.sbn, g.sbb, g.b_bf16 = sbk, sbn, sbb, int(b.dtype == torch.bfloat16)
+    g.C = c.data_ptr() + c_off * 4
+    g.ldc, g.scn, g.scb = ldc, scn, scb
+    g.alpha, g.accumulate = alpha, accumulate
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.relu, g.splitk = int(relu), splitk
+    check(lib().step_gemm(ctypes.byref(g), stream()), "step_gemm")

@@ -1,0 +1,93 @@
+// Shared host/device helpers for libstep_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define STEP_OK 0
+#define STEP_ERR_ARG 1
+#define STEP_ERR_HIP 2
+
+void step_set_error(const char* fmt, ...);
+
+#define STEP_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            step_set_error(__VA_ARGS__);        \
+            return STEP_ERR_ARG;                \
+        }                                       \
+    } while (0)
+
+#define STEP_LAUNCH_CHECK(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            step_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return STEP_ERR_HIP;                                                  \
+        }                                                                         \
+    } while (0)
+
+#define STEP_TRY(expr)                       \
+    do {                                     \
+        int rc_ = (expr);                    \
+        if (rc_ != STEP_OK) return rc_;      \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 (round to nearest even; NaN not expected on these paths) -------------
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// 8 consecutive f32 -> one MFMA bf16 operand (4 VGPRs)
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    u32x4 r;
+    r[0] = pack_bf16x2(v[0], v[1]);
+    r[1] = pack_bf16x2(v[2], v[3]);
+    r[2] = pack_bf16x2(v[4], v[5]);
+    r[3] = pack_bf16x2(v[6], v[7]);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// ---- wave64 helpers --------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- counter-based RNG (Philox4x32-10) --------------------------------------------------
+// Used for on-device Gumbel noise and dropout masks; deterministic in (seed, counter).
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// uniform in [0,1) with 24 bits, like torch.rand's float path
+__device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }

@@ -1,0 +1,19 @@
+// Internal C++ declarations shared by the translation units of libstep_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/step_hip.h"
+
+int step_gemm_launch(StepGemm g, hipStream_t st);
+
+// convenience builder for the common dense cases (f32 operands, batch 1)
+static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbk,
+                                 long sbn, float* C, long ldc) {
+    StepGemm g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K; g.batch = 1;
+    g.A = A; g.sam = sam; g.sak = sak;
+    g.B = B; g.sbk = sbk; g.sbn = sbn;
+    g.C = C; g.ldc = ldc; g.scn = 1;
+    g.alpha = 1.f; g.splitk = 1;
+    return g;
+}

@@ -1,0 +1,446 @@
+// Fused TSFormer encoder forward for gfx950 (forecasting mode, frozen weights).
+//
+// One workgroup per sequence s = (sample, node); one wave per 32-token tile (P <= 512 tokens,
+// 336 for PEMS04).  The residual stream of a wave's 32 tokens lives in f32 accumulator
+// registers for the whole kernel: activations are kept TRANSPOSED ([feature][token], token =
+// lane & 31), weights are the MFMA A operand, and thanks to the k-slot map in
+// tsformer_layout.h every accumulator tile becomes the next MFMA's B operand by a plain
+// f32->bf16 pack.  The only inter-wave traffic is the per-head K and V operand fragments
+// (2 KB per key tile each), exchanged through double-buffered LDS with one barrier per head.
+//
+//   patch embed + pos-emb (f32 VALU)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> S^T = K Q^T
+//   -> exact two-pass softmax (exp2, scale folded into Wq) -> O^T = V^T P^T (row 24 of V is
+//   all-ones, so the softmax denominator falls out of the same MFMA) -> out-proj accumulates
+//   onto (x + b_o) ; LN1 ; FFN in 12 chunks of 32 hidden units, never leaving registers ;
+//   LN2 }  ->  encoder_norm  ->  hidden (bf16 and/or f32), last-patch state, squared norms.
+//
+// MFMA work per token-layer: 221 184*1.33(q/k/v/o head padding 24->32 only) ... see DESIGN.md
+// for the flop accounting used by bench.py's roofline.
+#include "common.h"
+#include "step_internal.h"
+#include "tsformer_layout.h"
+
+namespace {
+
+struct EncArgs {
+    const float* series;
+    int S, L, P, depth, nkt;
+    const char* wpack;
+    uint16_t* hid_bf16;
+    float* hid_f32;
+    float* last_f32;
+    float* sqn;
+    float drop_p;
+    uint32_t seed;
+};
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ bf16x8 gfrag(const char* base, int frag, int lane) {
+    return *(const bf16x8*)(base + (long)frag * TSF_FRAG + lane * 16);
+}
+__device__ __forceinline__ bf16x8 lfrag(const char* lds, int frag, int lane) {
+    return *(const bf16x8*)(lds + frag * TSF_FRAG + lane * 16);
+}
+__device__ __forceinline__ bf16x8 pack_half(const f32x16& v, int s) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[8 * s + j];
+    return pack8(t);
+}
+
+// dropout keep-mask bits: one 32-bit mix per element pair (two 16-bit Bernoulli draws)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+struct Dropper {
+    uint32_t base;      // seed ^ per-(seq, layer, site) salt
+    uint32_t thresh;    // keep iff draw16 >= thresh
+    float scale;        // 1/(1-p)
+    __device__ __forceinline__ void apply16(f32x16& v, uint32_t elem_salt) const {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            uint32_t r = mix32(base + (elem_salt + (uint32_t)i) * 0x9E3779B1u);
+            v[i] = ((r & 0xffffu) >= thresh) ? v[i] * scale : 0.f;
+            v[i + 1] = ((r >> 16) >= thresh) ? v[i + 1] * scale : 0.f;
+        }
+    }
+};
+
+// training-mode tail of a sub-layer: acc = dropout(acc) + x, with x taken from the bf16 operand
+// copy of the residual stream (the f32 copy is not kept live across the sub-layer)
+__device__ __forceinline__ void add_residual_bf16(f32x16 (&acc)[3], const bf16x8 (&xb)[6], const Dropper& dr,
+                                                  uint32_t salt) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        dr.apply16(acc[t], salt + (uint32_t)(t * 16));
+        u32x4 lo = __builtin_bit_cast(u32x4, xb[2 * t]), hi = __builtin_bit_cast(u32x4, xb[2 * t + 1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t wl = lo[j >> 1], wh = hi[j >> 1];
+            acc[t][j] += bf16_bits_to_f32((j & 1) ? (wl >> 16) : (wl & 0xffffu));
+            acc[t][8 + j] += bf16_bits_to_f32((j & 1) ? (wh >> 16) : (wh & 0xffffu));
+        }
+    }
+}
+
+// LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest
+__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* g, const float* b, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += a[t][i];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 96.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
+    const float* gg = g + h * 48;
+    const float* bb = b + h * 48;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[t][i] = (a[t][i] - mean) * rstd * gg[t * 16 + i] + bb[t * 16 + i];
+}
+
+template <int MAXW, bool DROP>
+__global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int seq = blockIdx.x;
+    const int P = A.P, nkt = A.nkt;
+    const int tok = wave * 32 + c;
+    const bool tok_ok = tok < P;
+    const int tokc = tok_ok ? tok : 0;
+    const char* W = A.wpack;
+    constexpr bool drop = DROP;
+    Dropper dr;
+    dr.thresh = (uint32_t)(A.drop_p * 65536.0f);
+    dr.scale = drop ? 1.0f / (1.0f - A.drop_p) : 1.0f;
+    const uint32_t seq_salt = A.seed ^ ((uint32_t)seq * 0x7FEB352Du);
+
+    // LDS: [2 buffers][K frags nkt*2 | V frags nkt*2]
+    const int buf_bytes = nkt * 4 * TSF_FRAG;
+
+    // ------------------------------------------------------------------ patch embedding + pos
+    f32x16 xT[3];
+    {
+        float xin[12];
+        const float4* src = (const float4*)(A.series + (long)seq * A.L + (long)tokc * TSF_PATCH);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            float4 t4 = tok_ok ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xin[4 * v] = t4.x; xin[4 * v + 1] = t4.y; xin[4 * v + 2] = t4.z; xin[4 * v + 3] = t4.w;
+        }
+        const float4* wpe = (const float4*)(W + TSF_G_WPE) + h * 48 * 3;
+        const float* bpe = (const float*)(W + TSF_G_BPE) + h * 48;
+        const float* pos = (const float*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc * 2 + h) * 48;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qd = t * 16 + i;
+                float4 w0 = wpe[qd * 3], w1 = wpe[qd * 3 + 1], w2 = wpe[qd * 3 + 2];
+                float acc = bpe[qd];
+                acc += w0.x * xin[0] + w0.y * xin[1] + w0.z * xin[2] + w0.w * xin[3];
+                acc += w1.x * xin[4] + w1.y * xin[5] + w1.z * xin[6] + w1.w * xin[7];
+                acc += w2.x * xin[8] + w2.y * xin[9] + w2.z * xin[10] + w2.w * xin[11];
+                xT[t][i] = acc + pos[qd];
+            }
+        if constexpr (drop) {
+            dr.base = seq_salt ^ 0xA511E9B3u;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dr.apply16(xT[t], (uint32_t)(tok * 96 + h * 48 + t * 16));
+        }
+        const float sc = 9.797958971132712f;   // sqrt(96), transformer_layers.py:15
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xT[t][i] *= sc;
+    }
+
+    // ------------------------------------------------------------------ encoder layers
+#pragma unroll 1
+    for (int layer = 0; layer < A.depth; ++layer) {
+        const char* LW = W + TSF_LAYER0 + (long)layer * TSF_LAYER_BYTES;
+        const uint32_t lsalt = seq_salt + (uint32_t)(layer + 1) * 0x632BE5ABu;
+
+        bf16x8 xb[6];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+
+        f32x16 acc[3];
+        {
+            const float* bo = (const float*)(LW + TSF_L_BO) + h * 48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : xT[t][i]) + bo[t * 16 + i];
+        }
+
+#pragma unroll 1
+        for (int hd = 0; hd < TSF_HEADS; ++hd) {
+            char* kbuf = smem + (hd & 1) * buf_bytes;
+            char* vbuf = kbuf + nkt * 2 * TSF_FRAG;
+
+            // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
+            bf16x8 qb[2];
+            {
+                f32x16 q;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(gfrag(LW + TSF_L_WQ, hd * 6 + ks, lane), xb[ks], q);
+                const float* bq = (const float*)(LW + TSF_L_BQ) + (hd * 2 + h) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] += bq[i];
+                qb[0] = pack_half(q, 0);
+                qb[1] = pack_half(q, 1);
+            }
+            // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
+            {
+                f32x16 kk;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kk[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) kk = MFMA_BF16(gfrag(LW + TSF_L_WK, hd * 6 + ks, lane), xb[ks], kk);
+                *(bf16x8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(kk, 0);
+                *(bf16x8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(kk, 1);
+            }
+            // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T
+            {
+                f32x16 vv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vv[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], gfrag(LW + TSF_L_WV, hd * 6 + ks, lane), vv);
+                const float bv = ((const float*)(LW + TSF_L_BV))[hd * 32 + c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vv[i] += bv;
+                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(vv, 0);
+                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(vv, 1);
+            }
+            __syncthreads();
+
+            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes)
+            float mx = -INFINITY;
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                f32x16 s;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
+                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
+                if (kt == nkt - 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+
+            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator)
+            f32x16 o;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.f;
+            float lsum = 0.f;
+            if constexpr (drop) dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1));
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                f32x16 s;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
+                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
+                if (kt == nkt - 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
+                if constexpr (drop) {
+                    // attention-prob dropout acts on the normalised probabilities: keep the
+                    // denominator dropout-free (VALU sum) and mask the numerator only
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) lsum += s[i];
+                    dr.apply16(s, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
+                }
+                bf16x8 p0 = pack_half(s, 0), p1 = pack_half(s, 1);
+                o = MFMA_BF16(lfrag(vbuf, kt * 2, lane), p0, o);
+                o = MFMA_BF16(lfrag(vbuf, kt * 2 + 1, lane), p1, o);
+            }
+            float den;
+            if constexpr (drop) {
+                den = lsum + __shfl_xor(lsum, 32, 64);
+            } else {
+                den = __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
+            }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] *= inv;
+            bf16x8 ob0 = pack_half(o, 0), ob1 = pack_half(o, 1);
+            // ---- out-projection of this head accumulates onto the residual
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_WO, (hd * 3 + t) * 2 + 0, lane), ob0, acc[t]);
+                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_WO, (hd * 3 + t) * 2 + 1, lane), ob1, acc[t]);
+            }
+        }  // heads
+
+        if constexpr (drop) {
+            // dropout1 on (attention output + b_o); residual re-read from its bf16 operand copy
+            dr.base = lsalt ^ 0x51ED27u;
+            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
+        }
+        layer_norm96(acc, (const float*)(LW + TSF_L_LN1G), (const float*)(LW + TSF_L_LN1B), h);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) xT[t] = acc[t];
+
+        // ---- FFN 96 -> 384 -> 96 in 12 chunks of 32 hidden units
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+        {
+            const float* b2 = (const float*)(LW + TSF_L_B2) + h * 48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : xT[t][i]) + b2[t * 16 + i];
+        }
+        if constexpr (drop) dr.base = lsalt ^ 0x2545F491u;
+#pragma unroll 1
+        for (int ch = 0; ch < 12; ++ch) {
+            f32x16 hh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hh[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(gfrag(LW + TSF_L_W1, ch * 6 + ks, lane), xb[ks], hh);
+            const float* b1 = (const float*)(LW + TSF_L_B1) + (ch * 2 + h) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i] + b1[i], 0.f);
+            if constexpr (drop) dr.apply16(hh, (uint32_t)((tok * 12 + ch) * 32 + h * 16));
+            bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_W2, (ch * 3 + t) * 2 + 0, lane), hb0, acc[t]);
+                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_W2, (ch * 3 + t) * 2 + 1, lane), hb1, acc[t]);
+            }
+        }
+        if constexpr (drop) {
+            dr.base = lsalt ^ 0x9E3779B9u;
+            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
+        }
+        layer_norm96(acc, (const float*)(LW + TSF_L_LN2G), (const float*)(LW + TSF_L_LN2B), h);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) xT[t] = acc[t];
+    }  // layers
+
+    // ------------------------------------------------------------------ encoder_norm + outputs
+    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G), (const float*)(W + TSF_G_NORM_B), h);
+    float sq = 0.f;
+    if (tok_ok) {
+        const long row = ((long)seq * P + tok) * TSF_D;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int f0 = t * 32 + 8 * g4 + 4 * h;
+                float v0 = xT[t][4 * g4], v1 = xT[t][4 * g4 + 1], v2 = xT[t][4 * g4 + 2], v3 = xT[t][4 * g4 + 3];
+                u32x2 pk;
+                pk[0] = pack_bf16x2(v0, v1);
+                pk[1] = pack_bf16x2(v2, v3);
+                if (A.hid_bf16) *(u32x2*)(A.hid_bf16 + row + f0) = pk;
+                if (A.hid_f32) *(float4*)(A.hid_f32 + row + f0) = make_float4(v0, v1, v2, v3);
+                if (A.last_f32 && tok == P - 1) *(float4*)(A.last_f32 + (long)seq * TSF_D + f0) = make_float4(v0, v1, v2, v3);
+                float r0 = bf16_bits_to_f32(pk[0] & 0xffffu), r1 = bf16_bits_to_f32(pk[0] >> 16);
+                float r2 = bf16_bits_to_f32(pk[1] & 0xffffu), r3 = bf16_bits_to_f32(pk[1] >> 16);
+                sq += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+            }
+    }
+    if (A.sqn) {
+        sq = wave_sum(sq);
+        if (lane == 0) A.sqn[(long)seq * 16 + wave] = sq;
+        if (wave == 0 && lane >= nkt && lane < 16) A.sqn[(long)seq * 16 + lane] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// [B, L, N, C] -> [B*N, L] (channel ch): LDS-tiled transpose, reads coalesced along n, writes
+// coalesced along t.
+__global__ __launch_bounds__(256) void pack_long_history_kernel(const float* __restrict__ x, int B, int L, int N,
+                                                                int C, int ch, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int t = t0 + r, n = n0 + tx;
+        tile[r][tx] = (t < L && n < N) ? x[(((long)b * L + t) * N + n) * C + ch] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int n = n0 + r, t = t0 + tx;
+        if (n < N && t < L) out[((long)b * N + n) * L + t] = tile[tx][r];
+    }
+}
+
+template <int MAXW, bool DROP>
+int launch_enc(const EncArgs& a, hipStream_t st) {
+    size_t lds = (size_t)a.nkt * 8 * TSF_FRAG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+            return STEP_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    tsformer_encoder_kernel<MAXW, DROP><<<a.S, a.nkt * 64, lds, st>>>(a);
+    STEP_LAUNCH_CHECK("step_tsformer_encode");
+    return STEP_OK;
+}
+
+}  // namespace
+
+extern "C" int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
+                                    int depth, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
+                                    float* sqnorm_part, float dropout_p, uint64_t seed, void* stream) {
+    STEP_REQUIRE(series && wpack, "tsformer_encode: null input");
+    STEP_REQUIRE(S > 0 && L > 0 && L % TSF_PATCH == 0, "tsformer_encode: L=%d must be a positive multiple of %d", L, TSF_PATCH);
+    const int P = L / TSF_PATCH;
+    STEP_REQUIRE(P <= 512, "tsformer_encode: %d tokens exceed the 512-token workgroup limit", P);
+    STEP_REQUIRE(depth >= 1 && depth <= 16, "tsformer_encode: bad depth %d", depth);
+    STEP_REQUIRE(wpack_bytes >= TSF_TOTAL_BYTES(depth, P), "tsformer_encode: packed weights too small (%ld < %ld)",
+                 wpack_bytes, (long)TSF_TOTAL_BYTES(depth, P));
+    STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "tsformer_encode: bad dropout %f", dropout_p);
+    EncArgs a;
+    a.series = series; a.S = S; a.L = L; a.P = P; a.depth = depth; a.nkt = (P + 31) / 32;
+    a.wpack = (const char*)wpack; a.hid_bf16 = hidden_bf16; a.hid_f32 = hidden_f32; a.last_f32 = last_f32;
+    a.sqn = sqnorm_part; a.drop_p = dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
+    hipStream_t st = (hipStream_t)stream;
+    const bool dr = dropout_p > 0.f;
+    if (a.nkt <= 4) return dr ? launch_enc<4, true>(a, st) : launch_enc<4, false>(a, st);
+    if (a.nkt <= 8) return dr ? launch_enc<8, true>(a, st) : launch_enc<8, false>(a, st);
+    if (a.nkt <= 12) return dr ? launch_enc<12, true>(a, st) : launch_enc<12, false>(a, st);
+    return dr ? launch_enc<16, true>(a, st) : launch_enc<16, false>(a, st);
+}
+
+extern "C" int step_pack_long_history(const float* x, int B, int L, int N, int C, int ch, float* out, void* stream) {
+    STEP_REQUIRE(x && out && B > 0 && L > 0 && N > 0 && C > 0 && ch >= 0 && ch < C, "pack_long_history: bad arguments");
+    dim3 grid(cdiv(L, 32), cdiv(N, 32), B);
+    pack_long_history_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, B, L, N, C, ch, out);
+    STEP_LAUNCH_CHECK("step_pack_long_history");
+    return STEP_OK;
+}

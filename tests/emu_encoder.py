@@ -1,0 +1,177 @@
+"""Lane-level numpy emulation of csrc/tsformer_encoder.hip (TEST INFRASTRUCTURE).
+
+Replays the kernel's data flow -- operand fragments read from the packed weight buffer at the
+byte offsets of csrc/tsformer_layout.h, MFMA 32x32x16 evaluated in (lane, slot) space, LDS
+fragment exchange between waves -- so that packing and index arithmetic can be checked on a
+machine without a GPU.  ``round_bf16=False`` keeps every operand in float64, which must agree
+with the oracle to round-off; ``True`` mimics the kernel's bf16 operand rounding.
+"""
+import numpy as np
+import torch
+
+from step_amd import tsformer_pack as TP
+
+LANES = np.arange(64)
+H = LANES // 32
+C = LANES % 32
+ROW = np.stack([(np.arange(16) & 3) + 8 * (np.arange(16) >> 2) + 4 * h for h in (0, 1)])   # [2,16]
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+class Buf:
+    def __init__(self, packed):
+        self.raw = packed.numpy().tobytes()
+
+    def f32(self, off, n):
+        return np.frombuffer(self.raw, dtype=np.float32, count=n, offset=off).astype(np.float64)
+
+    def frag(self, off, idx):
+        b = np.frombuffer(self.raw, dtype=np.int16, count=512, offset=off + idx * 1024)
+        return torch.from_numpy(b.copy()).view(torch.bfloat16).to(torch.float64).numpy().reshape(64, 8)
+
+
+def mfma(a, b, c):
+    """a, b: [64, 8] operand slots; c: [64, 16] accumulator.  D[lane(h,col)][i] += sum_{h',j}
+    a[32 h' + row(i,h)][j] * b[32 h' + col][j]."""
+    d = c.copy()
+    for l in range(64):
+        h, col = l // 32, l % 32
+        for i in range(16):
+            row = ROW[h, i]
+            d[l, i] += a[row] @ b[col] + a[32 + row] @ b[32 + col]
+    return d
+
+
+def mfma_fast(a, b, c):
+    full = np.einsum("hrj,hcj->rc", a.reshape(2, 32, 8), b.reshape(2, 32, 8))        # [row, col]
+    d = c.copy()
+    for h in (0, 1):
+        d[32 * h:32 * h + 32, :] += full[ROW[h]][:, :].T                              # lane col, reg i
+    return d
+
+
+def pack_half(v, s, rnd):
+    x = v[:, 8 * s:8 * s + 8]
+    return bf16_round(x) if rnd else x.copy()
+
+
+def layer_norm(acc, g, b):
+    """acc: [3, 64, 16]; g, b: [2, 48]."""
+    tot = acc.sum(axis=(0, 2))
+    tot = tot + tot[LANES ^ 32]
+    mean = tot / 96.0
+    d = acc - mean[None, :, None]
+    q = (d * d).sum(axis=(0, 2))
+    q = q + q[LANES ^ 32]
+    rstd = 1.0 / np.sqrt(q / 96.0 + 1e-5)
+    gg = g[H].reshape(64, 3, 16).transpose(1, 0, 2)
+    bb = b[H].reshape(64, 3, 16).transpose(1, 0, 2)
+    return d * rstd[None, :, None] * gg + bb
+
+
+def encode_sequence(series, packed, P, depth, round_bf16=True):
+    """series: [L] float; returns hidden [P, 96] (float64)."""
+    B = Buf(packed)
+    rnd = round_bf16
+    nkt = (P + 31) // 32
+    LB = TP.layer_bytes()
+    G_WPE = TP.HDR
+    G_BPE = G_WPE + 2 * 48 * 12 * 4
+    G_NG = G_BPE + 2 * 48 * 4
+    G_NB = G_NG + 2 * 48 * 4
+    L0 = G_NB + 2 * 48 * 4
+    POS = L0 + depth * LB
+    o = {}
+    off = 0
+    for name, sz in (("WQ", 24 * 1024), ("WK", 24 * 1024), ("WV", 24 * 1024), ("WO", 24 * 1024), ("W1", 72 * 1024),
+                     ("W2", 72 * 1024), ("BQ", 512), ("BV", 512), ("BO", 384), ("LN1G", 384), ("LN1B", 384),
+                     ("B1", 1536), ("B2", 384), ("LN2G", 384), ("LN2B", 384)):
+        o[name] = off
+        off += sz
+    assert off == LB
+    wpe = B.f32(G_WPE, 2 * 48 * 12).reshape(2, 48, 12)
+    bpe = B.f32(G_BPE, 96).reshape(2, 48)
+    xT = []
+    for w in range(nkt):
+        tok = w * 32 + C
+        ok = tok < P
+        tokc = np.where(ok, tok, 0)
+        xin = np.where(ok[:, None], series[tokc[:, None] * 12 + np.arange(12)[None, :]], 0.0)     # [64,12]
+        pos = np.stack([B.f32(POS + (int(tokc[l]) * 2 + int(H[l])) * 48 * 4, 48) for l in range(64)])
+        e = np.einsum("lqj,lj->lq", wpe[H], xin) + bpe[H] + pos                                  # [64,48]
+        xT.append((e * np.sqrt(96.0)).reshape(64, 3, 16).transpose(1, 0, 2).copy())              # [3,64,16]
+    for layer in range(depth):
+        base = L0 + layer * LB
+        f32 = lambda name, n: B.f32(base + o[name], n)
+        xb = [[pack_half(xT[w][t], s, rnd) for t in range(3) for s in range(2)] for w in range(nkt)]
+        bo = f32("BO", 96).reshape(2, 48)
+        acc = [xT[w] + bo[H].reshape(64, 3, 16).transpose(1, 0, 2) for w in range(nkt)]
+        for hd in range(4):
+            kf, vf, qb = {}, {}, []
+            bq = f32("BQ", 128).reshape(4, 2, 16)
+            bv = f32("BV", 128).reshape(4, 32)
+            for w in range(nkt):
+                q = np.zeros((64, 16)); kk = np.zeros((64, 16)); vv = np.zeros((64, 16))
+                for ks in range(6):
+                    q = mfma_fast(B.frag(base + o["WQ"], hd * 6 + ks), xb[w][ks], q)
+                    kk = mfma_fast(B.frag(base + o["WK"], hd * 6 + ks), xb[w][ks], kk)
+                    vv = mfma_fast(xb[w][ks], B.frag(base + o["WV"], hd * 6 + ks), vv)
+                q = q + bq[hd][H]
+                vv = vv + bv[hd][C][:, None]
+                qb.append([pack_half(q, 0, rnd), pack_half(q, 1, rnd)])
+                for s in range(2):
+                    kf[(w, s)] = pack_half(kk, s, rnd)
+                    vf[(w, s)] = pack_half(vv, s, rnd)
+            for w in range(nkt):
+                def scores(kt):
+                    s_ = mfma_fast(kf[(kt, 0)], qb[w][0], np.zeros((64, 16)))
+                    s_ = mfma_fast(kf[(kt, 1)], qb[w][1], s_)
+                    key = kt * 32 + ROW[H]                                # [64,16]
+                    return np.where(key >= P, -np.inf, s_)
+                mx = np.full(64, -np.inf)
+                for kt in range(nkt):
+                    mx = np.maximum(mx, scores(kt).max(axis=1))
+                mx = np.maximum(mx, mx[LANES ^ 32])
+                ov = np.zeros((64, 16))
+                for kt in range(nkt):
+                    p = np.exp2(scores(kt) - mx[:, None])
+                    ov = mfma_fast(vf[(kt, 0)], pack_half(p, 0, rnd), ov)
+                    ov = mfma_fast(vf[(kt, 1)], pack_half(p, 1, rnd), ov)
+                den = ov[C, 12]
+                ov = ov / den[:, None]
+                ob = [pack_half(ov, 0, rnd), pack_half(ov, 1, rnd)]
+                for t in range(3):
+                    for s in range(2):
+                        acc[w][t] = mfma_fast(B.frag(base + o["WO"], (hd * 3 + t) * 2 + s), ob[s], acc[w][t])
+        g1, b1n = f32("LN1G", 96).reshape(2, 48), f32("LN1B", 96).reshape(2, 48)
+        g2, b2n = f32("LN2G", 96).reshape(2, 48), f32("LN2B", 96).reshape(2, 48)
+        b1 = f32("B1", 384).reshape(12, 2, 16)
+        b2 = f32("B2", 96).reshape(2, 48)
+        for w in range(nkt):
+            x1 = layer_norm(acc[w], g1, b1n)
+            xbw = [pack_half(x1[t], s, rnd) for t in range(3) for s in range(2)]
+            a2 = x1 + b2[H].reshape(64, 3, 16).transpose(1, 0, 2)
+            for ch in range(12):
+                hh = np.zeros((64, 16))
+                for ks in range(6):
+                    hh = mfma_fast(B.frag(base + o["W1"], ch * 6 + ks), xbw[ks], hh)
+                hh = np.maximum(hh + b1[ch][H], 0.0)
+                hb = [pack_half(hh, 0, rnd), pack_half(hh, 1, rnd)]
+                for t in range(3):
+                    for s in range(2):
+                        a2[t] = mfma_fast(B.frag(base + o["W2"], (ch * 3 + t) * 2 + s), hb[s], a2[t])
+            xT[w] = layer_norm(a2, g2, b2n)
+    ng, nb = B.f32(G_NG, 96).reshape(2, 48), B.f32(G_NB, 96).reshape(2, 48)
+    hidden = np.zeros((P, 96))
+    for w in range(nkt):
+        y = layer_norm(xT[w], ng, nb)
+        for l in range(64):
+            tok = w * 32 + C[l]
+            if tok >= P:
+                continue
+            for t in range(3):
+                hidden[tok, t * 32 + ROW[H[l]]] = y[t, l]
+    return hidden
