@@ -39,6 +39,16 @@ typedef struct StepGemm {
     int accumulate;                        /* 0: C = ..., 1: C += ..., 2: atomicAdd(C, ...) */
     const float* bias; int relu;           /* epilogue, only with accumulate 0/1 */
     int splitk;                            /* >1 requires accumulate == 2 */
+    /* optional index remaps idx -> (idx / blk) * stride + idx % blk (blk == 0: off); they let the
+       contraction read / write one 32-channel slot of the [.., T, 224] concatenated gcn buffer
+       (graphwavenet/model.py:45) in place */
+    int a_kblk; long a_kstride;
+    int b_kblk; long b_kstride;
+    int b_nblk; long b_nstride;
+    int c_nblk; long c_nstride;
+    /* optional affine on A along k: A'(m,k) = A(m,k) * a_kscale[k / a_kperiod] + a_kshift[k / a_kperiod]
+       (folds BatchNorm1d(16) into the DGL fc, discrete_graph_learning.py:132-134) */
+    const float* a_kscale; const float* a_kshift; int a_kperiod;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 
@@ -80,6 +90,81 @@ int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, int B, int 
 /* same selection on a caller-provided f32 similarity matrix (tests, N-scaling config) */
 int step_topk_mask(const float* sim, int B, int N, int k_total, float* adj, void* work, long work_bytes,
                    void* stream);
+
+/* ---------------------------------------------------------------- DiscreteGraphLearning ---
+ * Device pointers named after the reference state_dict keys of `discrete_graph_learning.*`
+ * (discrete_graph_learning.py:63-78).  The same struct carries gradients (running stats unused);
+ * backward entry points ACCUMULATE (+=) into it, the caller zeroes.  fc_mean is never used by
+ * the reference forward (:142 is commented out) and is therefore absent. */
+typedef struct StepDglParams {
+    float *conv1_w, *conv1_b;                  /* [8,1,10], [8] */
+    float *conv2_w, *conv2_b;                  /* [16,8,10], [16] */
+    float *fc_w, *fc_b;                        /* [100, 16*(T-18)], [100] */
+    float *bn1_w, *bn1_b, *bn1_rm, *bn1_rv;    /* BatchNorm1d(8): weight, bias, running_mean, running_var */
+    float *bn2_w, *bn2_b, *bn2_rm, *bn2_rv;    /* BatchNorm1d(16) */
+    float *bn3_w, *bn3_b, *bn3_rm, *bn3_rv;    /* BatchNorm1d(100) */
+    float *fc_out_w, *fc_out_b;                /* [100,200], [100] */
+    float *fc_cat_w, *fc_cat_b;                /* [2,100], [2] */
+} StepDglParams;
+
+/* Global node feature g[N,100] (discrete_graph_learning.py:131-136) from the constant train
+ * series series_nt[N,T] (node-major copy of node_feats).  training!=0: batch statistics +
+ * running-stat update (momentum 0.1, unbiased variance) exactly like torch.nn.BatchNorm1d.
+ * saved/work: caller-owned scratch of step_dgl_global_{saved,work}_floats floats. */
+long step_dgl_global_saved_floats(int N, int T);
+long step_dgl_global_work_floats(int N, int T, int backward);
+int step_dgl_global_forward(const float* series_nt, int N, int T, const StepDglParams* p, int training,
+                            float momentum, float* saved, float* work, float* g, void* stream);
+int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
+                             const float* dg, float* work, const StepDglParams* grads, void* stream);
+
+/* Edge logits + Gumbel-softmax hard sample (discrete_graph_learning.py:148-161, :11-45).
+ *  g [N,100]; u f32 [B, N*N, 2] uniform noise as drawn by torch.rand (:12) or NULL for the
+ *  on-device Philox stream keyed by seed.  Outputs theta[B,N,N] = softmax(logits)[...,0]
+ *  (step.py:72) and the sampled adjacency [B,N,N] with the diagonal cleared. */
+long step_dgl_edges_saved_floats(int B, int N);
+long step_dgl_edges_work_floats(int N);
+int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
+                           float temperature, float* saved, float* theta_out, float* adj_out, void* stream);
+int step_dgl_edges_backward(const float* g, int N, int B, const StepDglParams* p, const float* saved,
+                            const float* dtheta, const float* dadj, float temperature, float* work,
+                            const StepDglParams* grads, float* dg, void* stream);
+
+/* ---------------------------------------------------------------- GraphWaveNet backbone ----
+ * Device pointers named after the reference state_dict keys of `backend.*`
+ * (graphwavenet/model.py:57-117).  residual_convs.* are never executed when gcn_bool is set
+ * (model.py:202-208) and therefore absent; gconv[7] / bn[7] exist in the struct but the last
+ * layer's gcn output is dead code in the reference, so they are neither read nor given a
+ * gradient.  The same struct carries gradients: backward ACCUMULATES (+=), the caller zeroes. */
+typedef struct StepGwnetParams {
+    float *nodevec1, *nodevec2;                       /* [N,10], [10,N] */
+    float *start_w, *start_b;                         /* [32,2,1,1], [32] */
+    float *filter_w[8], *filter_b[8];                 /* [32,32,1,2], [32] */
+    float *gate_w[8], *gate_b[8];
+    float *skip_w[8], *skip_b[8];                     /* [256,32,1,1], [256] */
+    float *bn_w[8], *bn_b[8], *bn_rm[8], *bn_rv[8];   /* BatchNorm2d(32) */
+    float *gconv_w[8], *gconv_b[8];                   /* [32,224,1,1], [32] */
+    float *fc_his0_w, *fc_his0_b, *fc_his2_w, *fc_his2_b;   /* [512,96], [256,512] */
+    float *end1_w, *end1_b, *end2_w, *end2_b;         /* [512,256,1,1], [12,512,1,1] */
+} StepGwnetParams;
+
+/* GraphWaveNet.forward (model.py:132-224) fused with the transposes of step.py:65,72:
+ *  hist [B,12,N,Cin] f32 (first two channels used), hidden_last [B*N,96] f32, adj [B,N,N] f32
+ *  -> pred [B,12,N] f32.  training!=0: batch-stat BatchNorm (+running-stat update) and, if
+ *  dropout_p>0, inverted dropout after each gcn (model.py:47) from the Philox stream `seed`.
+ *  saved/work: caller-owned scratch of step_gwnet_{saved,work}_floats floats; `saved` must be
+ *  kept unchanged until step_gwnet_backward. */
+long step_gwnet_saved_floats(int B, int N, int dropout);
+long step_gwnet_work_floats(int B, int N, int backward);
+long step_gwnet_saved_offset(int B, int N, int dropout, int item, int layer);
+int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
+                       const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
+                       float* saved, float* work, float* pred, void* stream);
+/* dpred [B,12,N] -> parameter gradients (+=) and dadj [B,N,N] (gradient w.r.t. the sampled adjacency,
+ * through both random-walk normalisations, model.py:121-130,160). */
+int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
+                        const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
+                        float* dadj, int dropout, void* stream);
 
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on

@@ -200,14 +200,15 @@ def cosine_knn_graph(hidden, k_total):
 
 
 def dgl_forward(long_hist0, node_feats, p, u, k, training=True, stats=None,
-                pre="discrete_graph_learning."):
+                pre="discrete_graph_learning.", hidden=None):
     """DiscreteGraphLearning.forward (discrete_graph_learning.py:113-168).
     long_hist0[B, L, N] is channel 0 of the long history; u is the uniform noise the
     reference draws with torch.rand at :12.  Returns (logits[B,N*N,2], hidden[B,N,P,96],
     adj_knn[B,N,N], sampled_adj[B,N,N])."""
     B, _, N = long_hist0.shape
     g = dgl_global_feature(node_feats, p, pre, training, stats)
-    hidden = tsformer_encode(long_hist0, p).detach()
+    if hidden is None:        # tests may inject the device encoder's (bf16) hidden states instead
+        hidden = tsformer_encode(long_hist0, p).detach()
     logits = dgl_edge_logits(g, p, pre).unsqueeze(0).expand(B, N * N, 2)
     samp = gumbel_hard_sample(logits, u)[..., 0].reshape(B, N, N)
     samp = samp * (1.0 - torch.eye(N, dtype=samp.dtype))
@@ -293,12 +294,15 @@ def gwnet_forward(hist, hidden_last, sampled_adj, p, pre="backend.", training=Tr
 
 # ----------------------------------------------------------------------------- STEP + loss
 def step_forward(hist, long_hist, node_feats, p, u, k, epoch, training=True,
-                 drop_masks=None, stats=None):
+                 drop_masks=None, stats=None, hidden=None, hidden_last=None, aux=None):
     """STEP.forward (step/step_arch/step.py:37-72).  Returns
     (prediction[B,12,N,1], theta[B,N,N], adj_knn[B,N,N], gsl_coefficient)."""
     B, _, N, _ = hist.shape
-    logits, hidden, adj_knn, samp = dgl_forward(long_hist[..., 0], node_feats, p, u, k, training, stats)
-    y = gwnet_forward(hist, hidden[:, :, -1, :], samp, p, training=training,
+    logits, hidden, adj_knn, samp = dgl_forward(long_hist[..., 0], node_feats, p, u, k, training, stats, hidden=hidden)
+    if aux is not None:
+        aux["sampled_adj"] = samp.detach()
+    last = hidden[:, :, -1, :] if hidden_last is None else hidden_last
+    y = gwnet_forward(hist, last, samp, p, training=training,
                       drop_masks=drop_masks, stats=stats).transpose(1, 2)
     coef = 1 / (int(epoch / 6) + 1) if epoch is not None else 0
     theta = torch.softmax(logits, -1)[..., 0].reshape(B, N, N)

@@ -19,8 +19,31 @@ class StepGemm(ctypes.Structure):
                 ("A", _vp), ("sam", _l), ("sak", _l), ("sab", _l), ("a_bf16", _i),
                 ("B", _vp), ("sbk", _l), ("sbn", _l), ("sbb", _l), ("b_bf16", _i),
                 ("C", _vp), ("ldc", _l), ("scn", _l), ("scb", _l),
-                ("alpha", _f), ("accumulate", _i), ("bias", _vp), ("relu", _i), ("splitk", _i)]
+                ("alpha", _f), ("accumulate", _i), ("bias", _vp), ("relu", _i), ("splitk", _i),
+                ("a_kblk", _i), ("a_kstride", _l), ("b_kblk", _i), ("b_kstride", _l),
+                ("b_nblk", _i), ("b_nstride", _l), ("c_nblk", _i), ("c_nstride", _l),
+                ("a_kscale", _vp), ("a_kshift", _vp), ("a_kperiod", _i)]
 
+
+class StepDglParams(ctypes.Structure):
+    NAMES = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "fc_w", "fc_b",
+             "bn1_w", "bn1_b", "bn1_rm", "bn1_rv", "bn2_w", "bn2_b", "bn2_rm", "bn2_rv",
+             "bn3_w", "bn3_b", "bn3_rm", "bn3_rv", "fc_out_w", "fc_out_b", "fc_cat_w", "fc_cat_b"]
+    _fields_ = [(n, _vp) for n in NAMES]
+
+
+class StepGwnetParams(ctypes.Structure):
+    _fields_ = [("nodevec1", _vp), ("nodevec2", _vp), ("start_w", _vp), ("start_b", _vp),
+                ("filter_w", _vp * 8), ("filter_b", _vp * 8), ("gate_w", _vp * 8), ("gate_b", _vp * 8),
+                ("skip_w", _vp * 8), ("skip_b", _vp * 8),
+                ("bn_w", _vp * 8), ("bn_b", _vp * 8), ("bn_rm", _vp * 8), ("bn_rv", _vp * 8),
+                ("gconv_w", _vp * 8), ("gconv_b", _vp * 8),
+                ("fc_his0_w", _vp), ("fc_his0_b", _vp), ("fc_his2_w", _vp), ("fc_his2_b", _vp),
+                ("end1_w", _vp), ("end1_b", _vp), ("end2_w", _vp), ("end2_b", _vp)]
+
+
+_PD = ctypes.POINTER(StepDglParams)
+_PG = ctypes.POINTER(StepGwnetParams)
 
 _SIGS = {
     "step_last_error": (ctypes.c_char_p, []),
@@ -32,6 +55,19 @@ _SIGS = {
     "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "step_topk_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp]),
     "step_selftest_mfma": (_i, [_vp, _vp]),
+    "step_dgl_global_saved_floats": (_l, [_i, _i]),
+    "step_dgl_global_work_floats": (_l, [_i, _i, _i]),
+    "step_dgl_global_forward": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp]),
+    "step_dgl_global_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _PD, _vp]),
+    "step_dgl_edges_saved_floats": (_l, [_i, _i]),
+    "step_dgl_edges_work_floats": (_l, [_i]),
+    "step_dgl_edges_forward": (_i, [_vp, _i, _i, _PD, _vp, _u64, _f, _vp, _vp, _vp, _vp]),
+    "step_dgl_edges_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _f, _vp, _PD, _vp, _vp]),
+    "step_gwnet_saved_floats": (_l, [_i, _i, _i]),
+    "step_gwnet_work_floats": (_l, [_i, _i, _i]),
+    "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),
+    "step_gwnet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _vp]),
+    "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp]),
 }
 
 _lib = None
@@ -79,7 +115,8 @@ def call(name, *args):
 
 
 def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0, scn=1, alpha=1.0,
-         accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0):
+         accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0, a_k=(0, 0), b_k=(0, 0),
+         b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0):
     """Thin descriptor builder around step_gemm; a/b/c are device tensors (f32 or bf16 for a, b),
     offsets are in elements."""
     g = StepGemm()
@@ -93,4 +130,10 @@ def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0
     g.alpha, g.accumulate = alpha, accumulate
     g.bias = bias.data_ptr() if bias is not None else None
     g.relu, g.splitk = int(relu), splitk
+    g.a_kblk, g.a_kstride = a_k
+    g.b_kblk, g.b_kstride = b_k
+    g.b_nblk, g.b_nstride = b_n
+    g.c_nblk, g.c_nstride = c_n
+    if a_kscale is not None:
+        g.a_kscale, g.a_kshift, g.a_kperiod = a_kscale.data_ptr(), a_kshift.data_ptr(), a_kperiod
     check(lib().step_gemm(ctypes.byref(g), stream()), "step_gemm")

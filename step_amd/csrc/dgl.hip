@@ -1,0 +1,734 @@
+// DiscreteGraphLearning on device (reference: step/step_arch/discrete_graph_learning.py).
+//
+//  global feature  (:131-136)  Conv1d(1->8,k10) ReLU BN1 Conv1d(8->16,k10) ReLU BN2 flatten fc ReLU BN3
+//  edge logits     (:148-153)  factorised: the one-hot gathers rel_rec/rel_send (:81-89) mean
+//                              recv = g[e / N], send = g[e % N], so
+//                              fc_out([send, recv]) = W[:, :100] g_j + W[:, 100:] g_i + b
+//  Gumbel sampling (:11-45,157-161), straight-through backward
+//
+// The batch-norms are folded into their consumers (BN1 into conv2's input read, BN2 into the fc
+// contraction via the GEMM's per-k affine) so the 267 MB conv2 activation is written once and
+// read once per pass.  Everything here is HBM-bound f32 VALU work except the fc, which runs on
+// the f32 matrix cores through step_gemm.
+#include "common.h"
+#include "step_internal.h"
+
+namespace {
+
+constexpr int KW = 10;      // conv kernel width
+constexpr int EMB = 100;    // embedding_dim
+
+// ------------------------------------------------------------------------------------------
+// conv1d (valid) + ReLU, optional per-input-channel affine (a folded BatchNorm), per-block
+// partial sums for the following BatchNorm.  in [N][CI][Tin] -> out [N][CO][Tin-9]
+template <int CI, int CO, int TPT>
+__global__ __launch_bounds__(256) void conv_relu_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ in_sc,
+                                                            const float* __restrict__ in_sh, float* __restrict__ out,
+                                                            float* __restrict__ partial, int Tin) {
+    __shared__ __attribute__((aligned(16))) float ws[CI * KW * CO];   // [ci][k][co]
+    __shared__ float red[4][2 * CO];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int Tout = Tin - (KW - 1);
+    for (int e = tid; e < CI * KW * CO; e += 256) {
+        int co = e % CO, k = (e / CO) % KW, ci = e / (CO * KW);
+        ws[e] = w[(co * CI + ci) * KW + k];
+    }
+    __syncthreads();
+    const int t0 = (blockIdx.x * 256 + tid) * TPT;
+    float acc[CO][TPT];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) acc[co][j] = b[co];
+    if (t0 < Tout) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const float* src = in + ((long)n * CI + ci) * Tin + t0;
+            const float sc = in_sc ? in_sc[ci] : 1.f, sh = in_sh ? in_sh[ci] : 0.f;
+            float x[TPT + KW - 1];
+#pragma unroll
+            for (int q = 0; q < TPT + KW - 1; ++q) x[q] = (t0 + q < Tin) ? src[q] * sc + sh : 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const float* wk = ws + (ci * KW + k) * CO;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = wk[co];
+#pragma unroll
+                    for (int j = 0; j < TPT; ++j) acc[co][j] += wv * x[k + j];
+                }
+            }
+        }
+    }
+    float s1[CO], s2[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        s1[co] = 0.f; s2[co] = 0.f;
+        float* dst = out + ((long)n * CO + co) * Tout + t0;
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            if (t0 + j < Tout) {
+                float v = fmaxf(acc[co][j], 0.f);
+                dst[j] = v;
+                s1[co] += v; s2[co] += v * v;
+            }
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        float a = wave_sum(s1[co]), q = wave_sum(s2[co]);
+        if (lane == 0) { red[wave][co] = a; red[wave][CO + co] = q; }
+    }
+    __syncthreads();
+    if (tid < 2 * CO)
+        partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * CO) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// BatchNorm statistics from per-block partials -> folded scale/shift, saved mean/rstd, running stats.
+// One block per channel.  stat layout: [4][C] = scale, shift, mean, rstd
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar, int training,
+                                                          float momentum, float* __restrict__ stat) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double mean, var;
+    if (training) {
+        double a = 0.0, q = 0.0;
+        for (int i = tid; i < nblk; i += 256) { a += partial[(long)i * 2 * C + c]; q += partial[(long)i * 2 * C + C + c]; }
+        r1[tid] = a; r2[tid] = q;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+            __syncthreads();
+        }
+        mean = r1[0] / count;
+        var = fmax(r2[0] / count - mean * mean, 0.0);
+        if (tid == 0) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * count / fmax(count - 1.0, 1.0));
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    if (tid == 0) {
+        float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        float sc = gamma[c] * rstd;
+        stat[c] = sc;
+        stat[C + c] = beta[c] - (float)mean * sc;
+        stat[2 * C + c] = (float)mean;
+        stat[3 * C + c] = rstd;
+    }
+}
+
+// gpre[n][j] += bias[j]   (in place; the value saved for backward is fc(x)+b)
+// g[n][j] = BN3(relu(gpre[n][j]))    one block per feature column j
+__global__ __launch_bounds__(256) void fc_post_bn3_kernel(float* __restrict__ gpre, const float* __restrict__ bias, int N,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar, int training,
+                                                          float momentum, float* __restrict__ stat, float* __restrict__ g) {
+    __shared__ double r1[256], r2[256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const float bj = bias[j];
+    double a = 0.0, q = 0.0;
+    for (int n = tid; n < N; n += 256) {
+        float v = gpre[(long)n * EMB + j] + bj;
+        gpre[(long)n * EMB + j] = v;
+        v = fmaxf(v, 0.f);
+        a += v; q += (double)v * v;
+    }
+    r1[tid] = a; r2[tid] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+        __syncthreads();
+    }
+    double mean, var;
+    if (training) {
+        mean = r1[0] / N;
+        var = fmax(r2[0] / N - mean * mean, 0.0);
+        if (tid == 0) {
+            rmean[j] = (1.f - momentum) * rmean[j] + momentum * (float)mean;
+            rvar[j] = (1.f - momentum) * rvar[j] + momentum * (float)(var * N / fmax((double)N - 1.0, 1.0));
+        }
+    } else {
+        mean = rmean[j]; var = rvar[j];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    if (tid == 0) { stat[2 * EMB + j] = (float)mean; stat[3 * EMB + j] = rstd; }
+    const float sc = gamma[j] * rstd, sh = beta[j] - (float)mean * sc;
+    for (int n = tid; n < N; n += 256) g[(long)n * EMB + j] = fmaxf(gpre[(long)n * EMB + j], 0.f) * sc + sh;
+}
+
+// backward of g = BN3(relu(gpre)) (training): one block per feature.
+__global__ __launch_bounds__(256) void bn3_relu_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ gpre, int N,
+                                                           const float* __restrict__ gamma, const float* __restrict__ stat,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias, float* __restrict__ dgpre) {
+    __shared__ double r1[256], r2[256];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const float mean = stat[2 * EMB + j], rstd = stat[3 * EMB + j];
+    double a = 0.0, q = 0.0;
+    for (int n = tid; n < N; n += 256) {
+        float d = dg[(long)n * EMB + j];
+        float xh = (fmaxf(gpre[(long)n * EMB + j], 0.f) - mean) * rstd;
+        a += d; q += (double)d * xh;
+    }
+    r1[tid] = a; r2[tid] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+        __syncthreads();
+    }
+    const float m1 = (float)(r1[0] / N), m2 = (float)(r2[0] / N);
+    const float k = gamma[j] * rstd;
+    __syncthreads();
+    double sb = 0.0;
+    for (int n = tid; n < N; n += 256) {
+        float pre = gpre[(long)n * EMB + j];
+        float xh = (fmaxf(pre, 0.f) - mean) * rstd;
+        float dh = k * (dg[(long)n * EMB + j] - m1 - xh * m2);
+        float v = pre > 0.f ? dh : 0.f;
+        dgpre[(long)n * EMB + j] = v;
+        sb += v;
+    }
+    if (tid == 0) { dgamma[j] += (float)r2[0]; dbeta[j] += (float)r1[0]; }
+    __syncthreads();
+    r1[tid] = sb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) r1[tid] += r1[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) dbias[j] += (float)r1[0];
+}
+
+// dfc_w[o][k] += sc[c(k)] * raw[o][k] + sh[c(k)] * colsum[o],  c(k) = k / period
+__global__ __launch_bounds__(256) void fc_wgrad_fixup_kernel(const float* __restrict__ raw, const float* __restrict__ dgpre, int N,
+                                                             const float* __restrict__ stat, int C, int period, long K,
+                                                             float* __restrict__ dw) {
+    __shared__ float cs;
+    const int o = blockIdx.y;
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int n = threadIdx.x; n < N; n += 64) s += dgpre[(long)n * EMB + o];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) cs = s;
+    }
+    __syncthreads();
+    const float colsum = cs;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < K; k += (long)gridDim.x * 256) {
+        int c = (int)(k / period);
+        dw[(long)o * K + k] += stat[c] * raw[(long)o * K + k] + stat[C + c] * colsum;
+    }
+}
+
+// BatchNorm (over n, t per channel) backward, pass 1: S1 = sum dy, S2 = sum dy * xhat, per block partials
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stat, int Tlen, float* __restrict__ partial) {
+    __shared__ float red[4][2];
+    const int n = blockIdx.z, c = blockIdx.y, tid = threadIdx.x;
+    const float mean = stat[2 * C + c], rstd = stat[3 * C + c];
+    const long base = ((long)n * C + c) * Tlen;
+    float a = 0.f, q = 0.f;
+    for (int t = blockIdx.x * 1024 + tid; t < min(Tlen, (int)(blockIdx.x + 1) * 1024); t += 256) {
+        float d = dy[base + t];
+        a += d; q += d * ((x[base + t] - mean) * rstd);
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = a; red[tid >> 6][1] = q; }
+    __syncthreads();
+    if (tid < 2) {
+        long blk = (long)n * gridDim.x + blockIdx.x;
+        partial[(blk * C + c) * 2 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+// pass 2: coefficients; coef layout [3][C]: m1 = S1/count, m2 = S2/count, k = gamma*rstd; also dgamma/dbeta
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ stat,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int i = tid; i < nblk; i += 256) { a += partial[((long)i * C + c) * 2]; q += partial[((long)i * C + c) * 2 + 1]; }
+    r1[tid] = a; r2[tid] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dgamma[c] += (float)r2[0];
+        dbeta[c] += (float)r1[0];
+        coef[c] = (float)(r1[0] / count);
+        coef[C + c] = (float)(r2[0] / count);
+        coef[2 * C + c] = gamma[c] * stat[3 * C + c];
+    }
+}
+// pass 3 (in place on dy): dz = [x > 0] * k * (dy - m1 - xhat * m2)      (x is the post-ReLU conv output)
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ stat, const float* __restrict__ coef, int Tlen) {
+    const int n = blockIdx.z, c = blockIdx.y;
+    const float mean = stat[2 * C + c], rstd = stat[3 * C + c];
+    const float m1 = coef[c], m2 = coef[C + c], k = coef[2 * C + c];
+    const long base = ((long)n * C + c) * Tlen;
+    for (int t = blockIdx.x * 1024 + threadIdx.x; t < min(Tlen, (int)(blockIdx.x + 1) * 1024); t += 256) {
+        float xv = x[base + t];
+        float d = k * (dy[base + t] - m1 - (xv - mean) * rstd * m2);
+        dy[base + t] = xv > 0.f ? d : 0.f;
+    }
+}
+
+// conv backward w.r.t. its input: din[n][ci][t'] = sum_{co,k} w[co][ci][k] * dz[n][co][t'-k]
+template <int CI, int CO, int TPT>
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                            float* __restrict__ din, int Tin) {
+    __shared__ float ws[CO * KW * CI];    // [co][k][ci]
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int Tout = Tin - (KW - 1);
+    for (int e = tid; e < CO * KW * CI; e += 256) {
+        int ci = e % CI, k = (e / CI) % KW, co = e / (CI * KW);
+        ws[e] = w[(co * CI + ci) * KW + k];
+    }
+    __syncthreads();
+    const int t0 = (blockIdx.x * 256 + tid) * TPT;
+    if (t0 >= Tin) return;
+    float acc[CI][TPT];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) acc[ci][j] = 0.f;
+#pragma unroll 2
+    for (int co = 0; co < CO; ++co) {
+        const float* src = dz + ((long)n * CO + co) * Tout;
+        float d[TPT + KW - 1];           // d[q] = dz[t0 - 9 + q]
+#pragma unroll
+        for (int q = 0; q < TPT + KW - 1; ++q) {
+            int t = t0 - (KW - 1) + q;
+            d[q] = (t >= 0 && t < Tout) ? src[t] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const float* wk = ws + (co * KW + k) * CI;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const float wv = wk[ci];
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) acc[ci][j] += wv * d[j + (KW - 1) - k];
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int j = 0; j < TPT; ++j)
+            if (t0 + j < Tin) din[((long)n * CI + ci) * Tin + t0 + j] = acc[ci][j];
+}
+
+// conv backward w.r.t. weight and bias, one block per node:
+//   dw[co][ci][k] += sum_t dz[n][co][t] * (in[n][ci][t+k] * sc[ci] + sh[ci]);  db[co] += sum_t dz[n][co][t]
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ in,
+                                                              const float* __restrict__ in_sc, const float* __restrict__ in_sh,
+                                                              float* __restrict__ dw, float* __restrict__ db, int Tin) {
+    constexpr int CH = 512;
+    constexpr int NOUT = CO * CI * KW;
+    constexpr int PER = (NOUT + 255) / 256;
+    __shared__ float sdz[CO][CH];
+    __shared__ float sin_[CI][CH + KW];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int Tout = Tin - (KW - 1);
+    float acc[PER], accb = 0.f;
+#pragma unroll
+    for (int p = 0; p < PER; ++p) acc[p] = 0.f;
+    for (int t0 = 0; t0 < Tout; t0 += CH) {
+        __syncthreads();
+        for (int e = tid; e < CO * CH; e += 256) {
+            int co = e / CH, t = e % CH;
+            sdz[co][t] = (t0 + t < Tout) ? dz[((long)n * CO + co) * Tout + t0 + t] : 0.f;
+        }
+        for (int e = tid; e < CI * (CH + KW - 1); e += 256) {
+            int ci = e / (CH + KW - 1), t = e % (CH + KW - 1);
+            float v = 0.f;
+            if (t0 + t < Tin) {
+                v = in[((long)n * CI + ci) * Tin + t0 + t];
+                if (in_sc) v = v * in_sc[ci] + in_sh[ci];
+            }
+            sin_[ci][t] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int o = tid + p * 256;
+            if (o < NOUT) {
+                int k = o % KW, ci = (o / KW) % CI, co = o / (KW * CI);
+                float s = 0.f;
+                for (int t = 0; t < CH; ++t) s += sdz[co][t] * sin_[ci][t + k];
+                acc[p] += s;
+            }
+        }
+        if (tid < CO) {
+            float s = 0.f;
+            for (int t = 0; t < CH; ++t) s += sdz[tid][t];
+            accb += s;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        int o = tid + p * 256;
+        if (o < NOUT) atomicAdd(&dw[o], acc[p]);      // dw is [co][ci][k] == flat index o
+    }
+    if (tid < CO) atomicAdd(&db[tid], accb);
+}
+
+// ------------------------------------------------------------------------------------------ edges
+// z[i*N + j] = (wc0 - wc1) . relu(rcv[i] + snd[j]) + (bc0 - bc1),  theta = sigmoid(z)
+// sndT is [EMB][N] (coalesced along j), rcv is [N][EMB] and already contains fc_out.bias.
+__global__ __launch_bounds__(256) void edge_logit_kernel(const float* __restrict__ sndT, const float* __restrict__ rcv,
+                                                         const float* __restrict__ wcat, const float* __restrict__ bcat, int N,
+                                                         float* __restrict__ z) {
+    __shared__ float sr[EMB], sw[EMB];
+    const int i = blockIdx.y;
+    if (threadIdx.x < EMB) {
+        sr[threadIdx.x] = rcv[(long)i * EMB + threadIdx.x];
+        sw[threadIdx.x] = wcat[threadIdx.x] - wcat[EMB + threadIdx.x];
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    float acc = bcat[0] - bcat[1];
+#pragma unroll 4
+    for (int f = 0; f < EMB; ++f) acc += sw[f] * fmaxf(sr[f] + sndT[(long)f * N + j], 0.f);
+    z[(long)i * N + j] = acc;
+}
+
+// theta[b][e] = sigmoid(z[e]);  y0 = sigmoid((z + g0 - g1)/tau), adj = [y0 >= y1] with the diagonal cleared
+__global__ __launch_bounds__(256) void gumbel_sample_kernel(const float* __restrict__ z, const float* __restrict__ u, int B, int N,
+                                                            uint32_t seed_lo, uint32_t seed_hi, float inv_tau,
+                                                            float* __restrict__ theta, float* __restrict__ y0, float* __restrict__ adj) {
+    const long E = (long)N * N;
+    const int b = blockIdx.y;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
+        const float zv = z[e];
+        float u0, u1;
+        if (u) {
+            u0 = u[((long)b * E + e) * 2];
+            u1 = u[((long)b * E + e) * 2 + 1];
+        } else {
+            uint32_t r[4];
+            philox4x32((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)b, 0x5EEDu, seed_lo, seed_hi, r);
+            u0 = u32_to_unit(r[0]); u1 = u32_to_unit(r[1]);
+        }
+        // sample_gumbel with eps = 1e-10 (discrete_graph_learning.py:11-18,36)
+        const float g0 = -logf(-logf(u0 + 1e-10f) + 1e-10f);
+        const float g1 = -logf(-logf(u1 + 1e-10f) + 1e-10f);
+        const float a0 = (zv + g0 - g1) * inv_tau;         // (l0+g0)/tau - (l1+g1)/tau
+        const float ys = 1.f / (1.f + __expf(-a0));
+        const int i = (int)(e / N), j = (int)(e % N);
+        theta[(long)b * E + e] = 1.f / (1.f + __expf(-zv));
+        y0[(long)b * E + e] = ys;
+        adj[(long)b * E + e] = (i != j && a0 >= 0.f) ? 1.f : 0.f;
+    }
+}
+
+// dz[e] = sum_b dtheta*theta(1-theta) + [i != j] dadj * y0 (1-y0) / tau
+__global__ __launch_bounds__(256) void edge_dz_kernel(const float* __restrict__ dtheta, const float* __restrict__ dadj,
+                                                      const float* __restrict__ theta, const float* __restrict__ y0, int B, int N,
+                                                      float inv_tau, float* __restrict__ dz) {
+    const long E = (long)N * N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const long o = (long)b * E + e;
+            float th = theta[o];
+            if (dtheta) s += dtheta[o] * th * (1.f - th);
+            if (dadj && i != j) { float y = y0[o]; s += dadj[o] * y * (1.f - y) * inv_tau; }
+        }
+        dz[e] = s;
+    }
+}
+
+// Row pass (one block per receiver i): drcv[i][f] = sum_j dz[i][j] * wd[f] * [hid > 0];  also the
+// fc_cat weight/bias gradients.  Column pass (one block per 64 senders): dsndT[f][j] = sum_i ...
+__global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restrict__ dz, const float* __restrict__ sndT,
+                                                           const float* __restrict__ rcv, const float* __restrict__ wcat, int N,
+                                                           float* __restrict__ drcv, float* __restrict__ dwcat, float* __restrict__ dbcat) {
+    __shared__ float sr[EMB], sw[EMB];
+    __shared__ float red[4][2 * EMB + 1];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (tid < EMB) { sr[tid] = rcv[(long)i * EMB + tid]; sw[tid] = wcat[tid] - wcat[EMB + tid]; }
+    __syncthreads();
+    float sdz = 0.f;
+    for (int j = tid; j < N; j += 256) sdz += dz[(long)i * N + j];
+    sdz = wave_sum(sdz);
+    if ((tid & 63) == 0) red[tid >> 6][2 * EMB] = sdz;
+    for (int f = 0; f < EMB; ++f) {
+        float a = 0.f, h = 0.f;          // a -> drcv, h -> dwcat (sum dz * hid)
+        for (int j = tid; j < N; j += 256) {
+            float d = dz[(long)i * N + j];
+            float hid = sr[f] + sndT[(long)f * N + j];
+            if (hid > 0.f) { a += d; h += d * hid; }
+        }
+        a = wave_sum(a); h = wave_sum(h);
+        if ((tid & 63) == 0) { red[tid >> 6][f] = a; red[tid >> 6][EMB + f] = h; }
+    }
+    __syncthreads();
+    if (tid < EMB) {
+        float a = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        float h = red[0][EMB + tid] + red[1][EMB + tid] + red[2][EMB + tid] + red[3][EMB + tid];
+        drcv[(long)i * EMB + tid] = a * sw[tid];
+        atomicAdd(&dwcat[tid], h);
+        atomicAdd(&dwcat[EMB + tid], -h);
+    }
+    if (tid == 0) {
+        float s = red[0][2 * EMB] + red[1][2 * EMB] + red[2][2 * EMB] + red[3][2 * EMB];
+        atomicAdd(&dbcat[0], s);
+        atomicAdd(&dbcat[1], -s);
+    }
+}
+__global__ __launch_bounds__(256) void edge_bwd_col_kernel(const float* __restrict__ dz, const float* __restrict__ sndT,
+                                                           const float* __restrict__ rcv, const float* __restrict__ wcat, int N,
+                                                           float* __restrict__ dsndT) {
+    // block: 64 columns j (lanes) x 4 waves splitting the features
+    __shared__ float sw[EMB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < EMB) sw[tid] = wcat[tid] - wcat[EMB + tid];
+    __syncthreads();
+    const int j = blockIdx.x * 64 + lane;
+    if (j >= N) return;
+    for (int f = wave; f < EMB; f += 4) {
+        const float s = sndT[(long)f * N + j];
+        float a = 0.f;
+        for (int i = 0; i < N; ++i) {
+            float hid = rcv[(long)i * EMB + f] + s;
+            if (hid > 0.f) a += dz[(long)i * N + j];
+        }
+        dsndT[(long)f * N + j] = a * sw[f];
+    }
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, long rows, int cols, long ld, float* __restrict__ out) {
+    // out[c] += sum_r x[r*ld + c]; grid.x = cols tiles of 64, grid.y = row chunks
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (long r = (long)blockIdx.y * 4 + w; r < rows; r += (long)gridDim.y * 4) s += x[r * ld + c];
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out, hipStream_t st) {
+    int chunks = (int)((rows + 255) / 256);
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
+    colsum_kernel<<<dim3(cdiv(cols, 64), chunks), 256, 0, st>>>(x, rows, cols, ld, out);
+    STEP_LAUNCH_CHECK("colsum");
+    return STEP_OK;
+}
+
+// =========================================================================================== C ABI
+extern "C" long step_dgl_global_saved_floats(int N, int T) {
+    long T1 = T - 9, T2 = T - 18;
+    return (long)N * 8 * T1 + (long)N * 16 * T2 + (long)N * EMB + 4 * 8 + 4 * 16 + 4 * EMB;
+}
+extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
+    long T1 = T - 9, T2 = T - 18;
+    long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
+    long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
+    if (!backward) return part;
+    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + (long)N * EMB + 256;
+}
+
+static void carve_saved(float* saved, int N, int T, float** a1, float** a2, float** gpre, float** st1, float** st2, float** st3) {
+    long T1 = T - 9, T2 = T - 18;
+    *a1 = saved; saved += (long)N * 8 * T1;
+    *a2 = saved; saved += (long)N * 16 * T2;
+    *gpre = saved; saved += (long)N * EMB;
+    *st1 = saved; saved += 4 * 8;
+    *st2 = saved; saved += 4 * 16;
+    *st3 = saved;
+}
+
+extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, const StepDglParams* p, int training,
+                                       float momentum, float* saved, float* work, float* g, void* stream) {
+    STEP_REQUIRE(series_nt && p && saved && work && g && N > 0 && T > 18, "dgl_global_forward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int T1 = T - 9, T2 = T - 18;
+    float *a1, *a2, *gpre, *st1, *st2, *st3;
+    carve_saved(saved, N, T, &a1, &a2, &gpre, &st1, &st2, &st3);
+    float* partial = work;
+    {
+        dim3 grid(cdiv(T1, 256 * 4), N);
+        conv_relu_fwd_kernel<1, 8, 4><<<grid, 256, 0, st>>>(series_nt, p->conv1_w, p->conv1_b, nullptr, nullptr, a1, partial, T);
+        STEP_LAUNCH_CHECK("conv1");
+        bn_finalize_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, (double)N * T1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv,
+                                              training, momentum, st1);
+        STEP_LAUNCH_CHECK("bn1");
+    }
+    {
+        dim3 grid(cdiv(T2, 256 * 4), N);
+        conv_relu_fwd_kernel<8, 16, 4><<<grid, 256, 0, st>>>(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, T1);
+        STEP_LAUNCH_CHECK("conv2");
+        bn_finalize_kernel<<<16, 256, 0, st>>>(partial, grid.x * grid.y, 16, (double)N * T2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv,
+                                               training, momentum, st2);
+        STEP_LAUNCH_CHECK("bn2");
+    }
+    const long K = 16L * T2;
+    if (hipMemsetAsync(gpre, 0, (size_t)N * EMB * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+    StepGemm gm = gemm_desc(N, EMB, (int)K, a2, K, 1, p->fc_w, 1, K, gpre, EMB);
+    gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
+    gm.accumulate = 2;
+    gm.splitk = 256 / (cdiv(N, 64) * 2) + 1;
+    if (gm.splitk > cdiv(K, 16) / 8) gm.splitk = cdiv(K, 16) / 8 > 0 ? cdiv(K, 16) / 8 : 1;
+    STEP_TRY(step_gemm_launch(gm, st));
+    fc_post_bn3_kernel<<<EMB, 256, 0, st>>>(gpre, p->fc_b, N, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, training, momentum, st3, g);
+    STEP_LAUNCH_CHECK("fc_post_bn3");
+    return STEP_OK;
+}
+
+extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
+                                        const float* dg, float* work, const StepDglParams* grads, void* stream) {
+    STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18, "dgl_global_backward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int T1 = T - 9, T2 = T - 18;
+    const long K = 16L * T2;
+    float *a1, *a2, *gpre, *st1, *st2, *st3;
+    carve_saved((float*)saved, N, T, &a1, &a2, &gpre, &st1, &st2, &st3);
+    long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
+    float* partial = work;
+    float* d_a2 = work + (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
+    float* d_a1 = d_a2 + (long)N * 16 * T2;
+    float* wraw = d_a1 + (long)N * 8 * T1;
+    float* dgpre = wraw + (long)EMB * K;
+    float* coef = dgpre + (long)N * EMB;
+    // BN3 + ReLU backward, fc bias gradient
+    bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre);
+    STEP_LAUNCH_CHECK("bn3_bwd");
+    // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
+    {
+        StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
+        STEP_TRY(step_gemm_launch(gm, st));
+        fc_wgrad_fixup_kernel<<<dim3(256, EMB), 256, 0, st>>>(wraw, dgpre, N, st2, 16, T2, K, grads->fc_w);
+        STEP_LAUNCH_CHECK("fc_wgrad_fixup");
+    }
+    // d(BN2 output) = dgpre @ fc_w
+    {
+        StepGemm gm = gemm_desc(N, (int)K, EMB, dgpre, EMB, 1, p->fc_w, K, 1, d_a2, K);
+        STEP_TRY(step_gemm_launch(gm, st));
+    }
+    // BN2 backward (+ReLU mask) in place -> dz2
+    {
+        dim3 grid(cdiv(T2, 1024), 16, N);
+        bn_bwd_reduce_kernel<16><<<grid, 256, 0, st>>>(d_a2, a2, st2, T2, partial);
+        STEP_LAUNCH_CHECK("bn2_bwd_reduce");
+        bn_bwd_finalize_kernel<<<16, 256, 0, st>>>(partial, (int)nb2, 16, (double)N * T2, p->bn2_w, st2, grads->bn2_w, grads->bn2_b, coef);
+        STEP_LAUNCH_CHECK("bn2_bwd_finalize");
+        bn_bwd_apply_kernel<16><<<grid, 256, 0, st>>>(d_a2, a2, st2, coef, T2);
+        STEP_LAUNCH_CHECK("bn2_bwd_apply");
+    }
+    // conv2 backward: weights (BN1 affine folded into the input read) and data
+    conv_bwd_weight_kernel<8, 16><<<N, 256, 0, st>>>(d_a2, a1, st1, st1 + 8, grads->conv2_w, grads->conv2_b, T1);
+    STEP_LAUNCH_CHECK("conv2_bwd_weight");
+    conv_bwd_data_kernel<8, 16, 4><<<dim3(cdiv(T1, 1024), N), 256, 0, st>>>(d_a2, p->conv2_w, d_a1, T1);
+    STEP_LAUNCH_CHECK("conv2_bwd_data");
+    // BN1 backward in place -> dz1
+    {
+        dim3 grid(cdiv(T1, 1024), 8, N);
+        bn_bwd_reduce_kernel<8><<<grid, 256, 0, st>>>(d_a1, a1, st1, T1, partial);
+        STEP_LAUNCH_CHECK("bn1_bwd_reduce");
+        bn_bwd_finalize_kernel<<<8, 256, 0, st>>>(partial, (int)nb1, 8, (double)N * T1, p->bn1_w, st1, grads->bn1_w, grads->bn1_b, coef);
+        STEP_LAUNCH_CHECK("bn1_bwd_finalize");
+        bn_bwd_apply_kernel<8><<<grid, 256, 0, st>>>(d_a1, a1, st1, coef, T1);
+        STEP_LAUNCH_CHECK("bn1_bwd_apply");
+    }
+    conv_bwd_weight_kernel<1, 8><<<N, 256, 0, st>>>(d_a1, series_nt, nullptr, nullptr, grads->conv1_w, grads->conv1_b, T);
+    STEP_LAUNCH_CHECK("conv1_bwd_weight");
+    return STEP_OK;
+}
+
+extern "C" long step_dgl_edges_saved_floats(int B, int N) { return 2L * N * EMB + (long)N * N + 2L * B * N * N; }
+
+// saved layout: sndT [EMB][N] | rcv [N][EMB] | z [N*N] | theta [B][N*N] | y0 [B][N*N]
+extern "C" int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
+                                      float temperature, float* saved, float* theta_out, float* adj_out, void* stream) {
+    STEP_REQUIRE(g && p && saved && adj_out && N > 0 && B > 0 && temperature > 0.f, "dgl_edges_forward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* sndT = saved;
+    float* rcv = sndT + (long)N * EMB;
+    float* z = rcv + (long)N * EMB;
+    float* theta = z + (long)N * N;
+    float* y0 = theta + (long)B * N * N;
+    // sndT[f][j] = sum_c g[j][c] * W[f][c]              (fc_out.weight[:, :100])
+    StepGemm gs = gemm_desc(N, EMB, EMB, g, EMB, 1, p->fc_out_w, 1, 2 * EMB, sndT, 1);
+    gs.scn = N;
+    STEP_TRY(step_gemm_launch(gs, st));
+    // rcv[i][f] = sum_c g[i][c] * W[f][100 + c] + b[f]
+    StepGemm gr = gemm_desc(N, EMB, EMB, g, EMB, 1, p->fc_out_w + EMB, 1, 2 * EMB, rcv, EMB);
+    gr.bias = p->fc_out_b;
+    STEP_TRY(step_gemm_launch(gr, st));
+    edge_logit_kernel<<<dim3(cdiv(N, 256), N), 256, 0, st>>>(sndT, rcv, p->fc_cat_w, p->fc_cat_b, N, z);
+    STEP_LAUNCH_CHECK("edge_logit");
+    int gx = cdiv((long)N * N, 256);
+    if (gx > 4096) gx = 4096;
+    gumbel_sample_kernel<<<dim3(gx, B), 256, 0, st>>>(z, u, B, N, (uint32_t)seed, (uint32_t)(seed >> 32), 1.f / temperature, theta, y0, adj_out);
+    STEP_LAUNCH_CHECK("gumbel_sample");
+    if (theta_out && theta_out != theta) {
+        if (hipMemcpyAsync(theta_out, theta, (size_t)B * N * N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            step_set_error("dgl_edges_forward: theta copy failed");
+            return STEP_ERR_HIP;
+        }
+    }
+    return STEP_OK;
+}
+
+// work: dz [N*N] | drcv [N][EMB] | dsndT [EMB][N]
+extern "C" long step_dgl_edges_work_floats(int N) { return (long)N * N + 2L * N * EMB; }
+
+extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepDglParams* p, const float* saved,
+                                       const float* dtheta, const float* dadj, float temperature, float* work,
+                                       const StepDglParams* grads, float* dg, void* stream) {
+    STEP_REQUIRE(g && p && saved && work && grads && dg && N > 0 && B > 0, "dgl_edges_backward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float* sndT = saved;
+    const float* rcv = sndT + (long)N * EMB;
+    const float* theta = rcv + (long)N * EMB + (long)N * N;
+    const float* y0 = theta + (long)B * N * N;
+    float* dz = work;
+    float* drcv = dz + (long)N * N;
+    float* dsndT = drcv + (long)N * EMB;
+    int gx = cdiv((long)N * N, 256);
+    if (gx > 4096) gx = 4096;
+    edge_dz_kernel<<<gx, 256, 0, st>>>(dtheta, dadj, theta, y0, B, N, 1.f / temperature, dz);
+    STEP_LAUNCH_CHECK("edge_dz");
+    edge_bwd_row_kernel<<<N, 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
+    STEP_LAUNCH_CHECK("edge_bwd_row");
+    edge_bwd_col_kernel<<<cdiv(N, 64), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
+    STEP_LAUNCH_CHECK("edge_bwd_col");
+    // dg = drcv @ W[:, 100:] + dsnd @ W[:, :100]
+    StepGemm g1 = gemm_desc(N, EMB, EMB, drcv, EMB, 1, p->fc_out_w + EMB, 2 * EMB, 1, dg, EMB);
+    STEP_TRY(step_gemm_launch(g1, st));
+    StepGemm g2 = gemm_desc(N, EMB, EMB, dsndT, 1, N, p->fc_out_w, 2 * EMB, 1, dg, EMB);
+    g2.accumulate = 1;
+    STEP_TRY(step_gemm_launch(g2, st));
+    // dW[:, 100:] += drcv^T @ g ;  dW[:, :100] += dsnd^T @ g ;  db += colsum(drcv)
+    StepGemm g3 = gemm_desc(EMB, EMB, N, drcv, 1, EMB, g, EMB, 1, grads->fc_out_w + EMB, 2 * EMB);
+    g3.accumulate = 1;
+    STEP_TRY(step_gemm_launch(g3, st));
+    StepGemm g4 = gemm_desc(EMB, EMB, N, dsndT, N, 1, g, EMB, 1, grads->fc_out_w, 2 * EMB);
+    g4.accumulate = 1;
+    STEP_TRY(step_gemm_launch(g4, st));
+    STEP_TRY(step_colsum_launch(drcv, N, EMB, EMB, grads->fc_out_b, st));
+    return STEP_OK;
+}

@@ -70,7 +70,13 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
             int kk, mm;
             if (a_kc) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
             int gm = m0 + mm, gk = k0 + kk;
-            ra[r] = (gm < g.M && gk < kend) ? ld_elem<TA>(Ab, (long)gm * g.sam + (long)gk * g.sak) : 0.f;
+            float v = 0.f;
+            if (gm < g.M && gk < kend) {
+                long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+                v = ld_elem<TA>(Ab, (long)gm * g.sam + ki * g.sak);
+                if (g.a_kscale) { int c = gk / g.a_kperiod; v = v * g.a_kscale[c] + g.a_kshift[c]; }
+            }
+            ra[r] = v;
         }
 #pragma unroll
         for (int r = 0; r < BE; ++r) {
@@ -78,7 +84,13 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
             int kk, nn;
             if (b_kc) { kk = e % BK; nn = e / BK; } else { nn = e % BN; kk = e / BN; }
             int gn = n0 + nn, gk = k0 + kk;
-            rb[r] = (gn < g.N && gk < kend) ? ld_elem<TB>(Bb, (long)gk * g.sbk + (long)gn * g.sbn) : 0.f;
+            float v = 0.f;
+            if (gn < g.N && gk < kend) {
+                long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+                long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+                v = ld_elem<TB>(Bb, ki * g.sbk + ni * g.sbn);
+            }
+            rb[r] = v;
         }
     };
     auto store_tiles = [&]() {
@@ -144,7 +156,8 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
                 int gm = m0 + wr * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (gm >= g.M) continue;
                 float v = g.alpha * acc[i][j][e];
-                float* dst = Cb + (long)gm * g.ldc + (long)gn * g.scn;
+                long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
+                float* dst = Cb + (long)gm * g.ldc + ni * g.scn;
                 if (g.accumulate == 2) {
                     atomicAdd(dst, v);
                 } else {

@@ -17,3 +17,5 @@ static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, 
     g.alpha = 1.f; g.splitk = 1;
     return g;
 }
+
+int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out, hipStream_t st);

@@ -1,0 +1,99 @@
+"""DiscreteGraphLearning with the reference's module surface (parameter holder + native calls).
+
+Mirrors ``step/step_arch/discrete_graph_learning.py:48-168``: same constructor keywords
+(``dataset_name, k, input_seq_len, output_seq_len``), same ``state_dict`` keys (``conv1, conv2,
+fc, bn1..3, fc_mean`` (unused by the reference forward), ``fc_cat, fc_out``), same side effect of
+reading ``datasets/<name>/data_in{in}_out{out}.pkl`` relative to the cwd (:57).
+
+Differences that are deliberate (SURVEY.md headline 5):
+  * the ``[N^2, N]`` one-hot gather matrices ``rel_rec``/``rel_send`` (:81-89) are never built;
+    the edge MLP is evaluated in its factorised form on device;
+  * sizes come from the data file instead of hard-coded per-dataset tables, so any dataset name
+    works (optional ``num_nodes`` / ``train_length`` / ``data`` keywords override, which is how the
+    4096-node stress config is built).  For the reference's dataset names the table values
+    (:55-56) are used so ``fc`` has the reference's shape.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+
+# discrete_graph_learning.py:56 (train_length per dataset); num_nodes comes from the data file
+_TRAIN_LENGTH = {"METR-LA": 23990, "PEMS04": 13599, "PEMS03": 15303, "PEMS07": 16513, "PEMS-BAY": 36482,
+                 "PEMS08": 14284}
+
+
+def _load_pkl(path):
+    with open(path, "rb") as f:
+        try:
+            return pickle.load(f)
+        except UnicodeDecodeError:
+            f.seek(0)
+            return pickle.load(f, encoding="latin1")
+
+
+class DiscreteGraphLearning(nn.Module):
+    def __init__(self, dataset_name, k, input_seq_len, output_seq_len, num_nodes=None, train_length=None, data=None,
+                 tsformer_tokens=None):
+        super().__init__()
+        self.k = k
+        if data is None:
+            path = "datasets/" + dataset_name + "/data_in{0}_out{1}.pkl".format(input_seq_len, output_seq_len)
+            data = _load_pkl(path)["processed_data"]
+        data = np.asarray(data)
+        if train_length is None:
+            train_length = _TRAIN_LENGTH.get(dataset_name, int(data.shape[0] * 0.8))
+        self.train_length = int(min(train_length, data.shape[0]))
+        self.num_nodes = int(num_nodes if num_nodes is not None else data.shape[1])
+        feats = torch.from_numpy(np.ascontiguousarray(data[:self.train_length, :self.num_nodes, 0])).float()
+        # node-major copy [N, T] (the reference transposes on every forward, :130)
+        self.register_buffer("_series_nt", feats.t().contiguous(), persistent=False)
+        self.dim_fc = 16 * (self.train_length - 18)
+        self.embedding_dim = 100
+        self.conv1 = nn.Conv1d(1, 8, 10, stride=1)
+        self.conv2 = nn.Conv1d(8, 16, 10, stride=1)
+        self.fc = nn.Linear(self.dim_fc, self.embedding_dim)
+        self.bn1 = nn.BatchNorm1d(8)
+        self.bn2 = nn.BatchNorm1d(16)
+        self.bn3 = nn.BatchNorm1d(self.embedding_dim)
+        # fc_mean is dead in the reference forward (:142 commented out) but part of its state_dict
+        tokens = tsformer_tokens if tsformer_tokens is not None else \
+            {"METR-LA": 168, "PEMS-BAY": 168, "PEMS03": 336, "PEMS04": 336, "PEMS07": 168, "PEMS08": 336}.get(dataset_name, 168)
+        self.dim_fc_mean = tokens * 96
+        self.fc_mean = nn.Linear(self.dim_fc_mean, 100)
+        self.fc_cat = nn.Linear(self.embedding_dim, 2)
+        self.fc_out = nn.Linear(self.embedding_dim * 2, self.embedding_dim)
+
+    @property
+    def node_feats(self):          # [T, N], the reference attribute (:57)
+        return self._series_nt.t()
+
+    def native_tensors(self):
+        return {"conv1_w": self.conv1.weight, "conv1_b": self.conv1.bias, "conv2_w": self.conv2.weight,
+                "conv2_b": self.conv2.bias, "fc_w": self.fc.weight, "fc_b": self.fc.bias,
+                "bn1_w": self.bn1.weight, "bn1_b": self.bn1.bias, "bn1_rm": self.bn1.running_mean, "bn1_rv": self.bn1.running_var,
+                "bn2_w": self.bn2.weight, "bn2_b": self.bn2.bias, "bn2_rm": self.bn2.running_mean, "bn2_rv": self.bn2.running_var,
+                "bn3_w": self.bn3.weight, "bn3_b": self.bn3.bias, "bn3_rm": self.bn3.running_mean, "bn3_rv": self.bn3.running_var,
+                "fc_out_w": self.fc_out.weight, "fc_out_b": self.fc_out.bias,
+                "fc_cat_w": self.fc_cat.weight, "fc_cat_b": self.fc_cat.bias}
+
+    def trainable_native(self):
+        return {k: v for k, v in self.native_tensors().items() if not (k.endswith("_rm") or k.endswith("_rv"))}
+
+    def forward(self, long_term_history, tsformer):
+        raise RuntimeError("step_amd.DiscreteGraphLearning is driven through step_amd.STEP (native forward+backward); "
+                           "it has no standalone PyTorch path")
+
+
+def fill_dgl_struct(tensors):
+    s = _lib.StepDglParams()
+    for k, v in tensors.items():
+        if v is None:
+            continue
+        assert v.is_cuda and v.is_contiguous() and v.dtype == torch.float32, k
+        setattr(s, k, v.data_ptr())
+    return s

@@ -1,0 +1,200 @@
+"""STEP with the reference's module surface; forward and backward run in libstep_hip.
+
+Mirrors ``step/step_arch/step.py:9-72``: ``STEP(dataset_name, pre_trained_tsformer_path,
+tsformer_args, backend_args, dgl_args)``, called by keyword from ``STEPRunner.forward``
+(``step_runner.py:66``) and returning ``(prediction [B,12,N,1], theta [B,N,N], adj_knn [B,N,N],
+gsl_coefficient)``.  ``prediction`` and ``theta`` are autograd-connected to the trainable
+parameters through one ``torch.autograd.Function`` whose forward/backward only launch HIP
+kernels through the C ABI (PyTorch supplies device memory, the stream and ``.grad`` plumbing).
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .tsformer import TSFormer
+from .graphwavenet import GraphWaveNet, fill_gwnet_struct
+from .discrete_graph_learning import DiscreteGraphLearning, fill_dgl_struct
+
+TEMPERATURE = 0.5        # discrete_graph_learning.py:157
+BN_MOMENTUM = 0.1
+
+
+def _f32(n, device):
+    return torch.empty(int(n), device=device, dtype=torch.float32)
+
+
+class _StepFunction(torch.autograd.Function):
+    """Inputs: (model, hist [B,12,N,C], long_hist [B,L,N,C], u or None, *trainable tensors)."""
+
+    @staticmethod
+    def forward(ctx, model, hist, long_hist, u, *params):
+        L = _lib
+        dev = hist.device
+        B, T12, N, Cin = hist.shape
+        Lh = long_hist.shape[1]
+        training = model.training
+        st = L.stream()
+        hist = hist.contiguous().float()
+        long_hist = long_hist.contiguous().float()
+        # ---- TSFormer (frozen): [B,L,N,C] -> hidden bf16 [B*N, P, 96]
+        series = _f32(B * N * Lh, dev).view(B * N, Lh)
+        L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
+        enc = model.tsformer.encode_series(series)
+        P = Lh // 12
+        # ---- kNN prior graph (no grad)
+        sim = _f32(B * N * N, dev).view(B, N, N)
+        adj_knn = _f32(B * N * N, dev).view(B, N, N)
+        dgl = model.discrete_graph_learning
+        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, dgl.k * N, L.ptr(sim),
+               L.ptr(adj_knn), None, 0, st)
+        # ---- DGL: global feature, edge logits, Gumbel sample
+        dt = dgl.native_tensors()
+        dstruct = fill_dgl_struct(dt)
+        Ttr = dgl.train_length
+        gsaved = _f32(L.lib().step_dgl_global_saved_floats(N, Ttr), dev)
+        gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 0), dev)
+        g = _f32(N * 100, dev).view(N, 100)
+        L.call("step_dgl_global_forward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
+               L.ptr(gsaved), L.ptr(gwork), L.ptr(g), st)
+        esaved = _f32(L.lib().step_dgl_edges_saved_floats(B, N), dev)
+        theta = _f32(B * N * N, dev).view(B, N, N)
+        adj = _f32(B * N * N, dev).view(B, N, N)
+        seed = model._next_seed()
+        L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
+               TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), st)
+        # ---- GraphWaveNet
+        be = model.backend
+        bstruct = fill_gwnet_struct(be.native_tensors())
+        drop = be.dropout if training else 0.0
+        wsaved = _f32(L.lib().step_gwnet_saved_floats(B, N, int(drop > 0)), dev)
+        wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 0), dev)
+        pred = _f32(B * 12 * N, dev).view(B, 12, N)
+        L.call("step_gwnet_forward", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), L.ptr(adj), ctypes.byref(bstruct),
+               int(training), float(drop), model._next_seed(), BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), st)
+        if training:
+            with torch.no_grad():
+                for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:7]):
+                    m.num_batches_tracked += 1
+        ctx.model = model
+        ctx.dims = (B, N, Cin, Ttr, float(drop))
+        ctx.held = (hist, enc["last"], g, gsaved, esaved, wsaved)
+        ctx.mark_non_differentiable(adj_knn)
+        model._last = {"sampled_adj": adj, "sim": sim, "hidden_bf16": enc["hidden_bf16"], "saved_gwnet": wsaved, "g": g}
+        return pred.unsqueeze(-1), theta, adj_knn
+
+    @staticmethod
+    def backward(ctx, dpred, dtheta, _dknn):
+        L = _lib
+        model = ctx.model
+        B, N, Cin, Ttr, drop = ctx.dims
+        hist, last, g, gsaved, esaved, wsaved = ctx.held
+        dev = hist.device
+        st = L.stream()
+        be, dgl = model.backend, model.discrete_graph_learning
+        layout = model._grad_layout()
+        flat = torch.zeros(layout["total"], device=dev, dtype=torch.float32)
+        views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
+        gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
+        dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
+        bstruct = fill_gwnet_struct(be.native_tensors())
+        dstruct = fill_dgl_struct(dgl.native_tensors())
+        dpred = dpred.contiguous().float().view(B, 12, N) if dpred is not None else torch.zeros(B, 12, N, device=dev)
+        dadj = _f32(B * N * N, dev)
+        wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
+        L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
+               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), st)
+        del wwork
+        ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
+        dgv = _f32(N * 100, dev)
+        dth = dtheta.contiguous().float() if dtheta is not None else None
+        L.call("step_dgl_edges_backward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(esaved), L.ptr(dth) if dth is not None else None,
+               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), st)
+        gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
+        L.call("step_dgl_global_backward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+               L.ptr(gwork), ctypes.byref(dg_grads), st)
+        model._reduce_flat_grads(flat)
+        ctx.held = None
+        return (None, None, None, None) + tuple(views[k] for k in layout["order"])
+
+
+class STEP(nn.Module):
+    """Pre-training Enhanced Spatial-temporal Graph Neural Network -- MI355X-native drop-in."""
+
+    def __init__(self, dataset_name, pre_trained_tsformer_path, tsformer_args, backend_args, dgl_args):
+        super().__init__()
+        self.dataset_name = dataset_name
+        self.pre_trained_tsformer_path = pre_trained_tsformer_path
+        self.tsformer = TSFormer(**tsformer_args)
+        self.backend = GraphWaveNet(**backend_args)
+        self.load_pre_trained_model()
+        self.discrete_graph_learning = DiscreteGraphLearning(**dgl_args)
+        self.gumbel_noise = "device"        # "torch_cpu": draw torch.rand on the host like the reference (:12)
+        self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
+        self._seed_ctr = 0
+        self._process_group = None
+        self._layout = None
+        self._last = {}
+
+    def load_pre_trained_model(self):
+        """step.py:27-35: load {"model_state_dict": ...} and freeze."""
+        if self.pre_trained_tsformer_path is not None:
+            ckpt = torch.load(self.pre_trained_tsformer_path, map_location="cpu")
+            self.tsformer.load_state_dict(ckpt["model_state_dict"])
+        for p in self.tsformer.parameters():
+            p.requires_grad = False
+
+    # ------------------------------------------------------------------ helpers
+    def _next_seed(self):
+        self._seed_ctr += 1
+        return (torch.initial_seed() * 2654435761 + self._seed_ctr * 40503) & ((1 << 63) - 1)
+
+    def _trainable(self):
+        items = [("be." + k, v) for k, v in self.backend.trainable_native().items()]
+        items += [("dgl." + k, v) for k, v in self.discrete_graph_learning.trainable_native().items()]
+        return items
+
+    def _grad_layout(self):
+        if self._layout is None:
+            off, items, order = 0, {}, []
+            for k, v in self._trainable():
+                n = v.numel()
+                items[k] = (off, n, tuple(v.shape))
+                order.append(k)
+                off += (n + 3) & ~3
+            self._layout = {"items": items, "order": order, "total": off}
+        return self._layout
+
+    def enable_native_data_parallel(self, process_group=None):
+        """Average the flat gradient buffer over ranks with ONE RCCL all-reduce per step inside backward
+        (replaces DDP's bucketed reducer; do not also wrap the module in DistributedDataParallel)."""
+        import torch.distributed as dist
+        self._process_group = process_group if process_group is not None else dist.group.WORLD
+
+    def _reduce_flat_grads(self, flat):
+        if self._process_group is not None:
+            import torch.distributed as dist
+            ws = dist.get_world_size(self._process_group)
+            if ws > 1:
+                dist.all_reduce(flat, group=self._process_group)
+                flat.mul_(1.0 / ws)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, history_data, long_history_data, future_data, batch_seen, epoch, **kwargs):
+        if not history_data.is_cuda:
+            raise RuntimeError("step_amd.STEP runs only on an AMD GPU: libstep_hip has no CPU fallback")
+        B, _, N, _ = history_data.shape
+        if self._noise_override is not None:
+            u = self._noise_override.to(history_data.device).float().contiguous()
+        elif self.gumbel_noise == "torch_cpu":
+            u = torch.rand(B, N * N, 2).to(history_data.device)
+        else:
+            u = None
+        params = [v for _, v in self._trainable()]
+        pred, theta, adj_knn = _StepFunction.apply(self, history_data, long_history_data, u, *params)
+        if epoch is not None:
+            gsl_coefficient = 1 / (int(epoch / 6) + 1)
+        else:
+            gsl_coefficient = 0
+        return pred, theta, adj_knn, gsl_coefficient

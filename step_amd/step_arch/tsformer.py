@@ -1,0 +1,148 @@
+"""TSFormer with the reference's module surface, computed by the fused HIP encoder.
+
+Mirrors ``step/step_arch/tsformer/tsformer.py:21-191`` of the reference: same constructor
+arguments, same ``forward`` keywords, and a ``state_dict`` whose keys and shapes are identical
+(``encoder.transformer_encoder.layers.{i}.self_attn.in_proj_weight`` ...), so reference
+checkpoints load unchanged.  The sub-modules below only *hold* parameters; arithmetic happens in
+``libstep_hip`` (``step_tsformer_encode``).  There is no PyTorch fallback: CPU tensors raise.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..tsformer_pack import pack_tsformer
+
+
+class _SelfAttnParams(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter holder with nn.TransformerEncoderLayer's names."""
+
+    def __init__(self, d, ffn):
+        super().__init__()
+        self.self_attn = _SelfAttnParams(d)
+        self.linear1 = nn.Linear(d, ffn)
+        self.linear2 = nn.Linear(ffn, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class _EncoderStack(nn.Module):
+    def __init__(self, d, ffn, depth):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayerParams(d, ffn) for _ in range(depth)])
+
+
+class TransformerLayers(nn.Module):
+    """Holder named like the reference's TransformerLayers (transformer_layers.py:6-11)."""
+
+    def __init__(self, hidden_dim, nlayers, mlp_ratio, num_heads=4, dropout=0.1):
+        super().__init__()
+        self.d_model = hidden_dim
+        self.transformer_encoder = _EncoderStack(hidden_dim, hidden_dim * mlp_ratio, nlayers)
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, patch_size, in_channel, embed_dim):
+        super().__init__()
+        self.len_patch = patch_size
+        self.input_embedding = nn.Conv2d(in_channel, embed_dim, kernel_size=(patch_size, 1), stride=(patch_size, 1))
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, hidden_dim, dropout=0.1, max_len=1000):
+        super().__init__()
+        self.p = dropout
+        self.position_embedding = nn.Parameter(torch.empty(max_len, hidden_dim))
+
+
+class TSFormer(nn.Module):
+    """Drop-in for the reference TSFormer (forecasting mode on device)."""
+
+    def __init__(self, patch_size, in_channel, embed_dim, num_heads, mlp_ratio, dropout, num_token, mask_ratio,
+                 encoder_depth, decoder_depth, mode="pre-train"):
+        super().__init__()
+        assert mode in ["pre-train", "forecasting"], "Error mode."
+        if (patch_size, in_channel, embed_dim, num_heads, mlp_ratio) != (12, 1, 96, 4, 4):
+            raise NotImplementedError("the HIP encoder is specialised to patch 12, 1 channel, d=96, 4 heads, mlp x4 "
+                                      "(every STEP/TSFormer config of the reference)")
+        self.patch_size, self.in_channel, self.embed_dim, self.num_heads = patch_size, in_channel, embed_dim, num_heads
+        self.num_token, self.mask_ratio, self.encoder_depth, self.mode, self.mlp_ratio = \
+            num_token, mask_ratio, encoder_depth, mode, mlp_ratio
+        self.dropout_p = float(dropout)
+        self.selected_feature = 0
+        self.encoder_norm = nn.LayerNorm(embed_dim)
+        self.decoder_norm = nn.LayerNorm(embed_dim)
+        self.patch_embedding = PatchEmbedding(patch_size, in_channel, embed_dim)
+        self.positional_encoding = PositionalEncoding(embed_dim, dropout=dropout)
+        self.encoder = TransformerLayers(embed_dim, encoder_depth, mlp_ratio, num_heads, dropout)
+        self.enc_2_dec_emb = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, embed_dim))
+        self.decoder = TransformerLayers(embed_dim, decoder_depth, mlp_ratio, num_heads, dropout)
+        self.output_layer = nn.Linear(embed_dim, patch_size)
+        nn.init.uniform_(self.positional_encoding.position_embedding, -.02, .02)
+        nn.init.trunc_normal_(self.mask_token, std=.02)
+        self._packed = None
+        self._packed_key = None
+        self._seed_counter = 0
+
+    # ------------------------------------------------------------------ packed operand cache
+    def _pack_key(self, P):
+        return (P, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+
+    def packed_weights(self, P, device):
+        key = self._pack_key(P)
+        if self._packed is None or self._packed_key != key or self._packed.device != device:
+            sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+            self._packed = pack_tsformer(sd, P, depth=self.encoder_depth).to(device)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ device entry points
+    def encode_series(self, series, want_f32=False, want_bf16=True):
+        """series: f32 cuda [S, L] (one row per (sample, node)).  Returns dict with hidden_bf16 [S,P,96],
+        optional hidden_f32, last [S,96] and sqnorm [S,16] (per-wave partial squared norms)."""
+        if not series.is_cuda:
+            raise RuntimeError("step_amd.TSFormer runs only on an AMD GPU (no CPU fallback)")
+        S, L = series.shape
+        if L % self.patch_size != 0:
+            raise AssertionError("long history length must be a multiple of the patch size")   # patch.py:41
+        P = L // self.patch_size
+        pk = self.packed_weights(P, series.device)
+        out = {"hidden_bf16": torch.empty(S, P, 96, device=series.device, dtype=torch.bfloat16) if want_bf16 else None,
+               "hidden_f32": torch.empty(S, P, 96, device=series.device) if want_f32 else None,
+               "last": torch.empty(S, 96, device=series.device),
+               "sqnorm": torch.empty(S, 16, device=series.device)}
+        drop = self.dropout_p if self.training else 0.0
+        self._seed_counter += 1
+        seed = (torch.initial_seed() * 1000003 + self._seed_counter) & ((1 << 63) - 1) if drop > 0 else 0
+        _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
+                  _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
+                  _lib.ptr(out["sqnorm"]), float(drop), int(seed), _lib.stream())
+        return out
+
+    def forward(self, history_data, future_data=None, batch_seen=None, epoch=None, **kwargs):
+        """history_data [B, L*P, N, C] -> hidden [B, N, P, 96] (forecasting mode, tsformer.py:189-191)."""
+        if self.mode == "pre-train":
+            raise NotImplementedError("TSFormer pre-training (masked reconstruction, forward+backward) is not part of "
+                                      "this round's native path; see DESIGN.md 'next'")
+        if not history_data.is_cuda:
+            raise RuntimeError("step_amd.TSFormer runs only on an AMD GPU (no CPU fallback)")
+        B, L, N, Cc = history_data.shape
+        x = history_data.contiguous().float()
+        series = torch.empty(B * N, L, device=x.device)
+        _lib.call("step_pack_long_history", _lib.ptr(x), B, L, N, Cc, self.selected_feature, _lib.ptr(series), _lib.stream())
+        out = self.encode_series(series, want_f32=True, want_bf16=False)
+        return out["hidden_f32"].view(B, N, L // self.patch_size, 96)

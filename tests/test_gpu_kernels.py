@@ -179,3 +179,33 @@ def test_knn_graph(L, Bn, N, F, k):
     eye = torch.eye(N).reshape(1, -1).bool()
     assert bool(((flat > kth_d[:, None]) & ~eye <= (a2 > 0)).all())
     assert bool((((flat < kth_d[:, None]) | eye) <= (a2 == 0)).all())
+
+
+def test_gemm_slot_remap_and_kscale(L):
+    """Index remaps used by the GraphWaveNet gcn buffer and the per-channel affine used by the DGL fc."""
+    g = torch.Generator().manual_seed(9)
+    Nn, T, S = 21, 5, 7                       # nodes, time, slots of 32 channels
+    cat = torch.randn(Nn, T, S * 32, generator=g)
+    P = torch.rand(Nn, Nn, generator=g)
+    catd, Pd = cat.cuda(), P.cuda()
+    # out[w][t][slot 3] = sum_v P[v][w] * cat[v][t][slot 1]     (nconv, model.py:13-15)
+    L.gemm(Pd, catd, catd, Nn, T * 32, Nn, 1, Nn, T * S * 32, 1, T * S * 32, b_off=32, c_off=96,
+           b_n=(32, S * 32), c_n=(32, S * 32))
+    want = torch.einsum("vw,vtc->wtc", P.double(), cat[:, :, 32:64].double())
+    got = catd.cpu()
+    assert rel_l2(got[:, :, 96:128], want) < 1e-5
+    assert torch.equal(got[:, :, :96], cat[:, :, :96]) and torch.equal(got[:, :, 128:], cat[:, :, 128:])
+    # dP[v][w] = sum_{t,c} cat[v][t][slot 1] * cat[w][t][slot 2]   (k-remap on both operands)
+    dP = torch.empty(Nn, Nn, device="cuda")
+    L.gemm(catd, catd, dP, Nn, Nn, T * 32, T * S * 32, 1, 1, T * S * 32, Nn, a_off=32, b_off=64,
+           a_k=(32, S * 32), b_k=(32, S * 32))
+    want = torch.einsum("vtc,wtc->vw", cat[:, :, 32:64].double(), cat[:, :, 64:96].double())
+    assert rel_l2(dP.cpu(), want) < 1e-5
+    # per-channel affine along k
+    A = torch.randn(19, 6 * 50, generator=g)
+    B = torch.randn(6 * 50, 10, generator=g)
+    sc, sh = torch.randn(6, generator=g), torch.randn(6, generator=g)
+    C = torch.empty(19, 10, device="cuda")
+    L.gemm(A.cuda(), B.cuda(), C, 19, 10, 300, 300, 1, 10, 1, 10, a_kscale=sc.cuda(), a_kshift=sh.cuda(), a_kperiod=50)
+    An = A.double().reshape(19, 6, 50) * sc.double()[None, :, None] + sh.double()[None, :, None]
+    assert rel_l2(C.cpu(), An.reshape(19, 300) @ B.double()) < 1e-5
