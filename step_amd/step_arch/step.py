@@ -81,7 +81,8 @@ class _StepFunction(torch.autograd.Function):
         ctx.dims = (B, N, Cin, Ttr, float(drop))
         ctx.held = (hist, enc["last"], g, gsaved, esaved, wsaved)
         ctx.mark_non_differentiable(adj_knn)
-        model._last = {"sampled_adj": adj, "sim": sim, "hidden_bf16": enc["hidden_bf16"], "saved_gwnet": wsaved, "g": g}
+        model._last = {"sampled_adj": adj, "sim": sim, "hidden_bf16": enc["hidden_bf16"], "saved_gwnet": wsaved, "g": g,
+                       "hidden_last": enc["last"]}
         return pred.unsqueeze(-1), theta, adj_knn
 
     @staticmethod
