@@ -1,0 +1,191 @@
+"""bench.py -- STEP training windows/s on MI355X (BASELINE.json metric, config C2 = STEP_PEMS04).
+
+One "step" = one full training step of the native STEP model on one synthetic minibatch that is already
+resident in HBM: TSFormer encoder forward (frozen) + kNN prior + DiscreteGraphLearning forward/backward +
+GraphWaveNet forward/backward + step_loss + gradient all-reduce (N>1) + clip_grad_norm_(3.0) + Adam.
+Prints ONE JSON line (rank 0).  Launch:  python bench.py [--gpus N --steps K --warmup W]
+(for N>1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (nodes, long-history length L, train_length, total series length, batch per GPU)
+    "STEP_PEMS04": dict(N=307, L=288 * 7 * 2, T_train=13599, T_all=16992, B=8, k=10),
+    "STEP_PEMS07": dict(N=883, L=288 * 7, T_train=16513, T_all=28224, B=4, k=10),
+    "STEP_METR-LA": dict(N=207, L=288 * 7, T_train=23990, T_all=34272, B=2, k=10),
+}
+
+
+def synth_series(T, N, seed=0):
+    """ch0 z-scored signal sin(2 pi t/288 + phi_n) + 0.5 N(0,1); ch1 time of day; ch2 day of week."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float32)[:, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, N)).astype(np.float32)
+    ch0 = np.sin(2 * np.pi * t / 288.0 + phase) + 0.5 * rng.standard_normal((T, N), dtype=np.float32)
+    ch1 = np.broadcast_to((t % 288) / 288.0, (T, N))
+    ch2 = np.broadcast_to((t // 288) % 7, (T, N))
+    return np.stack([ch0, ch1, ch2], -1).astype(np.float32)
+
+
+def make_model(cfg, data):
+    from step_amd import STEP
+    N, L = cfg["N"], cfg["L"]
+    targs = dict(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=L / 12,
+                 mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode="forecasting")
+    bargs = dict(num_nodes=N, support_len=2, dropout=0.3, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=2, out_dim=12,
+                 residual_channels=32, dilation_channels=32, skip_channels=256, end_channels=512, kernel_size=2, blocks=4, layers=2)
+    dargs = dict(dataset_name="SYNTH", k=cfg["k"], input_seq_len=12, output_seq_len=12, data=data, train_length=cfg["T_train"],
+                 tsformer_tokens=L // 12)
+    torch.manual_seed(0)
+    return STEP("SYNTH", None, targs, bargs, dargs)
+
+
+def encoder_flops(cfg, B):
+    """Algorithmic FLOPs of one encoder launch (SURVEY.md 8d, row T4 + T1): per window
+    N*P*(4*(221184 + 384*P) + 2304)."""
+    P = cfg["L"] // 12
+    return B * cfg["N"] * P * (4 * (221184 + 384 * P) + 2304)
+
+
+def cpu_baseline(cfg, data, seed=0):
+    """The CPU oracle (restatement of the reference algorithm, kind "port") timed on this host's cores on ONE
+    training window of the same workload (forward + step_loss + backward)."""
+    from oracle import step_oracle as O
+    from tests.helpers import rel_l2  # noqa: F401
+    torch.manual_seed(seed)
+    N, L, Ttr = cfg["N"], cfg["L"], cfg["T_train"]
+    model = make_model(cfg, data)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in p.items():
+        if v.is_floating_point() and not k.startswith("tsformer.") and "running_" not in k:
+            v.requires_grad_(True)
+    d = torch.from_numpy(data)
+    t = L + 17
+    hist, fut, longh = d[t - 12:t][None], d[t:t + 12][None], d[t - L:t][None]
+    u = torch.rand(1, N * N, 2)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    pred, theta, knn, coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, cfg["k"], 1, training=True)
+    loss = O.step_loss(O.rescale(pred, 200.0, 150.0), O.rescale(fut[..., [0]], 200.0, 150.0), theta, knn, coef)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"1 window (B=1) of the same workload, fwd+loss+bwd, {dt:.1f} s, torch CPU fp32 oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="STEP_PEMS04", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from step_amd.step_loss import step_loss
+    import step_amd._lib as L
+    L.lib()
+
+    N, Lh, B = cfg["N"], cfg["L"], cfg["B"]
+    data = synth_series(cfg["T_all"], N)
+    model = make_model(cfg, data).to(dev)
+    model.train()
+    if args.eval_dropout_off:
+        model.backend.dropout = 0.0
+        model.tsformer.dropout_p = 0.0
+    if world > 1:
+        model.enable_native_data_parallel()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)        # step/STEP_PEMS04.py:90-96
+    dser = torch.from_numpy(data).to(dev)
+    rng = np.random.default_rng(1234 + rank)
+    nb = args.steps + args.warmup
+    batches = []
+    for _ in range(min(nb, 8)):                       # resident input batches, cycled (119 MB each at C2)
+        ts = rng.integers(Lh, cfg["T_all"] - 12, size=B)
+        hist = torch.stack([dser[t - 12:t] for t in ts])
+        fut = torch.stack([dser[t:t + 12] for t in ts])
+        longh = torch.stack([dser[t - Lh:t] for t in ts])
+        batches.append((hist, longh, fut))
+    mean, std = 200.0, 150.0
+
+    def step(i, epoch=1):
+        hist, longh, fut = batches[i % len(batches)]
+        opt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
+        loss = step_loss(pred[..., [0]] * std + mean, fut[..., [0]] * std + mean, theta, knn, coef, null_val=0.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)                        # STEP_PEMS04.py:103-105
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    model.tsformer._events = []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt)
+    ev = model.tsformer._events
+    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    model.tsformer._events = None
+    if rank == 0:
+        flops = encoder_flops(cfg, B)
+        ach = flops / (enc_ms * 1e-3) / 1e12
+        out = {
+            "metric": "training windows/sec on PEMS04, horizon-12 MAE parity, 1/2/4/8 MI355X",
+            "value": B * world * args.steps / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: N={N} nodes, long history L={Lh} (P={Lh // 12} patches), 12->12, "
+                                   f"train series T={cfg['T_train']}, batch {B}/GPU, random-init weights, "
+                                   "full train step (fwd+bwd+clip+Adam)", "global_batch": B * world,
+                       "parallelism": f"dp{world}", "final_loss": float(loss)},
+            "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,
+                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "ms_per_launch": enc_ms,
+                         "algorithmic_flop_per_launch": flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, data)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

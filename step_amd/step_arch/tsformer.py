@@ -97,6 +97,7 @@ class TSFormer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._seed_counter = 0
+        self._events = None          # bench.py: list collecting (start, end) events around the encoder launch
 
     # ------------------------------------------------------------------ packed operand cache
     def _pack_key(self, P):
@@ -128,9 +129,15 @@ class TSFormer(nn.Module):
         drop = self.dropout_p if self.training else 0.0
         self._seed_counter += 1
         seed = (torch.initial_seed() * 1000003 + self._seed_counter) & ((1 << 63) - 1) if drop > 0 else 0
+        if self._events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
                   _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
                   _lib.ptr(out["sqnorm"]), float(drop), int(seed), _lib.stream())
+        if self._events is not None:
+            ev[1].record()
+            self._events.append(ev)
         return out
 
     def forward(self, history_data, future_data=None, batch_seen=None, epoch=None, **kwargs):
