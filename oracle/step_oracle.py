@@ -135,10 +135,9 @@ def tsformer_pretrain(hist, p, unmasked, masked, pre="tsformer.", enc_depth=4, d
 
 # ----------------------------------------------------------------------------- DGL
 def conv1d_valid(x, w, b):
-    """Plain 'valid' cross-correlation, x[N, Ci, T], w[Co, Ci, K] -> [N, Co, T-K+1]."""
-    K = w.shape[-1]
-    cols = x.unfold(2, K, 1)                       # [N, Ci, T-K+1, K]
-    return torch.einsum("nitk,oik->not", cols, w) + b.view(1, -1, 1)
+    """Plain 'valid' cross-correlation, x[N, Ci, T], w[Co, Ci, K] -> [N, Co, T-K+1]
+    (what torch.nn.Conv1d(stride=1, padding=0) computes, discrete_graph_learning.py:63-64)."""
+    return torch.nn.functional.conv1d(x, w, b)
 
 
 def dgl_global_feature(node_feats, p, pre="discrete_graph_learning.", training=True, stats=None):

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_relu_fwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < TPT; ++j) acc[co][j] = b[co];
     if (t0 < Tout) {
-#pragma unroll
+#pragma unroll 1
         for (int ci = 0; ci < CI; ++ci) {
             const float* src = in + ((long)n * CI + ci) * Tin + t0;
             const float sc = in_sc ? in_sc[ci] : 1.f, sh = in_sh ? in_sh[ci] : 0.f;
@@ -333,58 +333,72 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(const float* __restr
 
 // conv backward w.r.t. weight and bias, one block per node:
 //   dw[co][ci][k] += sum_t dz[n][co][t] * (in[n][ci][t+k] * sc[ci] + sh[ci]);  db[co] += sum_t dz[n][co][t]
+// Each thread owns one (co, ci) pair and a slice of the time chunk; the 10-tap input window slides
+// through registers, so one LDS read of dz and one of the input feed 10 FMAs.
 template <int CI, int CO>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __restrict__ dz, const float* __restrict__ in,
                                                               const float* __restrict__ in_sc, const float* __restrict__ in_sh,
                                                               float* __restrict__ dw, float* __restrict__ db, int Tin) {
-    constexpr int CH = 512;
-    constexpr int NOUT = CO * CI * KW;
-    constexpr int PER = (NOUT + 255) / 256;
-    __shared__ float sdz[CO][CH];
+    constexpr int CH = 640;
+    constexpr int NP = CO * CI;                 // pairs
+    constexpr int SPL = 256 / NP;               // time slices per pair
+    constexpr int SL = CH / SPL;                // slice length (multiple of 10)
+    static_assert(256 % NP == 0 && CH % SPL == 0 && SL % 10 == 0, "tiling");
+    __shared__ float sdz[CO][CH + 1];
     __shared__ float sin_[CI][CH + KW];
     const int tid = threadIdx.x, n = blockIdx.x;
     const int Tout = Tin - (KW - 1);
-    float acc[PER], accb = 0.f;
+    const int pr = tid % NP, sl = tid / NP;
+    const int co = pr / CI, ci = pr % CI;
+    float acc[KW], accb = 0.f;
 #pragma unroll
-    for (int p = 0; p < PER; ++p) acc[p] = 0.f;
+    for (int k = 0; k < KW; ++k) acc[k] = 0.f;
     for (int t0 = 0; t0 < Tout; t0 += CH) {
         __syncthreads();
         for (int e = tid; e < CO * CH; e += 256) {
-            int co = e / CH, t = e % CH;
-            sdz[co][t] = (t0 + t < Tout) ? dz[((long)n * CO + co) * Tout + t0 + t] : 0.f;
+            int c2 = e / CH, t = e % CH;
+            sdz[c2][t] = (t0 + t < Tout) ? dz[((long)n * CO + c2) * Tout + t0 + t] : 0.f;
         }
         for (int e = tid; e < CI * (CH + KW - 1); e += 256) {
-            int ci = e / (CH + KW - 1), t = e % (CH + KW - 1);
+            int c2 = e / (CH + KW - 1), t = e % (CH + KW - 1);
             float v = 0.f;
             if (t0 + t < Tin) {
-                v = in[((long)n * CI + ci) * Tin + t0 + t];
-                if (in_sc) v = v * in_sc[ci] + in_sh[ci];
+                v = in[((long)n * CI + c2) * Tin + t0 + t];
+                if (in_sc) v = v * in_sc[c2] + in_sh[c2];
             }
-            sin_[ci][t] = v;
+            sin_[c2][t] = v;
         }
         __syncthreads();
+        const float* zr = &sdz[co][sl * SL];
+        const float* xr = &sin_[ci][sl * SL];
+        float w[KW];                               // w[q] = x[t + q]
 #pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            int o = tid + p * 256;
-            if (o < NOUT) {
-                int k = o % KW, ci = (o / KW) % CI, co = o / (KW * CI);
-                float s = 0.f;
-                for (int t = 0; t < CH; ++t) s += sdz[co][t] * sin_[ci][t + k];
-                acc[p] += s;
+        for (int q = 0; q < KW - 1; ++q) w[q] = xr[q];
+        for (int tb = 0; tb < SL; tb += KW) {
+#pragma unroll
+            for (int u = 0; u < KW; ++u) {         // fully unrolled so the rotating window has static indices
+                w[(u + KW - 1) % KW] = xr[tb + u + KW - 1];
+                const float d = zr[tb + u];
+                if (ci == 0) accb += d;
+#pragma unroll
+                for (int k = 0; k < KW; ++k) acc[k] += d * w[(u + k) % KW];
             }
         }
-        if (tid < CO) {
-            float s = 0.f;
-            for (int t = 0; t < CH; ++t) s += sdz[tid][t];
-            accb += s;
-        }
     }
+    // combine the time slices inside the block (reusing sdz), then one atomic per output per block
+    __syncthreads();
+    float* red = &sdz[0][0];                     // [SPL][NP][KW + 1]
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-        int o = tid + p * 256;
-        if (o < NOUT) atomicAdd(&dw[o], acc[p]);      // dw is [co][ci][k] == flat index o
+    for (int k = 0; k < KW; ++k) red[(sl * NP + pr) * (KW + 1) + k] = acc[k];
+    red[(sl * NP + pr) * (KW + 1) + KW] = accb;
+    __syncthreads();
+    for (int o = tid; o < NP * (KW + 1); o += 256) {
+        const int p2 = o / (KW + 1), k = o % (KW + 1);
+        float s = 0.f;
+        for (int q = 0; q < SPL; ++q) s += red[(q * NP + p2) * (KW + 1) + k];
+        if (k < KW) atomicAdd(&dw[p2 * KW + k], s);
+        else if (p2 % CI == 0) atomicAdd(&db[p2 / CI], s);
     }
-    if (tid < CO) atomicAdd(&db[tid], accb);
 }
 
 // ------------------------------------------------------------------------------------------ edges
@@ -496,22 +510,21 @@ __global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restri
 __global__ __launch_bounds__(256) void edge_bwd_col_kernel(const float* __restrict__ dz, const float* __restrict__ sndT,
                                                            const float* __restrict__ rcv, const float* __restrict__ wcat, int N,
                                                            float* __restrict__ dsndT) {
-    // block: 64 columns j (lanes) x 4 waves splitting the features
-    __shared__ float sw[EMB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < EMB) sw[tid] = wcat[tid] - wcat[EMB + tid];
-    __syncthreads();
+    // block: 64 sender columns j (lanes) x 4 features (one per wave); grid (N/64, EMB/4)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
-    if (j >= N) return;
-    for (int f = wave; f < EMB; f += 4) {
-        const float s = sndT[(long)f * N + j];
-        float a = 0.f;
-        for (int i = 0; i < N; ++i) {
-            float hid = rcv[(long)i * EMB + f] + s;
-            if (hid > 0.f) a += dz[(long)i * N + j];
-        }
-        dsndT[(long)f * N + j] = a * sw[f];
+    const int f = blockIdx.y * 4 + wave;
+    if (j >= N || f >= EMB) return;
+    const float s = sndT[(long)f * N + j];
+    const float wd = wcat[f] - wcat[EMB + f];
+    float a = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < N; ++i) {
+        float hid = rcv[(long)i * EMB + f] + s;
+        float d = dz[(long)i * N + j];
+        a += hid > 0.f ? d : 0.f;
     }
+    dsndT[(long)f * N + j] = a * wd;
 }
 
 __global__ void colsum_kernel(const float* __restrict__ x, long rows, int cols, long ld, float* __restrict__ out) {
@@ -590,8 +603,7 @@ extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, con
     StepGemm gm = gemm_desc(N, EMB, (int)K, a2, K, 1, p->fc_w, 1, K, gpre, EMB);
     gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
     gm.accumulate = 2;
-    gm.splitk = 256 / (cdiv(N, 64) * 2) + 1;
-    if (gm.splitk > cdiv(K, 16) / 8) gm.splitk = cdiv(K, 16) / 8 > 0 ? cdiv(K, 16) / 8 : 1;
+    gm.splitk = -1;
     STEP_TRY(step_gemm_launch(gm, st));
     fc_post_bn3_kernel<<<EMB, 256, 0, st>>>(gpre, p->fc_b, N, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, training, momentum, st3, g);
     STEP_LAUNCH_CHECK("fc_post_bn3");
@@ -714,7 +726,7 @@ extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepD
     STEP_LAUNCH_CHECK("edge_dz");
     edge_bwd_row_kernel<<<N, 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
     STEP_LAUNCH_CHECK("edge_bwd_row");
-    edge_bwd_col_kernel<<<cdiv(N, 64), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
+    edge_bwd_col_kernel<<<dim3(cdiv(N, 64), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
     STEP_LAUNCH_CHECK("edge_bwd_col");
     // dg = drcv @ W[:, 100:] + dsnd @ W[:, :100]
     StepGemm g1 = gemm_desc(N, EMB, EMB, drcv, EMB, 1, p->fc_out_w + EMB, 2 * EMB, 1, dg, EMB);

@@ -190,8 +190,17 @@ int launch(const StepGemm& g, hipStream_t st) {
 int step_gemm_launch(StepGemm g, hipStream_t st) {
     STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && g.batch > 0, "step_gemm: bad sizes M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
     STEP_REQUIRE(g.A && g.B && g.C, "step_gemm: null operand");
-    if (g.splitk < 1) g.splitk = 1;
     if (g.scn == 0) g.scn = 1;
+    if (g.splitk < 0) {            // auto: enough workgroups to fill 256 CUs, at least 4 k-steps each
+        STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
+        const int bm = (g.N <= 32 && g.M > 64) ? 128 : (g.M <= 32 && g.N > 64) ? 32 : (g.M <= 64 || g.N <= 64) ? 64 : 128;
+        const int bn = (g.N <= 32 && g.M > 64) ? 32 : (g.M <= 32 && g.N > 64) ? 128 : (g.M <= 64 || g.N <= 64) ? 64 : 128;
+        long tiles = (long)cdiv(g.M, bm) * cdiv(g.N, bn) * g.batch;
+        long want = (768 + tiles - 1) / tiles;
+        long maxs = cdiv(g.K, 16) / 4;
+        g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
+    }
+    if (g.splitk < 1) g.splitk = 1;
     if (g.splitk > 1) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2 (atomic) and a pre-zeroed/accumulating C");
     }

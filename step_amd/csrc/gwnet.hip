@@ -264,14 +264,21 @@ __global__ __launch_bounds__(256) void mix_post_kernel(const float* __restrict__
     }
 }
 // channel-last BN statistics -> stat [4][32] = scale, shift, mean, rstd (+ running stats)
-__global__ void bn_cl_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, int training,
-                                      float momentum, float* __restrict__ stat) {
-    const int c = threadIdx.x;      // 32 threads
+__global__ __launch_bounds__(256) void bn_cl_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ rm, float* __restrict__ rv, int training,
+                                                             float momentum, float* __restrict__ stat) {
+    __shared__ double ra[8][32], rq[8][32];
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;      // 256 threads: 8 partial sums per channel
+    double a = 0.0, q = 0.0;
+    if (training)
+        for (int i = part; i < nblk; i += 8) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+    ra[part][c] = a; rq[part][c] = q;
+    __syncthreads();
+    if (part != 0) return;
     double mean, var;
     if (training) {
-        double a = 0.0, q = 0.0;
-        for (int i = 0; i < nblk; ++i) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+        for (int r = 1; r < 8; ++r) { a += ra[r][c]; q += rq[r][c]; }
         mean = a / count;
         var = fmax(q / count - mean * mean, 0.0);
         rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
@@ -308,12 +315,18 @@ __global__ __launch_bounds__(256) void bn_cl_bwd_reduce_kernel(const float* __re
         partial[(long)blockIdx.x * 64 + threadIdx.x] = a;
     }
 }
-__global__ void bn_cl_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
-                                          const float* __restrict__ stat, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                          float* __restrict__ coef) {
-    const int c = threadIdx.x;
+__global__ __launch_bounds__(256) void bn_cl_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ stat,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ coef) {
+    __shared__ double ra[8][32], rq[8][32];
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
     double a = 0.0, q = 0.0;
-    for (int i = 0; i < nblk; ++i) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+    for (int i = part; i < nblk; i += 8) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+    ra[part][c] = a; rq[part][c] = q;
+    __syncthreads();
+    if (part != 0) return;
+    for (int r = 1; r < 8; ++r) { a += ra[r][c]; q += rq[r][c]; }
     dgamma[c] += (float)q; dbeta[c] += (float)a;
     coef[c] = (float)(a / count); coef[32 + c] = (float)(q / count); coef[64 + c] = gamma[c] * stat[96 + c];
 }
@@ -415,7 +428,7 @@ struct Work {
     float *d_e1, *d_xh, *d_h2, *d_h1;
     long total;
 };
-constexpr int BN_BLOCKS = 1024;
+constexpr int BN_BLOCKS = 512;
 Work carve_work(float* base, int B, int N, bool backward) {
     Carver cv(base);
     Work w;
@@ -563,7 +576,7 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         mix_post_kernel<<<nblk, 256, 0, st>>>(W.h, S.x_in[i], BN, Tin, Tout, dil, use_drop ? dropout_p : 0.f, (uint32_t)seed,
                                               (uint32_t)(seed >> 32), (uint32_t)i, S.mask[i], S.y[i], W.partial);
         STEP_LAUNCH_CHECK("mix_post");
-        bn_cl_finalize_kernel<<<1, 32, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], training,
+        bn_cl_finalize_kernel<<<1, 256, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], training,
                                                 momentum, S.bnstat[i]);
         bn_cl_apply_kernel<<<g1(npos * C), 256, 0, st>>>(S.y[i], npos * C, S.bnstat[i], S.x_in[i + 1]);
         STEP_LAUNCH_CHECK("bn_apply");
@@ -603,7 +616,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     Saved S = carve_saved((float*)saved, B, N, dropout != 0);
     Work W = carve_work(work, B, N, true);
     const long BN = (long)B * N;
-    auto split_for = [](long K) { int s = (int)(K / 1024); return s < 1 ? 1 : (s > 64 ? 64 : s); };
+    auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
     for (int i = 0; i < NL; ++i)
         pack_gate_kernel<<<16, 256, 0, st>>>(p->filter_w[i], p->filter_b[i], p->gate_w[i], p->gate_b[i], W.wcat + i * 4096, W.bcat + i * 64);
@@ -665,7 +678,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             int nblk = (int)((npos + 7) / 8);
             if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
             bn_cl_bwd_reduce_kernel<<<nblk, 256, 0, st>>>(dx_next, S.y[i], npos, S.bnstat[i], W.partial);
-            bn_cl_bwd_finalize_kernel<<<1, 32, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], W.coef);
+            bn_cl_bwd_finalize_kernel<<<1, 256, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], W.coef);
             bn_cl_bwd_apply_kernel<<<g1(npos * C), 256, 0, st>>>(dx_next, S.y[i], npos * C, S.bnstat[i], W.coef, S.mask[i], W.dres, W.dh);
             STEP_LAUNCH_CHECK("bn_bwd");
             // mix (gconv.i.mlp) gradients
