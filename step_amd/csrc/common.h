@@ -53,14 +53,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
-// 8 consecutive f32 -> one MFMA bf16 operand (4 VGPRs)
+// 8 consecutive f32 -> one MFMA bf16 operand (4 VGPRs); lowers to 4 x v_cvt_pk_bf16_f32 (RNE)
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
-    u32x4 r;
-    r[0] = pack_bf16x2(v[0], v[1]);
-    r[1] = pack_bf16x2(v[2], v[3]);
-    r[2] = pack_bf16x2(v[4], v[5]);
-    r[3] = pack_bf16x2(v[6], v[7]);
-    return __builtin_bit_cast(bf16x8, r);
+    f32x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[j];
+    return __builtin_convertvector(t, bf16x8);
 }
 
 // ---- wave64 helpers --------------------------------------------------------------------

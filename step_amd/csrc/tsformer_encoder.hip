@@ -5,8 +5,9 @@
 // registers for the whole kernel: activations are kept TRANSPOSED ([feature][token], token =
 // lane & 31), weights are the MFMA A operand, and thanks to the k-slot map in
 // tsformer_layout.h every accumulator tile becomes the next MFMA's B operand by a plain
-// f32->bf16 pack.  The only inter-wave traffic is the per-head K and V operand fragments
-// (2 KB per key tile each), exchanged through double-buffered LDS with one barrier per head.
+// f32->bf16 pack.  Inter-wave traffic: the per-head K and V operand fragments (2 KB per key tile
+// each) through LDS, and the weights, which every workgroup streams ONCE from L2 into a 2-slot
+// LDS ring (global_load_lds DMA, 25 KB stage blocks, prefetched one stage ahead) shared by all waves.
 //
 //   patch embed + pos-emb (f32 VALU)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> S^T = K Q^T
 //   -> exact two-pass softmax (exp2, scale folded into Wq) -> O^T = V^T P^T (row 24 of V is
@@ -49,21 +50,24 @@ __device__ __forceinline__ bf16x8 pack_half(const f32x16& v, int s) {
     return pack8(t);
 }
 
-// dropout keep-mask bits: one 32-bit mix per element pair (two 16-bit Bernoulli draws)
+// dropout keep-mask bits: one 32-bit mix yields four 8-bit Bernoulli draws (p_eff = thresh/256;
+// the survivor scale uses p_eff, so the estimator stays unbiased)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 struct Dropper {
     uint32_t base;      // seed ^ per-(seq, layer, site) salt
-    uint32_t thresh;    // keep iff draw16 >= thresh
-    float scale;        // 1/(1-p)
+    uint32_t thresh;    // keep iff draw8 >= thresh
+    float scale;        // 1/(1-p_eff)
     __device__ __forceinline__ void apply16(f32x16& v, uint32_t elem_salt) const {
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            uint32_t r = mix32(base + (elem_salt + (uint32_t)i) * 0x9E3779B1u);
-            v[i] = ((r & 0xffffu) >= thresh) ? v[i] * scale : 0.f;
-            v[i + 1] = ((r >> 16) >= thresh) ? v[i + 1] * scale : 0.f;
+        for (int i = 0; i < 16; i += 4) {
+            const uint32_t r = mix32(base + (elem_salt + (uint32_t)i) * 0x9E3779B1u);
+            v[i] = ((r & 0xffu) >= thresh) ? v[i] * scale : 0.f;
+            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
+            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] * scale : 0.f;
+            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] * scale : 0.f;
         }
     }
 };
@@ -85,8 +89,9 @@ __device__ __forceinline__ void add_residual_bf16(f32x16 (&acc)[3], const bf16x8
     }
 }
 
-// LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest
-__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* g, const float* b, int h) {
+// LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest.
+// g / b point at this lane-half's 48 values (accumulator-register order).
+__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -101,17 +106,28 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* g, con
         for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
     q += __shfl_xor(q, 32, 64);
     const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
-    const float* gg = g + h * 48;
-    const float* bb = b + h * 48;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[t][i] = (a[t][i] - mean) * rstd * gg[t * 16 + i] + bb[t * 16 + i];
 }
 
+// One 1 KB piece global -> LDS by the DMA path (no VGPR round trip, invisible to hipcc's waitcnt
+// bookkeeping: the kernel waits with an explicit vmcnt(0) at the next stage boundary).
+// lds_dst is wave-uniform; lane i's 16 bytes land at lds_dst + 16 i.
+__device__ __forceinline__ void dma_1k(const char* gsrc_lane, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+#define LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(p))
+
 template <int MAXW, bool DROP>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool drop = DROP;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -121,14 +137,32 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     const bool tok_ok = tok < P;
     const int tokc = tok_ok ? tok : 0;
     const char* W = A.wpack;
-    constexpr bool drop = DROP;
     Dropper dr;
-    dr.thresh = (uint32_t)(A.drop_p * 65536.0f);
-    dr.scale = drop ? 1.0f / (1.0f - A.drop_p) : 1.0f;
+    dr.thresh = (uint32_t)(A.drop_p * 256.0f + 0.5f);
+    dr.scale = drop ? 256.0f / (256.0f - (float)dr.thresh) : 1.0f;
     const uint32_t seq_salt = A.seed ^ ((uint32_t)seq * 0x7FEB352Du);
 
-    // LDS: [2 buffers][K frags nkt*2 | V frags nkt*2]
-    const int buf_bytes = nkt * 4 * TSF_FRAG;
+    // LDS: [K frags nkt*2 KB][V frags nkt*2 KB][weight ring: 2 stage blocks of 25 KB]
+    char* kbuf = smem;
+    char* vbuf = smem + nkt * 2 * TSF_FRAG;
+    char* ring = smem + nkt * 4 * TSF_FRAG;
+    const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(ring));
+    const int nstage = A.depth * TSF_STAGES;
+
+    auto issue_fill = [&](int g) {            // stage block g -> ring slot g & 1, pieces spread over the waves
+        const char* src = W + TSF_LAYER0 + (long)g * TSF_BLOCK + lane * 16;
+        const uint32_t dst = ring_addr + (uint32_t)(g & 1) * TSF_BLOCK;
+        for (int pc = wave; pc < 25; pc += nkt) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
+    };
+    // Stage boundary: my DMA pieces of block g have landed (vmcnt), everybody's have (barrier), and
+    // everybody is done reading the other slot, which is then refilled with block g+1.
+    auto stage_begin = [&](int g) -> const char* {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (g + 1 < nstage) issue_fill(g + 1);
+        return ring + (g & 1) * TSF_BLOCK;
+    };
+
+    issue_fill(0);
 
     // ------------------------------------------------------------------ patch embedding + pos
     f32x16 xT[3];
@@ -168,29 +202,32 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     }
 
     // ------------------------------------------------------------------ encoder layers
+    int g = 0;                                  // global stage index (10 per layer)
 #pragma unroll 1
     for (int layer = 0; layer < A.depth; ++layer) {
-        const char* LW = W + TSF_LAYER0 + (long)layer * TSF_LAYER_BYTES;
         const uint32_t lsalt = seq_salt + (uint32_t)(layer + 1) * 0x632BE5ABu;
-
         bf16x8 xb[6];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
-
         f32x16 acc[3];
+
+        // the first head's stage is opened outside the loop so that the f32 residual stream xT is
+        // dead (folded into acc / xb) while the head loop runs
+        const char* blk = stage_begin(g);
+        const float* tail = (const float*)(blk + TSF_TAIL);
         {
-            const float* bo = (const float*)(LW + TSF_L_BO) + h * 48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+            const float* bo = tail + 64 + h * 48;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : xT[t][i]) + bo[t * 16 + i];
         }
-
 #pragma unroll 1
-        for (int hd = 0; hd < TSF_HEADS; ++hd) {
-            char* kbuf = smem + (hd & 1) * buf_bytes;
-            char* vbuf = kbuf + nkt * 2 * TSF_FRAG;
-
+        for (int hd = 0; hd < TSF_HEADS; ++hd, ++g) {
+            if (hd > 0) {
+                blk = stage_begin(g);
+                tail = (const float*)(blk + TSF_TAIL);
+            }
             // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
             bf16x8 qb[2];
             {
@@ -198,8 +235,8 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(gfrag(LW + TSF_L_WQ, hd * 6 + ks, lane), xb[ks], q);
-                const float* bq = (const float*)(LW + TSF_L_BQ) + (hd * 2 + h) * 16;
+                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(lfrag(blk, ks, lane), xb[ks], q);
+                const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] += bq[i];
                 qb[0] = pack_half(q, 0);
@@ -211,7 +248,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) kk[i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) kk = MFMA_BF16(gfrag(LW + TSF_L_WK, hd * 6 + ks, lane), xb[ks], kk);
+                for (int ks = 0; ks < 6; ++ks) kk = MFMA_BF16(lfrag(blk, 6 + ks, lane), xb[ks], kk);
                 *(bf16x8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(kk, 0);
                 *(bf16x8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(kk, 1);
             }
@@ -221,31 +258,39 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) vv[i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], gfrag(LW + TSF_L_WV, hd * 6 + ks, lane), vv);
-                const float bv = ((const float*)(LW + TSF_L_BV))[hd * 32 + c];
+                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], lfrag(blk, 12 + ks, lane), vv);
+                const float bv = tail[32 + c];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) vv[i] += bv;
                 *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(vv, 0);
                 *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(vv, 1);
             }
-            __syncthreads();
+            // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes)
+            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes); the next
+            // key tile's operand fragments are fetched from LDS while the current one is in the matrix pipe
             float mx = -INFINITY;
+            {
+                bf16x8 k0 = lfrag(kbuf, 0, lane), k1 = lfrag(kbuf, 1, lane);
 #pragma unroll 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                f32x16 s;
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const int nx = (kt + 1 < nkt) ? kt + 1 : kt;
+                    bf16x8 n0 = lfrag(kbuf, nx * 2, lane), n1 = lfrag(kbuf, nx * 2 + 1, lane);
+                    f32x16 s;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] = 0.f;
-                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
-                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
-                if (kt == nkt - 1) {
+                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                    s = MFMA_BF16(k0, qb[0], s);
+                    s = MFMA_BF16(k1, qb[1], s);
+                    if (kt == nkt - 1) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                        for (int i = 0; i < 16; ++i)
+                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[i]);
+                    k0 = n0; k1 = n1;
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[i]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 
@@ -255,30 +300,37 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
             float lsum = 0.f;
             if constexpr (drop) dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1));
+            {
+                bf16x8 k0 = lfrag(kbuf, 0, lane), k1 = lfrag(kbuf, 1, lane);
 #pragma unroll 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                f32x16 s;
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const int nx = (kt + 1 < nkt) ? kt + 1 : kt;
+                    bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
+                    bf16x8 n0 = lfrag(kbuf, nx * 2, lane), n1 = lfrag(kbuf, nx * 2 + 1, lane);
+                    f32x16 s;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] = 0.f;
-                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
-                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
-                if (kt == nkt - 1) {
+                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                    s = MFMA_BF16(k0, qb[0], s);
+                    s = MFMA_BF16(k1, qb[1], s);
+                    if (kt == nkt - 1) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                        for (int i = 0; i < 16; ++i)
+                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
+                    if constexpr (drop) {
+                        // attention-prob dropout acts on the normalised probabilities: keep the
+                        // denominator dropout-free (VALU sum) and mask the numerator only
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) lsum += s[i];
+                        dr.apply16(s, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
+                    }
+                    bf16x8 p0 = pack_half(s, 0), p1 = pack_half(s, 1);
+                    o = MFMA_BF16(v0, p0, o);
+                    o = MFMA_BF16(v1, p1, o);
+                    k0 = n0; k1 = n1;
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
-                if constexpr (drop) {
-                    // attention-prob dropout acts on the normalised probabilities: keep the
-                    // denominator dropout-free (VALU sum) and mask the numerator only
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) lsum += s[i];
-                    dr.apply16(s, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
-                }
-                bf16x8 p0 = pack_half(s, 0), p1 = pack_half(s, 1);
-                o = MFMA_BF16(lfrag(vbuf, kt * 2, lane), p0, o);
-                o = MFMA_BF16(lfrag(vbuf, kt * 2 + 1, lane), p1, o);
             }
             float den;
             if constexpr (drop) {
@@ -293,60 +345,66 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             // ---- out-projection of this head accumulates onto the residual
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_WO, (hd * 3 + t) * 2 + 0, lane), ob0, acc[t]);
-                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_WO, (hd * 3 + t) * 2 + 1, lane), ob1, acc[t]);
+                acc[t] = MFMA_BF16(lfrag(blk, 18 + t * 2, lane), ob0, acc[t]);
+                acc[t] = MFMA_BF16(lfrag(blk, 19 + t * 2, lane), ob1, acc[t]);
             }
         }  // heads
-
         if constexpr (drop) {
             // dropout1 on (attention output + b_o); residual re-read from its bf16 operand copy
             dr.base = lsalt ^ 0x51ED27u;
             add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
         }
-        layer_norm96(acc, (const float*)(LW + TSF_L_LN1G), (const float*)(LW + TSF_L_LN1B), h);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) xT[t] = acc[t];
+        layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
 
-        // ---- FFN 96 -> 384 -> 96 in 12 chunks of 32 hidden units
-#pragma unroll
-        for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+        // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
+        if constexpr (drop) dr.base = lsalt ^ 0x2545F491u;
+        blk = stage_begin(g);
+        tail = (const float*)(blk + TSF_TAIL);
         {
-            const float* b2 = (const float*)(LW + TSF_L_B2) + h * 48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(acc[t], 0); xb[2 * t + 1] = pack_half(acc[t], 1); }
+            const float* b2 = tail + 64 + h * 48;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : xT[t][i]) + b2[t * 16 + i];
+                for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : acc[t][i]) + b2[t * 16 + i];
         }
-        if constexpr (drop) dr.base = lsalt ^ 0x2545F491u;
 #pragma unroll 1
-        for (int ch = 0; ch < 12; ++ch) {
-            f32x16 hh;
+        for (int j = 0; j < 6; ++j, ++g) {
+            if (j > 0) {
+                blk = stage_begin(g);
+                tail = (const float*)(blk + TSF_TAIL);
+            }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hh[i] = 0.f;
+            for (int cc = 0; cc < 2; ++cc) {
+                f32x16 hh;
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(gfrag(LW + TSF_L_W1, ch * 6 + ks, lane), xb[ks], hh);
-            const float* b1 = (const float*)(LW + TSF_L_B1) + (ch * 2 + h) * 16;
+                for (int i = 0; i < 16; ++i) hh[i] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i] + b1[i], 0.f);
-            if constexpr (drop) dr.apply16(hh, (uint32_t)((tok * 12 + ch) * 32 + h * 16));
-            bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
+                for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(lfrag(blk, cc * 12 + ks, lane), xb[ks], hh);
+                const float* b1 = tail + (cc * 2 + h) * 16;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_W2, (ch * 3 + t) * 2 + 0, lane), hb0, acc[t]);
-                acc[t] = MFMA_BF16(gfrag(LW + TSF_L_W2, (ch * 3 + t) * 2 + 1, lane), hb1, acc[t]);
+                for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i] + b1[i], 0.f);
+                if constexpr (drop) dr.apply16(hh, (uint32_t)((tok * 12 + j * 2 + cc) * 32 + h * 16));
+                bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = MFMA_BF16(lfrag(blk, cc * 12 + 6 + t * 2, lane), hb0, acc[t]);
+                    acc[t] = MFMA_BF16(lfrag(blk, cc * 12 + 7 + t * 2, lane), hb1, acc[t]);
+                }
             }
         }
         if constexpr (drop) {
             dr.base = lsalt ^ 0x9E3779B9u;
             add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
         }
-        layer_norm96(acc, (const float*)(LW + TSF_L_LN2G), (const float*)(LW + TSF_L_LN2B), h);
+        layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN2 params ride in the last ffn block
 #pragma unroll
         for (int t = 0; t < 3; ++t) xT[t] = acc[t];
     }  // layers
 
     // ------------------------------------------------------------------ encoder_norm + outputs
-    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G), (const float*)(W + TSF_G_NORM_B), h);
+    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G) + h * 48, (const float*)(W + TSF_G_NORM_B) + h * 48);
     float sq = 0.f;
     if (tok_ok) {
         const long row = ((long)seq * P + tok) * TSF_D;
@@ -396,7 +454,7 @@ __global__ __launch_bounds__(256) void pack_long_history_kernel(const float* __r
 
 template <int MAXW, bool DROP>
 int launch_enc(const EncArgs& a, hipStream_t st) {
-    size_t lds = (size_t)a.nkt * 8 * TSF_FRAG;
+    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP>,

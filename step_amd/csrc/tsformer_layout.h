@@ -1,6 +1,5 @@
 // Byte layout of the packed TSFormer weight buffer consumed by tsformer_encoder.hip.
-// The python packer (step_amd/tsformer_pack.py) mirrors these constants; a self-describing
-// header at the start of the buffer is checked by the kernel launcher.
+// The python packer (step_amd/tsformer_pack.py) mirrors these constants.
 //
 // MFMA "chain" k-slot map (v_mfma_f32_32x32x16_bf16, lane = 32*h + r, operand slot j in 0..8):
 //     F(s, h, j) = 16*s + 8*(j >> 2) + 4*h + (j & 3)            (s = which K=16 step of a 32-wide block)
@@ -8,6 +7,20 @@
 // tile converted to bf16 is directly the next MFMA's operand (no cross-lane movement).
 // Weight fragments are stored so that slot (h, j) of k-step s holds input feature
 // 32*block + F(s, h, j).  One fragment = 64 lanes * 8 bf16 = 1024 bytes, lane-major.
+//
+// Each encoder layer is 10 "stage blocks" of 25 KB (24 operand fragments + 1 KB of f32 vectors):
+// the kernel streams them through a 2-slot LDS ring with global_load_lds, one block per stage,
+// so every workgroup reads each weight byte from L2 exactly once.
+//   head block hd (stage hd):   frags  0..5  Wq(hd) k-steps (A operand, pre-scaled by log2(e)/sqrt(24))
+//                                      6..11 Wk(hd) k-steps (A operand)
+//                                     12..17 Wv(hd) k-steps (B operand)
+//                                     18..23 Wo(hd) [tile 3][s 2] (A operand)
+//                               tail f32 [0..31] bq [2][16] (pre-scaled)   [32..63] bv [32] (slot 24 = 1.0)
+//                                        hd==0: [64..159] bo [2][48]       hd==3: [64..159] LN1 gamma, [160..255] LN1 beta
+//   ffn block j (stage 4+j), chunks c = 2j, 2j+1 of 32 hidden units:
+//                               frags 12*(c&1) + 0..5  W1(c) k-steps,  12*(c&1) + 6..11 W2(c) [tile 3][s 2]
+//                               tail f32 [0..63] b1 of both chunks [2][2][16]
+//                                        j==0: [64..159] b2 [2][48]        j==5: [64..159] LN2 gamma, [160..255] LN2 beta
 #pragma once
 
 #define TSF_D 96
@@ -17,7 +30,7 @@
 #define TSF_PATCH 12
 #define TSF_FRAG 1024
 
-#define TSF_MAGIC 0x54534631 /* "TSF1" */
+#define TSF_MAGIC 0x54534632 /* "TSF2" */
 
 // header: int32 magic, P (tokens), depth, reserved
 #define TSF_HDR_BYTES 64
@@ -26,24 +39,12 @@
 #define TSF_G_BPE (TSF_G_WPE + 2 * 48 * 12 * 4)         /* [2][48] */
 #define TSF_G_NORM_G (TSF_G_BPE + 2 * 48 * 4)           /* encoder_norm weight [2][48] */
 #define TSF_G_NORM_B (TSF_G_NORM_G + 2 * 48 * 4)
-#define TSF_LAYER0 (TSF_G_NORM_B + 2 * 48 * 4)
-// --- per layer section ---
-#define TSF_L_WQ 0                                      /* [4 heads][6 ksteps] frags (A operand) */
-#define TSF_L_WK (TSF_L_WQ + 24 * TSF_FRAG)
-#define TSF_L_WV (TSF_L_WK + 24 * TSF_FRAG)             /* B operand frags */
-#define TSF_L_WO (TSF_L_WV + 24 * TSF_FRAG)             /* [4 heads][3 tiles][2 s] */
-#define TSF_L_W1 (TSF_L_WO + 24 * TSF_FRAG)             /* [12 chunks][6 ksteps] */
-#define TSF_L_W2 (TSF_L_W1 + 72 * TSF_FRAG)             /* [12 chunks][3 tiles][2 s] */
-#define TSF_L_BQ (TSF_L_W2 + 72 * TSF_FRAG)             /* f32 [4][2][16] (pre-scaled) */
-#define TSF_L_BV (TSF_L_BQ + 4 * 2 * 16 * 4)            /* f32 [4][32]  (slot 24 = 1.0) */
-#define TSF_L_BO (TSF_L_BV + 4 * 32 * 4)                /* f32 [2][48] */
-#define TSF_L_LN1G (TSF_L_BO + 2 * 48 * 4)
-#define TSF_L_LN1B (TSF_L_LN1G + 2 * 48 * 4)
-#define TSF_L_B1 (TSF_L_LN1B + 2 * 48 * 4)              /* f32 [12][2][16] */
-#define TSF_L_B2 (TSF_L_B1 + 12 * 2 * 16 * 4)           /* f32 [2][48] */
-#define TSF_L_LN2G (TSF_L_B2 + 2 * 48 * 4)
-#define TSF_L_LN2B (TSF_L_LN2G + 2 * 48 * 4)
-#define TSF_LAYER_BYTES (TSF_L_LN2B + 2 * 48 * 4)
+#define TSF_LAYER0 ((TSF_G_NORM_B + 2 * 48 * 4 + 1023) / 1024 * 1024)   /* 1 KB aligned */
+// --- stage blocks ---
+#define TSF_BLOCK (25 * TSF_FRAG)
+#define TSF_STAGES 10
+#define TSF_LAYER_BYTES (TSF_STAGES * TSF_BLOCK)
+#define TSF_TAIL (24 * TSF_FRAG)
 // --- positional table follows the last layer: f32 [P][2][48] ---
 #define TSF_POS_OFF(depth) (TSF_LAYER0 + (long)(depth) * TSF_LAYER_BYTES)
 #define TSF_TOTAL_BYTES(depth, P) (TSF_POS_OFF(depth) + (long)(P) * 2 * 48 * 4)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 D, HEADS, HDIM, FFN, PATCH, FRAG = 96, 4, 24, 384, 12, 1024
-MAGIC = 0x54534631
+MAGIC = 0x54534632
 HDR = 64
 
 _h = np.arange(64) // 32
@@ -48,37 +48,42 @@ def _lane_vec32(v):
     return v[_rows16()]                                # [2,16]
 
 
+BLOCK = 25 * FRAG
+STAGES = 10
+TAIL = 24 * FRAG
+LAYER0 = (HDR + 2 * 48 * 12 * 4 + 3 * 2 * 48 * 4 + 1023) // 1024 * 1024
+
+
 def layer_bytes():
-    o = 24 * 4 * FRAG + 72 * 2 * FRAG
-    o += 4 * 2 * 16 * 4 + 4 * 32 * 4 + 3 * 2 * 48 * 4 + 12 * 2 * 16 * 4 + 3 * 2 * 48 * 4
-    return o
+    return STAGES * BLOCK
 
 
 def total_bytes(depth, P):
-    return HDR + 2 * 48 * 12 * 4 + 3 * 2 * 48 * 4 + depth * layer_bytes() + P * 2 * 48 * 4
+    return LAYER0 + depth * layer_bytes() + P * 2 * 48 * 4
 
 
 def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder"):
     """sd: mapping name -> tensor (reference TSFormer state_dict keys, optionally prefixed).
-    Returns a uint8 CPU tensor of ``total_bytes(depth, P)`` bytes."""
+    Returns a uint8 CPU tensor of ``total_bytes(depth, P)`` bytes (layout: csrc/tsformer_layout.h)."""
     g = lambda k: sd[prefix + k].detach().to(torch.float32).cpu().numpy()
-    f32_parts, out = [], bytearray()
+    out = bytearray()
 
-    def put_f32(a):
-        out.extend(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+    def f32_bytes(a):
+        return np.ascontiguousarray(a, dtype=np.float32).tobytes()
 
-    def put_bf16(a):
+    def bf16_bytes(a):
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16)
-        out.extend(t.view(torch.int16).numpy().tobytes())
+        return t.view(torch.int16).numpy().tobytes()
 
     hdr = np.zeros(HDR // 4, dtype=np.int32)
     hdr[0], hdr[1], hdr[2] = MAGIC, P, depth
     out.extend(hdr.tobytes())
     wpe = g("patch_embedding.input_embedding.weight")[:, 0, :, 0]        # [96, 12]
-    put_f32(np.stack([wpe[_lane_vec96(np.arange(96))[h]] for h in (0, 1)]))   # [2,48,12]
-    put_f32(_lane_vec96(g("patch_embedding.input_embedding.bias")))
-    put_f32(_lane_vec96(g(enc + "_norm.weight")))
-    put_f32(_lane_vec96(g(enc + "_norm.bias")))
+    out.extend(f32_bytes(np.stack([wpe[_lane_vec96(np.arange(96))[h]] for h in (0, 1)])))   # [2,48,12]
+    out.extend(f32_bytes(_lane_vec96(g("patch_embedding.input_embedding.bias"))))
+    out.extend(f32_bytes(_lane_vec96(g(enc + "_norm.weight"))))
+    out.extend(f32_bytes(_lane_vec96(g(enc + "_norm.bias"))))
+    out.extend(b"\0" * (LAYER0 - len(out)))
     qscale = math.log2(math.e) / math.sqrt(HDIM)
     for l in range(depth):
         lp = f"{enc}.transformer_encoder.layers.{l}."
@@ -86,45 +91,61 @@ def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder"):
         wo, bo = g(lp + "self_attn.out_proj.weight"), g(lp + "self_attn.out_proj.bias")
         w1, b1 = g(lp + "linear1.weight"), g(lp + "linear1.bias")
         w2, b2 = g(lp + "linear2.weight"), g(lp + "linear2.bias")
-        assert len(out) == HDR + 2 * 48 * 12 * 4 + 3 * 2 * 48 * 4 + l * layer_bytes()
+        assert len(out) == LAYER0 + l * layer_bytes()
 
         def head_w(which, hd, scale=1.0):
             w = np.zeros((32, D), dtype=np.float32)
             w[:HDIM] = win[which * D + hd * HDIM: which * D + (hd + 1) * HDIM] * scale
             return w
-        for which, scale in ((0, qscale), (1, 1.0), (2, 1.0)):        # WQ, WK, WV
-            for hd in range(HEADS):
-                w = head_w(which, hd, scale)
-                for ks in range(6):
-                    put_bf16(_frag(w, 0, (ks // 2) * 32, ks % 2))
         wo_pad = np.zeros((D, HEADS, 32), dtype=np.float32)
         wo_pad[:, :, :HDIM] = wo.reshape(D, HEADS, HDIM)
-        for hd in range(HEADS):                                        # WO
-            for t in range(3):
-                for s in range(2):
-                    put_bf16(_frag(wo_pad[:, hd, :], t * 32, 0, s))
-        for ch in range(12):                                           # W1
-            for ks in range(6):
-                put_bf16(_frag(w1, ch * 32, (ks // 2) * 32, ks % 2))
-        for ch in range(12):                                           # W2
-            for t in range(3):
-                for s in range(2):
-                    put_bf16(_frag(w2, t * 32, ch * 32, s))
         bq = np.zeros((HEADS, 32), dtype=np.float32)
         bq[:, :HDIM] = bin_[:D].reshape(HEADS, HDIM) * qscale
-        put_f32(np.stack([_lane_vec32(bq[hd]) for hd in range(HEADS)]))          # [4,2,16]
         bv = np.zeros((HEADS, 32), dtype=np.float32)
         bv[:, :HDIM] = bin_[2 * D:].reshape(HEADS, HDIM)
         bv[:, HDIM] = 1.0                        # all-ones V row -> softmax denominator
-        put_f32(bv)
-        put_f32(_lane_vec96(bo))
-        put_f32(_lane_vec96(g(lp + "norm1.weight")))
-        put_f32(_lane_vec96(g(lp + "norm1.bias")))
-        put_f32(np.stack([_lane_vec32(b1[ch * 32:(ch + 1) * 32]) for ch in range(12)]))   # [12,2,16]
-        put_f32(_lane_vec96(b2))
-        put_f32(_lane_vec96(g(lp + "norm2.weight")))
-        put_f32(_lane_vec96(g(lp + "norm2.bias")))
+        for hd in range(HEADS):                                        # ---- head stage blocks
+            blk = bytearray()
+            for which, scale in ((0, qscale), (1, 1.0), (2, 1.0)):    # Wq, Wk, Wv
+                w = head_w(which, hd, scale)
+                for ks in range(6):
+                    blk.extend(bf16_bytes(_frag(w, 0, (ks // 2) * 32, ks % 2)))
+            for t in range(3):                                         # Wo
+                for s in range(2):
+                    blk.extend(bf16_bytes(_frag(wo_pad[:, hd, :], t * 32, 0, s)))
+            tail = np.zeros(256, dtype=np.float32)
+            tail[0:32] = _lane_vec32(bq[hd]).reshape(-1)
+            tail[32:64] = bv[hd]
+            if hd == 0:
+                tail[64:160] = _lane_vec96(bo).reshape(-1)
+            if hd == HEADS - 1:
+                tail[64:160] = _lane_vec96(g(lp + "norm1.weight")).reshape(-1)
+                tail[160:256] = _lane_vec96(g(lp + "norm1.bias")).reshape(-1)
+            blk.extend(tail.tobytes())
+            assert len(blk) == BLOCK
+            out.extend(blk)
+        for j in range(6):                                             # ---- ffn stage blocks
+            blk = bytearray()
+            for cc in range(2):
+                ch = 2 * j + cc
+                for ks in range(6):
+                    blk.extend(bf16_bytes(_frag(w1, ch * 32, (ks // 2) * 32, ks % 2)))
+                for t in range(3):
+                    for s in range(2):
+                        blk.extend(bf16_bytes(_frag(w2, t * 32, ch * 32, s)))
+            tail = np.zeros(256, dtype=np.float32)
+            for cc in range(2):
+                ch = 2 * j + cc
+                tail[cc * 32:(cc + 1) * 32] = _lane_vec32(b1[ch * 32:(ch + 1) * 32]).reshape(-1)
+            if j == 0:
+                tail[64:160] = _lane_vec96(b2).reshape(-1)
+            if j == 5:
+                tail[64:160] = _lane_vec96(g(lp + "norm2.weight")).reshape(-1)
+                tail[160:256] = _lane_vec96(g(lp + "norm2.bias")).reshape(-1)
+            blk.extend(tail.tobytes())
+            assert len(blk) == BLOCK
+            out.extend(blk)
     pos = g("positional_encoding.position_embedding")[:P]              # [P, 96]
-    put_f32(np.stack([_lane_vec96(pos[p]) for p in range(P)]))         # [P,2,48]
+    out.extend(f32_bytes(np.stack([_lane_vec96(pos[p]) for p in range(P)])))         # [P,2,48]
     assert len(out) == total_bytes(depth, P), (len(out), total_bytes(depth, P))
     return torch.frombuffer(bytes(out), dtype=torch.uint8).clone()

@@ -82,16 +82,8 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
     G_BPE = G_WPE + 2 * 48 * 12 * 4
     G_NG = G_BPE + 2 * 48 * 4
     G_NB = G_NG + 2 * 48 * 4
-    L0 = G_NB + 2 * 48 * 4
+    L0 = TP.LAYER0
     POS = L0 + depth * LB
-    o = {}
-    off = 0
-    for name, sz in (("WQ", 24 * 1024), ("WK", 24 * 1024), ("WV", 24 * 1024), ("WO", 24 * 1024), ("W1", 72 * 1024),
-                     ("W2", 72 * 1024), ("BQ", 512), ("BV", 512), ("BO", 384), ("LN1G", 384), ("LN1B", 384),
-                     ("B1", 1536), ("B2", 384), ("LN2G", 384), ("LN2B", 384)):
-        o[name] = off
-        off += sz
-    assert off == LB
     wpe = B.f32(G_WPE, 2 * 48 * 12).reshape(2, 48, 12)
     bpe = B.f32(G_BPE, 96).reshape(2, 48)
     xT = []
@@ -105,22 +97,24 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
         xT.append((e * np.sqrt(96.0)).reshape(64, 3, 16).transpose(1, 0, 2).copy())              # [3,64,16]
     for layer in range(depth):
         base = L0 + layer * LB
-        f32 = lambda name, n: B.f32(base + o[name], n)
+        hblk = lambda hd: base + hd * TP.BLOCK                       # head stage block
+        fblk = lambda j: base + (4 + j) * TP.BLOCK                   # ffn stage block
+        tailf = lambda blk, off, n: B.f32(blk + TP.TAIL + off * 4, n)
         xb = [[pack_half(xT[w][t], s, rnd) for t in range(3) for s in range(2)] for w in range(nkt)]
-        bo = f32("BO", 96).reshape(2, 48)
+        bo = tailf(hblk(0), 64, 96).reshape(2, 48)
         acc = [xT[w] + bo[H].reshape(64, 3, 16).transpose(1, 0, 2) for w in range(nkt)]
         for hd in range(4):
             kf, vf, qb = {}, {}, []
-            bq = f32("BQ", 128).reshape(4, 2, 16)
-            bv = f32("BV", 128).reshape(4, 32)
+            bq = tailf(hblk(hd), 0, 32).reshape(2, 16)
+            bv = tailf(hblk(hd), 32, 32)
             for w in range(nkt):
                 q = np.zeros((64, 16)); kk = np.zeros((64, 16)); vv = np.zeros((64, 16))
                 for ks in range(6):
-                    q = mfma_fast(B.frag(base + o["WQ"], hd * 6 + ks), xb[w][ks], q)
-                    kk = mfma_fast(B.frag(base + o["WK"], hd * 6 + ks), xb[w][ks], kk)
-                    vv = mfma_fast(xb[w][ks], B.frag(base + o["WV"], hd * 6 + ks), vv)
-                q = q + bq[hd][H]
-                vv = vv + bv[hd][C][:, None]
+                    q = mfma_fast(B.frag(hblk(hd), ks), xb[w][ks], q)
+                    kk = mfma_fast(B.frag(hblk(hd), 6 + ks), xb[w][ks], kk)
+                    vv = mfma_fast(xb[w][ks], B.frag(hblk(hd), 12 + ks), vv)
+                q = q + bq[H]
+                vv = vv + bv[C][:, None]
                 qb.append([pack_half(q, 0, rnd), pack_half(q, 1, rnd)])
                 for s in range(2):
                     kf[(w, s)] = pack_half(kk, s, rnd)
@@ -145,24 +139,25 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
                 ob = [pack_half(ov, 0, rnd), pack_half(ov, 1, rnd)]
                 for t in range(3):
                     for s in range(2):
-                        acc[w][t] = mfma_fast(B.frag(base + o["WO"], (hd * 3 + t) * 2 + s), ob[s], acc[w][t])
-        g1, b1n = f32("LN1G", 96).reshape(2, 48), f32("LN1B", 96).reshape(2, 48)
-        g2, b2n = f32("LN2G", 96).reshape(2, 48), f32("LN2B", 96).reshape(2, 48)
-        b1 = f32("B1", 384).reshape(12, 2, 16)
-        b2 = f32("B2", 96).reshape(2, 48)
+                        acc[w][t] = mfma_fast(B.frag(hblk(hd), 18 + t * 2 + s), ob[s], acc[w][t])
+        g1, b1n = tailf(hblk(3), 64, 96).reshape(2, 48), tailf(hblk(3), 160, 96).reshape(2, 48)
+        g2, b2n = tailf(fblk(5), 64, 96).reshape(2, 48), tailf(fblk(5), 160, 96).reshape(2, 48)
+        b2 = tailf(fblk(0), 64, 96).reshape(2, 48)
         for w in range(nkt):
             x1 = layer_norm(acc[w], g1, b1n)
             xbw = [pack_half(x1[t], s, rnd) for t in range(3) for s in range(2)]
             a2 = x1 + b2[H].reshape(64, 3, 16).transpose(1, 0, 2)
             for ch in range(12):
+                j, cc = ch // 2, ch % 2
+                b1 = tailf(fblk(j), cc * 32, 32).reshape(2, 16)
                 hh = np.zeros((64, 16))
                 for ks in range(6):
-                    hh = mfma_fast(B.frag(base + o["W1"], ch * 6 + ks), xbw[ks], hh)
-                hh = np.maximum(hh + b1[ch][H], 0.0)
+                    hh = mfma_fast(B.frag(fblk(j), cc * 12 + ks), xbw[ks], hh)
+                hh = np.maximum(hh + b1[H], 0.0)
                 hb = [pack_half(hh, 0, rnd), pack_half(hh, 1, rnd)]
                 for t in range(3):
                     for s in range(2):
-                        a2[t] = mfma_fast(B.frag(base + o["W2"], (ch * 3 + t) * 2 + s), hb[s], a2[t])
+                        a2[t] = mfma_fast(B.frag(fblk(j), cc * 12 + 6 + t * 2 + s), hb[s], a2[t])
             xT[w] = layer_norm(a2, g2, b2n)
     ng, nb = B.f32(G_NG, 96).reshape(2, 48), B.f32(G_NB, 96).reshape(2, 48)
     hidden = np.zeros((P, 96))
