@@ -49,6 +49,10 @@ typedef struct StepGemm {
     /* optional affine on A along k: A'(m,k) = A(m,k) * a_kscale[k / a_kperiod] + a_kshift[k / a_kperiod]
        (folds BatchNorm1d(16) into the DGL fc, discrete_graph_learning.py:132-134) */
     const float* a_kscale; const float* a_kshift; int a_kperiod;
+    /* optional second batch level: batch index z = i1 * batch0 + i0 (batch0 == 0: off), operand offsets
+       i0 * s?b + i1 * s?b1.  Lets one launch run the same contraction for the three diffusion supports
+       (different adjacency stack entry and gcn slot, same sample index) */
+    int batch0; long sab1, sbb1, scb1;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 

@@ -22,7 +22,8 @@ class StepGemm(ctypes.Structure):
                 ("alpha", _f), ("accumulate", _i), ("bias", _vp), ("relu", _i), ("splitk", _i),
                 ("a_kblk", _i), ("a_kstride", _l), ("b_kblk", _i), ("b_kstride", _l),
                 ("b_nblk", _i), ("b_nstride", _l), ("c_nblk", _i), ("c_nstride", _l),
-                ("a_kscale", _vp), ("a_kshift", _vp), ("a_kperiod", _i)]
+                ("a_kscale", _vp), ("a_kshift", _vp), ("a_kperiod", _i),
+                ("batch0", _i), ("sab1", _l), ("sbb1", _l), ("scb1", _l)]
 
 
 class StepDglParams(ctypes.Structure):
@@ -116,7 +117,7 @@ def call(name, *args):
 
 def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0, scn=1, alpha=1.0,
          accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0, a_k=(0, 0), b_k=(0, 0),
-         b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0):
+         b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0, batch0=0, sab1=0, sbb1=0, scb1=0):
     """Thin descriptor builder around step_gemm; a/b/c are device tensors (f32 or bf16 for a, b),
     offsets are in elements."""
     g = StepGemm()
@@ -134,6 +135,7 @@ def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0
     g.b_kblk, g.b_kstride = b_k
     g.b_nblk, g.b_nstride = b_n
     g.c_nblk, g.c_nstride = c_n
+    g.batch0, g.sab1, g.sbb1, g.scb1 = batch0, sab1, sbb1, scb1
     if a_kscale is not None:
         g.a_kscale, g.a_kshift, g.a_kperiod = a_kscale.data_ptr(), a_kshift.data_ptr(), a_kperiod
     check(lib().step_gemm(ctypes.byref(g), stream()), "step_gemm")

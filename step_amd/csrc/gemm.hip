@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
     const int kbeg = zs * per * BK;
     const int kend = min(g.K, (zs + 1) * per * BK);
 
-    const char* Ab = (const char*)g.A + (long)zb * g.sab * (long)sizeof(TA);
-    const char* Bb = (const char*)g.B + (long)zb * g.sbb * (long)sizeof(TB);
+    // two-level batch: zb = i1 * batch0 + i0 (batch0 == 0: single level)
+    const int i0 = g.batch0 ? zb % g.batch0 : zb, i1 = g.batch0 ? zb / g.batch0 : 0;
+    const char* Ab = (const char*)g.A + ((long)i0 * g.sab + (long)i1 * g.sab1) * (long)sizeof(TA);
+    const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * (long)sizeof(TB);
 
     // loader maps: make the thread index run along whichever dimension is contiguous
     constexpr int AE = BM * BK / 256;     // elements per thread
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
     }
 
     // epilogue: D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    float* Cb = g.C + (long)zb * g.scb;
+    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -170,6 +172,190 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct-fragment variant for short contractions (K <= 1024): one wave per 32x32 output tile,
+// no LDS and no barriers -- each lane fetches its own MFMA operand words straight from global
+// memory (the operands of these calls are L2-resident), so a [307 x 384 x 307] diffusion hop
+// becomes ~1000 independent waves instead of 240 latency-bound workgroups.
+// k-slot trick: a lane loads 4 consecutive k for its row/column (one dwordx4 when that operand is
+// k-contiguous) and MFMA j of the group consumes element j, i.e. MFMA j contracts
+// k in {k0 + j, k0 + 4 + j}; A and B use the same map, so the sum over the group is exact.
+// Addressing: the k-dependent part of every address is wave-uniform (scalar unit), the lane part
+// is a loop-invariant 32-bit offset; slot remaps must have a power-of-two block (shift/mask).
+struct DirectArgs {
+    int tiles_m, tiles_n;
+    int a_sh, a_mask, b_sh, b_mask, bn_sh, bn_mask, cn_sh, cn_mask;   // remap(x) = (x >> sh) * stride + (x & mask)
+    int a_vec, b_vec;
+};
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs d) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile = (long)blockIdx.x * 4 + wave;
+    const long per_batch = (long)d.tiles_m * d.tiles_n;
+    if (tile >= per_batch * g.batch) return;
+    const int zb = (int)(tile / per_batch);
+    const int tr = (int)(tile % per_batch);
+    const int m0 = (tr / d.tiles_n) * 32, n0 = (tr % d.tiles_n) * 32;
+    const int li = lane & 31, lk = lane >> 5;
+    const int i0 = g.batch0 ? zb % g.batch0 : zb, i1 = g.batch0 ? zb / g.batch0 : 0;
+    const TA* Ab = (const TA*)g.A + (long)i0 * g.sab + (long)i1 * g.sab1;          // wave-uniform
+    const TB* Bb = (const TB*)g.B + (long)i0 * g.sbb + (long)i1 * g.sbb1;
+    const int gm = m0 + li, gn = n0 + li;
+    const bool m_ok = gm < g.M, n_ok = gn < g.N;
+    const int K = g.K;
+    const int sak = (int)g.sak, sbk = (int)g.sbk;
+    // loop-invariant lane offsets (elements); out-of-range rows/columns read element 0 and are zeroed
+    const int a_row = m_ok ? (int)((long)gm * g.sam) : 0;
+    const int b_col = n_ok ? (int)((((long)(gn >> d.bn_sh)) * g.b_nstride + (gn & d.bn_mask)) * g.sbn) : 0;
+    const int a_lane = a_row + 4 * lk * sak;
+    const int b_lane = b_col + 4 * lk * sbk;
+
+    auto ldA = [&](const TA* p, int off) -> float {
+        if constexpr (sizeof(TA) == 2) return bf16_bits_to_f32(((const uint16_t*)p)[off]); else return p[off];
+    };
+    auto ldB = [&](const TB* p, int off) -> float {
+        if constexpr (sizeof(TB) == 2) return bf16_bits_to_f32(((const uint16_t*)p)[off]); else return p[off];
+    };
+    // unchecked group load at uniform k0 (multiple of 8, k0 + 8 <= K)
+    auto load_a = [&](int k0, float (&v)[4]) {
+        const TA* pu = Ab + (long)(((k0 >> d.a_sh) * (int)g.a_kstride + (k0 & d.a_mask)) * sak);
+        if (sizeof(TA) == 4 && d.a_vec) {
+            float4 t = *(const float4*)((const float*)pu + a_lane);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ldA(pu, a_lane + j * sak);
+        }
+    };
+    auto load_b = [&](int k0, float (&v)[4]) {
+        const TB* pu = Bb + (long)(((k0 >> d.b_sh) * (int)g.b_kstride + (k0 & d.b_mask)) * sbk);
+        if (sizeof(TB) == 4 && d.b_vec) {
+            float4 t = *(const float4*)((const float*)pu + b_lane);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ldB(pu, b_lane + j * sbk);
+        }
+    };
+    // checked variant for the ragged tail
+    auto load_a_tail = [&](int k0, float (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gk = k0 + 4 * lk + j;
+            const int gkc = gk < K ? gk : 0;
+            const long ki = (long)(gkc >> d.a_sh) * g.a_kstride + (gkc & d.a_mask);
+            float x = ldA(Ab, a_row + (int)(ki * sak));
+            v[j] = gk < K ? x : 0.f;
+        }
+    };
+    auto load_b_tail = [&](int k0, float (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gk = k0 + 4 * lk + j;
+            const int gkc = gk < K ? gk : 0;
+            const long ki = (long)(gkc >> d.b_sh) * g.b_kstride + (gkc & d.b_mask);
+            float x = ldB(Bb, b_col + (int)(ki * sbk));
+            v[j] = gk < K ? x : 0.f;
+        }
+    };
+
+    // Deep software pipeline: with ~1 wave per SIMD there is no thread-level parallelism to hide the
+    // load latency, so a whole 64-deep k-chunk (8 groups of 4 MFMAs = 2048 matrix-pipe cycles) is kept
+    // in flight in registers while the previous chunk is being consumed.
+    // (the vmcnt counter saturates at 63 outstanding loads: two chunks in flight must stay below that)
+    constexpr int G = 3, CH = 8 * G;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int kfull = K / CH * CH;
+    if (kfull > 0) {
+        float a[G][4], b[G][4], an[G][4], bn[G][4];
+#pragma unroll
+        for (int q = 0; q < G; ++q) { load_a(8 * q, a[q]); load_b(8 * q, b[q]); }
+        for (int k0 = 0; k0 < kfull; k0 += CH) {
+            const int kn = k0 + CH;
+            if (kn < kfull) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) { load_a(kn + 8 * q, an[q]); load_b(kn + 8 * q, bn[q]); }
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[q][j] : 0.f, n_ok ? b[q][j] : 0.f, acc, 0, 0, 0);
+            if (kn < kfull) {
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[q][j] = an[q][j]; b[q][j] = bn[q][j]; }
+            }
+        }
+    }
+    for (int k0 = kfull; k0 < K; k0 += 8) {          // tail: up to 7 groups, bounds-checked
+        float a[4], b[4];
+        load_a_tail(k0, a); load_b_tail(k0, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[j] : 0.f, n_ok ? b[j] : 0.f, acc, 0, 0, 0);
+    }
+
+    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+    if (!n_ok) return;
+    const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
+    const long ni = (long)(gn >> d.cn_sh) * g.c_nstride + (gn & d.cn_mask);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rm = m0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        if (rm >= g.M) continue;
+        float v = g.alpha * acc[e];
+        float* dst = Cb + (long)rm * g.ldc + ni * g.scn;
+        if (g.accumulate == 2) {
+            atomicAdd(dst, v);
+        } else {
+            if (g.accumulate == 1) v += *dst;
+            v += bv;
+            if (g.relu) v = fmaxf(v, 0.f);
+            *dst = v;
+        }
+    }
+}
+
+static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+static int ilog2(int x) { int s = 0; while ((1 << s) < x) ++s; return s; }
+
+// the direct kernel takes: K <= 1024, no per-k affine, power-of-two remap blocks, 32-bit element offsets
+bool direct_eligible(const StepGemm& g) {
+    if (g.K > 1024 || g.a_kscale) return false;
+    if (g.sak == 1 || g.sbk == 1) return false;   // k-contiguous operands: fragment-shaped loads thrash the TA; LDS-tiled kernel instead
+    if ((g.a_kblk && (!pow2(g.a_kblk) || g.a_kblk < 8)) || (g.b_kblk && (!pow2(g.b_kblk) || g.b_kblk < 8))) return false;
+    if ((g.b_nblk && !pow2(g.b_nblk)) || (g.c_nblk && !pow2(g.c_nblk))) return false;
+    const long lim = 1L << 30;
+    if ((long)g.M * (g.sam < 0 ? -g.sam : g.sam) + (long)g.K * g.sak >= lim) return false;
+    if ((long)g.N * (g.sbn < 0 ? -g.sbn : g.sbn) * (g.b_nblk ? g.b_nstride / g.b_nblk + 1 : 1) + (long)g.K * g.sbk >= lim) return false;
+    return true;
+}
+
+int launch_direct(const StepGemm& g, hipStream_t st) {
+    DirectArgs d;
+    d.tiles_m = cdiv(g.M, 32); d.tiles_n = cdiv(g.N, 32);
+    auto sm = [](int blk, int& sh, int& mask) { if (blk) { sh = ilog2(blk); mask = blk - 1; } else { sh = 31; mask = 0x7fffffff; } };
+    sm(g.a_kblk, d.a_sh, d.a_mask); sm(g.b_kblk, d.b_sh, d.b_mask); sm(g.b_nblk, d.bn_sh, d.bn_mask); sm(g.c_nblk, d.cn_sh, d.cn_mask);
+    // 16-byte operand loads: f32, unit k-stride, everything that moves the address a multiple of 4 elements
+    d.a_vec = !g.a_bf16 && g.sak == 1 && (g.sam % 4 == 0) && (g.sab % 4 == 0) && (((uintptr_t)g.A & 15) == 0) &&
+              (g.a_kblk == 0 || g.a_kstride % 4 == 0) && (g.sab1 % 4 == 0);
+    d.b_vec = !g.b_bf16 && g.sbk == 1 && (g.sbn % 4 == 0) && (g.sbb % 4 == 0) && (((uintptr_t)g.B & 15) == 0) &&
+              (g.b_kblk == 0 || g.b_kstride % 4 == 0) && (g.b_nblk == 0 || g.b_nstride % 4 == 0) && (g.sbb1 % 4 == 0);
+    const long waves = (long)d.tiles_m * d.tiles_n * g.batch;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (g.a_bf16 && g.b_bf16) gemm_direct_kernel<uint16_t, uint16_t><<<grid, 256, 0, st>>>(g, d);
+    else if (g.a_bf16) gemm_direct_kernel<uint16_t, float><<<grid, 256, 0, st>>>(g, d);
+    else if (g.b_bf16) gemm_direct_kernel<float, uint16_t><<<grid, 256, 0, st>>>(g, d);
+    else gemm_direct_kernel<float, float><<<grid, 256, 0, st>>>(g, d);
+    STEP_LAUNCH_CHECK("step_gemm(direct)");
+    return STEP_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const StepGemm& g, hipStream_t st) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
@@ -191,6 +377,7 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
     STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && g.batch > 0, "step_gemm: bad sizes M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
     STEP_REQUIRE(g.A && g.B && g.C, "step_gemm: null operand");
     if (g.scn == 0) g.scn = 1;
+    if (g.splitk < 0 && direct_eligible(g)) g.splitk = 1;      // short contraction: the direct kernel, no split
     if (g.splitk < 0) {            // auto: enough workgroups to fill 256 CUs, at least 4 k-steps each
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         const int bm = (g.N <= 32 && g.M > 64) ? 128 : (g.M <= 32 && g.N > 64) ? 32 : (g.M <= 64 || g.N <= 64) ? 64 : 128;
@@ -201,6 +388,7 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
         g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
     }
     if (g.splitk < 1) g.splitk = 1;
+    if (g.splitk == 1 && direct_eligible(g)) return launch_direct(g, st);
     if (g.splitk > 1) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2 (atomic) and a pre-zeroed/accumulating C");
     }

@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void col_sums_kernel(const float* __restrict__
     if (w == 0 && j < N) cs[(long)b * N + j] = 1.f + red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 // P_f = D^-1 (A + I),  P_b = Dc^-1 (A^T + I)       (model.py:121-130,160); 32x32 tiles, grid (N/32, N/32, B)
+// Writes both supports and their transposes (the adjoint hops read the transposed stack so that the
+// contraction index is never the contiguous one).
 __global__ __launch_bounds__(256) void rw_build_kernel(const float* __restrict__ A, int N, const float* __restrict__ rs,
-                                                       const float* __restrict__ cs, float* __restrict__ Pf, float* __restrict__ Pb) {
+                                                       const float* __restrict__ cs, float* __restrict__ Pf, float* __restrict__ Pb,
+                                                       float* __restrict__ PfT, float* __restrict__ PbT) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -96,13 +99,37 @@ __global__ __launch_bounds__(256) void rw_build_kernel(const float* __restrict__
         int i = i0 + r, j = j0 + tx;
         float a = (i < N && j < N) ? A[base + (long)i * N + j] : 0.f;
         tile[r][tx] = a;
-        if (i < N && j < N) Pf[base + (long)i * N + j] = (a + (i == j ? 1.f : 0.f)) / rs[(long)b * N + i];
+        if (i < N && j < N) {
+            const float v = a + (i == j ? 1.f : 0.f);
+            Pf[base + (long)i * N + j] = v / rs[(long)b * N + i];
+            PbT[base + (long)i * N + j] = v / cs[(long)b * N + j];        // P_b^T[i][j] = P_b[j][i]
+        }
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {                       // P_b[j][i] for the transposed tile
+    for (int r = ty; r < 32; r += 8) {                       // transposed tile: element (i, j) = tile[tx][r]
         int j = j0 + r, i = i0 + tx;
-        if (i < N && j < N) Pb[base + (long)j * N + i] = (tile[tx][r] + (i == j ? 1.f : 0.f)) / cs[(long)b * N + j];
+        if (i < N && j < N) {
+            const float v = tile[tx][r] + (i == j ? 1.f : 0.f);
+            Pb[base + (long)j * N + i] = v / cs[(long)b * N + j];
+            PfT[base + (long)j * N + i] = v / rs[(long)b * N + i];        // P_f^T[j][i] = P_f[i][j]
+        }
     }
+}
+// adaptive support replicated per sample into stack slot 2 (and its transpose)
+__global__ void replicate_adp_kernel(const float* __restrict__ Pa, int N, int B, float* __restrict__ P2, float* __restrict__ PT2) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * N) return;
+    int i = idx / N, j = idx % N;
+    float v = Pa[idx], vt = Pa[(long)j * N + i];
+    for (int b = 0; b < B; ++b) { P2[(long)b * N * N + idx] = v; PT2[(long)b * N * N + idx] = vt; }
+}
+// out[e] = sum_b x[b][e]
+__global__ void sum_batches_kernel(const float* __restrict__ x, long n, int B, float* __restrict__ out) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(long)b * n + idx];
+    out[idx] = s;
 }
 // rdot[row] = sum_k dP[row][k] * P[row][k]
 __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ dP, const float* __restrict__ P, int N,
@@ -390,7 +417,7 @@ struct Carver {
 
 struct Saved {
     float *x_in[NL], *cat[NL], *tf[NL], *sg[NL], *y[NL], *mask[NL], *bnstat[NL];
-    float *Pf, *Pb, *Pa, *Madp, *rs, *cs;
+    float *Pstk, *PTstk, *Pa, *Madp, *rs, *cs;      // stacks: [3 supports f,b,a][B][N][N]
     float *skip, *h1, *h2, *xh, *e1;
     long total;
 };
@@ -407,8 +434,8 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
         s.mask[i] = (i < NL - 1 && dropout) ? cv.take(BN * TOUT[i] * C) : nullptr;
         s.bnstat[i] = cv.take(128);
     }
-    s.Pf = cv.take((long)B * N * N);
-    s.Pb = cv.take((long)B * N * N);
+    s.Pstk = cv.take(3L * B * N * N);
+    s.PTstk = cv.take(3L * B * N * N);
     s.Pa = cv.take((long)N * N);
     s.Madp = cv.take((long)N * N);
     s.rs = cv.take(BN);
@@ -424,7 +451,7 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
 struct Work {
     float *wcat, *bcat, *dwcat, *dbcat;       // [8][64][64], [8][64]
     float *xcat, *pre, *h, *partial, *bsum;
-    float *dcat, *dpre, *dxcat, *dh, *dres, *dxa, *dxb, *dskip, *dPf, *dPb, *dPa, *dM, *rf, *rb, *coef;
+    float *dcat, *dpre, *dxcat, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb, *coef;
     float *d_e1, *d_xh, *d_h2, *d_h1;
     long total;
 };
@@ -451,8 +478,7 @@ Work carve_work(float* base, int B, int N, bool backward) {
         w.dxa = cv.take(BN * 13 * C);
         w.dxb = cv.take(BN * 13 * C);
         w.dskip = cv.take(BN * CS);
-        w.dPf = cv.take((long)B * N * N);
-        w.dPb = cv.take((long)B * N * N);
+        w.dPstk = cv.take(3L * B * N * N);
         w.dPa = cv.take((long)N * N);
         w.dM = cv.take((long)N * N);
         w.rf = cv.take(BN > N ? BN : N);
@@ -475,28 +501,39 @@ int zero(float* p, long n, hipStream_t st) {
     return STEP_OK;
 }
 
-// diffusion hop on cat slots: dst_slot = P^T-contract(src_slot)   Out[b][w][n] = sum_v P[b][v][w] X[b][v][n]
-int nconv_fwd(const float* P, long p_bstride, float* cat, int src, int dst, int B, int N, int T, hipStream_t st) {
-    StepGemm g = gemm_desc(N, T * C, N, P, 1, N, cat + src * C, (long)T * CAT, 1, cat + dst * C, (long)T * CAT);
-    g.batch = B; g.sab = p_bstride; g.sbb = (long)N * T * CAT; g.scb = (long)N * T * CAT;
+// One launch = the same diffusion hop for the three supports (two-level batch: i1 = support, i0 = sample).
+// Forward hop  Out_s[b][w][n] = sum_v P_s[b][v][w] X_s[b][v][n]  reading slot src0 + sstep*s, writing dst0 + 2*s.
+int nconv_fwd3(const float* Pstk, float* cat, int src0, int sstep, int dst0, int B, int N, int T, hipStream_t st) {
+    StepGemm g = gemm_desc(N, T * C, N, Pstk, 1, N, cat + src0 * C, (long)T * CAT, 1, cat + dst0 * C, (long)T * CAT);
+    g.batch = 3 * B; g.batch0 = B;
+    g.sab = (long)N * N; g.sab1 = (long)B * N * N;
+    g.sbb = (long)N * T * CAT; g.sbb1 = (long)sstep * C;
+    g.scb = (long)N * T * CAT; g.scb1 = 2L * C;
     g.b_nblk = C; g.b_nstride = CAT; g.c_nblk = C; g.c_nstride = CAT;
     return step_gemm_launch(g, st);
 }
-// adjoint of the hop: d_dst_slot += sum_w P[b][v][w] d_src_slot[b][w][n]
-int nconv_bwd_data(const float* P, long p_bstride, float* dcat, int src, int dst, int B, int N, int T, hipStream_t st) {
-    StepGemm g = gemm_desc(N, T * C, N, P, N, 1, dcat + src * C, (long)T * CAT, 1, dcat + dst * C, (long)T * CAT);
-    g.batch = B; g.sab = p_bstride; g.sbb = (long)N * T * CAT; g.scb = (long)N * T * CAT;
+// Adjoint hop  dDst_s[b][v][n] += sum_w P_s[b][v][w] dSrc_s[b][w][n]  (reads the transposed stack: A(m=v,k=w) = PT[w][v]).
+// dstep == 0: the three supports accumulate into the same slot -> atomics.
+int nconv_bwd_data3(const float* PTstk, float* dcat, int src0, int dst0, int dstep, int B, int N, int T, hipStream_t st) {
+    StepGemm g = gemm_desc(N, T * C, N, PTstk, 1, N, dcat + src0 * C, (long)T * CAT, 1, dcat + dst0 * C, (long)T * CAT);
+    g.batch = 3 * B; g.batch0 = B;
+    g.sab = (long)N * N; g.sab1 = (long)B * N * N;
+    g.sbb = (long)N * T * CAT; g.sbb1 = 2L * C;
+    g.scb = (long)N * T * CAT; g.scb1 = (long)dstep * C;
     g.b_nblk = C; g.b_nstride = CAT; g.c_nblk = C; g.c_nstride = CAT;
-    g.accumulate = 1;
+    g.accumulate = dstep == 0 ? 2 : 1;
     return step_gemm_launch(g, st);
 }
-// dP[b][v][w] += sum_n X[b][v][n] * dOut[b][w][n]   (x from cat slot xs, dOut from dcat slot ds)
-int nconv_bwd_adj(const float* cat, int xs, const float* dcat, int ds, float* dP, long dp_bstride, int B, int N, int T,
-                  hipStream_t st) {
-    StepGemm g = gemm_desc(N, N, T * C, cat + xs * C, (long)T * CAT, 1, dcat + ds * C, 1, (long)T * CAT, dP, N);
-    g.batch = B; g.sab = (long)N * T * CAT; g.sbb = (long)N * T * CAT; g.scb = dp_bstride;
+// dP_s[b][v][w] += sum_n X_s[b][v][n] * dOut_s[b][w][n]   (x from cat slot xs0 + xstep*s, dOut from dcat slot ds0 + 2*s)
+int nconv_bwd_adj3(const float* cat, int xs0, int xstep, const float* dcat, int ds0, float* dPstk, int B, int N, int T,
+                   hipStream_t st) {
+    StepGemm g = gemm_desc(N, N, T * C, cat + xs0 * C, (long)T * CAT, 1, dcat + ds0 * C, 1, (long)T * CAT, dPstk, N);
+    g.batch = 3 * B; g.batch0 = B;
+    g.sab = (long)N * T * CAT; g.sab1 = (long)xstep * C;
+    g.sbb = (long)N * T * CAT; g.sbb1 = 2L * C;
+    g.scb = (long)N * N; g.scb1 = (long)B * N * N;
     g.a_kblk = C; g.a_kstride = CAT; g.b_kblk = C; g.b_kstride = CAT;
-    g.accumulate = dp_bstride == 0 ? 2 : 1;          // shared (adaptive) adjacency: batches race -> atomics
+    g.accumulate = 1;
     return step_gemm_launch(g, st);
 }
 
@@ -529,12 +566,15 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     // supports (model.py:160-166)
     row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs);
     col_sums_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(adj, N, S.cs);
-    rw_build_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(adj, N, S.rs, S.cs, S.Pf, S.Pb);
+    const long NN = (long)N * N;
+    rw_build_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(adj, N, S.rs, S.cs, S.Pstk, S.Pstk + B * NN, S.PTstk,
+                                                                       S.PTstk + B * NN);
     STEP_LAUNCH_CHECK("rw_build");
     {
         StepGemm g = gemm_desc(N, N, 10, p->nodevec1, 10, 1, p->nodevec2, N, 1, S.Madp, N);
         STEP_TRY(step_gemm_launch(g, st));
         softmax_relu_rows_kernel<<<N, 256, 0, st>>>(S.Madp, N, S.Pa);
+        replicate_adp_kernel<<<g1(NN), 256, 0, st>>>(S.Pa, N, B, S.Pstk + 2 * B * NN, S.PTstk + 2 * B * NN);
         STEP_LAUNCH_CHECK("adp_softmax");
     }
     for (int i = 0; i < NL; ++i) {
@@ -560,12 +600,8 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
             STEP_TRY(step_gemm_launch(g, st));
         }
         if (i == NL - 1) break;
-        STEP_TRY(nconv_fwd(S.Pf, (long)N * N, S.cat[i], 0, 1, B, N, Tout, st));
-        STEP_TRY(nconv_fwd(S.Pf, (long)N * N, S.cat[i], 1, 2, B, N, Tout, st));
-        STEP_TRY(nconv_fwd(S.Pb, (long)N * N, S.cat[i], 0, 3, B, N, Tout, st));
-        STEP_TRY(nconv_fwd(S.Pb, (long)N * N, S.cat[i], 3, 4, B, N, Tout, st));
-        STEP_TRY(nconv_fwd(S.Pa, 0, S.cat[i], 0, 5, B, N, Tout, st));
-        STEP_TRY(nconv_fwd(S.Pa, 0, S.cat[i], 5, 6, B, N, Tout, st));
+        STEP_TRY(nconv_fwd3(S.Pstk, S.cat[i], 0, 0, 1, B, N, Tout, st));      // slots 1,3,5 = P_s z
+        STEP_TRY(nconv_fwd3(S.Pstk, S.cat[i], 1, 2, 2, B, N, Tout, st));      // slots 2,4,6 = P_s (P_s z)
         {   // h = cat @ Wmix^T + b
             StepGemm g = gemm_desc((int)npos, C, CAT, S.cat[i], CAT, 1, p->gconv_w[i], 1, CAT, W.h, C);
             g.bias = p->gconv_b[i];
@@ -623,9 +659,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     STEP_LAUNCH_CHECK("pack_gate");
     STEP_TRY(zero(W.dwcat, NL * 4096, st));
     STEP_TRY(zero(W.dbcat, NL * 64, st));
-    STEP_TRY(zero(W.dPf, (long)B * N * N, st));
-    STEP_TRY(zero(W.dPb, (long)B * N * N, st));
-    STEP_TRY(zero(W.dPa, (long)N * N, st));
+    const long NN = (long)N * N;
+    STEP_TRY(zero(W.dPstk, 3L * B * NN, st));
 
     // ---------------------------------------------------------------- head (model.py:215-220)
     {
@@ -688,17 +723,11 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             STEP_TRY(step_colsum_launch(W.dh, npos, C, C, grads->gconv_b[i], st));
             StepGemm gd = gemm_desc((int)npos, CAT, C, W.dh, C, 1, p->gconv_w[i], CAT, 1, W.dcat, CAT);
             STEP_TRY(step_gemm_launch(gd, st));
-            // diffusion hops: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
-            const float* Ps[3] = {S.Pf, S.Pb, S.Pa};
-            float* dPs[3] = {W.dPf, W.dPb, W.dPa};
-            const long strides[3] = {(long)N * N, (long)N * N, 0};
-            for (int s = 0; s < 3; ++s) {
-                const int s1 = 1 + 2 * s, s2 = 2 + 2 * s;
-                STEP_TRY(nconv_bwd_data(Ps[s], strides[s], W.dcat, s2, s1, B, N, Tout, st));      // d_x1 += P (d_x2)
-                STEP_TRY(nconv_bwd_adj(cat, s1, W.dcat, s2, dPs[s], strides[s], B, N, Tout, st));  // dP += x1 (x) d_x2
-                STEP_TRY(nconv_bwd_adj(cat, 0, W.dcat, s1, dPs[s], strides[s], B, N, Tout, st));   // dP += z  (x) d_x1
-                STEP_TRY(nconv_bwd_data(Ps[s], strides[s], W.dcat, s1, 0, B, N, Tout, st));       // d_z  += P (d_x1)
-            }
+            // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
+            STEP_TRY(nconv_bwd_data3(S.PTstk, W.dcat, 2, 1, 2, B, N, Tout, st));          // d_x1 += P (d_x2)
+            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, st));      // dP += x1 (x) d_x2
+            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, st));      // dP += z  (x) d_x1
+            STEP_TRY(nconv_bwd_data3(S.PTstk, W.dcat, 1, 0, 0, B, N, Tout, st));          // d_z  += sum_s P_s (d_x1_s)
         } else {
             STEP_TRY(zero(W.dcat, npos * CAT, st));
         }
@@ -735,9 +764,10 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     STEP_LAUNCH_CHECK("start_conv_bwd");
 
     // ---------------------------------------------------------------- supports
-    {   // adaptive adjacency softmax(relu(E1 E2), dim=1)
+    {   // adaptive adjacency softmax(relu(E1 E2), dim=1); its gradient is the sum over samples of stack slot 2
+        sum_batches_kernel<<<g1(NN), 256, 0, st>>>(W.dPstk + 2 * B * NN, NN, B, W.dPa);
         row_dot_kernel<<<N, 256, 0, st>>>(W.dPa, S.Pa, N, W.rf);
-        softmax_relu_bwd_kernel<<<g1((long)N * N), 256, 0, st>>>(S.Madp, S.Pa, W.dPa, W.rf, N, W.dM);
+        softmax_relu_bwd_kernel<<<g1(NN), 256, 0, st>>>(S.Madp, S.Pa, W.dPa, W.rf, N, W.dM);
         STEP_LAUNCH_CHECK("adp_bwd");
         StepGemm g1_ = gemm_desc(N, 10, N, W.dM, N, 1, p->nodevec2, 1, N, grads->nodevec1, 10);
         g1_.accumulate = 1;
@@ -746,9 +776,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         g2_.accumulate = 1;
         STEP_TRY(step_gemm_launch(g2_, st));
     }
-    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPf, S.Pf, N, W.rf);
-    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPb, S.Pb, N, W.rb);
-    rw_bwd_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(W.dPf, W.dPb, N, S.rs, S.cs, W.rf, W.rb, dadj);
+    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk, S.Pstk, N, W.rf);
+    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk + B * NN, S.Pstk + B * NN, N, W.rb);
+    rw_bwd_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(W.dPstk, W.dPstk + B * NN, N, S.rs, S.cs, W.rf, W.rb, dadj);
     STEP_LAUNCH_CHECK("rw_bwd");
     return STEP_OK;
 }

@@ -209,3 +209,32 @@ def test_gemm_slot_remap_and_kscale(L):
     L.gemm(A.cuda(), B.cuda(), C, 19, 10, 300, 300, 1, 10, 1, 10, a_kscale=sc.cuda(), a_kshift=sh.cuda(), a_kperiod=50)
     An = A.double().reshape(19, 6, 50) * sc.double()[None, :, None] + sh.double()[None, :, None]
     assert rel_l2(C.cpu(), An.reshape(19, 300) @ B.double()) < 1e-5
+
+
+def test_gemm_two_level_batch(L):
+    """One launch = the same hop for three adjacency stacks (i1) x samples (i0), slot-strided operands."""
+    g = torch.Generator().manual_seed(21)
+    Bn, Nn, T, S = 2, 37, 3, 7
+    P = torch.rand(3, Bn, Nn, Nn, generator=g)
+    cat = torch.randn(Bn, Nn, T, S * 32, generator=g)
+    Pd, catd = P.cuda(), cat.cuda()
+    # slots 2,4,6 = P_s^T-contract(slots 1,3,5)
+    L.gemm(Pd, catd, catd, Nn, T * 32, Nn, 1, Nn, T * S * 32, 1, T * S * 32, batch=3 * Bn, batch0=Bn, sab=Nn * Nn, sab1=Bn * Nn * Nn,
+           sbb=Nn * T * S * 32, sbb1=64, scb=Nn * T * S * 32, scb1=64, b_off=32, c_off=64, b_n=(32, S * 32), c_n=(32, S * 32))
+    got = catd.cpu()
+    for s in range(3):
+        want = torch.einsum("bvw,bvtc->bwtc", P[s].double(), cat[..., 32 + 64 * s:64 + 64 * s].double())
+        assert rel_l2(got[..., 64 + 64 * s:96 + 64 * s], want) < 1e-5, s
+    assert torch.equal(got[..., :64], cat[..., :64])
+    # atomic accumulation of the three supports into one slot, and the k-contiguous (LDS-tiled) two-level path
+    out = torch.zeros(Bn, Nn, T, S * 32, device="cuda")
+    L.gemm(Pd, catd, out, Nn, T * 32, Nn, 1, Nn, T * S * 32, 1, T * S * 32, batch=3 * Bn, batch0=Bn, sab=Nn * Nn, sab1=Bn * Nn * Nn,
+           sbb=Nn * T * S * 32, sbb1=64, scb=Nn * T * S * 32, scb1=0, b_off=32, b_n=(32, S * 32), c_n=(32, S * 32), accumulate=2)
+    want = sum(torch.einsum("bvw,bvtc->bwtc", P[s].double(), got[..., 32 + 64 * s:64 + 64 * s].double()) for s in range(3))
+    assert rel_l2(out.cpu()[..., :32], want) < 1e-5
+    dP = torch.zeros(3, Bn, Nn, Nn, device="cuda")
+    L.gemm(catd, catd, dP, Nn, Nn, T * 32, T * S * 32, 1, 1, T * S * 32, Nn, batch=3 * Bn, batch0=Bn, sab=Nn * T * S * 32, sab1=64,
+           sbb=Nn * T * S * 32, sbb1=64, scb=Nn * Nn, scb1=Bn * Nn * Nn, a_off=32, b_off=64, a_k=(32, S * 32), b_k=(32, S * 32), accumulate=1)
+    for s in range(3):
+        want = torch.einsum("bvtc,bwtc->bvw", got[..., 32 + 64 * s:64 + 64 * s].double(), got[..., 64 + 64 * s:96 + 64 * s].double())
+        assert rel_l2(dP.cpu()[s], want) < 1e-5, s
