@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs
     // in flight in registers while the previous chunk is being consumed.
     // (the vmcnt counter saturates at 63 outstanding loads: two chunks in flight must stay below that)
     constexpr int G = 3, CH = 8 * G;
-    f32x16 acc;
+    // two independent accumulators: consecutive MFMAs never wait on each other's result
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
     const int kfull = K / CH * CH;
     if (kfull > 0) {
         float a[G][4], b[G][4], an[G][4], bn[G][4];
@@ -283,8 +284,10 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs
 #pragma unroll
             for (int q = 0; q < G; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; j += 2) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[q][j] : 0.f, n_ok ? b[q][j] : 0.f, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[q][j + 1] : 0.f, n_ok ? b[q][j + 1] : 0.f, acc2, 0, 0, 0);
+                }
             if (kn < kfull) {
 #pragma unroll
                 for (int q = 0; q < G; ++q)
@@ -293,12 +296,17 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs
             }
         }
     }
-    for (int k0 = kfull; k0 < K; k0 += 8) {          // tail: up to 7 groups, bounds-checked
+    for (int k0 = kfull; k0 < K; k0 += 8) {          // tail: up to G-1 groups, bounds-checked
         float a[4], b[4];
         load_a_tail(k0, a); load_b_tail(k0, b);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[j] : 0.f, n_ok ? b[j] : 0.f, acc, 0, 0, 0);
+        for (int j = 0; j < 4; j += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[j] : 0.f, n_ok ? b[j] : 0.f, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(m_ok ? a[j + 1] : 0.f, n_ok ? b[j + 1] : 0.f, acc2, 0, 0, 0);
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
 
     float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
     if (!n_ok) return;

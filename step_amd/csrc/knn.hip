@@ -49,6 +49,108 @@ __global__ void cosine_diag_kernel(float* sim, int N) {   // only for the sqn_pa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Symmetric Gram matrix of the bf16 hidden states on the bf16 matrix cores:
+//   raw[b][i][j] = sum_k H[b][i][k] H[b][j][k],  K = P*96 (32 256 at PEMS04) -- 6.1 GFLOP per window.
+// 128x128 output tile per workgroup (4 waves x 64x64 = 2x2 MFMA 32x32x16 tiles), only tiles with
+// tm <= tn are computed and mirrored, split-K over grid.z with f32 atomics into the zeroed output.
+// Operands are staged through LDS in 64-deep k-chunks with 16-byte global loads (rows are k-contiguous)
+// and read back as MFMA fragments (lane = row, 8 consecutive k) with ds_read_b128; the 144-byte row
+// pitch keeps the eight 16-byte reads of a lane group on different banks.
+constexpr int GBK = 64;                  // k-chunk
+constexpr int GPITCH = GBK * 2 + 16;     // bytes per staged row
+
+__global__ __launch_bounds__(256) void gram_bf16_kernel(const uint16_t* __restrict__ H, int N, int K, int splitk,
+                                                        float* __restrict__ raw) {
+    __shared__ __attribute__((aligned(16))) char As[128 * GPITCH];
+    __shared__ __attribute__((aligned(16))) char Bs[128 * GPITCH];
+    // upper-triangular tile pair from blockIdx.x
+    const int nt = (N + 127) / 128;
+    int tm = 0, rem = blockIdx.x;
+    while (rem >= nt - tm) { rem -= nt - tm; ++tm; }
+    const int tn = tm + rem;
+    const int b = blockIdx.y;
+    const int zs = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int chunks = (K + GBK - 1) / GBK;
+    const int per = (chunks + splitk - 1) / splitk;
+    const int c0 = zs * per, c1 = min(chunks, c0 + per);
+    const uint16_t* Hb = H + (long)b * N * K;
+    const bool diag = tm == tn;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // staging map: 128 rows x 8 pieces of 16 B = 1024 pieces, 4 per thread
+    u32x4 ra[4], rb[4];
+    auto load = [&](int ck) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = tid + q * 256, row = pc >> 3, kp = (pc & 7) * 8;
+            const int k = ck * GBK + kp;
+            const int gi = tm * 128 + row, gj = tn * 128 + row;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            // K is a multiple of 8 here (96 features per token), so a piece is either fully inside or outside
+            ra[q] = (gi < N && k < K) ? *(const u32x4*)(Hb + (long)gi * K + k) : z;
+            if (!diag) rb[q] = (gj < N && k < K) ? *(const u32x4*)(Hb + (long)gj * K + k) : z;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pc = tid + q * 256, row = pc >> 3, kp = (pc & 7) * 16;
+            *(u32x4*)(As + row * GPITCH + kp) = ra[q];
+            if (!diag) *(u32x4*)(Bs + row * GPITCH + kp) = rb[q];
+        }
+    };
+    const char* Bsrc = diag ? As : Bs;
+    const int r = lane & 31, h = lane >> 5;
+    if (c0 < c1) {
+        load(c0);
+        for (int ck = c0; ck < c1; ++ck) {
+            __syncthreads();
+            store();
+            __syncthreads();
+            if (ck + 1 < c1) load(ck + 1);
+#pragma unroll
+            for (int ks = 0; ks < GBK / 16; ++ks) {
+                bf16x8 a[2], bb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(As + (wr * 64 + i * 32 + r) * GPITCH + ks * 32 + h * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bb[j] = *(const bf16x8*)(Bsrc + (wc * 64 + j * 32 + r) * GPITCH + ks * 32 + h * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = raw + (long)b * N * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gj = tn * 128 + wc * 64 + j * 32 + r;
+            if (gj >= N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int gi = tm * 128 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gi >= N) continue;
+                const float v = acc[i][j][e];
+                atomicAdd(out + (long)gi * N + gj, v);
+                if (!diag) atomicAdd(out + (long)gj * N + gi, v);
+            }
+        }
+}
+
 // One workgroup (1024 threads) per sample.
 __global__ __launch_bounds__(1024) void topk_mask_kernel(const float* __restrict__ sim, int N, int k_total,
                                                          float* __restrict__ adj) {
@@ -145,20 +247,17 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
         step_set_error("knn_graph: memset failed");
         return STEP_ERR_HIP;
     }
-    StepGemm g;
-    memset(&g, 0, sizeof(g));
-    g.M = N; g.N = N; g.K = F; g.batch = B;
-    g.A = hidden; g.sam = F; g.sak = 1; g.sab = (long)N * F; g.a_bf16 = 1;
-    g.B = hidden; g.sbk = 1; g.sbn = F; g.sbb = (long)N * F; g.b_bf16 = 1;
-    g.C = sim; g.ldc = N; g.scn = 1; g.scb = (long)N * N;
-    g.alpha = 1.f; g.accumulate = 2;
-    long tiles = (long)cdiv(N, 64) * cdiv(N, 64) * B;
-    int split = (int)((2048 + tiles - 1) / tiles);
-    int ksteps = cdiv(F, 16);
-    if (split > ksteps / 8) split = ksteps / 8;
-    if (split < 1) split = 1;
-    g.splitk = split;
-    STEP_TRY(step_gemm_launch(g, st));
+    STEP_REQUIRE(F % 8 == 0, "knn_graph: feature length %d must be a multiple of 8", F);
+    {
+        const int nt = cdiv(N, 128);
+        const int pairs = nt * (nt + 1) / 2;
+        int split = (1024 + pairs * B - 1) / (pairs * B);
+        const int chunks = cdiv(F, GBK);
+        if (split > chunks / 4) split = chunks / 4;
+        if (split < 1) split = 1;
+        gram_bf16_kernel<<<dim3(pairs, B, split), 256, 0, st>>>(hidden, N, F, split, sim);
+        STEP_LAUNCH_CHECK("gram_bf16");
+    }
     dim3 grid(cdiv(N, 256) > 4 ? 4 : cdiv(N, 256), N, B);
     cosine_finalize_kernel<<<grid, 256, 0, st>>>(sim, sqnorm_part, N);
     STEP_LAUNCH_CHECK("cosine_finalize");
