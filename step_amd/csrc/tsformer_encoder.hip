@@ -124,7 +124,7 @@ __device__ __forceinline__ void dma_1k(const char* gsrc_lane, uint32_t lds_dst) 
 }
 #define LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(p))
 
-template <int MAXW, bool DROP>
+template <int MAXW, bool DROP, bool PARK>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
@@ -146,6 +146,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     char* kbuf = smem;
     char* vbuf = smem + nkt * 2 * TSF_FRAG;
     char* ring = smem + nkt * 4 * TSF_FRAG;
+    // PARK: the bf16 operand copy of the residual stream (6 fragments per wave) lives in a wave-private LDS
+    // area while the attention loops run, which frees 24 VGPRs for the software-pipelined score tiles
+    char* xpark = ring + 2 * TSF_BLOCK + wave * 6 * TSF_FRAG;
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(ring));
     const int nstage = A.depth * TSF_STAGES;
 
@@ -216,6 +219,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         {
 #pragma unroll
             for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+            if constexpr (PARK) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) *(bf16x8*)(xpark + f * TSF_FRAG + lane * 16) = xb[f];
+            }
             const float* bo = tail + 64 + h * 48;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -227,6 +234,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             if (hd > 0) {
                 blk = stage_begin(g);
                 tail = (const float*)(blk + TSF_TAIL);
+            }
+            if constexpr (PARK) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) xb[f] = lfrag(xpark, f, lane);
             }
             // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
             bf16x8 qb[2];
@@ -268,68 +279,65 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes); the next
-            // key tile's operand fragments are fetched from LDS while the current one is in the matrix pipe
+            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes).  Software pipeline:
+            // the MFMAs of key tile kt+1 are issued before the VALU work on tile kt, so the matrix pipe and
+            // the vector ALU of this wave overlap (the last trip recomputes the final tile, 2 wasted MFMAs)
+            auto score_tile = [&](int kt) -> f32x16 {
+                f32x16 s;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
+                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
+                return s;
+            };
             float mx = -INFINITY;
             {
-                bf16x8 k0 = lfrag(kbuf, 0, lane), k1 = lfrag(kbuf, 1, lane);
+                f32x16 sc = score_tile(0);
 #pragma unroll 1
                 for (int kt = 0; kt < nkt; ++kt) {
-                    const int nx = (kt + 1 < nkt) ? kt + 1 : kt;
-                    bf16x8 n0 = lfrag(kbuf, nx * 2, lane), n1 = lfrag(kbuf, nx * 2 + 1, lane);
-                    f32x16 s;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
-                    s = MFMA_BF16(k0, qb[0], s);
-                    s = MFMA_BF16(k1, qb[1], s);
+                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt);
                     if (kt == nkt - 1) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[i]);
-                    k0 = n0; k1 = n1;
+                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[i]);
+                    sc = sn;
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 
-            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator)
+            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator), same pipeline
             f32x16 o;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
             float lsum = 0.f;
             if constexpr (drop) dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1));
             {
-                bf16x8 k0 = lfrag(kbuf, 0, lane), k1 = lfrag(kbuf, 1, lane);
+                f32x16 sc = score_tile(0);
 #pragma unroll 1
                 for (int kt = 0; kt < nkt; ++kt) {
-                    const int nx = (kt + 1 < nkt) ? kt + 1 : kt;
+                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt);
                     bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
-                    bf16x8 n0 = lfrag(kbuf, nx * 2, lane), n1 = lfrag(kbuf, nx * 2 + 1, lane);
-                    f32x16 s;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
-                    s = MFMA_BF16(k0, qb[0], s);
-                    s = MFMA_BF16(k1, qb[1], s);
                     if (kt == nkt - 1) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) s[i] = -INFINITY;
+                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mx);
+                    for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i] - mx);
                     if constexpr (drop) {
                         // attention-prob dropout acts on the normalised probabilities: keep the
                         // denominator dropout-free (VALU sum) and mask the numerator only
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) lsum += s[i];
-                        dr.apply16(s, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
+                        for (int i = 0; i < 16; ++i) lsum += sc[i];
+                        dr.apply16(sc, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
                     }
-                    bf16x8 p0 = pack_half(s, 0), p1 = pack_half(s, 1);
+                    bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
                     o = MFMA_BF16(v0, p0, o);
                     o = MFMA_BF16(v1, p1, o);
-                    k0 = n0; k1 = n1;
+                    sc = sn;
                 }
             }
             float den;
@@ -352,6 +360,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         if constexpr (drop) {
             // dropout1 on (attention output + b_o); residual re-read from its bf16 operand copy
             dr.base = lsalt ^ 0x51ED27u;
+            if constexpr (PARK) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) xb[f] = lfrag(xpark, f, lane);
+            }
             add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
@@ -452,12 +464,12 @@ __global__ __launch_bounds__(256) void pack_long_history_kernel(const float* __r
     }
 }
 
-template <int MAXW, bool DROP>
+template <int MAXW, bool DROP, bool PARK>
 int launch_enc(const EncArgs& a, hipStream_t st) {
-    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK;
+    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP>,
+        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
@@ -465,7 +477,7 @@ int launch_enc(const EncArgs& a, hipStream_t st) {
         }
         attr_set = true;
     }
-    tsformer_encoder_kernel<MAXW, DROP><<<a.S, a.nkt * 64, lds, st>>>(a);
+    tsformer_encoder_kernel<MAXW, DROP, PARK><<<a.S, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
 }
@@ -489,10 +501,12 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.sqn = sqnorm_part; a.drop_p = dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
     hipStream_t st = (hipStream_t)stream;
     const bool dr = dropout_p > 0.f;
-    if (a.nkt <= 4) return dr ? launch_enc<4, true>(a, st) : launch_enc<4, false>(a, st);
-    if (a.nkt <= 8) return dr ? launch_enc<8, true>(a, st) : launch_enc<8, false>(a, st);
-    if (a.nkt <= 12) return dr ? launch_enc<12, true>(a, st) : launch_enc<12, false>(a, st);
-    return dr ? launch_enc<16, true>(a, st) : launch_enc<16, false>(a, st);
+    // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
+    if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);
+    if (a.nkt <= 8) return dr ? launch_enc<8, true, true>(a, st) : launch_enc<8, false, true>(a, st);
+    if (a.nkt <= 11) return dr ? launch_enc<12, true, true>(a, st) : launch_enc<12, false, true>(a, st);
+    if (a.nkt <= 12) return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
+    return dr ? launch_enc<16, true, false>(a, st) : launch_enc<16, false, false>(a, st);
 }
 
 extern "C" int step_pack_long_history(const float* x, int B, int L, int N, int C, int ch, float* out, void* stream) {
