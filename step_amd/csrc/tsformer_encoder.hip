@@ -50,8 +50,10 @@ __device__ __forceinline__ bf16x8 pack_half(const f32x16& v, int s) {
     return pack8(t);
 }
 
-// dropout keep-mask bits: one 32-bit mix yields four 8-bit Bernoulli draws (p_eff = thresh/256;
-// the survivor scale uses p_eff, so the estimator stays unbiased)
+// dropout keep-mask bits: a per-lane xorshift32 stream (6 full-rate VALU ops per 32 bits, no integer
+// multiplies in the hot loops) yields four 8-bit Bernoulli draws per step (p_eff = thresh/256; the
+// survivor scale uses p_eff, so the estimator stays unbiased).  The stream is re-seeded per
+// (sequence, layer, site, token) with a multiplicative hash, so results are launch-deterministic.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
@@ -60,25 +62,44 @@ struct Dropper {
     uint32_t base;      // seed ^ per-(seq, layer, site) salt
     uint32_t thresh;    // keep iff draw8 >= thresh
     float scale;        // 1/(1-p_eff)
-    __device__ __forceinline__ void apply16(f32x16& v, uint32_t elem_salt) const {
+    uint32_t st;        // xorshift state
+    __device__ __forceinline__ void seed(uint32_t elem_salt) { st = mix32(base + elem_salt * 0x9E3779B1u) | 1u; }
+    __device__ __forceinline__ uint32_t next() {
+        st ^= st << 13; st ^= st >> 17; st ^= st << 5;
+        return st;
+    }
+    // 16 accumulator registers of this lane; the stream must have been seeded by the caller
+    __device__ __forceinline__ void apply16(f32x16& v) {
 #pragma unroll
         for (int i = 0; i < 16; i += 4) {
-            const uint32_t r = mix32(base + (elem_salt + (uint32_t)i) * 0x9E3779B1u);
+            const uint32_t r = next();
             v[i] = ((r & 0xffu) >= thresh) ? v[i] * scale : 0.f;
             v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
             v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] * scale : 0.f;
             v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] * scale : 0.f;
         }
     }
+    // unscaled variant (the caller folds the survivor scale into a later multiply)
+    __device__ __forceinline__ void mask16(f32x16& v) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const uint32_t r = next();
+            v[i] = ((r & 0xffu) >= thresh) ? v[i] : 0.f;
+            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] : 0.f;
+            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] : 0.f;
+            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] : 0.f;
+        }
+    }
 };
 
 // training-mode tail of a sub-layer: acc = dropout(acc) + x, with x taken from the bf16 operand
 // copy of the residual stream (the f32 copy is not kept live across the sub-layer)
-__device__ __forceinline__ void add_residual_bf16(f32x16 (&acc)[3], const bf16x8 (&xb)[6], const Dropper& dr,
+__device__ __forceinline__ void add_residual_bf16(f32x16 (&acc)[3], const bf16x8 (&xb)[6], Dropper& dr,
                                                   uint32_t salt) {
+    dr.seed(salt);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        dr.apply16(acc[t], salt + (uint32_t)(t * 16));
+        dr.apply16(acc[t]);
         u32x4 lo = __builtin_bit_cast(u32x4, xb[2 * t]), hi = __builtin_bit_cast(u32x4, xb[2 * t + 1]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -194,8 +215,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             }
         if constexpr (drop) {
             dr.base = seq_salt ^ 0xA511E9B3u;
+            dr.seed((uint32_t)(tok * 2 + h));
 #pragma unroll
-            for (int t = 0; t < 3; ++t) dr.apply16(xT[t], (uint32_t)(tok * 96 + h * 48 + t * 16));
+            for (int t = 0; t < 3; ++t) dr.apply16(xT[t]);
         }
         const float sc = 9.797958971132712f;   // sqrt(96), transformer_layers.py:15
 #pragma unroll
@@ -243,13 +265,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             bf16x8 qb[2];
             {
                 f32x16 q;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) q[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(lfrag(blk, ks, lane), xb[ks], q);
                 const float* bq = tail + h * 16;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) q[i] += bq[i];
+                for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(lfrag(blk, ks, lane), xb[ks], q);
                 qb[0] = pack_half(q, 0);
                 qb[1] = pack_half(q, 1);
             }
@@ -266,13 +286,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T
             {
                 f32x16 vv;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) vv[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], lfrag(blk, 12 + ks, lane), vv);
                 const float bv = tail[32 + c];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) vv[i] += bv;
+                for (int i = 0; i < 16; ++i) vv[i] = bv;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], lfrag(blk, 12 + ks, lane), vv);
                 *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(vv, 0);
                 *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(vv, 1);
             }
@@ -282,43 +300,46 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes).  Software pipeline:
             // the MFMAs of key tile kt+1 are issued before the VALU work on tile kt, so the matrix pipe and
             // the vector ALU of this wave overlap (the last trip recomputes the final tile, 2 wasted MFMAs)
-            auto score_tile = [&](int kt) -> f32x16 {
-                f32x16 s;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] = 0.f;
-                s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], s);
-                s = MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
-                return s;
+            auto score_tile = [&](int kt, const f32x16& init) -> f32x16 {
+                f32x16 s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], init);
+                return MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
             };
             float mx = -INFINITY;
             {
-                f32x16 sc = score_tile(0);
+                f32x16 zero;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+                f32x16 sc = score_tile(0, zero);
 #pragma unroll 1
                 for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt);
+                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt, zero);
                     if (kt == nkt - 1) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
                             if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[i]);
+                    for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[i]), sc[i + 1]);     // v_max3_f32
                     sc = sn;
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 
-            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator), same pipeline
+            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator), same pipeline;
+            // the subtraction of the row maximum rides in the MFMA accumulator (C = -max on every row)
             f32x16 o;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
             float lsum = 0.f;
-            if constexpr (drop) dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1));
+            if constexpr (drop) { dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1)); dr.seed((uint32_t)(tok * 2 + h)); }
             {
-                f32x16 sc = score_tile(0);
+                f32x16 nmx;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nmx[i] = -mx;
+                f32x16 sc = score_tile(0, nmx);
 #pragma unroll 1
                 for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt);
+                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt, nmx);
                     bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
                     if (kt == nkt - 1) {
 #pragma unroll
@@ -326,13 +347,13 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                             if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i] - mx);
+                    for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
                     if constexpr (drop) {
-                        // attention-prob dropout acts on the normalised probabilities: keep the
-                        // denominator dropout-free (VALU sum) and mask the numerator only
+                        // attention-prob dropout acts on the normalised probabilities: keep the denominator
+                        // dropout-free (VALU sum), mask the numerator only; the survivor scale is folded into 1/den
 #pragma unroll
                         for (int i = 0; i < 16; ++i) lsum += sc[i];
-                        dr.apply16(sc, (uint32_t)((tok * 16 + kt) * 32 + h * 16));
+                        dr.mask16(sc);
                     }
                     bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
                     o = MFMA_BF16(v0, p0, o);
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             }
             float den;
             if constexpr (drop) {
-                den = lsum + __shfl_xor(lsum, 32, 64);
+                den = (lsum + __shfl_xor(lsum, 32, 64)) * (1.0f / dr.scale);
             } else {
                 den = __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
             }
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int f = 0; f < 6; ++f) xb[f] = lfrag(xpark, f, lane);
             }
-            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
+            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 2 + h));
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
 
@@ -390,14 +411,14 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 f32x16 hh;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) hh[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(lfrag(blk, cc * 12 + ks, lane), xb[ks], hh);
                 const float* b1 = tail + (cc * 2 + h) * 16;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i] + b1[i], 0.f);
-                if constexpr (drop) dr.apply16(hh, (uint32_t)((tok * 12 + j * 2 + cc) * 32 + h * 16));
+                for (int i = 0; i < 16; ++i) hh[i] = b1[i];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(lfrag(blk, cc * 12 + ks, lane), xb[ks], hh);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i], 0.f);
+                if constexpr (drop) dr.apply16(hh);
                 bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         }
         if constexpr (drop) {
             dr.base = lsalt ^ 0x9E3779B9u;
-            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 96 + h * 48));
+            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 2 + h));
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN2 params ride in the last ffn block
 #pragma unroll
