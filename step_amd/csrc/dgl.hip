@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void fc_post_bn3_kernel(float* __restrict__ gp
 __global__ __launch_bounds__(256) void bn3_relu_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ gpre, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ stat,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ dbias, float* __restrict__ dgpre) {
+                                                           float* __restrict__ dbias, float* __restrict__ dgpre,
+                                                           float* __restrict__ dgpreT) {
     __shared__ double r1[256], r2[256];
     const int j = blockIdx.x, tid = threadIdx.x;
     const float mean = stat[2 * EMB + j], rstd = stat[3 * EMB + j];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void bn3_relu_bwd_kernel(const float* __restri
         float dh = k * (dg[(long)n * EMB + j] - m1 - xh * m2);
         float v = pre > 0.f ? dh : 0.f;
         dgpre[(long)n * EMB + j] = v;
+        dgpreT[(long)j * N + n] = v;          // [EMB][N]: node index contiguous
         sb += v;
     }
     if (tid == 0) { dgamma[j] += (float)r2[0]; dbeta[j] += (float)r1[0]; }
@@ -561,7 +563,7 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
     if (!backward) return part;
-    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + (long)N * EMB + 256;
+    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + 256;
 }
 
 static void carve_saved(float* saved, int N, int T, float** a1, float** a2, float** gpre, float** st1, float** st2, float** st3) {
@@ -624,9 +626,10 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     float* d_a1 = d_a2 + (long)N * 16 * T2;
     float* wraw = d_a1 + (long)N * 8 * T1;
     float* dgpre = wraw + (long)EMB * K;
-    float* coef = dgpre + (long)N * EMB;
+    float* dgpreT = dgpre + (long)N * EMB;
+    float* coef = dgpreT + (long)N * EMB;
     // BN3 + ReLU backward, fc bias gradient
-    bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre);
+    bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT);
     STEP_LAUNCH_CHECK("bn3_bwd");
     // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
     {
@@ -637,7 +640,7 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     }
     // d(BN2 output) = dgpre @ fc_w
     {
-        StepGemm gm = gemm_desc(N, (int)K, EMB, dgpre, EMB, 1, p->fc_w, K, 1, d_a2, K);
+        StepGemm gm = gemm_desc(N, (int)K, EMB, dgpreT, 1, N, p->fc_w, K, 1, d_a2, K);     // A(m=n, k=o) = dgpreT[o][n]
         STEP_TRY(step_gemm_launch(gm, st));
     }
     // BN2 backward (+ReLU mask) in place -> dz2

@@ -40,11 +40,12 @@ __global__ void start_conv_kernel(const float* __restrict__ hist, int B, int N, 
     }
     x0[idx] = v;
 }
-__global__ void start_conv_bwd_kernel(const float* __restrict__ hist, int B, int N, int Cin, const float* __restrict__ dx0,
-                                      float* __restrict__ dw, float* __restrict__ db) {
-    // one wave per group of positions; lane = channel pair handling; simple: thread = (chunk, c)
+__global__ __launch_bounds__(256) void start_conv_bwd_kernel(const float* __restrict__ hist, int B, int N, int Cin,
+                                                             const float* __restrict__ dx0, float* __restrict__ dw,
+                                                             float* __restrict__ db) {
+    __shared__ float red[8][96];
     const int c = threadIdx.x & 31;
-    const int sub = threadIdx.x >> 5;                       // 8 sub-rows per block
+    const int sub = threadIdx.x >> 5;                       // 8 position sub-rows per block
     long npos = (long)B * N * 13;
     float a0 = 0.f, a1 = 0.f, ab = 0.f;
     for (long p = (long)blockIdx.x * 8 + sub; p < npos; p += (long)gridDim.x * 8) {
@@ -58,9 +59,15 @@ __global__ void start_conv_bwd_kernel(const float* __restrict__ hist, int B, int
             a0 += d * src[0]; a1 += d * src[1];
         }
     }
-    atomicAdd(&dw[c * 2], a0);
-    atomicAdd(&dw[c * 2 + 1], a1);
-    atomicAdd(&db[c], ab);
+    red[sub][c] = a0; red[sub][32 + c] = a1; red[sub][64 + c] = ab;
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+        const int cc = threadIdx.x & 31, kind = threadIdx.x >> 5;
+        if (kind == 2) atomicAdd(&db[cc], s); else atomicAdd(&dw[cc * 2 + kind], s);
+    }
 }
 
 // degree vectors: rs[b][i] = 1 + sum_j A[b][i][j] ; cs[b][j] = 1 + sum_i A[b][i][j]
@@ -376,12 +383,24 @@ __global__ void head_combine_kernel(const float* __restrict__ skip, const float*
     if (idx >= n) return;
     xh[idx] = fmaxf(skip[idx] + bsum[idx % CS] + h2[idx], 0.f);
 }
-__global__ void add_bias_vectors_kernel(float* __restrict__ out, const float* const* __restrict__ srcs, int count, int n) {
+struct Ptr8 { const float* p[8]; };
+struct MPtr8 { float* p[8]; };
+// out[i] = sum of the 8 skip-conv biases
+__global__ void sum8_kernel(float* __restrict__ out, Ptr8 srcs, int n) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < count; ++k) s += srcs[k][i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += srcs.p[k][i];
     out[i] = s;
+}
+// dst_k[i] += v[i] for the 8 skip-conv bias gradients
+__global__ void add_to8_kernel(MPtr8 dst, const float* __restrict__ v, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = v[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst.p[k][i] += x;
 }
 // in place: d *= (y > 0)
 __global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, long n) {
@@ -626,8 +645,9 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         g2.bias = p->fc_his2_b; g2.relu = 1;
         STEP_TRY(step_gemm_launch(g2, st));
         // sum of the 8 skip biases
-        if (zero(W.bsum, CS, st)) return STEP_ERR_HIP;
-        for (int i = 0; i < NL; ++i) STEP_TRY(step_colsum_launch(p->skip_b[i], 1, CS, CS, W.bsum, st));
+        Ptr8 sb;
+        for (int i = 0; i < NL; ++i) sb.p[i] = p->skip_b[i];
+        sum8_kernel<<<1, 256, 0, st>>>(W.bsum, sb, CS);
         head_combine_kernel<<<g1(BN * CS), 256, 0, st>>>(S.skip, W.bsum, S.h2, BN * CS, S.xh);
         STEP_LAUNCH_CHECK("head_combine");
         StepGemm g3 = gemm_desc((int)BN, CE, CS, S.xh, CS, 1, p->end1_w, 1, CS, S.e1, CE);
@@ -682,7 +702,13 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
         STEP_TRY(step_gemm_launch(gx, st));
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_xh, S.xh, BN * CS);       // = d skip = d h2 (pre-mask)
-        for (int i = 0; i < NL; ++i) STEP_TRY(step_colsum_launch(W.d_xh, BN, CS, CS, grads->skip_b[i], st));
+        {   // the 8 skip biases all receive colsum(d skip)
+            STEP_TRY(zero(W.bsum, CS, st));
+            STEP_TRY(step_colsum_launch(W.d_xh, BN, CS, CS, W.bsum, st));
+            MPtr8 gb;
+            for (int i = 0; i < NL; ++i) gb.p[i] = grads->skip_b[i];
+            add_to8_kernel<<<1, 256, 0, st>>>(gb, W.bsum, CS);
+        }
         // fc_his
         if (hipMemcpyAsync(W.d_h2, W.d_xh, (size_t)BN * CS * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
             step_set_error("gwnet_backward: copy failed");
@@ -760,7 +786,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     for (int i = 0; i < NL; ++i)
         unpack_gate_grad_kernel<<<16, 256, 0, st>>>(W.dwcat + i * 4096, W.dbcat + i * 64, grads->filter_w[i], grads->filter_b[i],
                                                     grads->gate_w[i], grads->gate_b[i]);
-    start_conv_bwd_kernel<<<256, 256, 0, st>>>(hist, B, N, Cin, dx_next, grads->start_w, grads->start_b);
+    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx_next, grads->start_w, grads->start_b);
     STEP_LAUNCH_CHECK("start_conv_bwd");
 
     // ---------------------------------------------------------------- supports
