@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
 template <typename T>
 __device__ __forceinline__ float ld_elem(const void* p, long idx) {
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
     constexpr int TN = BN / WN / 32;
     constexpr int LDA = BM + 4;           // +4 words: k-rows land on different banks
     constexpr int LDB = BN + 4;
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
+    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -57,58 +57,133 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
     const char* Ab = (const char*)g.A + ((long)i0 * g.sab + (long)i1 * g.sab1) * (long)sizeof(TA);
     const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * (long)sizeof(TB);
 
-    // loader maps: make the thread index run along whichever dimension is contiguous
-    constexpr int AE = BM * BK / 256;     // elements per thread
-    constexpr int BE = BN * BK / 256;
+    // Loader: every thread moves groups of 4 elements that are consecutive along the operand's contiguous
+    // dimension (k when the k-stride is 1, otherwise m / n); a group is one 16-byte global load when the
+    // alignment conditions hold (checked once, wave-uniform) and 4 bounds-checked scalar loads otherwise.
+    constexpr int GA = BM * BK / 4 / 256;     // groups per thread
+    constexpr int GB = BN * BK / 4 / 256;
     const bool a_kc = (g.sak == 1);
     const bool b_kc = (g.sbk == 1);
+    const bool f32a = sizeof(TA) == 4, f32b = sizeof(TB) == 4;
+    const bool a_al = f32a && (((uintptr_t)g.A & 15) == 0) && g.sab % 4 == 0 && g.sab1 % 4 == 0;
+    const bool b_al = f32b && (((uintptr_t)g.B & 15) == 0) && g.sbb % 4 == 0 && g.sbb1 % 4 == 0;
+    const bool a_vec = a_al && (a_kc ? (g.sam % 4 == 0 && (g.a_kblk == 0 || (g.a_kblk % 4 == 0 && g.a_kstride % 4 == 0)))
+                                     : (g.sam == 1 && g.sak % 4 == 0));
+    const bool b_vec = b_al && (b_kc ? (g.sbn % 4 == 0 && (g.b_kblk == 0 || (g.b_kblk % 4 == 0 && g.b_kstride % 4 == 0)) &&
+                                        (g.b_nblk == 0 || g.b_nstride % 4 == 0))
+                                     : (g.sbn == 1 && g.sbk % 4 == 0 && (g.b_nblk == 0 || (g.b_nblk % 4 == 0 && g.b_nstride % 4 == 0))));
 
-    float ra[AE], rb[BE];
+    float ra[GA][4], rb[GB][4];
 
+    auto a_elem = [&](int gm, int gk) -> float {
+        float v = 0.f;
+        if (gm < g.M && gk < kend) {
+            long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+            v = ld_elem<TA>(Ab, (long)gm * g.sam + ki * g.sak);
+            if (g.a_kscale) { int c = gk / g.a_kperiod; v = v * g.a_kscale[c] + g.a_kshift[c]; }
+        }
+        return v;
+    };
+    auto b_elem = [&](int gk, int gn) -> float {
+        float v = 0.f;
+        if (gn < g.N && gk < kend) {
+            long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+            long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+            v = ld_elem<TB>(Bb, ki * g.sbk + ni * g.sbn);
+        }
+        return v;
+    };
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < AE; ++r) {
-            int e = tid + r * 256;
-            int kk, mm;
-            if (a_kc) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
-            int gm = m0 + mm, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < g.M && gk < kend) {
-                long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
-                v = ld_elem<TA>(Ab, (long)gm * g.sam + ki * g.sak);
-                if (g.a_kscale) { int c = gk / g.a_kperiod; v = v * g.a_kscale[c] + g.a_kshift[c]; }
+        for (int r = 0; r < GA; ++r) {
+            const int e4 = tid + r * 256;
+            if (a_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, mm = e4 / (BK / 4);
+                const int gm = m0 + mm, gk = k0 + kk;
+                if (a_vec && gm < g.M && gk + 3 < kend) {
+                    long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+                    float4 t = *(const float4*)((const float*)Ab + (long)gm * g.sam + ki);
+                    ra[r][0] = t.x; ra[r][1] = t.y; ra[r][2] = t.z; ra[r][3] = t.w;
+                    if (g.a_kscale) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { int c = (gk + i) / g.a_kperiod; ra[r][i] = ra[r][i] * g.a_kscale[c] + g.a_kshift[c]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[r][i] = a_elem(gm, gk + i);
+                }
+            } else {
+                const int mm = (e4 % (BM / 4)) * 4, kk = e4 / (BM / 4);
+                const int gm = m0 + mm, gk = k0 + kk;
+                if (a_vec && gm + 3 < g.M && gk < kend) {
+                    long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+                    float4 t = *(const float4*)((const float*)Ab + gm + ki * g.sak);
+                    ra[r][0] = t.x; ra[r][1] = t.y; ra[r][2] = t.z; ra[r][3] = t.w;
+                    if (g.a_kscale) {
+                        int c = gk / g.a_kperiod;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ra[r][i] = ra[r][i] * g.a_kscale[c] + g.a_kshift[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[r][i] = a_elem(gm + i, gk);
+                }
             }
-            ra[r] = v;
         }
 #pragma unroll
-        for (int r = 0; r < BE; ++r) {
-            int e = tid + r * 256;
-            int kk, nn;
-            if (b_kc) { kk = e % BK; nn = e / BK; } else { nn = e % BN; kk = e / BN; }
-            int gn = n0 + nn, gk = k0 + kk;
-            float v = 0.f;
-            if (gn < g.N && gk < kend) {
-                long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
-                long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
-                v = ld_elem<TB>(Bb, ki * g.sbk + ni * g.sbn);
+        for (int r = 0; r < GB; ++r) {
+            const int e4 = tid + r * 256;
+            if (b_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, nn = e4 / (BK / 4);
+                const int gn = n0 + nn, gk = k0 + kk;
+                if (b_vec && gn < g.N && gk + 3 < kend) {
+                    long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+                    long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+                    float4 t = *(const float4*)((const float*)Bb + ki + ni * g.sbn);
+                    rb[r][0] = t.x; rb[r][1] = t.y; rb[r][2] = t.z; rb[r][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb[r][i] = b_elem(gk + i, gn);
+                }
+            } else {
+                const int nn = (e4 % (BN / 4)) * 4, kk = e4 / (BN / 4);
+                const int gn = n0 + nn, gk = k0 + kk;
+                if (b_vec && gn + 3 < g.N && gk < kend) {
+                    long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+                    long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+                    float4 t = *(const float4*)((const float*)Bb + ki * g.sbk + ni);
+                    rb[r][0] = t.x; rb[r][1] = t.y; rb[r][2] = t.z; rb[r][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb[r][i] = b_elem(gk, gn + i);
+                }
             }
-            rb[r] = v;
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int r = 0; r < AE; ++r) {
-            int e = tid + r * 256;
-            int kk, mm;
-            if (a_kc) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
-            As[kk * LDA + mm] = ra[r];
+        for (int r = 0; r < GA; ++r) {
+            const int e4 = tid + r * 256;
+            if (a_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, mm = e4 / (BK / 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) As[(kk + i) * LDA + mm] = ra[r][i];
+            } else {
+                const int mm = (e4 % (BM / 4)) * 4, kk = e4 / (BM / 4);
+                *(float4*)&As[kk * LDA + mm] = make_float4(ra[r][0], ra[r][1], ra[r][2], ra[r][3]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < BE; ++r) {
-            int e = tid + r * 256;
-            int kk, nn;
-            if (b_kc) { kk = e % BK; nn = e / BK; } else { nn = e % BN; kk = e / BN; }
-            Bs[kk * LDB + nn] = rb[r];
+        for (int r = 0; r < GB; ++r) {
+            const int e4 = tid + r * 256;
+            if (b_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, nn = e4 / (BK / 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Bs[(kk + i) * LDB + nn] = rb[r][i];
+            } else {
+                const int nn = (e4 % (BN / 4)) * 4, kk = e4 / (BN / 4);
+                *(float4*)&Bs[kk * LDB + nn] = make_float4(rb[r][0], rb[r][1], rb[r][2], rb[r][3]);
+            }
         }
     };
 
@@ -392,7 +467,7 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
         const int bn = (g.N <= 32 && g.M > 64) ? 32 : (g.M <= 32 && g.N > 64) ? 128 : (g.M <= 64 || g.N <= 64) ? 64 : 128;
         long tiles = (long)cdiv(g.M, bm) * cdiv(g.N, bn) * g.batch;
         long want = (768 + tiles - 1) / tiles;
-        long maxs = cdiv(g.K, 16) / 4;
+        long maxs = cdiv(g.K, BK) / 2;
         g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
     }
     if (g.splitk < 1) g.splitk = 1;

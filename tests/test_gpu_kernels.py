@@ -28,7 +28,9 @@ def test_mfma_lane_maps(L):
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(70, 50, 33, False, False), (307, 307, 384, True, False),
                                          (129, 257, 1000, False, True), (33, 100, 2912, True, True),
-                                         (500, 32, 32, False, False), (32, 224, 5000, True, False)])
+                                         (500, 32, 32, False, False), (32, 224, 5000, True, False),
+                                         (256, 128, 2048, False, True), (128, 64, 1100, True, False), (64, 256, 1536, False, False),
+                                         (260, 132, 2052, True, True)])
 def test_gemm_layouts(L, M, N, K, ta, tb):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
