@@ -23,6 +23,7 @@ CONFIGS = {
     "STEP_PEMS04": dict(N=307, L=288 * 7 * 2, T_train=13599, T_all=16992, B=8, k=10),
     "STEP_PEMS07": dict(N=883, L=288 * 7, T_train=16513, T_all=28224, B=4, k=10),
     "STEP_METR-LA": dict(N=207, L=288 * 7, T_train=23990, T_all=34272, B=2, k=10),
+    "SYNTH_4096": dict(N=4096, L=288 * 7, T_train=16513, T_all=28224, B=1, k=10),      # BASELINE config 5 (N-scaling stress)
 }
 
 
@@ -94,6 +95,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
+    ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.batch:
@@ -121,7 +123,11 @@ def main():
     if world > 1:
         model.enable_native_data_parallel()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)        # step/STEP_PEMS04.py:90-96
+    if args.torch_optim:
+        opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)    # step/STEP_PEMS04.py:90-96
+    else:
+        from step_amd.optim import FusedAdamClip
+        opt = FusedAdamClip(model, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8, max_norm=3.0)   # same rule, one fused pass
     dser = torch.from_numpy(data).to(dev)
     rng = np.random.default_rng(1234 + rank)
     nb = args.steps + args.warmup
@@ -140,7 +146,8 @@ def main():
         pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
         loss = step_loss(pred[..., [0]] * std + mean, fut[..., [0]] * std + mean, theta, knn, coef, null_val=0.0)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)                        # STEP_PEMS04.py:103-105
+        if args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)                    # STEP_PEMS04.py:103-105
         opt.step()
         return loss
 

@@ -170,6 +170,16 @@ int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* h
                         const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
                         float* dadj, int dropout, void* stream);
 
+/* ---------------------------------------------------------------- optimizer side ---------
+ * clip_grad_norm_(max_norm) + Adam (L2 weight decay, bias correction, eps after sqrt) on flat f32 buffers
+ * of n elements; replaces easytorch's torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step for the
+ * native module (cfg step/STEP_PEMS04.py:90-106).  step >= 1 is the Adam step count after this update.
+ * work: step_adam_work_floats() floats of scratch; out_norm (nullable) receives the pre-clip gradient norm. */
+long step_adam_work_floats(void);
+int step_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float max_norm, float* work, float* out_norm,
+                   void* stream);
+
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on
  * (cdna_hip_programming.md section 3).  out: int32[8] failure counters, all zero when ok. */

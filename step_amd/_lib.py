@@ -69,6 +69,8 @@ _SIGS = {
     "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),
     "step_gwnet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _vp]),
     "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp]),
+    "step_adam_work_floats": (_l, []),
+    "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,48 @@
+"""Fused clip_grad_norm_ + Adam for the native STEP module (one pass over flat buffers, libstep_hip).
+
+Drop-in for the pair of torch calls the reference's training loop makes through easytorch
+(``CFG.TRAIN.CLIP_GRAD_PARAM`` + ``CFG.TRAIN.OPTIM``, reference ``step/STEP_PEMS04.py:90-106``): same update
+rule as ``torch.optim.Adam`` (L2 weight decay folded into the gradient, bias-corrected moments, eps added
+after the square root) preceded by ``torch.nn.utils.clip_grad_norm_``.  Parameters that receive no gradient
+(the reference leaves them at ``grad=None``, so torch's Adam skips them) are not part of the flat buffer.
+"""
+import torch
+
+from . import _lib
+
+
+class FusedAdamClip:
+    def __init__(self, model, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None):
+        self.model = model
+        self.flat = model._flat_param if model._flat_param is not None else model.flatten_parameters()
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]   # lr schedulers edit this
+        self.max_norm = max_norm
+        self.step_count = 0
+        self.work = torch.empty(int(_lib.lib().step_adam_work_floats()), device=self.flat.device)
+        self.grad_norm = torch.zeros(1, device=self.flat.device)
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad(set_to_none=set_to_none)
+        self.model._flat_grad = None
+
+    def step(self):
+        g = self.model._flat_grad
+        if g is None:
+            raise RuntimeError("FusedAdamClip.step(): no native backward has run since zero_grad()")
+        pg = self.param_groups[0]
+        self.step_count += 1
+        _lib.call("step_adam_clip", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                  self.flat.numel(), float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
+                  float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(self.work),
+                  _lib.ptr(self.grad_norm), _lib.stream())
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = sd["param_groups"]

@@ -116,6 +116,7 @@ class _StepFunction(torch.autograd.Function):
         L.call("step_dgl_global_backward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
                L.ptr(gwork), ctypes.byref(dg_grads), st)
         model._reduce_flat_grads(flat)
+        model._flat_grad = flat
         ctx.held = None
         return (None, None, None, None) + tuple(views[k] for k in layout["order"])
 
@@ -137,6 +138,8 @@ class STEP(nn.Module):
         self._process_group = None
         self._layout = None
         self._last = {}
+        self._flat_param = None
+        self._flat_grad = None
 
     def load_pre_trained_model(self):
         """step.py:27-35: load {"model_state_dict": ...} and freeze."""
@@ -166,6 +169,20 @@ class STEP(nn.Module):
                 off += (n + 3) & ~3
             self._layout = {"items": items, "order": order, "total": off}
         return self._layout
+
+    def flatten_parameters(self):
+        """Re-home every parameter that receives a gradient into ONE flat device buffer (same order and
+        offsets as the flat gradient buffer), so the fused clip+Adam kernel updates the model in one pass.
+        Call after the module is on its device; parameters keep their identity, names, shapes and values."""
+        lay = self._grad_layout()
+        dev = self.backend.nodevec1.device
+        flat = torch.zeros(lay["total"], device=dev, dtype=torch.float32)
+        for k, v in self._trainable():
+            o, n, shape = lay["items"][k]
+            flat[o:o + n].copy_(v.detach().reshape(-1))
+            v.data = flat[o:o + n].view(shape)
+        self._flat_param = flat
+        return flat
 
     def enable_native_data_parallel(self, process_group=None):
         """Average the flat gradient buffer over ranks with ONE RCCL all-reduce per step inside backward

@@ -197,3 +197,48 @@ def test_step_device_noise_and_dropout_run():
     assert 0.2 < dens < 0.8
     assert torch.equal(out[0][1], out[1][1])          # same seed -> same graph sample
     assert rel_l2(out[0][0].cpu(), out[1][0].cpu()) < 1e-4
+
+
+def test_fused_adam_clip_matches_torch():
+    """step_adam_clip == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over several steps, and the flattened
+    parameters keep driving the native forward."""
+    from step_amd.optim import FusedAdamClip
+    g = load_golden("step_tiny")
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    hist, long_hist, fut = inputs_of(g)
+
+    def run(fused):
+        torch.manual_seed(0)
+        model = build_native(g)
+        model.train()
+        model.backend.dropout = 0.0
+        model.tsformer.dropout_p = 0.0
+        model._noise_override = g["in.u"]
+        params = [p for p in model.parameters() if p.requires_grad]
+        if fused:
+            opt = FusedAdamClip(model, lr=2e-3, weight_decay=1e-5, eps=1e-8, max_norm=3.0)
+        else:
+            opt = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-5, eps=1e-8)
+        losses = []
+        for it in range(4):
+            opt.zero_grad(set_to_none=True)
+            pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
+            loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+            loss.backward()
+            if not fused:
+                torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)
+            opt.step()
+            losses.append(float(loss))
+        return losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+
+    l_t, p_t = run(False)
+    l_f, p_f = run(True)
+    print("losses torch", l_t, "fused", l_f)
+    assert l_f == pytest.approx(l_t, rel=2e-4)
+    for n in p_t:
+        if "gconv" in n and n.endswith("bias"):
+            # analytically zero gradient (a bias in front of a train-mode BatchNorm): Adam normalises pure
+            # round-off, so the two runs legitimately random-walk apart by O(lr) per step
+            assert max_abs(p_f[n], p_t[n]) < 4 * 2e-3, n
+            continue
+        assert max_abs(p_f[n], p_t[n]) < 2e-5 + 2e-4 * float(p_t[n].abs().max()), n
