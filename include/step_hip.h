@@ -170,6 +170,39 @@ int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* h
                         const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
                         float* dadj, int dropout, void* stream);
 
+/* ---------------------------------------------------------------- TSFormer pre-training -----
+ * Building blocks (exact f32) of the masked-autoencoder stage, forward and backward; the contractions
+ * go through step_gemm.  Replaces TSFormer.forward(mode="pre-train") = tsformer/tsformer.py:71-160,180-188
+ * (+ mask.py index lists, positional_encoding.py:28-32 with index, transformer_layers.py:13-20 /
+ * torch.nn.TransformerEncoderLayer) and its autograd.  All activations are [rows, 96] f32 with
+ * rows = sequence-major tokens.  Dropout masks are a pure function of (seed, site, element index), so a
+ * backward call with the same arguments replays the forward mask. */
+int step_pt_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream);
+int step_pt_add_dropout(const float* a, const float* b, float* out, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* x[s][p][:] += vec[idx ? idx[p] : p][:]   (positional embedding, positional_encoding.py:28-31) */
+int step_pt_add_rows(float* x, long S, int P, const float* vec, const int* idx, void* stream);
+/* dvec[idx ? idx[j] : j][:] += sum_s dx[s][p_off + j][:], j < p_cnt, dx row pitch ldp tokens per sequence */
+int step_pt_sum_over_seq(const float* dx, long S, int ldp, int p_off, int p_cnt, const int* idx, float* dvec, void* stream);
+/* dst[s][t] = scale * src[s][idx[t]]  and its adjoint (tsformer.py:94-96) */
+int step_pt_token_gather(const float* src, long S, int P, const int* idx, int T, float scale, float* dst, void* stream);
+int step_pt_token_scatter(const float* ddst, long S, int P, const int* idx, int T, float scale, float* dsrc, void* stream);
+/* decoder input = sqrt(96) * [ z | dropout(mask_token + pos[midx]) ]  (tsformer.py:120-127) and its adjoint */
+int step_pt_dec_input(const float* z, const float* mask_token, const float* pos, const int* midx, long S, int P, int Pu,
+                      float p, uint64_t seed, uint32_t site, float* out, void* stream);
+int step_pt_dec_input_bwd(const float* dout, long S, int P, int Pu, float p, uint64_t seed, uint32_t site, float* dz,
+                          float* dm, void* stream);
+/* LayerNorm(96, eps 1e-5) rows; stats [R][2] = mean, rstd; backward accumulates dgamma/dbeta (+=) */
+int step_pt_layernorm_fwd(const float* x, long R, const float* g, const float* b, float* y, float* stats, void* stream);
+int step_pt_layernorm_bwd(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx, float* dgamma,
+                          float* dbeta, void* stream);
+/* 4-head self-attention on qkv [S][T][288] -> out [S][T][96]; stats [S][4][T][2] = row max, row sum (for the backward) */
+int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
+                          void* stream);
+int step_pt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
+                          uint64_t seed, uint32_t site, float* dqkv, void* stream);
+int step_pt_relu_mask(float* d, const float* y, long n, void* stream);      /* d *= (y > 0) */
+int step_colsum(const float* x, long rows, int cols, long ld, float* out, void* stream);   /* out[c] += sum_r x[r*ld + c] */
+
 /* ---------------------------------------------------------------- optimizer side ---------
  * clip_grad_norm_(max_norm) + Adam (L2 weight decay, bias correction, eps after sqrt) on flat f32 buffers
  * of n elements; replaces easytorch's torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step for the

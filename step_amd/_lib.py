@@ -69,6 +69,20 @@ _SIGS = {
     "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),
     "step_gwnet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _vp]),
     "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp]),
+    "step_pt_dropout": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
+    "step_pt_add_dropout": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
+    "step_pt_add_rows": (_i, [_vp, _l, _i, _vp, _vp, _vp]),
+    "step_pt_sum_over_seq": (_i, [_vp, _l, _i, _i, _i, _vp, _vp, _vp]),
+    "step_pt_token_gather": (_i, [_vp, _l, _i, _vp, _i, _f, _vp, _vp]),
+    "step_pt_token_scatter": (_i, [_vp, _l, _i, _vp, _i, _f, _vp, _vp]),
+    "step_pt_dec_input": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_dec_input_bwd": (_i, [_vp, _l, _i, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
+    "step_pt_layernorm_fwd": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "step_pt_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "step_pt_attention_fwd": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
+    "step_pt_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_relu_mask": (_i, [_vp, _vp, _l, _vp]),
+    "step_colsum": (_i, [_vp, _l, _i, _l, _vp, _vp]),
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
 }

@@ -68,8 +68,218 @@ class PositionalEncoding(nn.Module):
         self.position_embedding = nn.Parameter(torch.empty(max_len, hidden_dim))
 
 
+class MaskGenerator(nn.Module):
+    """Host-side mask draw, same procedure as the reference (tsformer/mask.py:15-28)."""
+
+    def __init__(self, num_tokens, mask_ratio):
+        super().__init__()
+        self.num_tokens = num_tokens
+        self.mask_ratio = mask_ratio
+        self.sort = True
+
+    def forward(self):
+        import random
+        mask = list(range(int(self.num_tokens)))
+        random.shuffle(mask)
+        mask_len = int(self.num_tokens * self.mask_ratio)
+        self.masked_tokens = sorted(mask[:mask_len])
+        self.unmasked_tokens = sorted(mask[mask_len:])
+        return self.unmasked_tokens, self.masked_tokens
+
+
+SQRT_D = 9.797958971132712
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def _linear_fwd(x, w, b, relu=False):
+    """y[R,N] = x[R,K] @ w[N,K]^T + b   (step_gemm, f32 matrix cores)."""
+    R, K = x.shape
+    N = w.shape[0]
+    y = _empty(R, N, like=x)
+    _lib.gemm(x, w, y, R, N, K, K, 1, 1, K, N, bias=b, relu=relu)
+    return y
+
+
+def _linear_bwd(dy, x, w, dw, db, dx=None, accumulate_dx=False):
+    """dw[N,K] += dy^T x ; db[N] += colsum(dy) ; dx[R,K] (=|+=) dy @ w."""
+    R, N = dy.shape
+    K = x.shape[1]
+    _lib.gemm(dy, x, dw, N, K, R, 1, N, K, 1, K, accumulate=2, splitk=-1)
+    _lib.call("step_colsum", _lib.ptr(dy), R, N, N, _lib.ptr(db), _lib.stream())
+    if dx is not None:
+        _lib.gemm(dy, w, dx, R, K, N, N, 1, K, 1, K, accumulate=1 if accumulate_dx else 0)
+    return dx
+
+
+class _PretrainFunction(torch.autograd.Function):
+    """TSFormer pre-training forward + hand-written backward on libstep_hip (reference tsformer.py:71-136).
+    Inputs: (model, series [S, L], unmasked idx (int32 cuda), masked idx, *parameters in model._pt_names order).
+    Output: reconstruction of every token, [S, P, 12]."""
+
+    @staticmethod
+    def forward(ctx, model, series, um, mk, *params):
+        L = _lib
+        st = L.stream()
+        P_ = dict(zip(model._pt_names, params))
+        S, Lh = series.shape
+        P = Lh // 12
+        Pu, Pm = um.numel(), mk.numel()
+        p = model.dropout_p if model.training else 0.0
+        seed = model._next_seed()
+        saved = {"seed": seed, "p": p}
+        pos = P_["positional_encoding.position_embedding"]
+        # patch embedding + positional embedding (+dropout), gather the unmasked tokens, scale by sqrt(d)
+        patches = series.view(S * P, 12)
+        e0 = _linear_fwd(patches, P_["patch_embedding.input_embedding.weight"].view(96, 12), P_["patch_embedding.input_embedding.bias"])
+        L.call("step_pt_add_rows", L.ptr(e0), S, P, L.ptr(pos), None, st)
+        if p > 0:
+            L.call("step_pt_dropout", L.ptr(e0), L.ptr(e0), e0.numel(), p, seed, 100, st)
+        x = _empty(S * Pu, 96, like=series)
+        L.call("step_pt_token_gather", L.ptr(e0), S, P, L.ptr(um), Pu, SQRT_D, L.ptr(x), st)
+        del e0
+        layers = []
+        for l in range(model.encoder_depth):
+            x, sv = _PretrainFunction._layer_fwd(x, S, Pu, P_, f"encoder.transformer_encoder.layers.{l}.", p, seed, 16 * l)
+            layers.append(sv)
+        y = _empty(S * Pu, 96, like=series)
+        st_enc = _empty(S * Pu, 2, like=series)
+        L.call("step_pt_layernorm_fwd", L.ptr(x), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(P_["encoder_norm.bias"]), L.ptr(y), L.ptr(st_enc), st)
+        z = _linear_fwd(y, P_["enc_2_dec_emb.weight"], P_["enc_2_dec_emb.bias"])
+        d0 = _empty(S * P, 96, like=series)
+        L.call("step_pt_dec_input", L.ptr(z), L.ptr(P_["mask_token"]), L.ptr(pos), L.ptr(mk), S, P, Pu, p, seed, 101, L.ptr(d0), st)
+        dec_layers = []
+        d = d0
+        for l in range(model.decoder_depth):
+            d, sv = _PretrainFunction._layer_fwd(d, S, P, P_, f"decoder.transformer_encoder.layers.{l}.", p, seed, 16 * (8 + l))
+            dec_layers.append(sv)
+        d2 = _empty(S * P, 96, like=series)
+        st_dec = _empty(S * P, 2, like=series)
+        L.call("step_pt_layernorm_fwd", L.ptr(d), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(P_["decoder_norm.bias"]), L.ptr(d2), L.ptr(st_dec), st)
+        r = _linear_fwd(d2, P_["output_layer.weight"], P_["output_layer.bias"])
+        saved.update(dict(series=series, um=um, mk=mk, layers=layers, dec_layers=dec_layers, x_enc_out=x, st_enc=st_enc, y=y,
+                          d_out=d, st_dec=st_dec, d2=d2, dims=(S, P, Pu, Pm)))
+        ctx.saved = saved
+        ctx.model = model
+        return r.view(S, P, 12)
+
+    @staticmethod
+    def _layer_fwd(x, S, T, P_, pre, p, seed, site):
+        L = _lib
+        st = L.stream()
+        R = S * T
+        qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
+        a = _empty(R, 96, like=x)
+        stats = _empty(S * 4 * T, 2, like=x)
+        L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
+        o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
+        h1pre = _empty(R, 96, like=x)
+        L.call("step_pt_add_dropout", L.ptr(x), L.ptr(o), L.ptr(h1pre), R * 96, p, seed, site + 1, st)
+        h1 = _empty(R, 96, like=x)
+        st1 = _empty(R, 2, like=x)
+        L.call("step_pt_layernorm_fwd", L.ptr(h1pre), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]), L.ptr(h1), L.ptr(st1), st)
+        f1 = _linear_fwd(h1, P_[pre + "linear1.weight"], P_[pre + "linear1.bias"], relu=True)
+        f1d = f1
+        if p > 0:
+            f1d = _empty(R, 384, like=x)
+            L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
+        f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
+        h2pre = _empty(R, 96, like=x)
+        L.call("step_pt_add_dropout", L.ptr(h1), L.ptr(f2), L.ptr(h2pre), R * 96, p, seed, site + 3, st)
+        h2 = _empty(R, 96, like=x)
+        st2 = _empty(R, 2, like=x)
+        L.call("step_pt_layernorm_fwd", L.ptr(h2pre), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]), L.ptr(h2), L.ptr(st2), st)
+        return h2, dict(x=x, qkv=qkv, a=a, stats=stats, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
+                        site=site, T=T)
+
+    @staticmethod
+    def _layer_bwd(dh2, sv, S, P_, G, p, seed):
+        """dh2: gradient w.r.t. the layer output [R,96] (consumed); returns gradient w.r.t. the layer input."""
+        L = _lib
+        st = L.stream()
+        pre, site, T = sv["pre"], sv["site"], sv["T"]
+        R = S * T
+        dh2pre = _empty(R, 96, like=dh2)
+        L.call("step_pt_layernorm_bwd", L.ptr(dh2), L.ptr(sv["h2pre"]), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(sv["st2"]), L.ptr(dh2pre),
+               L.ptr(G[pre + "norm2.weight"]), L.ptr(G[pre + "norm2.bias"]), st)
+        df2 = dh2pre
+        if p > 0:
+            df2 = _empty(R, 96, like=dh2)
+            L.call("step_pt_dropout", L.ptr(dh2pre), L.ptr(df2), R * 96, p, seed, site + 3, st)
+        df1d = _empty(R, 384, like=dh2)
+        _linear_bwd(df2, sv["f1d"], P_[pre + "linear2.weight"], G[pre + "linear2.weight"], G[pre + "linear2.bias"], df1d)
+        if p > 0:
+            L.call("step_pt_dropout", L.ptr(df1d), L.ptr(df1d), R * 384, p, seed, site + 2, st)
+        L.call("step_pt_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, st)
+        dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
+        _linear_bwd(df1d, sv["h1"], P_[pre + "linear1.weight"], G[pre + "linear1.weight"], G[pre + "linear1.bias"], dh1, accumulate_dx=True)
+        dh1pre = _empty(R, 96, like=dh2)
+        L.call("step_pt_layernorm_bwd", L.ptr(dh1), L.ptr(sv["h1pre"]), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(sv["st1"]), L.ptr(dh1pre),
+               L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)
+        do = dh1pre
+        if p > 0:
+            do = _empty(R, 96, like=dh2)
+            L.call("step_pt_dropout", L.ptr(dh1pre), L.ptr(do), R * 96, p, seed, site + 1, st)
+        da = _empty(R, 96, like=dh2)
+        _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
+                    G[pre + "self_attn.out_proj.bias"], da)
+        dqkv = _empty(R, 288, like=dh2)
+        L.call("step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
+        dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
+        _linear_bwd(dqkv, sv["x"], P_[pre + "self_attn.in_proj_weight"], G[pre + "self_attn.in_proj_weight"],
+                    G[pre + "self_attn.in_proj_bias"], dx, accumulate_dx=True)
+        return dx
+
+    @staticmethod
+    def backward(ctx, dr):
+        L = _lib
+        st = L.stream()
+        model, sv = ctx.model, ctx.saved
+        S, P, Pu, Pm = sv["dims"]
+        p, seed = sv["p"], sv["seed"]
+        P_ = {n: prm for n, prm in zip(model._pt_names, model._pt_params())}
+        flat, G = model._pt_grad_buffers()
+        dev = dr.device
+        dr = dr.contiguous().float().view(S * P, 12)
+        pos = P_["positional_encoding.position_embedding"]
+        # output layer, decoder norm, decoder layer(s)
+        dd2 = _empty(S * P, 96, like=dr)
+        _linear_bwd(dr, sv["d2"], P_["output_layer.weight"], G["output_layer.weight"], G["output_layer.bias"], dd2)
+        dd = _empty(S * P, 96, like=dr)
+        L.call("step_pt_layernorm_bwd", L.ptr(dd2), L.ptr(sv["d_out"]), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(sv["st_dec"]), L.ptr(dd),
+               L.ptr(G["decoder_norm.weight"]), L.ptr(G["decoder_norm.bias"]), st)
+        for lsv in reversed(sv["dec_layers"]):
+            dd = _PretrainFunction._layer_bwd(dd, lsv, S, P_, G, p, seed)
+        # decoder input: split into d z and the mask-token / positional part
+        dz = _empty(S * Pu, 96, like=dr)
+        dm = _empty(S * Pm, 96, like=dr)
+        L.call("step_pt_dec_input_bwd", L.ptr(dd), S, P, Pu, p, seed, 101, L.ptr(dz), L.ptr(dm), st)
+        L.call("step_pt_sum_over_seq", L.ptr(dm), S, Pm, 0, Pm, L.ptr(sv["mk"]), L.ptr(G["positional_encoding.position_embedding"]), st)
+        L.call("step_colsum", L.ptr(dm), S * Pm, 96, 96, L.ptr(G["mask_token"]), st)
+        # enc_2_dec_emb, encoder norm, encoder layers
+        dy = _empty(S * Pu, 96, like=dr)
+        _linear_bwd(dz, sv["y"], P_["enc_2_dec_emb.weight"], G["enc_2_dec_emb.weight"], G["enc_2_dec_emb.bias"], dy)
+        dx = _empty(S * Pu, 96, like=dr)
+        L.call("step_pt_layernorm_bwd", L.ptr(dy), L.ptr(sv["x_enc_out"]), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(sv["st_enc"]), L.ptr(dx),
+               L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), st)
+        for lsv in reversed(sv["layers"]):
+            dx = _PretrainFunction._layer_bwd(dx, lsv, S, P_, G, p, seed)
+        # scatter back to all token positions (zeros at masked ones), dropout, positional and patch embedding
+        de = torch.zeros(S * P, 96, device=dev)
+        L.call("step_pt_token_scatter", L.ptr(dx), S, P, L.ptr(sv["um"]), Pu, SQRT_D, L.ptr(de), st)
+        if p > 0:
+            L.call("step_pt_dropout", L.ptr(de), L.ptr(de), de.numel(), p, seed, 100, st)
+        L.call("step_pt_sum_over_seq", L.ptr(de), S, P, 0, P, None, L.ptr(G["positional_encoding.position_embedding"]), st)
+        patches = sv["series"].view(S * P, 12)
+        _linear_bwd(de, patches, None, G["patch_embedding.input_embedding.weight"].view(96, 12), G["patch_embedding.input_embedding.bias"])
+        ctx.saved = None
+        return (None, None, None, None) + tuple(G[n] for n in model._pt_names)
+
+
 class TSFormer(nn.Module):
-    """Drop-in for the reference TSFormer (forecasting mode on device)."""
+    """Drop-in for the reference TSFormer (forecasting mode: fused encoder kernel; pre-train mode: native forward + backward)."""
 
     def __init__(self, patch_size, in_channel, embed_dim, num_heads, mlp_ratio, dropout, num_token, mask_ratio,
                  encoder_depth, decoder_depth, mode="pre-train"):
@@ -87,6 +297,8 @@ class TSFormer(nn.Module):
         self.decoder_norm = nn.LayerNorm(embed_dim)
         self.patch_embedding = PatchEmbedding(patch_size, in_channel, embed_dim)
         self.positional_encoding = PositionalEncoding(embed_dim, dropout=dropout)
+        self.mask = MaskGenerator(num_token, mask_ratio)
+        self.decoder_depth = decoder_depth
         self.encoder = TransformerLayers(embed_dim, encoder_depth, mlp_ratio, num_heads, dropout)
         self.enc_2_dec_emb = nn.Linear(embed_dim, embed_dim, bias=True)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, embed_dim))
@@ -94,6 +306,8 @@ class TSFormer(nn.Module):
         self.output_layer = nn.Linear(embed_dim, patch_size)
         nn.init.uniform_(self.positional_encoding.position_embedding, -.02, .02)
         nn.init.trunc_normal_(self.mask_token, std=.02)
+        self._pt_names = [n for n, _ in self.named_parameters()]
+        self._seed_ctr2 = 0
         self._packed = None
         self._packed_key = None
         self._seed_counter = 0
@@ -143,8 +357,7 @@ class TSFormer(nn.Module):
     def forward(self, history_data, future_data=None, batch_seen=None, epoch=None, **kwargs):
         """history_data [B, L*P, N, C] -> hidden [B, N, P, 96] (forecasting mode, tsformer.py:189-191)."""
         if self.mode == "pre-train":
-            raise NotImplementedError("TSFormer pre-training (masked reconstruction, forward+backward) is not part of "
-                                      "this round's native path; see DESIGN.md 'next'")
+            return self._forward_pretrain(history_data)
         if not history_data.is_cuda:
             raise RuntimeError("step_amd.TSFormer runs only on an AMD GPU (no CPU fallback)")
         B, L, N, Cc = history_data.shape
@@ -153,3 +366,41 @@ class TSFormer(nn.Module):
         _lib.call("step_pack_long_history", _lib.ptr(x), B, L, N, Cc, self.selected_feature, _lib.ptr(series), _lib.stream())
         out = self.encode_series(series, want_f32=True, want_bf16=False)
         return out["hidden_f32"].view(B, N, L // self.patch_size, 96)
+
+    # ------------------------------------------------------------------ pre-training (tsformer.py:180-188)
+    def _pt_params(self):
+        d = dict(self.named_parameters())
+        return [d[n] for n in self._pt_names]
+
+    def _pt_grad_buffers(self):
+        prm = self._pt_params()
+        total = sum((p.numel() + 3) & ~3 for p in prm)
+        flat = torch.zeros(total, device=prm[0].device, dtype=torch.float32)
+        G, off = {}, 0
+        for n, p in zip(self._pt_names, prm):
+            G[n] = flat[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 3) & ~3
+        self._flat_grad = flat
+        return flat, G
+
+    def _next_seed(self):
+        self._seed_ctr2 += 1
+        return (torch.initial_seed() * 6364136223846793005 + self._seed_ctr2 * 1442695040888963407) & ((1 << 63) - 1)
+
+    def _forward_pretrain(self, history_data):
+        """history_data [B, L, N, C] -> (reconstruction of the masked tokens [B, Pm*12, N], their labels [B, Pm*12, N])."""
+        if not history_data.is_cuda:
+            raise RuntimeError("step_amd.TSFormer runs only on an AMD GPU (no CPU fallback)")
+        B, L, N, Cc = history_data.shape
+        x = history_data.contiguous().float()
+        series = torch.empty(B * N, L, device=x.device)
+        _lib.call("step_pack_long_history", _lib.ptr(x), B, L, N, Cc, self.selected_feature, _lib.ptr(series), _lib.stream())
+        um_list, mk_list = self.mask()
+        um = torch.tensor(um_list, dtype=torch.int32, device=x.device)
+        mk = torch.tensor(mk_list, dtype=torch.int32, device=x.device)
+        P = L // self.patch_size
+        r = _PretrainFunction.apply(self, series, um, mk, *self._pt_params())              # [S, P, 12]
+        Pu = len(um_list)
+        recon = r.view(B, N, P, self.patch_size)[:, :, Pu:, :].reshape(B, N, -1).transpose(1, 2)      # tsformer.py:153-154
+        label = series.view(B, N, P, self.patch_size)[:, :, mk.long(), :].reshape(B, N, -1).transpose(1, 2)   # :156-158
+        return recon, label
