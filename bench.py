@@ -24,6 +24,8 @@ CONFIGS = {
     "STEP_PEMS07": dict(N=883, L=288 * 7, T_train=16513, T_all=28224, B=4, k=10),
     "STEP_METR-LA": dict(N=207, L=288 * 7, T_train=23990, T_all=34272, B=2, k=10),
     "SYNTH_4096": dict(N=4096, L=288 * 7, T_train=16513, T_all=28224, B=1, k=10),      # BASELINE config 5 (N-scaling stress)
+    # BASELINE config 3: masked pre-training of TSFormer (reference step/TSFormer_PEMS-BAY.py: B=16... batch per GPU)
+    "TSFormer_PEMS-BAY": dict(N=325, L=288 * 7, T_train=36482, T_all=52116, B=16, k=0, pretrain=True),
 }
 
 
@@ -86,6 +88,57 @@ def cpu_baseline(cfg, data, seed=0):
             "sample": f"2 windows (B=2) of the same workload, fwd+loss+bwd, {dt:.1f} s, torch CPU fp32 oracle"}
 
 
+def pretrain_main(args, cfg, world, rank, dev):
+    """Config C3: one step = TSFormer masked pre-training forward + masked_mae + backward + clip(5.0) + Adam
+    (reference step/TSFormer_PEMS-BAY.py:52-72), windows/s = sequences of L steps x N nodes per second."""
+    import random
+    from step_amd import TSFormer
+    from step_amd.step_loss import masked_mae
+    N, Lh, B = cfg["N"], cfg["L"], cfg["B"]
+    data = synth_series(cfg["T_all"], N)
+    torch.manual_seed(0)
+    random.seed(0)
+    model = TSFormer(12, 1, 96, 4, 4, 0.1, Lh / 12, 0.75, 4, 1, mode="pre-train").to(dev)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=0.001, weight_decay=0, eps=1.0e-8, betas=(0.9, 0.95))
+    dser = torch.from_numpy(data[:, :, :1]).to(dev)
+    rng = np.random.default_rng(99 + rank)
+    batches = []
+    for _ in range(4):
+        ts = rng.integers(Lh, cfg["T_all"] - 12, size=B)
+        batches.append(torch.stack([dser[t - Lh:t] for t in ts]))
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        recon, label = model(history_data=batches[i % len(batches)], future_data=None, batch_seen=i, epoch=1)
+        loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=5.0)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": B * world * args.steps / dt,
+                          "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"TSFormer_PEMS-BAY pre-train: N={N}, L={Lh} (P={Lh // 12}, 42 unmasked), batch {B}/GPU, "
+                                                 "fwd+bwd+clip+Adam, exact-f32 unfused path", "final_loss": float(loss.detach())}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +167,8 @@ def main():
     L.lib()
 
     N, Lh, B = cfg["N"], cfg["L"], cfg["B"]
+    if cfg.get("pretrain"):
+        return pretrain_main(args, cfg, world, rank, dev)
     data = synth_series(cfg["T_all"], N)
     model = make_model(cfg, data).to(dev)
     model.train()
