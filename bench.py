@@ -162,7 +162,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from step_amd.step_loss import step_loss
+    from step_amd.step_loss import step_loss_native as step_loss
     import step_amd._lib as L
     L.lib()
 

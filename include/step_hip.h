@@ -212,6 +212,11 @@ long step_adam_work_floats(void);
 int step_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float max_norm, float* work, float* out_norm,
                    void* stream);
+/* step_loss = masked_mae(pred, real, null_val) + coef * BCELoss(theta, prior)  (step/step_loss/step_loss.py:5-16,
+ * basicts/metrics/mae.py:5-28; pred/real are the RESCALED tensors the runner passes, base_tsf_runner.py:240-250).
+ * Writes the scalar loss and d loss/d pred, d loss/d theta.  work: 3 doubles of scratch. */
+int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const float* theta, const float* prior, long n_adj,
+                      float null_val, float coef, double* work, float* loss, float* dpred, float* dtheta, void* stream);
 
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on

@@ -82,3 +82,68 @@ extern "C" int step_adam_clip(float* params, const float* grads, float* exp_avg,
     STEP_LAUNCH_CHECK("adam_clip");
     return STEP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// step_loss (reference step/step_loss/step_loss.py:5-16 + basicts/metrics/mae.py:5-28), forward value and both
+// gradients in two launches:  loss = sum(|p - y| m) / sum(m) + coef * mean(BCE(theta, prior)),  m = |y - null| > 5e-5.
+namespace {
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1,
+                                                          const float* __restrict__ theta, const float* __restrict__ prior, long n2,
+                                                          float null_val, double* __restrict__ acc /*[3]*/) {
+    __shared__ double red[4][3];
+    double s_abs = 0.0, s_cnt = 0.0, s_bce = 0.0;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
+        const float y = real[i];
+        if (fabsf(y - null_val) > 5e-5f) { s_abs += fabsf(pred[i] - y); s_cnt += 1.0; }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const float t = theta[i], y = prior[i];
+        const float l1 = fmaxf(logf(t), -100.f), l0 = fmaxf(logf(1.f - t), -100.f);      // torch BCELoss clamps the logs at -100
+        s_bce -= (double)(y * l1 + (1.f - y) * l0);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s_abs += __shfl_xor(s_abs, o, 64); s_cnt += __shfl_xor(s_cnt, o, 64); s_bce += __shfl_xor(s_bce, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s_abs; red[threadIdx.x >> 6][1] = s_cnt; red[threadIdx.x >> 6][2] = s_bce; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&acc[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1,
+                                                          const float* __restrict__ theta, const float* __restrict__ prior, long n2,
+                                                          float null_val, float coef, const double* __restrict__ acc,
+                                                          float* __restrict__ loss, float* __restrict__ dpred, float* __restrict__ dtheta) {
+    const double cnt = acc[1];
+    const float inv_cnt = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *loss = (cnt > 0.0 ? (float)(acc[0] / cnt) : 0.f) + coef * (float)(acc[2] / (double)n2);
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
+        const float y = real[i], d = pred[i] - y;
+        const float m = fabsf(y - null_val) > 5e-5f ? inv_cnt : 0.f;
+        dpred[i] = d > 0.f ? m : (d < 0.f ? -m : 0.f);
+    }
+    const float sc = coef / (float)n2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const float t = theta[i], y = prior[i];
+        // d/dt of -(y log t + (1-y) log(1-t)), with torch's denominator floor
+        dtheta[i] = sc * (t - y) / fmaxf(t * (1.f - t), 1e-12f);
+    }
+}
+}  // namespace
+
+extern "C" int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const float* theta, const float* prior, long n_adj,
+                                 float null_val, float coef, double* work /*3 doubles*/, float* loss, float* dpred, float* dtheta,
+                                 void* stream) {
+    STEP_REQUIRE(pred && real && theta && prior && work && loss && dpred && dtheta && n_pred > 0 && n_adj > 0, "step_loss: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(work, 0, 3 * sizeof(double), st) != hipSuccess) { step_set_error("step_loss: memset failed"); return STEP_ERR_HIP; }
+    long nmax = n_pred > n_adj ? n_pred : n_adj;
+    int blocks = (int)((nmax + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    loss_reduce_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, theta, prior, n_adj, null_val, work);
+    STEP_LAUNCH_CHECK("loss_reduce");
+    loss_finish_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, theta, prior, n_adj, null_val, coef, work, loss, dpred, dtheta);
+    STEP_LAUNCH_CHECK("loss_finish");
+    return STEP_OK;
+}

@@ -242,3 +242,26 @@ def test_fused_adam_clip_matches_torch():
             assert max_abs(p_f[n], p_t[n]) < 4 * 2e-3, n
             continue
         assert max_abs(p_f[n], p_t[n]) < 2e-5 + 2e-4 * float(p_t[n].abs().max()), n
+
+
+def test_native_step_loss_matches_reference_loss():
+    from step_amd.step_loss import step_loss_native, step_loss
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 23
+    pred = (torch.randn(B, 12, N, 1, generator=g) * 150 + 200).cuda().requires_grad_(True)
+    real = (torch.randn(B, 12, N, 1, generator=g) * 150 + 200)
+    real[0, :, 3] = 0.0                                         # null values are masked out
+    real = real.cuda()
+    theta = torch.rand(B, N, N, generator=g).clamp(1e-4, 1 - 1e-4).cuda().requires_grad_(True)
+    prior = (torch.rand(B, N, N, generator=g) < 0.1).float().cuda()
+    for coef in (1.0, 0.5, 0):
+        l_ref = step_loss(pred, real, theta, prior, coef, null_val=0.0)
+        gp, gt = torch.autograd.grad(l_ref, [pred, theta], allow_unused=True)
+        l_nat = step_loss_native(pred, real, theta, prior, coef, null_val=0.0)
+        np_, nt_ = torch.autograd.grad(l_nat * 2.0, [pred, theta], allow_unused=True)
+        assert float(l_nat) == pytest.approx(float(l_ref), rel=1e-5)
+        assert rel_l2(np_.cpu() / 2.0, gp.cpu()) < 1e-5
+        if coef:
+            assert rel_l2(nt_.cpu() / 2.0, gt.cpu()) < 1e-5
+        else:
+            assert float(nt_.abs().max()) == 0.0
