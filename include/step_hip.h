@@ -53,6 +53,9 @@ typedef struct StepGemm {
        i0 * s?b + i1 * s?b1.  Lets one launch run the same contraction for the three diffusion supports
        (different adjacency stack entry and gcn slot, same sample index) */
     int batch0; long sab1, sbb1, scb1;
+    /* 0: exact f32 matrix cores (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 in LDS, v_mfma_f32_32x32x16_bf16,
+       f32 accumulate and output (16x the matrix-pipe rate) */
+    int compute_bf16;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 
@@ -109,6 +112,7 @@ typedef struct StepDglParams {
     float *bn3_w, *bn3_b, *bn3_rm, *bn3_rv;    /* BatchNorm1d(100) */
     float *fc_out_w, *fc_out_b;                /* [100,200], [100] */
     float *fc_cat_w, *fc_cat_b;                /* [2,100], [2] */
+    int gemm_bf16;                             /* 1: the fc forward/backward contractions run on the bf16 matrix cores */
 } StepDglParams;
 
 /* Global node feature g[N,100] (discrete_graph_learning.py:131-136) from the constant train
@@ -150,6 +154,7 @@ typedef struct StepGwnetParams {
     float *gconv_w[8], *gconv_b[8];                   /* [32,224,1,1], [32] */
     float *fc_his0_w, *fc_his0_b, *fc_his2_w, *fc_his2_b;   /* [512,96], [256,512] */
     float *end1_w, *end1_b, *end2_w, *end2_b;         /* [512,256,1,1], [12,512,1,1] */
+    int gemm_bf16;                                    /* 1: diffusion hops and their adjoints on the bf16 matrix cores */
 } StepGwnetParams;
 
 /* GraphWaveNet.forward (model.py:132-224) fused with the transposes of step.py:65,72:

@@ -23,14 +23,14 @@ class StepGemm(ctypes.Structure):
                 ("a_kblk", _i), ("a_kstride", _l), ("b_kblk", _i), ("b_kstride", _l),
                 ("b_nblk", _i), ("b_nstride", _l), ("c_nblk", _i), ("c_nstride", _l),
                 ("a_kscale", _vp), ("a_kshift", _vp), ("a_kperiod", _i),
-                ("batch0", _i), ("sab1", _l), ("sbb1", _l), ("scb1", _l)]
+                ("batch0", _i), ("sab1", _l), ("sbb1", _l), ("scb1", _l), ("compute_bf16", _i)]
 
 
 class StepDglParams(ctypes.Structure):
     NAMES = ["conv1_w", "conv1_b", "conv2_w", "conv2_b", "fc_w", "fc_b",
              "bn1_w", "bn1_b", "bn1_rm", "bn1_rv", "bn2_w", "bn2_b", "bn2_rm", "bn2_rv",
              "bn3_w", "bn3_b", "bn3_rm", "bn3_rv", "fc_out_w", "fc_out_b", "fc_cat_w", "fc_cat_b"]
-    _fields_ = [(n, _vp) for n in NAMES]
+    _fields_ = [(n, _vp) for n in NAMES] + [("gemm_bf16", _i)]
 
 
 class StepGwnetParams(ctypes.Structure):
@@ -40,7 +40,7 @@ class StepGwnetParams(ctypes.Structure):
                 ("bn_w", _vp * 8), ("bn_b", _vp * 8), ("bn_rm", _vp * 8), ("bn_rv", _vp * 8),
                 ("gconv_w", _vp * 8), ("gconv_b", _vp * 8),
                 ("fc_his0_w", _vp), ("fc_his0_b", _vp), ("fc_his2_w", _vp), ("fc_his2_b", _vp),
-                ("end1_w", _vp), ("end1_b", _vp), ("end2_w", _vp), ("end2_b", _vp)]
+                ("end1_w", _vp), ("end1_b", _vp), ("end2_w", _vp), ("end2_b", _vp), ("gemm_bf16", _i)]
 
 
 _PD = ctypes.POINTER(StepDglParams)
@@ -134,7 +134,7 @@ def call(name, *args):
 
 def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0, scn=1, alpha=1.0,
          accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0, a_k=(0, 0), b_k=(0, 0),
-         b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0, batch0=0, sab1=0, sbb1=0, scb1=0):
+         b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0, batch0=0, sab1=0, sbb1=0, scb1=0, compute_bf16=False):
     """Thin descriptor builder around step_gemm; a/b/c are device tensors (f32 or bf16 for a, b),
     offsets are in elements."""
     g = StepGemm()
@@ -153,6 +153,7 @@ def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0
     g.b_nblk, g.b_nstride = b_n
     g.c_nblk, g.c_nstride = c_n
     g.batch0, g.sab1, g.sbb1, g.scb1 = batch0, sab1, sbb1, scb1
+    g.compute_bf16 = int(compute_bf16)
     if a_kscale is not None:
         g.a_kscale, g.a_kshift, g.a_kperiod = a_kscale.data_ptr(), a_kshift.data_ptr(), a_kperiod
     check(lib().step_gemm(ctypes.byref(g), stream()), "step_gemm")

@@ -90,3 +90,40 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 }
 // uniform in [0,1) with 24 bits, like torch.rand's float path
 __device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Epilogue of one 32x32 MFMA accumulator tile held by a lane: column pointer `col` (= C + remapped n), rows
+// mb + (e&3) + 8*(e>>2).  The accumulate mode is uniform, so it is branched on once per tile: the plain-store
+// and atomic paths issue their 16 memory operations back to back (no s_waitcnt in between), the read-modify-write
+// path issues its 16 loads first.
+__device__ __forceinline__ void gemm_store_tile(const f32x16& acc, float* col, int mb, int M, long ldc, float alpha, int accumulate,
+                                                float bv, int relu) {
+    if (accumulate == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int gm = mb + (e & 3) + 8 * (e >> 2);
+            if (gm < M) atomicAdd(col + (long)gm * ldc, alpha * acc[e]);
+        }
+    } else if (accumulate == 1) {
+        float old[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int gm = mb + (e & 3) + 8 * (e >> 2);
+            old[e] = gm < M ? col[(long)gm * ldc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int gm = mb + (e & 3) + 8 * (e >> 2);
+            float v = alpha * acc[e] + old[e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            if (gm < M) col[(long)gm * ldc] = v;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int gm = mb + (e & 3) + 8 * (e >> 2);
+            float v = alpha * acc[e] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            if (gm < M) col[(long)gm * ldc] = v;
+        }
+    }
+}

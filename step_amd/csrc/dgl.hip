@@ -606,6 +606,7 @@ extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, con
     gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
     gm.accumulate = 2;
     gm.splitk = -1;
+    gm.compute_bf16 = p->gemm_bf16;
     STEP_TRY(step_gemm_launch(gm, st));
     fc_post_bn3_kernel<<<EMB, 256, 0, st>>>(gpre, p->fc_b, N, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, training, momentum, st3, g);
     STEP_LAUNCH_CHECK("fc_post_bn3");
@@ -634,6 +635,7 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
     {
         StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
+        gm.compute_bf16 = p->gemm_bf16;
         STEP_TRY(step_gemm_launch(gm, st));
         fc_wgrad_fixup_kernel<<<dim3(256, EMB), 256, 0, st>>>(wraw, dgpre, N, st2, 16, T2, K, grads->fc_w);
         STEP_LAUNCH_CHECK("fc_wgrad_fixup");
@@ -641,6 +643,8 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     // d(BN2 output) = dgpre @ fc_w
     {
         StepGemm gm = gemm_desc(N, (int)K, EMB, dgpreT, 1, N, p->fc_w, K, 1, d_a2, K);     // A(m=n, k=o) = dgpreT[o][n]
+        if (p->gemm_bf16) { gm.A = dgpre; gm.sam = EMB; gm.sak = 1; }                      // LDS-staged path: k-contiguous rows
+        gm.compute_bf16 = p->gemm_bf16;
         STEP_TRY(step_gemm_launch(gm, st));
     }
     // BN2 backward (+ReLU mask) in place -> dz2

@@ -227,23 +227,9 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
         for (int j = 0; j < TN; ++j) {
             int gn = n0 + wc * (TN * 32) + j * 32 + li;
             if (gn >= g.N) continue;
-            float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int gm = m0 + wr * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (gm >= g.M) continue;
-                float v = g.alpha * acc[i][j][e];
-                long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
-                float* dst = Cb + (long)gm * g.ldc + ni * g.scn;
-                if (g.accumulate == 2) {
-                    atomicAdd(dst, v);
-                } else {
-                    if (g.accumulate == 1) v += *dst;
-                    v += bv;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    *dst = v;
-                }
-            }
+            const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
+            const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
         }
 }
 
@@ -387,21 +373,7 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs
     if (!n_ok) return;
     const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
     const long ni = (long)(gn >> d.cn_sh) * g.c_nstride + (gn & d.cn_mask);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int rm = m0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        if (rm >= g.M) continue;
-        float v = g.alpha * acc[e];
-        float* dst = Cb + (long)rm * g.ldc + ni * g.scn;
-        if (g.accumulate == 2) {
-            atomicAdd(dst, v);
-        } else {
-            if (g.accumulate == 1) v += *dst;
-            v += bv;
-            if (g.relu) v = fmaxf(v, 0.f);
-            *dst = v;
-        }
-    }
+    gemm_store_tile(acc, Cb + ni * g.scn, m0 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
 }
 
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
@@ -460,6 +432,11 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
     STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && g.batch > 0, "step_gemm: bad sizes M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
     STEP_REQUIRE(g.A && g.B && g.C, "step_gemm: null operand");
     if (g.scn == 0) g.scn = 1;
+    if (g.compute_bf16) return step_gemm_bf16_launch(g, st);
+    {
+        const int rc = step_gemm_f32_fast_launch(g, st);
+        if (rc != -1) return rc;
+    }
     if (g.splitk < 0 && direct_eligible(g)) g.splitk = 1;      // short contraction: the direct kernel, no split
     if (g.splitk < 0) {            // auto: enough workgroups to fill 256 CUs, at least 4 k-steps each
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");

@@ -1,0 +1,627 @@
+// bf16-MFMA variant of the generic strided-batched GEMM (same StepGemm descriptor, compute_bf16 = 1):
+// f32 (or bf16) operands in global memory, rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 with f32
+// accumulation, f32 output.  16x the matrix-pipe rate of the exact-f32 path; used for the big contractions of the
+// training step (diffusion hops with the N x N supports and their adjoints, the DGL fc forward/backward) when the
+// module runs in its bf16 matmul mode (BASELINE.json config C2 "bf16").
+//
+// LDS holds both operands ROW-MAJOR WITH k CONTIGUOUS (As[m][k], Bs[n][k], 80-byte pitch) so an MFMA operand
+// fragment (lane = row, 8 consecutive k) is one ds_read_b128.  The loader transposes when the global operand is
+// m- / n-contiguous (4 x ds_write_b16 per 16-byte global load) and packs 4 k into one 8-byte LDS write otherwise.
+#include "common.h"
+#include "step_internal.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PITCH = BK * 2 + 16;        // bytes per staged row
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+// one v_cvt_pk_bf16_f32 on two arbitrary registers (RNE); written as asm so that the register-level 4x4 transposition of
+// the MC loader stays a choice of source operands (the vectoriser otherwise builds it through scratch memory)
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2(a, b), pack2(c, d)); }
+__device__ __forceinline__ uint2 pack4(const float (&v)[4]) { return pack4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ uint16_t bf16_of(float x) {
+    return __builtin_bit_cast(uint16_t, (__bf16)x);
+}
+template <typename T>
+__device__ __forceinline__ float ld1(const void* p, long idx) {
+    if constexpr (sizeof(T) == 2) return bf16_bits_to_f32(((const uint16_t*)p)[idx]); else return ((const float*)p)[idx];
+}
+
+template <int BM, int BN, typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(StepGemm g) {
+    constexpr int TM = BM / 64, TN = BN / 64;         // 32x32 tiles per wave (2 x 2 waves)
+    constexpr int GA = BM * BK / 4 / 256, GB = BN * BK / 4 / 256;
+    __shared__ __attribute__((aligned(16))) char As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) char Bs[BN * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksteps = (g.K + BK - 1) / BK;
+    const int per = (ksteps + g.splitk - 1) / g.splitk;
+    const int kbeg = zs * per * BK;
+    const int kend = min(g.K, (zs + 1) * per * BK);
+    const int i0 = g.batch0 ? zb % g.batch0 : zb, i1 = g.batch0 ? zb / g.batch0 : 0;
+    const char* Ab = (const char*)g.A + ((long)i0 * g.sab + (long)i1 * g.sab1) * (long)sizeof(TA);
+    const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * (long)sizeof(TB);
+
+    const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
+    const bool a_al = sizeof(TA) == 4 && (((uintptr_t)g.A & 15) == 0) && g.sab % 4 == 0 && g.sab1 % 4 == 0;
+    const bool b_al = sizeof(TB) == 4 && (((uintptr_t)g.B & 15) == 0) && g.sbb % 4 == 0 && g.sbb1 % 4 == 0;
+    const bool a_vec = a_al && (a_kc ? (g.sam % 4 == 0 && (g.a_kblk == 0 || (g.a_kblk % 4 == 0 && g.a_kstride % 4 == 0)))
+                                     : (g.sam == 1 && g.sak % 4 == 0));
+    const bool b_vec = b_al && (b_kc ? (g.sbn % 4 == 0 && (g.b_kblk == 0 || (g.b_kblk % 4 == 0 && g.b_kstride % 4 == 0)) &&
+                                        (g.b_nblk == 0 || g.b_nstride % 4 == 0))
+                                     : (g.sbn == 1 && g.sbk % 4 == 0 && (g.b_nblk == 0 || (g.b_nblk % 4 == 0 && g.b_nstride % 4 == 0))));
+
+    float ra[GA][4], rb[GB][4];
+    auto a_elem = [&](int gm, int gk) -> float {
+        float v = 0.f;
+        if (gm < g.M && gk < kend) {
+            long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+            v = ld1<TA>(Ab, (long)gm * g.sam + ki * g.sak);
+            if (g.a_kscale) { int c = gk / g.a_kperiod; v = v * g.a_kscale[c] + g.a_kshift[c]; }
+        }
+        return v;
+    };
+    auto b_elem = [&](int gk, int gn) -> float {
+        float v = 0.f;
+        if (gn < g.N && gk < kend) {
+            long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+            long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+            v = ld1<TB>(Bb, ki * g.sbk + ni * g.sbn);
+        }
+        return v;
+    };
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < GA; ++r) {
+            const int e4 = tid + r * 256;
+            if (a_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, mm = e4 / (BK / 4);
+                const int gm = m0 + mm, gk = k0 + kk;
+                if (a_vec && gm < g.M && gk + 3 < kend) {
+                    long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+                    float4 t = *(const float4*)((const float*)Ab + (long)gm * g.sam + ki);
+                    ra[r][0] = t.x; ra[r][1] = t.y; ra[r][2] = t.z; ra[r][3] = t.w;
+                    if (g.a_kscale) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { int c = (gk + i) / g.a_kperiod; ra[r][i] = ra[r][i] * g.a_kscale[c] + g.a_kshift[c]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[r][i] = a_elem(gm, gk + i);
+                }
+            } else {
+                const int mm = (e4 % (BM / 4)) * 4, kk = e4 / (BM / 4);
+                const int gm = m0 + mm, gk = k0 + kk;
+                if (a_vec && gm + 3 < g.M && gk < kend) {
+                    long ki = g.a_kblk ? (long)(gk / g.a_kblk) * g.a_kstride + (gk % g.a_kblk) : (long)gk;
+                    float4 t = *(const float4*)((const float*)Ab + gm + ki * g.sak);
+                    ra[r][0] = t.x; ra[r][1] = t.y; ra[r][2] = t.z; ra[r][3] = t.w;
+                    if (g.a_kscale) {
+                        int c = gk / g.a_kperiod;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ra[r][i] = ra[r][i] * g.a_kscale[c] + g.a_kshift[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[r][i] = a_elem(gm + i, gk);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GB; ++r) {
+            const int e4 = tid + r * 256;
+            if (b_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, nn = e4 / (BK / 4);
+                const int gn = n0 + nn, gk = k0 + kk;
+                if (b_vec && gn < g.N && gk + 3 < kend) {
+                    long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+                    long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+                    float4 t = *(const float4*)((const float*)Bb + ki + ni * g.sbn);
+                    rb[r][0] = t.x; rb[r][1] = t.y; rb[r][2] = t.z; rb[r][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb[r][i] = b_elem(gk + i, gn);
+                }
+            } else {
+                const int nn = (e4 % (BN / 4)) * 4, kk = e4 / (BN / 4);
+                const int gn = n0 + nn, gk = k0 + kk;
+                if (b_vec && gn + 3 < g.N && gk < kend) {
+                    long ki = g.b_kblk ? (long)(gk / g.b_kblk) * g.b_kstride + (gk % g.b_kblk) : (long)gk;
+                    long ni = g.b_nblk ? (long)(gn / g.b_nblk) * g.b_nstride + (gn % g.b_nblk) : (long)gn;
+                    float4 t = *(const float4*)((const float*)Bb + ki * g.sbk + ni);
+                    rb[r][0] = t.x; rb[r][1] = t.y; rb[r][2] = t.z; rb[r][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rb[r][i] = b_elem(gk, gn + i);
+                }
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int r = 0; r < GA; ++r) {
+            const int e4 = tid + r * 256;
+            if (a_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, mm = e4 / (BK / 4);
+                *(uint2*)(As + mm * PITCH + kk * 2) = pack4(ra[r]);
+            } else {
+                const int mm = (e4 % (BM / 4)) * 4, kk = e4 / (BM / 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint16_t*)(As + (mm + i) * PITCH + kk * 2) = bf16_of(ra[r][i]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GB; ++r) {
+            const int e4 = tid + r * 256;
+            if (b_kc) {
+                const int kk = (e4 % (BK / 4)) * 4, nn = e4 / (BK / 4);
+                *(uint2*)(Bs + nn * PITCH + kk * 2) = pack4(rb[r]);
+            } else {
+                const int nn = (e4 % (BN / 4)) * 4, kk = e4 / (BN / 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint16_t*)(Bs + (nn + i) * PITCH + kk * 2) = bf16_of(rb[r][i]);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+            if (k0 + BK < kend) load_tiles(k0 + BK);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(As + (wr * (TM * 32) + i * 32 + r) * PITCH + ks * 32 + h * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8*)(Bs + (wc * (TN * 32) + j * 32 + r) * PITCH + ks * 32 + h * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wc * (TN * 32) + j * 32 + r;
+            if (gn >= g.N) continue;
+            const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
+            const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * h, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: 16-byte global loads only, no integer division in the k loop, BK = 64, LDS double-buffered (one
+// barrier per k step), register prefetch one step ahead.  Each operand is staged by one of three loaders:
+//   KC_F32   rows with k contiguous, f32   : float4 along k -> cvt_pk_bf16 x2 -> one 8-byte LDS write
+//   KC_BF16  rows with k contiguous, bf16  : 8 bf16 (16 B) -> two 8-byte LDS writes
+//   MC_F32   k rows with m (n) contiguous  : a 4(k) x 4(m) register block from four float4 loads, transposed in
+//            registers -> four 8-byte LDS writes (2-way bank conflict at the 136-byte pitch)
+// LDS rows are k-contiguous with a 136-byte pitch: fragment reads (two ds_read_b64 per 32x16 operand) are
+// conflict-free.  Rows / columns past M / N are loaded as whatever the padded pitch holds (they only feed
+// outputs that are never stored); k past the end is zeroed in both operands.
+enum { KC_F32 = 0, KC_BF16 = 1, MC_F32 = 2 };
+constexpr int FBK = 64;
+constexpr int FPITCH = FBK * 2 + 8;          // bf16 rows: 64 x 2 B + 8
+constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64 x 4 B + 16
+
+struct FastArgs {
+    int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
+    int dbg;                           // tuning knobs (env STEP_GEMM_DBG): 1 no stores, 4/8 force 64/128 tiles, 32 general kernel
+};
+
+// no remap is encoded as lg = 30, stride = 0 (i >> 30 == 0): branch-free
+__device__ __forceinline__ long remap(int i, int lg, long stride) {
+    return (long)(i >> lg) * stride + (i & ((1 << lg) - 1));
+}
+
+template <int MODE, int BR>
+struct Stage {
+    static constexpr int NV = MODE == KC_F32 ? BR * FBK / 4 / 256 : (MODE == KC_BF16 ? BR * FBK / 8 / 256 : BR * FBK / 16 / 256);
+    static constexpr int NR = MODE == MC_F32 ? NV * 4 : NV;
+    float f[NR][4];                    // plain scalars: every index below is a compile-time constant after unrolling
+};
+
+// rows: extent of the non-k dimension (M or N); srow / sk: element strides of that dimension and of k.
+// stage_load only issues the loads (out-of-range lanes read the operand's first 16 bytes): straight-line code, every load
+// of a k step is in flight before anything waits.  stage_fix, called after the MFMAs of the previous step, zeroes the
+// out-of-range elements and applies the per-channel affine.
+template <int MODE, int BR>
+__device__ __forceinline__ void stage_load(Stage<MODE, BR>& s, const char* base, int row0, int rows, long srow, long sk, int k0,
+                                           int kend, int klog, long kstride, int rlog, long rstride, int tid) {
+    if constexpr (MODE == KC_F32) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int k = k0 + (e % (FBK / 4)) * 4, row = row0 + e / (FBK / 4);
+            const bool ok = row < rows && k < kend;
+            const long off = ok ? remap(row, rlog, rstride) * srow + remap(k, klog, kstride) : 0;
+            const float4 t = *(const float4*)((const float*)base + off);
+            s.f[r][0] = t.x; s.f[r][1] = t.y; s.f[r][2] = t.z; s.f[r][3] = t.w;
+        }
+    } else if constexpr (MODE == KC_BF16) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int k = k0 + (e % (FBK / 8)) * 8, row = row0 + e / (FBK / 8);
+            const bool ok = row < rows && k < kend;
+            const long off = ok ? remap(row, rlog, rstride) * srow + remap(k, klog, kstride) : 0;
+            const float4 t = *(const float4*)((const uint16_t*)base + off);
+            s.f[r][0] = t.x; s.f[r][1] = t.y; s.f[r][2] = t.z; s.f[r][3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int row = row0 + (e % (BR / 4)) * 4, kb = k0 + (e / (BR / 4)) * 4;
+            const long roff = remap(row, rlog, rstride) * srow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = row < rows && kb + j < kend;
+                const long off = ok ? roff + remap(kb + j, klog, kstride) * sk : 0;
+                const float4 t = *(const float4*)((const float*)base + off);
+                s.f[r * 4 + j][0] = t.x; s.f[r * 4 + j][1] = t.y; s.f[r * 4 + j][2] = t.z; s.f[r * 4 + j][3] = t.w;
+            }
+        }
+    }
+}
+
+template <int MODE, int BR>
+__device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows, int k0, int kend, const float* kscale,
+                                          const float* kshiftv, int kperiod, int tid) {
+    if constexpr (MODE == KC_F32) {
+        float ks0 = 1.f, kh0 = 0.f, ks1 = 1.f, kh1 = 0.f;
+        int kbnd = 0x7fffffff;
+        if (kscale) {      // the 64-wide k tile spans at most two channels (kperiod >= 64): uniform scalars, loaded once per tile
+            const int c0 = k0 / kperiod, c1 = (c0 + 1) * kperiod < kend ? c0 + 1 : c0;
+            ks0 = kscale[c0]; kh0 = kshiftv[c0]; ks1 = kscale[c1]; kh1 = kshiftv[c1];
+            kbnd = (c0 + 1) * kperiod;
+        }
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int k = k0 + (e % (FBK / 4)) * 4, row = row0 + e / (FBK / 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = k + i < kbnd ? s.f[r][i] * ks0 + kh0 : s.f[r][i] * ks1 + kh1;
+                s.f[r][i] = (row < rows && k + i < kend) ? a : 0.f;
+            }
+        }
+    } else if constexpr (MODE == KC_BF16) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int k = k0 + (e % (FBK / 8)) * 8, row = row0 + e / (FBK / 8);
+            const int left = row < rows ? kend - k : 0;          // valid elements in this 8-wide group
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t m = 2 * j + 1 < left ? 0xffffffffu : (2 * j < left ? 0xffffu : 0u);
+                s.f[r][j] = __uint_as_float(__float_as_uint(s.f[r][j]) & m);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int row = row0 + (e % (BR / 4)) * 4, kb = k0 + (e / (BR / 4)) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = row < rows && kb + j < kend;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.f[r * 4 + j][i] = ok ? s.f[r * 4 + j][i] : 0.f;
+            }
+        }
+    }
+}
+
+template <int MODE, int BR, bool F32C>
+__device__ __forceinline__ void stage_store(const Stage<MODE, BR>& s, char* lds, int tid) {
+    if constexpr (F32C) {                 // exact-f32 variant: rows of 64 f32, 16-byte writes
+        static_assert(MODE != KC_BF16, "bf16 operands only feed the bf16 variant");
+        if constexpr (MODE == KC_F32) {
+#pragma unroll
+            for (int r = 0; r < s.NV; ++r) {
+                const int e = tid + r * 256;
+                *(float4*)(lds + (e / (FBK / 4)) * FPITCH32 + (e % (FBK / 4)) * 16) = make_float4(s.f[r][0], s.f[r][1], s.f[r][2], s.f[r][3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < s.NV; ++r) {
+                const int e = tid + r * 256;
+                char* d = lds + ((e % (BR / 4)) * 4) * FPITCH32 + (e / (BR / 4)) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(float4*)(d + i * FPITCH32) = make_float4(s.f[r * 4][i], s.f[r * 4 + 1][i], s.f[r * 4 + 2][i], s.f[r * 4 + 3][i]);
+            }
+        }
+    } else if constexpr (MODE == KC_F32) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            *(uint2*)(lds + (e / (FBK / 4)) * FPITCH + (e % (FBK / 4)) * 8) = pack4(s.f[r][0], s.f[r][1], s.f[r][2], s.f[r][3]);
+        }
+    } else if constexpr (MODE == KC_BF16) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            char* d = lds + (e / (FBK / 8)) * FPITCH + (e % (FBK / 8)) * 16;
+            *(uint2*)d = make_uint2(__float_as_uint(s.f[r][0]), __float_as_uint(s.f[r][1]));
+            *(uint2*)(d + 8) = make_uint2(__float_as_uint(s.f[r][2]), __float_as_uint(s.f[r][3]));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            char* d = lds + ((e % (BR / 4)) * 4) * FPITCH + (e / (BR / 4)) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(uint2*)(d + i * FPITCH) = pack4(s.f[r * 4][i], s.f[r * 4 + 1][i], s.f[r * 4 + 2][i], s.f[r * 4 + 3][i]);
+        }
+    }
+}
+
+// F32C = true: same staging, but LDS keeps f32 and the products run on v_mfma_f32_32x32x2_f32 (exact f32).  A lane of that
+// instruction supplies one k per operand (k = lane >> 5); it reads 16-byte chunk 2*ks + (lane >> 5) of its row and feeds the
+// four values to four successive MFMAs -- both operands permute k identically, so the contraction is unchanged.
+template <int BM, int BN, int AMODE, int BMODE, bool F32C>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int PITCH_ = F32C ? FPITCH32 : FPITCH;
+    constexpr int BUF = (BM + BN) * PITCH_;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksteps = (g.K + FBK - 1) / FBK;
+    const int per = (ksteps + g.splitk - 1) / g.splitk;
+    const int kbeg = zs * per * FBK;
+    const int kend = min(g.K, (zs + 1) * per * FBK);
+    const int i0 = g.batch0 ? zb % g.batch0 : zb, i1 = g.batch0 ? zb / g.batch0 : 0;
+    const char* Ab = (const char*)g.A + ((long)i0 * g.sab + (long)i1 * g.sab1) * (AMODE == KC_BF16 ? 2 : 4);
+    const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * (BMODE == KC_BF16 ? 2 : 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    if (kbeg < kend) {
+        Stage<AMODE, BM> sa;
+        Stage<BMODE, BN> sb;
+        auto fetch = [&](int k0) {
+            stage_load<AMODE, BM>(sa, Ab, m0, g.M, g.sam, g.sak, k0, kend, fa.a_klog, g.a_kstride, 30, 0, tid);
+            stage_load<BMODE, BN>(sb, Bb, n0, g.N, g.sbn, g.sbk, k0, kend, fa.b_klog, g.b_kstride, fa.b_nlog, g.b_nstride, tid);
+        };
+        auto commit = [&](int k0, char* buf) {          // masks / affine, bf16 rounding, LDS writes
+            stage_fix<AMODE, BM>(sa, m0, g.M, k0, kend, g.a_kscale, g.a_kshift, g.a_kperiod, tid);
+            stage_fix<BMODE, BN>(sb, n0, g.N, k0, kend, nullptr, nullptr, 1, tid);
+            stage_store<AMODE, BM, F32C>(sa, buf, tid);
+            stage_store<BMODE, BN, F32C>(sb, buf + BM * PITCH_, tid);
+        };
+        fetch(kbeg);
+        commit(kbeg, lds);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+            const bool more = k0 + FBK < kend;
+            if (more) fetch(k0 + FBK);
+            const char* As = lds + cur * BUF;
+            const char* Bs = As + BM * PITCH_;
+            if constexpr (F32C) {
+#pragma unroll
+                for (int ks = 0; ks < FBK / 8; ++ks) {
+                    float4 a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = *(const float4*)(As + (wr * (TM * 32) + i * 32 + r) * PITCH_ + (2 * ks + h) * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = *(const float4*)(Bs + (wc * (TN * 32) + j * 32 + r) * PITCH_ + (2 * ks + h) * 16);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                        }
+                }
+            } else {
+#pragma unroll
+            for (int ks = 0; ks < FBK / 16; ++ks) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const char* q = As + (wr * (TM * 32) + i * 32 + r) * FPITCH + ks * 32 + h * 16;
+                    const uint2 lo = *(const uint2*)q, hi = *(const uint2*)(q + 8);
+                    a[i] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const char* q = Bs + (wc * (TN * 32) + j * 32 + r) * FPITCH + ks * 32 + h * 16;
+                    const uint2 lo = *(const uint2*)q, hi = *(const uint2*)(q + 8);
+                    b[j] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            }
+            if (more) commit(k0 + FBK, lds + (cur ^ 1) * BUF);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+    if ((fa.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + wc * (TN * 32) + j * 32 + r;
+            if (gn >= g.N) continue;
+            const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
+            const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * h, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+        }
+}
+
+static int ilog2_exact(int v) {        // log2 for powers of two >= 4, -2 otherwise
+    for (int l = 2; l < 31; ++l) if ((1 << l) == v) return l;
+    return -2;
+}
+
+// operand mode for the fast path, or -1 when the operand does not qualify
+static int fast_mode(const void* base, int is_bf16, long srow, long sk, long sb0, long sb1, int kblk, long kstride, int rblk,
+                     long rstride, int* klog, int* rlog) {
+    const int vec = is_bf16 ? 8 : 4;
+    if (((uintptr_t)base & 15) || sb0 % vec || sb1 % vec) return -1;
+    *klog = 30; *rlog = 30;
+    if (sk == 1) {                                   // k contiguous
+        if (srow % vec) return -1;
+        if (kblk) { *klog = ilog2_exact(kblk); if (*klog < 0 || kblk % vec || kstride % vec) return -1; }
+        if (rblk) { *rlog = ilog2_exact(rblk); if (*rlog < 0) return -1; }
+        return is_bf16 ? KC_BF16 : KC_F32;
+    }
+    if (srow == 1 && !is_bf16) {                     // m / n contiguous
+        if (sk % 4) return -1;
+        if (kblk) { *klog = ilog2_exact(kblk); if (*klog < 0) return -1; }
+        if (rblk) { *rlog = ilog2_exact(rblk); if (*rlog < 0 || rstride % 4) return -1; }
+        return MC_F32;
+    }
+    return -1;
+}
+
+template <int BM, int BN, int AMODE>
+int launch_fast_b(const StepGemm& g, const FastArgs& fa, int bmode, dim3 grid, hipStream_t st) {
+    if (bmode == KC_F32) gemm_fast_kernel<BM, BN, AMODE, KC_F32, false><<<grid, 256, 0, st>>>(g, fa);
+    else if (bmode == KC_BF16) gemm_fast_kernel<BM, BN, AMODE, KC_BF16, false><<<grid, 256, 0, st>>>(g, fa);
+    else gemm_fast_kernel<BM, BN, AMODE, MC_F32, false><<<grid, 256, 0, st>>>(g, fa);
+    STEP_LAUNCH_CHECK("step_gemm(bf16 fast)");
+    return STEP_OK;
+}
+template <int BM, int BN>
+int launch_fast(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
+    if (amode == KC_F32) return launch_fast_b<BM, BN, KC_F32>(g, fa, bmode, grid, st);
+    if (amode == KC_BF16) return launch_fast_b<BM, BN, KC_BF16>(g, fa, bmode, grid, st);
+    return launch_fast_b<BM, BN, MC_F32>(g, fa, bmode, grid, st);
+}
+int launch_fast_f32(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+    dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), g.batch * g.splitk);
+    if (amode == KC_F32 && bmode == KC_F32) gemm_fast_kernel<64, 64, KC_F32, KC_F32, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (amode == KC_F32) gemm_fast_kernel<64, 64, KC_F32, MC_F32, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (bmode == KC_F32) gemm_fast_kernel<64, 64, MC_F32, KC_F32, true><<<grid, 256, 0, st>>>(g, fa);
+    else gemm_fast_kernel<64, 64, MC_F32, MC_F32, true><<<grid, 256, 0, st>>>(g, fa);
+    STEP_LAUNCH_CHECK("step_gemm(f32 fast)");
+    return STEP_OK;
+}
+
+template <int BM, int BN>
+int launch_bf16(const StepGemm& g, hipStream_t st) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
+    if (g.a_bf16 && g.b_bf16) gemm_bf16mfma_kernel<BM, BN, uint16_t, uint16_t><<<grid, 256, 0, st>>>(g);
+    else if (g.a_bf16) gemm_bf16mfma_kernel<BM, BN, uint16_t, float><<<grid, 256, 0, st>>>(g);
+    else if (g.b_bf16) gemm_bf16mfma_kernel<BM, BN, float, uint16_t><<<grid, 256, 0, st>>>(g);
+    else gemm_bf16mfma_kernel<BM, BN, float, float><<<grid, 256, 0, st>>>(g);
+    STEP_LAUNCH_CHECK("step_gemm(bf16)");
+    return STEP_OK;
+}
+
+}  // namespace
+
+int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
+    FastArgs fa;
+    int dummy;
+    const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
+    const int bmode = fast_mode(g.B, g.b_bf16, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog,
+                                &fa.b_nlog);
+    bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK));
+    static const int dbg = getenv("STEP_GEMM_DBG") ? atoi(getenv("STEP_GEMM_DBG")) : 0;
+    fa.dbg = dbg;
+    if (dbg & 32) fast = false;
+    const int bk = fast ? FBK : BK;
+    if (g.splitk < 0) {
+        STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
+        long tiles = fast ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;
+        long want = ((fast ? 768 : 1024) + tiles - 1) / tiles;
+        long maxs = cdiv(g.K, bk) / 4;
+        g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
+    }
+    if (g.splitk < 1) g.splitk = 1;
+    if (g.splitk > 1) STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2");
+    STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
+    long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
+    bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
+    if (dbg & 4) big = false;
+    if (dbg & 8) big = true;
+    if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
+    if (big) return launch_bf16<128, 128>(g, st);
+    return launch_bf16<64, 64>(g, st);
+}
+
+// Exact-f32 GEMM through the same staged pipeline (64 x 64 tiles).  Returns -1 when the operands do not qualify
+// (alignment / layout), in which case the caller falls back to the general kernels of gemm.hip.
+int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st) {
+    static const int dbg = getenv("STEP_GEMM_DBG") ? atoi(getenv("STEP_GEMM_DBG")) : 0;
+    if ((dbg & 64) || g.a_bf16 || g.b_bf16) return -1;
+    FastArgs fa;
+    int dummy;
+    const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
+    const int bmode = fast_mode(g.B, 0, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog, &fa.b_nlog);
+    if (amode < 0 || bmode < 0 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
+    fa.dbg = dbg;
+    if (g.splitk < 0) {
+        STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
+        long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;
+        long want = (512 + tiles - 1) / tiles;
+        long maxs = cdiv(g.K, FBK) / 2;
+        g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
+    }
+    if (g.splitk < 1) g.splitk = 1;
+    if (g.splitk > 1) STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2");
+    STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
+    return launch_fast_f32(g, fa, amode, bmode, st);
+}

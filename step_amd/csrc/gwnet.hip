@@ -130,6 +130,21 @@ __global__ void replicate_adp_kernel(const float* __restrict__ Pa, int N, int B,
     float v = Pa[idx], vt = Pa[(long)j * N + i];
     for (int b = 0; b < B; ++b) { P2[(long)b * N * N + idx] = v; PT2[(long)b * N * N + idx] = vt; }
 }
+// bf16 copies of both stacks with the row pitch padded to N8 (pad = 0): the k-contiguous A operand of the bf16 hops
+__global__ void stacks_to_bf16_kernel(const float* __restrict__ P, const float* __restrict__ PT, long rows, int N, int N8,
+                                      uint16_t* __restrict__ P16, uint16_t* __restrict__ PT16) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * (N8 / 2)) return;
+    const long row = idx / (N8 / 2);
+    const int j = (int)(idx % (N8 / 2)) * 2;
+    const float* src = blockIdx.y ? PT : P;
+    uint16_t* dst = blockIdx.y ? PT16 : P16;
+    const float a = j < N ? src[row * N + j] : 0.f, b = j + 1 < N ? src[row * N + j + 1] : 0.f;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    f2 t = {a, b};
+    *(uint32_t*)(dst + row * N8 + j) = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, b2));
+}
 // out[e] = sum_b x[b][e]
 __global__ void sum_batches_kernel(const float* __restrict__ x, long n, int B, float* __restrict__ out) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -434,9 +449,12 @@ struct Carver {
     }
 };
 
+static inline int n8(int N) { return (N + 7) & ~7; }
+
 struct Saved {
     float *x_in[NL], *cat[NL], *tf[NL], *sg[NL], *y[NL], *mask[NL], *bnstat[NL];
     float *Pstk, *PTstk, *Pa, *Madp, *rs, *cs;      // stacks: [3 supports f,b,a][B][N][N]
+    uint16_t *P16, *PT16;                           // bf16 copies, rows zero-padded to N8 = roundup(N, 8) (bf16 hop operands)
     float *skip, *h1, *h2, *xh, *e1;
     long total;
 };
@@ -455,6 +473,8 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
     }
     s.Pstk = cv.take(3L * B * N * N);
     s.PTstk = cv.take(3L * B * N * N);
+    s.P16 = (uint16_t*)cv.take(3L * B * N * n8(N) / 2);
+    s.PT16 = (uint16_t*)cv.take(3L * B * N * n8(N) / 2);
     s.Pa = cv.take((long)N * N);
     s.Madp = cv.take((long)N * N);
     s.rs = cv.take(BN);
@@ -522,30 +542,37 @@ int zero(float* p, long n, hipStream_t st) {
 
 // One launch = the same diffusion hop for the three supports (two-level batch: i1 = support, i0 = sample).
 // Forward hop  Out_s[b][w][n] = sum_v P_s[b][v][w] X_s[b][v][n]  reading slot src0 + sstep*s, writing dst0 + 2*s.
-int nconv_fwd3(const float* Pstk, float* cat, int src0, int sstep, int dst0, int B, int N, int T, hipStream_t st) {
+// bf16 mode: A(m=w, k=v) = PT16[w][v] (k contiguous, bf16) -- no transposition on the way into LDS.
+int nconv_fwd3(const float* Pstk, const uint16_t* PT16, float* cat, int src0, int sstep, int dst0, int B, int N, int T, int bf16,
+               hipStream_t st) {
     StepGemm g = gemm_desc(N, T * C, N, Pstk, 1, N, cat + src0 * C, (long)T * CAT, 1, cat + dst0 * C, (long)T * CAT);
     g.batch = 3 * B; g.batch0 = B;
     g.sab = (long)N * N; g.sab1 = (long)B * N * N;
+    if (bf16) { g.A = PT16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N); }
     g.sbb = (long)N * T * CAT; g.sbb1 = (long)sstep * C;
     g.scb = (long)N * T * CAT; g.scb1 = 2L * C;
     g.b_nblk = C; g.b_nstride = CAT; g.c_nblk = C; g.c_nstride = CAT;
+    g.compute_bf16 = bf16;
     return step_gemm_launch(g, st);
 }
 // Adjoint hop  dDst_s[b][v][n] += sum_w P_s[b][v][w] dSrc_s[b][w][n]  (reads the transposed stack: A(m=v,k=w) = PT[w][v]).
 // dstep == 0: the three supports accumulate into the same slot -> atomics.
-int nconv_bwd_data3(const float* PTstk, float* dcat, int src0, int dst0, int dstep, int B, int N, int T, hipStream_t st) {
+int nconv_bwd_data3(const float* PTstk, const uint16_t* P16, float* dcat, int src0, int dst0, int dstep, int B, int N, int T, int bf16,
+                    hipStream_t st) {
     StepGemm g = gemm_desc(N, T * C, N, PTstk, 1, N, dcat + src0 * C, (long)T * CAT, 1, dcat + dst0 * C, (long)T * CAT);
     g.batch = 3 * B; g.batch0 = B;
     g.sab = (long)N * N; g.sab1 = (long)B * N * N;
+    if (bf16) { g.A = P16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N); }
     g.sbb = (long)N * T * CAT; g.sbb1 = 2L * C;
     g.scb = (long)N * T * CAT; g.scb1 = (long)dstep * C;
     g.b_nblk = C; g.b_nstride = CAT; g.c_nblk = C; g.c_nstride = CAT;
     g.accumulate = dstep == 0 ? 2 : 1;
+    g.compute_bf16 = bf16;
     return step_gemm_launch(g, st);
 }
 // dP_s[b][v][w] += sum_n X_s[b][v][n] * dOut_s[b][w][n]   (x from cat slot xs0 + xstep*s, dOut from dcat slot ds0 + 2*s)
 int nconv_bwd_adj3(const float* cat, int xs0, int xstep, const float* dcat, int ds0, float* dPstk, int B, int N, int T,
-                   hipStream_t st) {
+                   int bf16, hipStream_t st) {
     StepGemm g = gemm_desc(N, N, T * C, cat + xs0 * C, (long)T * CAT, 1, dcat + ds0 * C, 1, (long)T * CAT, dPstk, N);
     g.batch = 3 * B; g.batch0 = B;
     g.sab = (long)N * T * CAT; g.sab1 = (long)xstep * C;
@@ -553,6 +580,7 @@ int nconv_bwd_adj3(const float* cat, int xs0, int xstep, const float* dcat, int 
     g.scb = (long)N * N; g.scb1 = (long)B * N * N;
     g.a_kblk = C; g.a_kstride = CAT; g.b_kblk = C; g.b_kstride = CAT;
     g.accumulate = 1;
+    g.compute_bf16 = bf16;
     return step_gemm_launch(g, st);
 }
 
@@ -596,6 +624,12 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         replicate_adp_kernel<<<g1(NN), 256, 0, st>>>(S.Pa, N, B, S.Pstk + 2 * B * NN, S.PTstk + 2 * B * NN);
         STEP_LAUNCH_CHECK("adp_softmax");
     }
+    if (p->gemm_bf16) {
+        const long rows = 3L * B * N;
+        stacks_to_bf16_kernel<<<dim3((unsigned)cdiv(rows * (n8(N) / 2), 256), 2), 256, 0, st>>>(S.Pstk, S.PTstk, rows, N, n8(N), S.P16,
+                                                                                               S.PT16);
+        STEP_LAUNCH_CHECK("stacks_to_bf16");
+    }
     for (int i = 0; i < NL; ++i) {
         pack_gate_kernel<<<16, 256, 0, st>>>(p->filter_w[i], p->filter_b[i], p->gate_w[i], p->gate_b[i], W.wcat + i * 4096, W.bcat + i * 64);
     }
@@ -619,8 +653,8 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
             STEP_TRY(step_gemm_launch(g, st));
         }
         if (i == NL - 1) break;
-        STEP_TRY(nconv_fwd3(S.Pstk, S.cat[i], 0, 0, 1, B, N, Tout, st));      // slots 1,3,5 = P_s z
-        STEP_TRY(nconv_fwd3(S.Pstk, S.cat[i], 1, 2, 2, B, N, Tout, st));      // slots 2,4,6 = P_s (P_s z)
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, p->gemm_bf16, st));      // slots 1,3,5 = P_s z
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, p->gemm_bf16, st));      // slots 2,4,6 = P_s (P_s z)
         {   // h = cat @ Wmix^T + b
             StepGemm g = gemm_desc((int)npos, C, CAT, S.cat[i], CAT, 1, p->gconv_w[i], 1, CAT, W.h, C);
             g.bias = p->gconv_b[i];
@@ -750,10 +784,10 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             StepGemm gd = gemm_desc((int)npos, CAT, C, W.dh, C, 1, p->gconv_w[i], CAT, 1, W.dcat, CAT);
             STEP_TRY(step_gemm_launch(gd, st));
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
-            STEP_TRY(nconv_bwd_data3(S.PTstk, W.dcat, 2, 1, 2, B, N, Tout, st));          // d_x1 += P (d_x2)
-            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, st));      // dP += x1 (x) d_x2
-            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, st));      // dP += z  (x) d_x1
-            STEP_TRY(nconv_bwd_data3(S.PTstk, W.dcat, 1, 0, 0, B, N, Tout, st));          // d_z  += sum_s P_s (d_x1_s)
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 2, 1, 2, B, N, Tout, p->gemm_bf16, st));          // d_x1 += P (d_x2)
+            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, p->gemm_bf16, st));      // dP += x1 (x) d_x2
+            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, p->gemm_bf16, st));      // dP += z  (x) d_x1
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 1, 0, 0, B, N, Tout, p->gemm_bf16, st));          // d_z  += sum_s P_s (d_x1_s)
         } else {
             STEP_TRY(zero(W.dcat, npos * CAT, st));
         }

@@ -4,6 +4,8 @@
 #include "../../include/step_hip.h"
 
 int step_gemm_launch(StepGemm g, hipStream_t st);
+int step_gemm_bf16_launch(StepGemm g, hipStream_t st);
+int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st);      // -1: operands do not qualify
 
 // convenience builder for the common dense cases (f32 operands, batch 1)
 static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbk,

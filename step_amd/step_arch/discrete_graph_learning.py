@@ -89,8 +89,9 @@ class DiscreteGraphLearning(nn.Module):
                            "it has no standalone PyTorch path")
 
 
-def fill_dgl_struct(tensors):
+def fill_dgl_struct(tensors, gemm_bf16=False):
     s = _lib.StepDglParams()
+    s.gemm_bf16 = int(gemm_bf16)
     for k, v in tensors.items():
         if v is None:
             continue

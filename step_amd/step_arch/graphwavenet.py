@@ -110,9 +110,10 @@ class GraphWaveNet(nn.Module):
                            "it has no standalone PyTorch path")
 
 
-def fill_gwnet_struct(tensors):
+def fill_gwnet_struct(tensors, gemm_bf16=False):
     """tensors: dict name -> device tensor (names as in GraphWaveNet.native_tensors)."""
     s = _lib.StepGwnetParams()
+    s.gemm_bf16 = int(gemm_bf16)
     for k, v in tensors.items():
         if v is None:
             continue

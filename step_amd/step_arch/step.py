@@ -51,7 +51,8 @@ class _StepFunction(torch.autograd.Function):
                L.ptr(adj_knn), None, 0, st)
         # ---- DGL: global feature, edge logits, Gumbel sample
         dt = dgl.native_tensors()
-        dstruct = fill_dgl_struct(dt)
+        bf = model.matmul_precision == "bf16"
+        dstruct = fill_dgl_struct(dt, bf)
         Ttr = dgl.train_length
         gsaved = _f32(L.lib().step_dgl_global_saved_floats(N, Ttr), dev)
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 0), dev)
@@ -66,7 +67,7 @@ class _StepFunction(torch.autograd.Function):
                TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), st)
         # ---- GraphWaveNet
         be = model.backend
-        bstruct = fill_gwnet_struct(be.native_tensors())
+        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
         drop = be.dropout if training else 0.0
         wsaved = _f32(L.lib().step_gwnet_saved_floats(B, N, int(drop > 0)), dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 0), dev)
@@ -99,8 +100,9 @@ class _StepFunction(torch.autograd.Function):
         views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
         gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
         dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
-        bstruct = fill_gwnet_struct(be.native_tensors())
-        dstruct = fill_dgl_struct(dgl.native_tensors())
+        bf = model.matmul_precision == "bf16"
+        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
+        dstruct = fill_dgl_struct(dgl.native_tensors(), bf)
         dpred = dpred.contiguous().float().view(B, 12, N) if dpred is not None else torch.zeros(B, 12, N, device=dev)
         dadj = _f32(B * N * N, dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
@@ -133,6 +135,9 @@ class STEP(nn.Module):
         self.load_pre_trained_model()
         self.discrete_graph_learning = DiscreteGraphLearning(**dgl_args)
         self.gumbel_noise = "device"        # "torch_cpu": draw torch.rand on the host like the reference (:12)
+        # "f32": every contraction outside the TSFormer on the exact-f32 matrix cores (tight parity with the oracle);
+        # "bf16": the diffusion hops / their adjoints and the DGL fc run on the bf16 matrix cores (BASELINE config "bf16")
+        self.matmul_precision = "f32"
         self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
         self._seed_ctr = 0
         self._process_group = None

@@ -265,3 +265,47 @@ def test_native_step_loss_matches_reference_loss():
             assert rel_l2(nt_.cpu() / 2.0, gt.cpu()) < 1e-5
         else:
             assert float(nt_.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["step_tiny", "step_small"])
+def test_step_bf16_matmul_mode(name):
+    """matmul_precision="bf16": diffusion hops, their adjoints and the DGL fc on the bf16 matrix cores.  Operand rounding
+    is 2^-9 relative per element with random sign, so whole-tensor errors stay at the 1e-3..1e-2 level; the discrete outputs
+    (Gumbel sample, kNN prior) must not move."""
+    g = load_golden(name)
+    N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    outs = {}
+    for mode in ("f32", "bf16"):
+        model = build_native(g)
+        model.train()
+        model.matmul_precision = mode
+        model.backend.dropout = 0.0
+        model.tsformer.dropout_p = 0.0
+        model._noise_override = g["in.u"]
+        hist, long_hist, fut = inputs_of(g)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=epoch)
+        loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[mode] = dict(pred=pred.detach().cpu(), theta=theta.detach().cpu(), knn=knn.cpu(), loss=float(loss),
+                          adj=model._last["sampled_adj"].cpu(), grads={kk: t.grad.cpu() for kk, t in dict(model._trainable()).items()})
+    a, b = outs["f32"], outs["bf16"]
+    assert torch.equal(a["knn"], b["knn"])
+    flips = (a["adj"] != b["adj"]).sum().item()
+    print(name, "Gumbel sample flips f32 -> bf16 fc:", flips, "of", a["adj"].numel())
+    assert flips <= max(2, a["adj"].numel() // 500)
+    e_pred = rel_l2(b["pred"], a["pred"])
+    print(name, "bf16-mode pred rel-L2 vs f32 mode", e_pred, "loss", b["loss"], a["loss"])
+    assert e_pred < 1e-2
+    assert max_abs(b["theta"], a["theta"]) < 5e-3
+    assert b["loss"] == pytest.approx(a["loss"], rel=5e-3)
+    if flips == 0:
+        num = sum(float(((b["grads"][kk] - a["grads"][kk]) ** 2).sum()) for kk in a["grads"])
+        den = sum(float((a["grads"][kk] ** 2).sum()) for kk in a["grads"])
+        e_g = (num / den) ** 0.5
+        print(name, "bf16-mode whole-gradient rel-L2 vs f32 mode", e_g)
+        assert e_g < 5e-2
+    e_ref = rel_l2(b["pred"], g["out.pred"])
+    print(name, "bf16-mode pred rel-L2 vs reference", e_ref)
+    assert e_ref < 4e-2
