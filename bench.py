@@ -201,7 +201,8 @@ def main():
         hist, longh, fut = batches[i % len(batches)]
         opt.zero_grad(set_to_none=True)
         pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
-        loss = step_loss(pred[..., [0]] * std + mean, fut[..., [0]] * std + mean, theta, knn, coef, null_val=0.0)
+        # target-feature selection + inverse scaling, as the runner does (step_runner.py:86-92); slices, not index kernels
+        loss = step_loss(pred[..., :1] * std + mean, fut[..., :1] * std + mean, theta, knn, coef, null_val=0.0)
         loss.backward()
         if args.torch_optim:
             torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)                    # STEP_PEMS04.py:103-105

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);
+int step_abi_version(void);        /* 2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
  * C[b](m,n) (op)= alpha * sum_k A[b](m,k) B[b](k,n) (+bias[n]) (relu), element strides.
@@ -56,6 +56,9 @@ typedef struct StepGemm {
     /* 0: exact f32 matrix cores (v_mfma_f32_32x32x2_f32); 1: operands rounded to bf16 in LDS, v_mfma_f32_32x32x16_bf16,
        f32 accumulate and output (16x the matrix-pipe rate) */
     int compute_bf16;
+    /* optional: a_rowsum[m] += sum_k A(m,k)  (batch 1, alpha 1).  The bias gradient that accompanies a weight-gradient
+       GEMM; the staged kernels get it from the matrix cores as one extra all-ones column of B. */
+    float* a_rowsum;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 

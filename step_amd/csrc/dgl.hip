@@ -563,7 +563,7 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
     if (!backward) return part;
-    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + 256;
+    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + 256 + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
 static void carve_saved(float* saved, int N, int T, float** a1, float** a2, float** gpre, float** st1, float** st2, float** st3) {
@@ -593,10 +593,16 @@ extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, con
         STEP_LAUNCH_CHECK("bn1");
     }
     {
-        dim3 grid(cdiv(T2, 256 * 4), N);
-        conv_relu_fwd_kernel<8, 16, 4><<<grid, 256, 0, st>>>(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, T1);
-        STEP_LAUNCH_CHECK("conv2");
-        bn_finalize_kernel<<<16, 256, 0, st>>>(partial, grid.x * grid.y, 16, (double)N * T2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv,
+        int nblk;
+        if (p->gemm_bf16) {
+            STEP_TRY(dgl_conv2_fwd_mfma(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
+        } else {
+            dim3 grid(cdiv(T2, 256 * 4), N);
+            conv_relu_fwd_kernel<8, 16, 4><<<grid, 256, 0, st>>>(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, T1);
+            STEP_LAUNCH_CHECK("conv2");
+            nblk = grid.x * grid.y;
+        }
+        bn_finalize_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, (double)N * T2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv,
                                                training, momentum, st2);
         STEP_LAUNCH_CHECK("bn2");
     }
@@ -629,6 +635,7 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     float* dgpre = wraw + (long)EMB * K;
     float* dgpreT = dgpre + (long)N * EMB;
     float* coef = dgpreT + (long)N * EMB;
+    float* wg_scratch = coef + 256;
     // BN3 + ReLU backward, fc bias gradient
     bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT);
     STEP_LAUNCH_CHECK("bn3_bwd");
@@ -658,10 +665,15 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
         STEP_LAUNCH_CHECK("bn2_bwd_apply");
     }
     // conv2 backward: weights (BN1 affine folded into the input read) and data
-    conv_bwd_weight_kernel<8, 16><<<N, 256, 0, st>>>(d_a2, a1, st1, st1 + 8, grads->conv2_w, grads->conv2_b, T1);
-    STEP_LAUNCH_CHECK("conv2_bwd_weight");
-    conv_bwd_data_kernel<8, 16, 4><<<dim3(cdiv(T1, 1024), N), 256, 0, st>>>(d_a2, p->conv2_w, d_a1, T1);
-    STEP_LAUNCH_CHECK("conv2_bwd_data");
+    if (p->gemm_bf16) {
+        STEP_TRY(dgl_conv2_wgrad_mfma(d_a2, a1, st1, st1 + 8, wg_scratch, grads->conv2_w, grads->conv2_b, N, T1, st));
+        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, st));
+    } else {
+        conv_bwd_weight_kernel<8, 16><<<N, 256, 0, st>>>(d_a2, a1, st1, st1 + 8, grads->conv2_w, grads->conv2_b, T1);
+        STEP_LAUNCH_CHECK("conv2_bwd_weight");
+        conv_bwd_data_kernel<8, 16, 4><<<dim3(cdiv(T1, 1024), N), 256, 0, st>>>(d_a2, p->conv2_w, d_a1, T1);
+        STEP_LAUNCH_CHECK("conv2_bwd_data");
+    }
     // BN1 backward in place -> dz1
     {
         dim3 grid(cdiv(T1, 1024), 8, N);

@@ -1,0 +1,292 @@
+// bf16 matrix-core versions of the DiscreteGraphLearning conv2 stage (8 -> 16 channels, 10 taps, valid) and its two
+// adjoints -- reference discrete_graph_learning.py:133-134 (conv2 + relu, bn1 folded into the read) and their autograd.
+// Used when StepDglParams.gemm_bf16 is set; the exact-f32 VALU kernels of dgl.hip stay the parity path.
+//
+// All three are HBM-bound streams over the [N][C][T] activations (a1: 133 MB, a2 / d_a2: 267 MB at PEMS04):
+//   forward   reads a1, writes a2                        400 MB
+//   dgrad     reads dz2, writes d_a1                     400 MB
+//   wgrad     reads dz2 and a1, writes 16x8x10 numbers   400 MB
+// The arithmetic (10.7 GFLOP each) is mapped on v_mfma_f32_16x16x32_bf16 with the time axis as the n (forward, dgrad) or
+// k (wgrad) dimension; the im2col operand is never materialised: the input window lives in LDS as [t][channels] bf16
+// rows (one 16-byte row per time step) and the MFMA operand of lane (t, tap group) is one ds_read_b128 at row t + tap.
+//
+// Lane maps of v_mfma_f32_16x16x32_bf16 (guide "Fragment layout"): A[m = l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][n = l&15],
+// D[m = 4(l>>4)+e][n = l&15].
+#include "common.h"
+#include "step_internal.h"
+
+namespace {
+
+constexpr int KW = 10, CI = 8, CO = 16;
+constexpr int FW_TT = 1024;             // outputs per workgroup (forward, dgrad)
+
+__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ bf16x8 as_frag(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ------------------------------------------------------------------------------------------------ forward
+// a2[n][co][t] = relu(b[co] + sum_{ci,kk} w[co][ci][kk] * (a1[n][ci][t+kk] * sc[ci] + sh[ci])),  partial BN2 sums per block.
+// k index of the contraction = kk*8 + ci (three 32-wide steps, taps 10 and 11 carry zero weights).
+__global__ __launch_bounds__(256) void conv2_fwd_mfma_kernel(const float* __restrict__ a1, const float* __restrict__ w,
+                                                             const float* __restrict__ b, const float* __restrict__ sc,
+                                                             const float* __restrict__ sh, float* __restrict__ a2,
+                                                             float* __restrict__ partial, int T1) {
+    __shared__ uint4 xs[FW_TT + 16];              // [t][8 ci] bf16
+    __shared__ float red[4][2 * CO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
+    const int T2 = T1 - (KW - 1), t0 = blockIdx.x * FW_TT;
+    const int ln = lane & 15, q = lane >> 4;
+
+    float s8[CI], h8[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) { s8[ci] = sc[ci]; h8[ci] = sh[ci]; }
+    for (int tt = tid; tt < FW_TT + 16; tt += 256) {
+        const int t = t0 + tt;
+        float v[CI];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) v[ci] = t < T1 ? a1[((long)n * CI + ci) * T1 + t] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) v[ci] = t < T1 ? v[ci] * s8[ci] + h8[ci] : 0.f;
+        xs[tt] = make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7]));
+    }
+    bf16x8 wf[3];                                 // weights: lane (co = ln, tap = 4s + q), 8 input channels
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int kk = 4 * s + q;
+        float v[CI];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) v[ci] = kk < KW ? w[(ln * CI + ci) * KW + kk] : 0.f;
+        wf[s] = as_frag(make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7])));
+    }
+    float bias[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[e] = b[4 * q + e];
+    __syncthreads();
+
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = wave; tile < FW_TT / 16; tile += 4) {
+        const int tb = tile * 16;
+        if (t0 + tb >= T2) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], as_frag(xs[tb + ln + 4 * s + q]), acc, 0, 0, 0);
+        const int t = t0 + tb + ln;
+        if (t < T2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf(acc[e] + bias[e], 0.f);
+                a2[((long)n * CO + 4 * q + e) * T2 + t] = v;
+                s1[e] += v; s2[e] += v * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        if (ln == 0) { red[wave][4 * q + e] = s1[e]; red[wave][CO + 4 * q + e] = s2[e]; }
+    }
+    __syncthreads();
+    if (tid < 2 * CO)
+        partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * CO) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad
+// d_a1[n][ci][t] = sum_{co,kk} w[co][ci][kk] * dz[n][co][t-kk]      (dz = 0 outside [0, T2))
+// k index = kk*16 + co (five 32-wide steps); rows m = ci (8 of the 16 MFMA rows are used).
+__global__ __launch_bounds__(256) void conv2_dgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                               float* __restrict__ din, int T1) {
+    __shared__ uint4 zs[FW_TT + 16][2];           // [t - (t0 - 9)][16 co] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
+    const int T2 = T1 - (KW - 1), t0 = blockIdx.x * FW_TT;
+    const int ln = lane & 15, q = lane >> 4;
+    for (int tt = tid; tt < FW_TT + 16; tt += 256) {
+        const int t = t0 - (KW - 1) + tt;
+        const bool ok = t >= 0 && t < T2;
+        float v[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) v[co] = ok ? dz[((long)n * CO + co) * T2 + t] : 0.f;
+        zs[tt][0] = make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7]));
+        zs[tt][1] = make_uint4(cvt2(v[8], v[9]), cvt2(v[10], v[11]), cvt2(v[12], v[13]), cvt2(v[14], v[15]));
+    }
+    bf16x8 wf[5];                                 // lane (ci = ln, tap = 2s + (q>>1), co = 8(q&1) + j)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int kk = 2 * s + (q >> 1), c0 = 8 * (q & 1);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ln < CI ? w[((c0 + j) * CI + ln) * KW + kk] : 0.f;
+        wf[s] = as_frag(make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7])));
+    }
+    __syncthreads();
+    for (int tile = wave; tile < FW_TT / 16; tile += 4) {
+        const int tb = tile * 16;
+        if (t0 + tb >= T1) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int kk = 2 * s + (q >> 1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], as_frag(zs[tb + ln + (KW - 1) - kk][q & 1]), acc, 0, 0, 0);
+        }
+        const int t = t0 + tb + ln;
+        if (t < T1 && q < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) din[((long)n * CI + 4 * q + e) * T1 + t] = acc[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dw[co][ci][kk] += sum_{n,t} dz[n][co][t] * (a1[n][ci][t+kk] * sc[ci] + sh[ci]),   db[co] += sum_{n,t} dz[n][co][t]
+// Contraction over time: m = co, n = kk*8 + ci (five 16-wide tiles), k = 32 time steps per MFMA.  The shifted input rows are
+// read with 4-byte LDS loads; a second copy of the window shifted by one element serves the odd taps.
+constexpr int WG_SC = 256;               // time steps staged per pass
+constexpr int WG_PASSES = 14;            // passes per workgroup (3584 steps)
+constexpr int WG_OUT = CO * CI * KW + CO;
+
+__global__ __launch_bounds__(256) void conv2_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ a1,
+                                                               const float* __restrict__ sc, const float* __restrict__ sh,
+                                                               float* __restrict__ partial, int T1) {
+    constexpr int ZP = WG_SC + 8;        // bf16 elements per row (16-byte multiple)
+    constexpr int XP = WG_SC + 16;
+    __shared__ __attribute__((aligned(16))) uint16_t zs[CO][ZP];
+    __shared__ __attribute__((aligned(16))) uint16_t x0[CI][XP], x1[CI][XP];        // x1[c][i] = x0[c][i + 1]
+    __shared__ float red[3][5][64][4];
+    __shared__ float redb[4][CO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
+    const int T2 = T1 - (KW - 1), tbeg = blockIdx.x * (WG_SC * WG_PASSES);
+    const int ln = lane & 15, q = lane >> 4;
+    float s8[CI], h8[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) { s8[ci] = sc[ci]; h8[ci] = sh[ci]; }
+
+    f32x4 acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bsum[co] = 0.f;
+
+    for (int pass = 0; pass < WG_PASSES; ++pass) {
+        const int tp = tbeg + pass * WG_SC;
+        if (tp >= T2) break;
+        __syncthreads();
+        {   // stage dz (zero past T2) and the affine input window [tp, tp + 256 + 10]
+            const int t = tp + tid;
+            float v[CO];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) v[co] = t < T2 ? dz[((long)n * CO + co) * T2 + t] : 0.f;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                bsum[co] += v[co];
+                zs[co][tid] = (uint16_t)(cvt2(v[co], 0.f) & 0xffffu);
+            }
+            for (int tt = tid; tt < WG_SC + 10; tt += 256) {
+                const int tx = tp + tt;
+                float x[CI];
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) x[ci] = tx < T1 ? a1[((long)n * CI + ci) * T1 + tx] * s8[ci] + h8[ci] : 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const uint16_t hb = (uint16_t)(cvt2(x[ci], 0.f) & 0xffffu);
+                    x0[ci][tt] = hb;
+                    if (tt > 0) x1[ci][tt - 1] = hb;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tb = 64 * wave + 32 * u + 8 * q;          // first of this lane's 8 time steps
+            const bf16x8 a = as_frag(*(const uint4*)&zs[ln][tb]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int kk = 2 * j + (ln >> 3), ci = ln & 7;
+                const uint16_t* row = (kk & 1) ? &x1[ci][0] : &x0[ci][0];
+                const uint32_t* p = (const uint32_t*)(row + tb + (kk & ~1));
+                const bf16x8 bfr = as_frag(make_uint4(p[0], p[1], p[2], p[3]));
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // combine the four waves, then one row of partial results per workgroup: [co][ci][kk] then db[co]
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave - 1][j][lane][e] = acc[j][e];
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const float s = wave_sum(bsum[co]);
+        if (lane == 0) redb[wave][co] = s;
+    }
+    __syncthreads();
+    float* out = partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * WG_OUT;
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int kk = 2 * j + (ln >> 3), ci = ln & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = 4 * q + e;
+                out[(co * CI + ci) * KW + kk] = acc[j][e] + red[0][j][lane][e] + red[1][j][lane][e] + red[2][j][lane][e];
+            }
+        }
+    }
+    if (tid < CO) out[CO * CI * KW + tid] = redb[0][tid] + redb[1][tid] + redb[2][tid] + redb[3][tid];
+}
+
+// dw / db += column sums of the per-workgroup partial rows (grid.y row slices, one atomic per slice and output)
+__global__ __launch_bounds__(256) void conv2_wgrad_reduce_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+    __shared__ float red[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (o < WG_OUT)
+        for (int r = blockIdx.y * 4 + w; r < nrows; r += gridDim.y * 4) s += partial[(long)r * WG_OUT + o];
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && o < WG_OUT) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(o < CO * CI * KW ? &dw[o] : &db[o - CO * CI * KW], v);
+    }
+}
+
+}  // namespace
+
+int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
+                       int N, int T1, int* nblk, hipStream_t st) {
+    const int T2 = T1 - (KW - 1);
+    dim3 grid(cdiv(T2, FW_TT), N);
+    conv2_fwd_mfma_kernel<<<grid, 256, 0, st>>>(a1, w, b, sc, sh, a2, partial, T1);
+    STEP_LAUNCH_CHECK("conv2_fwd_mfma");
+    *nblk = grid.x * grid.y;
+    return STEP_OK;
+}
+
+int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, hipStream_t st) {
+    conv2_dgrad_mfma_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>(dz, w, din, T1);
+    STEP_LAUNCH_CHECK("conv2_dgrad_mfma");
+    return STEP_OK;
+}
+
+long dgl_conv2_wgrad_scratch_floats(int N, int T1) {
+    const int T2 = T1 - (KW - 1);
+    return (long)N * cdiv(T2, WG_SC * WG_PASSES) * WG_OUT;
+}
+
+int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
+                         int T1, hipStream_t st) {
+    const int T2 = T1 - (KW - 1);
+    dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
+    conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, sc, sh, scratch, T1);
+    STEP_LAUNCH_CHECK("conv2_wgrad_mfma");
+    conv2_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, dw, db);
+    STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
+    return STEP_OK;
+}

@@ -428,15 +428,26 @@ int launch(const StepGemm& g, hipStream_t st) {
 
 }  // namespace
 
+int step_gemm_rowsum_fallback(StepGemm* g, hipStream_t st) {
+    if (!g->a_rowsum) return STEP_OK;
+    STEP_REQUIRE(g->sam == 1 && g->a_kblk == 0, "step_gemm: a_rowsum on the general kernels needs an m-contiguous A without k remap");
+    STEP_TRY(step_colsum_launch((const float*)g->A, g->K, g->M, g->sak, g->a_rowsum, st));
+    g->a_rowsum = nullptr;
+    return STEP_OK;
+}
+
 int step_gemm_launch(StepGemm g, hipStream_t st) {
     STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && g.batch > 0, "step_gemm: bad sizes M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
     STEP_REQUIRE(g.A && g.B && g.C, "step_gemm: null operand");
     if (g.scn == 0) g.scn = 1;
+    if (g.a_rowsum)
+        STEP_REQUIRE(g.batch == 1 && g.alpha == 1.f && !g.a_bf16 && !g.a_kscale, "step_gemm: a_rowsum needs batch 1, alpha 1, f32 A without affine");
     if (g.compute_bf16) return step_gemm_bf16_launch(g, st);
     {
         const int rc = step_gemm_f32_fast_launch(g, st);
         if (rc != -1) return rc;
     }
+    STEP_TRY(step_gemm_rowsum_fallback(&g, st));
     if (g.splitk < 0 && direct_eligible(g)) g.splitk = 1;      // short contraction: the direct kernel, no split
     if (g.splitk < 0) {            // auto: enough workgroups to fill 256 CUs, at least 4 k-steps each
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");

@@ -302,7 +302,7 @@ __device__ __forceinline__ void stage_load(Stage<MODE, BR>& s, const char* base,
 
 template <int MODE, int BR>
 __device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows, int k0, int kend, const float* kscale,
-                                          const float* kshiftv, int kperiod, int tid) {
+                                          const float* kshiftv, int kperiod, int ones_row, int tid) {
     if constexpr (MODE == KC_F32) {
         float ks0 = 1.f, kh0 = 0.f, ks1 = 1.f, kh1 = 0.f;
         int kbnd = 0x7fffffff;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float a = k + i < kbnd ? s.f[r][i] * ks0 + kh0 : s.f[r][i] * ks1 + kh1;
-                s.f[r][i] = (row < rows && k + i < kend) ? a : 0.f;
+                s.f[r][i] = k + i < kend ? (row < rows ? a : (row == ones_row ? 1.f : 0.f)) : 0.f;
             }
         }
     } else if constexpr (MODE == KC_BF16) {
@@ -340,9 +340,10 @@ __device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows
             const int row = row0 + (e % (BR / 4)) * 4, kb = k0 + (e / (BR / 4)) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool ok = row < rows && kb + j < kend;
+                const bool kok = kb + j < kend;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s.f[r * 4 + j][i] = ok ? s.f[r * 4 + j][i] : 0.f;
+                for (int i = 0; i < 4; ++i)
+                    s.f[r * 4 + j][i] = kok ? (row + i == ones_row ? 1.f : (row < rows ? s.f[r * 4 + j][i] : 0.f)) : 0.f;
             }
         }
     }
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int r = lane & 31, h = lane >> 5;
+    const int ones_row = (BMODE != KC_BF16 && g.a_rowsum) ? g.N : -1;      // virtual all-ones column of B -> row sums of A
     if (kbeg < kend) {
         Stage<AMODE, BM> sa;
         Stage<BMODE, BN> sb;
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             stage_load<BMODE, BN>(sb, Bb, n0, g.N, g.sbn, g.sbk, k0, kend, fa.b_klog, g.b_kstride, fa.b_nlog, g.b_nstride, tid);
         };
         auto commit = [&](int k0, char* buf) {          // masks / affine, bf16 rounding, LDS writes
-            stage_fix<AMODE, BM>(sa, m0, g.M, k0, kend, g.a_kscale, g.a_kshift, g.a_kperiod, tid);
-            stage_fix<BMODE, BN>(sb, n0, g.N, k0, kend, nullptr, nullptr, 1, tid);
+            stage_fix<AMODE, BM>(sa, m0, g.M, k0, kend, g.a_kscale, g.a_kshift, g.a_kperiod, -1, tid);
+            stage_fix<BMODE, BN>(sb, n0, g.N, k0, kend, nullptr, nullptr, 1, ones_row, tid);
             stage_store<AMODE, BM, F32C>(sa, buf, tid);
             stage_store<BMODE, BN, F32C>(sb, buf + BM * PITCH_, tid);
         };
@@ -501,10 +503,12 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gn = n0 + wc * (TN * 32) + j * 32 + r;
+            const int mb = m0 + wr * (TM * 32) + i * 32 + 4 * h;
+            if (gn == ones_row) gemm_store_tile(acc[i][j], g.a_rowsum, mb, g.M, 1, g.alpha, 2, 0.f, 0);
             if (gn >= g.N) continue;
             const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
             const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
-            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * h, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, mb, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
         }
 }
 
@@ -544,13 +548,13 @@ int launch_fast_b(const StepGemm& g, const FastArgs& fa, int bmode, dim3 grid, h
 }
 template <int BM, int BN>
 int launch_fast(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch * g.splitk);
+    dim3 grid(cdiv(g.N + (g.a_rowsum ? 1 : 0), BN), cdiv(g.M, BM), g.batch * g.splitk);
     if (amode == KC_F32) return launch_fast_b<BM, BN, KC_F32>(g, fa, bmode, grid, st);
     if (amode == KC_BF16) return launch_fast_b<BM, BN, KC_BF16>(g, fa, bmode, grid, st);
     return launch_fast_b<BM, BN, MC_F32>(g, fa, bmode, grid, st);
 }
 int launch_fast_f32(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
-    dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), g.batch * g.splitk);
+    dim3 grid(cdiv(g.N + (g.a_rowsum ? 1 : 0), 64), cdiv(g.M, 64), g.batch * g.splitk);
     if (amode == KC_F32 && bmode == KC_F32) gemm_fast_kernel<64, 64, KC_F32, KC_F32, true><<<grid, 256, 0, st>>>(g, fa);
     else if (amode == KC_F32) gemm_fast_kernel<64, 64, KC_F32, MC_F32, true><<<grid, 256, 0, st>>>(g, fa);
     else if (bmode == KC_F32) gemm_fast_kernel<64, 64, MC_F32, KC_F32, true><<<grid, 256, 0, st>>>(g, fa);
@@ -578,7 +582,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
     const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, g.b_bf16, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog,
                                 &fa.b_nlog);
-    bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK));
+    bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
+                !(g.a_rowsum && bmode == KC_BF16);
     static const int dbg = getenv("STEP_GEMM_DBG") ? atoi(getenv("STEP_GEMM_DBG")) : 0;
     fa.dbg = dbg;
     if (dbg & 32) fast = false;
@@ -598,6 +603,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
     if (dbg & 4) big = false;
     if (dbg & 8) big = true;
     if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
+    STEP_TRY(step_gemm_rowsum_fallback(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
     return launch_bf16<64, 64>(g, st);
 }

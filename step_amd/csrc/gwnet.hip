@@ -313,21 +313,21 @@ __global__ __launch_bounds__(256) void mix_post_kernel(const float* __restrict__
     }
 }
 // channel-last BN statistics -> stat [4][32] = scale, shift, mean, rstd (+ running stats)
-__global__ __launch_bounds__(256) void bn_cl_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+__global__ __launch_bounds__(1024) void bn_cl_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rm, float* __restrict__ rv, int training,
                                                              float momentum, float* __restrict__ stat) {
-    __shared__ double ra[8][32], rq[8][32];
-    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;      // 256 threads: 8 partial sums per channel
+    __shared__ double ra[32][32], rq[32][32];
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;      // 1024 threads: 32 partial sums per channel
     double a = 0.0, q = 0.0;
     if (training)
-        for (int i = part; i < nblk; i += 8) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+        for (int i = part; i < nblk; i += 32) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
     ra[part][c] = a; rq[part][c] = q;
     __syncthreads();
     if (part != 0) return;
     double mean, var;
     if (training) {
-        for (int r = 1; r < 8; ++r) { a += ra[r][c]; q += rq[r][c]; }
+        for (int r = 1; r < 32; ++r) { a += ra[r][c]; q += rq[r][c]; }
         mean = a / count;
         var = fmax(q / count - mean * mean, 0.0);
         rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
@@ -364,18 +364,18 @@ __global__ __launch_bounds__(256) void bn_cl_bwd_reduce_kernel(const float* __re
         partial[(long)blockIdx.x * 64 + threadIdx.x] = a;
     }
 }
-__global__ __launch_bounds__(256) void bn_cl_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
+__global__ __launch_bounds__(1024) void bn_cl_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
                                                                  const float* __restrict__ gamma, const float* __restrict__ stat,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                  float* __restrict__ coef) {
-    __shared__ double ra[8][32], rq[8][32];
+    __shared__ double ra[32][32], rq[32][32];
     const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
     double a = 0.0, q = 0.0;
-    for (int i = part; i < nblk; i += 8) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
+    for (int i = part; i < nblk; i += 32) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
     ra[part][c] = a; rq[part][c] = q;
     __syncthreads();
     if (part != 0) return;
-    for (int r = 1; r < 8; ++r) { a += ra[r][c]; q += rq[r][c]; }
+    for (int r = 1; r < 32; ++r) { a += ra[r][c]; q += rq[r][c]; }
     dgamma[c] += (float)q; dbeta[c] += (float)a;
     coef[c] = (float)(a / count); coef[32 + c] = (float)(q / count); coef[64 + c] = gamma[c] * stat[96 + c];
 }
@@ -665,7 +665,7 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         mix_post_kernel<<<nblk, 256, 0, st>>>(W.h, S.x_in[i], BN, Tin, Tout, dil, use_drop ? dropout_p : 0.f, (uint32_t)seed,
                                               (uint32_t)(seed >> 32), (uint32_t)i, S.mask[i], S.y[i], W.partial);
         STEP_LAUNCH_CHECK("mix_post");
-        bn_cl_finalize_kernel<<<1, 256, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], training,
+        bn_cl_finalize_kernel<<<1, 1024, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], training,
                                                 momentum, S.bnstat[i]);
         bn_cl_apply_kernel<<<g1(npos * C), 256, 0, st>>>(S.y[i], npos * C, S.bnstat[i], S.x_in[i + 1]);
         STEP_LAUNCH_CHECK("bn_apply");
@@ -729,9 +729,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         rowsum_mod_kernel<<<B * OUT, 256, 0, st>>>(dpred, N, OUT, grads->end2_b);
         STEP_LAUNCH_CHECK("end2_bias_grad");
         relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_e1, S.e1, BN * CE);
-        STEP_TRY(step_colsum_launch(W.d_e1, BN, CE, CE, grads->end1_b, st));
         StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
         gw1.accumulate = 2; gw1.splitk = split_for(BN);
+        gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
         STEP_TRY(step_gemm_launch(gw1, st));
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
         STEP_TRY(step_gemm_launch(gx, st));
@@ -749,16 +749,16 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             return STEP_ERR_HIP;
         }
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_h2, S.h2, BN * CS);
-        STEP_TRY(step_colsum_launch(W.d_h2, BN, CS, CS, grads->fc_his2_b, st));
         StepGemm gw2 = gemm_desc(CS, CE, (int)BN, W.d_h2, 1, CS, S.h1, CE, 1, grads->fc_his2_w, CE);
         gw2.accumulate = 2; gw2.splitk = split_for(BN);
+        gw2.a_rowsum = grads->fc_his2_b;
         STEP_TRY(step_gemm_launch(gw2, st));
         StepGemm gh1 = gemm_desc((int)BN, CE, CS, W.d_h2, CS, 1, p->fc_his2_w, CE, 1, W.d_h1, CE);
         STEP_TRY(step_gemm_launch(gh1, st));
         relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_h1, S.h1, BN * CE);
-        STEP_TRY(step_colsum_launch(W.d_h1, BN, CE, CE, grads->fc_his0_b, st));
         StepGemm gw0 = gemm_desc(CE, HID, (int)BN, W.d_h1, 1, CE, hidden_last, HID, 1, grads->fc_his0_w, HID);
         gw0.accumulate = 2; gw0.splitk = split_for(BN);
+        gw0.a_rowsum = grads->fc_his0_b;
         STEP_TRY(step_gemm_launch(gw0, st));
     }
 
@@ -773,14 +773,14 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             int nblk = (int)((npos + 7) / 8);
             if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
             bn_cl_bwd_reduce_kernel<<<nblk, 256, 0, st>>>(dx_next, S.y[i], npos, S.bnstat[i], W.partial);
-            bn_cl_bwd_finalize_kernel<<<1, 256, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], W.coef);
+            bn_cl_bwd_finalize_kernel<<<1, 1024, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], W.coef);
             bn_cl_bwd_apply_kernel<<<g1(npos * C), 256, 0, st>>>(dx_next, S.y[i], npos * C, S.bnstat[i], W.coef, S.mask[i], W.dres, W.dh);
             STEP_LAUNCH_CHECK("bn_bwd");
             // mix (gconv.i.mlp) gradients
             StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = split_for(npos);
+            gw.a_rowsum = grads->gconv_b[i];
             STEP_TRY(step_gemm_launch(gw, st));
-            STEP_TRY(step_colsum_launch(W.dh, npos, C, C, grads->gconv_b[i], st));
             StepGemm gd = gemm_desc((int)npos, CAT, C, W.dh, C, 1, p->gconv_w[i], CAT, 1, W.dcat, CAT);
             STEP_TRY(step_gemm_launch(gd, st));
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
@@ -807,8 +807,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         {
             StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre, 1, 64, W.xcat, 64, 1, W.dwcat + i * 4096, 64);
             gw.accumulate = 2; gw.splitk = split_for(npos);
+            gw.a_rowsum = W.dbcat + i * 64;
             STEP_TRY(step_gemm_launch(gw, st));
-            STEP_TRY(step_colsum_launch(W.dpre, npos, 64, 64, W.dbcat + i * 64, st));
             StepGemm gx = gemm_desc((int)npos, 64, 64, W.dpre, 64, 1, W.wcat + i * 4096, 64, 1, W.dxcat, 64);
             STEP_TRY(step_gemm_launch(gx, st));
         }

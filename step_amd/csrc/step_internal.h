@@ -20,4 +20,13 @@ static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, 
     return g;
 }
 
+// general-kernel path of StepGemm.a_rowsum: a separate column-sum launch (needs A(m,k) = X[k*sak + m]); clears g->a_rowsum
+int step_gemm_rowsum_fallback(StepGemm* g, hipStream_t st);
+// bf16 matrix-core conv2 stage of the DGL (dgl_conv_mfma.hip)
+int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
+                       int N, int T1, int* nblk, hipStream_t st);
+int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, hipStream_t st);
+long dgl_conv2_wgrad_scratch_floats(int N, int T1);
+int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
+                         int T1, hipStream_t st);
 int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out, hipStream_t st);

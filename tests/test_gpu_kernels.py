@@ -240,3 +240,20 @@ def test_gemm_two_level_batch(L):
     for s in range(3):
         want = torch.einsum("bvtc,bwtc->bvw", got[..., 32 + 64 * s:64 + 64 * s].double(), got[..., 64 + 64 * s:96 + 64 * s].double())
         assert rel_l2(dP.cpu()[s], want) < 1e-5, s
+
+
+@pytest.mark.parametrize("M,N,K,lda,bf16", [(32, 224, 3000, 32, False), (64, 64, 2500, 64, False), (100, 60, 777, 100, False),
+                                            (33, 50, 400, 33, False), (32, 224, 3000, 32, True), (64, 128, 1000, 64, True)])
+def test_gemm_rowsum_column(L, M, N, K, lda, bf16):
+    """StepGemm.a_rowsum: the bias gradient that rides along a weight-gradient GEMM (dW = dY^T X, db = colsum(dY)).
+    Staged kernels compute it as an all-ones column of B; the general kernels fall back to a column-sum launch
+    (M = 33: rows not 16-byte aligned)."""
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(K, lda, generator=g)[:, :M].contiguous() if lda == M else torch.randn(K, M, generator=g)
+    X = torch.randn(K, N, generator=g)
+    dW = torch.zeros(M, N, device="cuda")
+    db = torch.full((M,), 0.5, device="cuda")              # accumulated into
+    L.gemm(dY.cuda(), X.cuda(), dW, M, N, K, 1, M, N, 1, N, accumulate=2, splitk=-1, a_rowsum=db, compute_bf16=bf16)
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+    assert rel_l2(dW.cpu(), rnd(dY).T @ rnd(X)) < 2e-5
+    assert rel_l2(db.cpu(), 0.5 + rnd(dY).sum(0)) < 2e-5

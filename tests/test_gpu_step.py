@@ -201,47 +201,41 @@ def test_step_device_noise_and_dropout_run():
 
 def test_fused_adam_clip_matches_torch():
     """step_adam_clip == torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over several steps, and the flattened
-    parameters keep driving the native forward."""
+    parameters keep driving the native forward.  Both optimizers are fed the same gradients every step (a shadow copy of
+    the parameters carries the torch optimizer): two independent training runs would not be comparable, the split-K /
+    bias-column reductions use atomics and Adam turns round-off on near-zero gradients into +-lr steps."""
     from step_amd.optim import FusedAdamClip
     g = load_golden("step_tiny")
     mean, std = [float(x) for x in g["meta.scaler"]]
     hist, long_hist, fut = inputs_of(g)
-
-    def run(fused):
-        torch.manual_seed(0)
-        model = build_native(g)
-        model.train()
-        model.backend.dropout = 0.0
-        model.tsformer.dropout_p = 0.0
-        model._noise_override = g["in.u"]
-        params = [p for p in model.parameters() if p.requires_grad]
-        if fused:
-            opt = FusedAdamClip(model, lr=2e-3, weight_decay=1e-5, eps=1e-8, max_norm=3.0)
-        else:
-            opt = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-5, eps=1e-8)
-        losses = []
-        for it in range(4):
-            opt.zero_grad(set_to_none=True)
-            pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
-            loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
-            loss.backward()
-            if not fused:
-                torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)
-            opt.step()
-            losses.append(float(loss))
-        return losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
-
-    l_t, p_t = run(False)
-    l_f, p_f = run(True)
-    print("losses torch", l_t, "fused", l_f)
-    assert l_f == pytest.approx(l_t, rel=2e-4)
-    for n in p_t:
-        if "gconv" in n and n.endswith("bias"):
-            # analytically zero gradient (a bias in front of a train-mode BatchNorm): Adam normalises pure
-            # round-off, so the two runs legitimately random-walk apart by O(lr) per step
-            assert max_abs(p_f[n], p_t[n]) < 4 * 2e-3, n
-            continue
-        assert max_abs(p_f[n], p_t[n]) < 2e-5 + 2e-4 * float(p_t[n].abs().max()), n
+    torch.manual_seed(0)
+    model = build_native(g)
+    model.train()
+    model.backend.dropout = 0.0
+    model.tsformer.dropout_p = 0.0
+    model._noise_override = g["in.u"]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    shadow = [p.detach().clone().requires_grad_(True) for _, p in named]
+    opt = FusedAdamClip(model, lr=2e-3, weight_decay=1e-5, eps=1e-8, max_norm=3.0)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]        # flattening re-creates the storage
+    topt = torch.optim.Adam(shadow, lr=2e-3, weight_decay=1e-5, eps=1e-8)
+    losses = []
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        topt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
+        loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+        loss.backward()
+        for sp, (_, p) in zip(shadow, named):
+            sp.grad = None if p.grad is None else p.grad.detach().clone()
+        torch.nn.utils.clip_grad_norm_([sp for sp in shadow if sp.grad is not None], max_norm=3.0)
+        topt.step()
+        opt.step()
+        losses.append(float(loss))
+        for sp, (n, p) in zip(shadow, named):
+            assert max_abs(p.detach().cpu(), sp.detach().cpu()) < 2e-6 + 2e-5 * float(sp.abs().max()), (it, n)
+    print("losses", losses)
+    assert losses[-1] < losses[0]               # the flattened parameters are the ones the native forward reads
 
 
 def test_native_step_loss_matches_reference_loss():

@@ -42,8 +42,11 @@ def _oracle_run(g, hidden, hidden_last, noises):
     return losses, _h12_mae(pred, g["in.future"], mean, std)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("name", ["step_tiny", "step_small"])
-def test_k_step_trajectory_and_h12_mae_parity(name):
+def test_k_step_trajectory_and_h12_mae_parity(name, mode):
+    """mode "f32": every contraction outside the TSFormer exact (tight); mode "bf16" (what bench.py times): diffusion hops,
+    DGL conv2 and fc on the bf16 matrix cores -- the trajectory must stay within a few % of the fp32 oracle's."""
     g = load_golden(name)
     N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
     mean, std = [float(x) for x in g["meta.scaler"]]
@@ -51,6 +54,7 @@ def test_k_step_trajectory_and_h12_mae_parity(name):
     noises = [torch.rand(B, N * N, 2, generator=gen) for _ in range(K_STEPS)]
     model = build_native(g)
     model.train()
+    model.matmul_precision = mode
     model.backend.dropout = 0.0
     model.tsformer.dropout_p = 0.0
     hist, long_hist, fut = inputs_of(g)
@@ -73,14 +77,21 @@ def test_k_step_trajectory_and_h12_mae_parity(name):
     hid = model._last["hidden_bf16"].float().cpu().view(B, N, L // 12, 96)
     last = model._last["hidden_last"].cpu().view(B, N, 96)
     o_losses, o_h12 = _oracle_run(g, hid, last, noises)
-    print(name, "native losses", [round(x, 3) for x in losses])
+    print(name, mode, "native losses", [round(x, 3) for x in losses])
     print(name, "oracle losses", [round(x, 3) for x in o_losses])
     print(name, "H12 MAE native", h12, "oracle(device hidden)", o_h12)
     # Adam turns round-off sized gradient differences into O(lr) parameter differences (sign-like updates), so two
     # correct implementations drift apart step by step; the first steps must agree tightly, the later ones to a few %
-    assert losses[:3] == pytest.approx(o_losses[:3], rel=2e-3)
-    assert losses == pytest.approx(o_losses, rel=5e-2)
-    assert h12 == pytest.approx(o_h12, rel=3e-2)             # horizon-12 MAE after K steps (0.02-2 % observed)
+    if mode == "f32":
+        assert losses[:3] == pytest.approx(o_losses[:3], rel=2e-3)
+        assert losses == pytest.approx(o_losses, rel=5e-2)
+        assert h12 == pytest.approx(o_h12, rel=3e-2)         # horizon-12 MAE after K steps (0.02-2 % observed)
+    else:
+        # bf16 contractions perturb every gradient by ~1e-2; under Adam the trajectories separate like the two oracle runs
+        # below do (fp32 vs bf16 encoder states): same band, and the run must end at the same loss level
+        assert losses[:3] == pytest.approx(o_losses[:3], rel=1e-2)
+        assert losses == pytest.approx(o_losses, rel=0.12)
+        assert losses[-1] == pytest.approx(o_losses[-1], rel=5e-2)
     f_losses, f_h12 = _oracle_run(g, None, None, noises)     # oracle with its own fp32 TSFormer
     print(name, "oracle(fp32 hidden) losses", [round(x, 3) for x in f_losses], "H12 MAE", f_h12)
     assert losses[:3] == pytest.approx(f_losses[:3], rel=2e-2)
