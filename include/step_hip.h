@@ -230,6 +230,9 @@ int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const f
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on
  * (cdna_hip_programming.md section 3).  out: int32[8] failure counters, all zero when ok. */
 int step_selftest_mfma(int32_t* out, void* stream);
+/* raw 32-bit draws of the encoder's dropout mask generator (gen 0: xorshift32, gen 1: v_prng_b32), out[streams][words];
+   lets the tests measure keep rates and serial / cross-stream correlations of the Bernoulli bytes */
+int step_selftest_dropout_stream(uint32_t seed, int gen, int streams, int words, uint32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

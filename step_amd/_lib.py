@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstep_hip.so")
+LIB_PATH = os.environ.get("STEP_HIP_LIB") or os.path.join(_HERE, "libstep_hip.so")     # override: A/B builds of the same ABI
 
 _vp, _i, _l, _f, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
 
@@ -56,6 +56,7 @@ _SIGS = {
     "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "step_topk_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp]),
     "step_selftest_mfma": (_i, [_vp, _vp]),
+    "step_selftest_dropout_stream": (_i, [ctypes.c_uint32, _i, _i, _i, _vp, _vp]),
     "step_dgl_global_saved_floats": (_l, [_i, _i]),
     "step_dgl_global_work_floats": (_l, [_i, _i, _i]),
     "step_dgl_global_forward": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,6 @@
 // kNN prior graph on device: cosine similarities of the TSFormer hidden states and an exact
-// global top-k over the flattened N*N matrix per sample (radix select, 4 x 8-bit passes).
+// global top-k over the flattened N*N matrix per sample (radix select, 3 digits of 11/11/10 bits, many workgroups
+// per sample).  The Gram matrix runs on the staged bf16 GEMM of gemm_bf16.hip.
 //
 // Tie rule (documented in DESIGN.md): entries strictly above the k-th largest value are always
 // selected; entries equal to it are selected in ascending flat-index order until k are chosen.
@@ -50,192 +51,189 @@ __global__ void cosine_diag_kernel(float* sim, int N) {   // only for the sqn_pa
 }
 
 // ------------------------------------------------------------------------------------------
-// Symmetric Gram matrix of the bf16 hidden states on the bf16 matrix cores:
-//   raw[b][i][j] = sum_k H[b][i][k] H[b][j][k],  K = P*96 (32 256 at PEMS04) -- 6.1 GFLOP per window.
-// 128x128 output tile per workgroup (4 waves x 64x64 = 2x2 MFMA 32x32x16 tiles), only tiles with
-// tm <= tn are computed and mirrored, split-K over grid.z with f32 atomics into the zeroed output.
-// Operands are staged through LDS in 64-deep k-chunks with 16-byte global loads (rows are k-contiguous)
-// and read back as MFMA fragments (lane = row, 8 consecutive k) with ds_read_b128; the 144-byte row
-// pitch keeps the eight 16-byte reads of a lane group on different banks.
-constexpr int GBK = 64;                  // k-chunk
-constexpr int GPITCH = GBK * 2 + 16;     // bytes per staged row
+// Exact global top-k over the flattened N*N similarities of a sample: radix select of the k-th largest key in three
+// 11-bit digits (most significant first), many workgroups per sample.  Every workgroup owns a contiguous slice of
+// TK_SLICE elements (16 consecutive elements per thread: 16 independent loads in flight), histograms its slice in LDS
+// and merges the non-empty bins into the sample's global histogram.  The selection state (prefix, how many still to
+// take) is recomputed by each workgroup from the finished histograms of the earlier digits -- 2048 bins, a block scan.
+// Launches: digit 0, digit 1, digit 2, threshold ties per slice, mask.  (The previous version ran one 1024-thread
+// workgroup per sample and spent 240 us in 460 dependent load round trips.)
+constexpr int TK_BITS = 11, TK_BINS = 1 << TK_BITS, TK_THREADS = 256, TK_EPT = 16, TK_SLICE = TK_THREADS * TK_EPT;
+__host__ __device__ inline int tk_shift(int digit) { return digit == 0 ? 21 : (digit == 1 ? 10 : 0); }       // 11 + 11 + 10 bits
+__host__ __device__ inline uint32_t tk_mask(int digit) { return digit == 2 ? 0x3ffu : 0x7ffu; }
 
-__global__ __launch_bounds__(256) void gram_bf16_kernel(const uint16_t* __restrict__ H, int N, int K, int splitk,
-                                                        float* __restrict__ raw) {
-    __shared__ __attribute__((aligned(16))) char As[128 * GPITCH];
-    __shared__ __attribute__((aligned(16))) char Bs[128 * GPITCH];
-    // upper-triangular tile pair from blockIdx.x
-    const int nt = (N + 127) / 128;
-    int tm = 0, rem = blockIdx.x;
-    while (rem >= nt - tm) { rem -= nt - tm; ++tm; }
-    const int tn = tm + rem;
-    const int b = blockIdx.y;
-    const int zs = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int chunks = (K + GBK - 1) / GBK;
-    const int per = (chunks + splitk - 1) / splitk;
-    const int c0 = zs * per, c1 = min(chunks, c0 + per);
-    const uint16_t* Hb = H + (long)b * N * K;
-    const bool diag = tm == tn;
+struct TkWork {            // per sample, all zeroed before the first launch
+    uint32_t* hist;        // [B][3][TK_BINS]
+    uint32_t* ties;        // [B][slices]
+    uint32_t* sel;         // [B][2]: threshold key, number of threshold-valued entries to keep
+};
 
-    f32x16 acc[2][2];
+// exclusive prefix sum of one value per thread over the 256-thread block (wave scans by shuffles + 4 wave totals)
+__device__ uint32_t tk_block_scan(uint32_t v, uint32_t* sm /*[4]*/, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // staging map: 128 rows x 8 pieces of 16 B = 1024 pieces, 4 per thread
-    u32x4 ra[4], rb[4];
-    auto load = [&](int ck) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pc = tid + q * 256, row = pc >> 3, kp = (pc & 7) * 8;
-            const int k = ck * GBK + kp;
-            const int gi = tm * 128 + row, gj = tn * 128 + row;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            // K is a multiple of 8 here (96 features per token), so a piece is either fully inside or outside
-            ra[q] = (gi < N && k < K) ? *(const u32x4*)(Hb + (long)gi * K + k) : z;
-            if (!diag) rb[q] = (gj < N && k < K) ? *(const u32x4*)(Hb + (long)gj * K + k) : z;
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pc = tid + q * 256, row = pc >> 3, kp = (pc & 7) * 16;
-            *(u32x4*)(As + row * GPITCH + kp) = ra[q];
-            if (!diag) *(u32x4*)(Bs + row * GPITCH + kp) = rb[q];
-        }
-    };
-    const char* Bsrc = diag ? As : Bs;
-    const int r = lane & 31, h = lane >> 5;
-    if (c0 < c1) {
-        load(c0);
-        for (int ck = c0; ck < c1; ++ck) {
-            __syncthreads();
-            store();
-            __syncthreads();
-            if (ck + 1 < c1) load(ck + 1);
-#pragma unroll
-            for (int ks = 0; ks < GBK / 16; ++ks) {
-                bf16x8 a[2], bb[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(As + (wr * 64 + i * 32 + r) * GPITCH + ks * 32 + h * 16);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bb[j] = *(const bf16x8*)(Bsrc + (wc * 64 + j * 32 + r) * GPITCH + ks * 32 + h * 16);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
-            }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += t;
     }
-    float* out = raw + (long)b * N * N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int gj = tn * 128 + wc * 64 + j * 32 + r;
-            if (gj >= N) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int gi = tm * 128 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (gi >= N) continue;
-                const float v = acc[i][j][e];
-                atomicAdd(out + (long)gi * N + gj, v);
-                if (!diag) atomicAdd(out + (long)gj * N + gi, v);
-            }
-        }
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w2 = 0; w2 < wave; ++w2) off += sm[w2];
+    total = sm[0] + sm[1] + sm[2] + sm[3];
+    __syncthreads();
+    return off + inc - v;
 }
 
-// One workgroup (1024 threads) per sample.
-__global__ __launch_bounds__(1024) void topk_mask_kernel(const float* __restrict__ sim, int N, int k_total,
-                                                         float* __restrict__ adj) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_remaining, s_run;
-    __shared__ uint32_t wave_cnt[16];
-    const int b = blockIdx.x;
-    const long E = (long)N * N;
+// scan one finished histogram from the top bin down: the bin where the running count reaches `rem`, and what is left to
+// take inside that bin.  All threads return the same values.
+__device__ void tk_select(const uint32_t* __restrict__ hist, uint32_t rem, uint32_t* scratch /*[TK_THREADS + 2]*/, uint32_t& bin_out,
+                          uint32_t& rem_out) {
+    const int tid = threadIdx.x;
+    constexpr int PER = TK_BINS / TK_THREADS;                 // 8 consecutive bins per thread, thread 0 holds the top ones
+    uint32_t c[PER], tot = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { c[i] = hist[TK_BINS - 1 - (tid * PER + i)]; tot += c[i]; }
+    uint32_t all;
+    uint32_t run = tk_block_scan(tot, scratch, all);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (run < rem && run + c[i] >= rem) { scratch[TK_THREADS] = (uint32_t)(TK_BINS - 1 - (tid * PER + i)); scratch[TK_THREADS + 1] = rem - run; }
+        run += c[i];
+    }
+    __syncthreads();
+    bin_out = scratch[TK_THREADS];
+    rem_out = scratch[TK_THREADS + 1];
+    __syncthreads();
+}
+
+// selection state before digit `upto`: prefix (the digits already fixed, in place) and the remaining count
+__device__ void tk_state(const TkWork& w, int b, int upto, uint32_t k_total, uint32_t* scratch, uint32_t& prefix, uint32_t& rem) {
+    prefix = 0u; rem = k_total;
+    for (int d = 0; d < upto; ++d) {
+        uint32_t bin, r;
+        tk_select(w.hist + ((long)b * 3 + d) * TK_BINS, rem, scratch, bin, r);
+        prefix |= bin << tk_shift(d);
+        rem = r;
+    }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void tk_hist_kernel(const float* __restrict__ sim, long E, uint32_t k_total, int digit, TkWork w) {
+    __shared__ uint32_t hist[TK_BINS];
+    __shared__ uint32_t scratch[TK_THREADS + 2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < TK_BINS; i += TK_THREADS) hist[i] = 0u;
+    uint32_t prefix, rem;
+    tk_state(w, b, digit, k_total, scratch, prefix, rem);          // contains barriers: also orders the zeroing above
+    const uint32_t himask = digit == 0 ? 0u : (0xFFFFFFFFu << tk_shift(digit - 1));
+    const float* v = sim + (long)b * E;
+    const long e0 = (long)blockIdx.x * TK_SLICE + (long)tid * TK_EPT;
+    float x[TK_EPT];
+#pragma unroll
+    for (int j = 0; j < TK_EPT; ++j) x[j] = e0 + j < E ? v[e0 + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TK_EPT; ++j) {
+        const uint32_t key = f32_order_key(x[j]);
+        if (e0 + j < E && (key & himask) == prefix) atomicAdd(&hist[(key >> tk_shift(digit)) & tk_mask(digit)], 1u);
+    }
+    __syncthreads();
+    uint32_t* gh = w.hist + ((long)b * 3 + digit) * TK_BINS;
+    for (int i = tid; i < TK_BINS; i += TK_THREADS)
+        if (hist[i]) atomicAdd(&gh[i], hist[i]);
+}
+
+// number of entries equal to the threshold key in each slice; slice 0 also publishes (threshold, need_eq)
+__global__ __launch_bounds__(TK_THREADS) void tk_ties_kernel(const float* __restrict__ sim, long E, uint32_t k_total, TkWork w) {
+    __shared__ uint32_t scratch[TK_THREADS + 2];
+    __shared__ uint32_t cnt;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) cnt = 0u;
+    uint32_t thr, need_eq;
+    tk_state(w, b, 3, k_total, scratch, thr, need_eq);
+    const float* v = sim + (long)b * E;
+    const long e0 = (long)blockIdx.x * TK_SLICE + (long)tid * TK_EPT;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < TK_EPT; ++j)
+        if (e0 + j < E && f32_order_key(v[e0 + j]) == thr) ++c;
+    if (c) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (tid == 0) {
+        w.ties[(long)b * gridDim.x + blockIdx.x] = cnt;
+        if (blockIdx.x == 0) { w.sel[b * 2] = thr; w.sel[b * 2 + 1] = need_eq; }
+    }
+}
+
+// adj = 1 for keys above the threshold and for the first need_eq threshold-valued entries in flat-index order
+// (discrete_graph_learning.py:108 keeps scattered values != 0; :165-166 clears the diagonal)
+__global__ __launch_bounds__(TK_THREADS) void tk_mask_kernel(const float* __restrict__ sim, long E, int N, TkWork w, float* __restrict__ adj) {
+    __shared__ uint32_t scan[TK_THREADS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t thr = w.sel[b * 2], need_eq = w.sel[b * 2 + 1];
+    uint32_t part = 0;                                         // threshold-valued entries in earlier slices
+    for (int g = tid; g < (int)blockIdx.x; g += TK_THREADS) part += w.ties[(long)b * gridDim.x + g];
+    uint32_t before;
+    tk_block_scan(part, scan, before);
     const float* v = sim + (long)b * E;
     float* out = adj + (long)b * E;
-    const int tid = threadIdx.x;
-
-    if (tid == 0) { s_prefix = 0u; s_remaining = (uint32_t)min((long)k_total, E); }
-    __syncthreads();
-    // radix select of the k-th largest key, most significant byte first
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        const uint32_t prefix = s_prefix;
-        const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (long e = tid; e < E; e += 1024) {
-            uint32_t key = f32_order_key(v[e]);
-            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t rem = s_remaining, cum = 0u;
-            int bin = 255;
-            for (; bin > 0; --bin) {
-                if (cum + hist[bin] >= rem) break;
-                cum += hist[bin];
-            }
-            s_prefix = prefix | ((uint32_t)bin << shift);
-            s_remaining = rem - cum;           // how many still to take inside this bin
-        }
-        __syncthreads();
+    const long e0 = (long)blockIdx.x * TK_SLICE + (long)tid * TK_EPT;
+    float x[TK_EPT];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < TK_EPT; ++j) {
+        x[j] = e0 + j < E ? v[e0 + j] : 0.f;
+        if (e0 + j < E && f32_order_key(x[j]) == thr) ++mine;
     }
-    const uint32_t thr = s_prefix;             // key of the k-th largest element
-    const uint32_t need_eq = s_remaining;      // number of threshold-valued entries to keep
-    if (tid == 0) s_run = 0u;
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    for (long base = 0; base < E; base += 1024) {
-        const long e = base + tid;
-        float val = 0.f;
-        uint32_t key = 0u;
-        bool in = e < E;
-        if (in) { val = v[e]; key = f32_order_key(val); }
-        const bool eq = in && key == thr;
-        const unsigned long long bal = __ballot(eq);
-        const uint32_t before = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t off = s_run;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (in) {
-            bool sel = key > thr || (eq && (off + before) < need_eq);
-            const int i = (int)(e / N), j = (int)(e % N);
-            // discrete_graph_learning.py:108 keeps scattered values != 0; :165-166 clears the diagonal
-            out[e] = (sel && val != 0.f && i != j) ? 1.f : 0.f;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int w = 0; w < 16; ++w) t += wave_cnt[w];
-            s_run += t;
-        }
-        __syncthreads();
+    uint32_t slice_ties;
+    uint32_t rank = before + tk_block_scan(mine, scan, slice_ties);
+#pragma unroll
+    for (int j = 0; j < TK_EPT; ++j) {
+        const long e = e0 + j;
+        if (e >= E) break;
+        const uint32_t key = f32_order_key(x[j]);
+        bool sel = key > thr;
+        if (key == thr) { sel = rank < need_eq; ++rank; }
+        const int i = (int)(e / N), jj = (int)(e % N);
+        out[e] = (sel && x[j] != 0.f && i != jj) ? 1.f : 0.f;
     }
 }
 
 }  // namespace
 
+static long tk_slices(int N) { return ((long)N * N + TK_SLICE - 1) / TK_SLICE; }
+
 extern "C" long step_knn_workspace_bytes(int B, int N, int F) {
-    (void)B; (void)N; (void)F;
-    return 256;   // the selection runs in LDS; kept for ABI stability
+    (void)F;
+    return (long)B * (3 * TK_BINS + tk_slices(N) + 2) * (long)sizeof(uint32_t);
 }
 
 extern "C" int step_topk_mask(const float* sim, int B, int N, int k_total, float* adj, void* work, long work_bytes,
                               void* stream) {
-    (void)work; (void)work_bytes;
-    STEP_REQUIRE(sim && adj && B > 0 && N > 0 && k_total > 0, "topk_mask: bad arguments");
-    topk_mask_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(sim, N, k_total, adj);
-    STEP_LAUNCH_CHECK("step_topk_mask");
+    STEP_REQUIRE(sim && adj && work && B > 0 && N > 0 && k_total > 0, "topk_mask: bad arguments");
+    STEP_REQUIRE(work_bytes >= step_knn_workspace_bytes(B, N, 0), "topk_mask: workspace of %ld bytes, need %ld", work_bytes,
+                 step_knn_workspace_bytes(B, N, 0));
+    hipStream_t st = (hipStream_t)stream;
+    const long E = (long)N * N;
+    const int slices = (int)tk_slices(N);
+    TkWork w;
+    w.hist = (uint32_t*)work;
+    w.ties = w.hist + (long)B * 3 * TK_BINS;
+    w.sel = w.ties + (long)B * slices;
+    if (hipMemsetAsync(work, 0, (size_t)step_knn_workspace_bytes(B, N, 0), st) != hipSuccess) {
+        step_set_error("topk_mask: memset failed");
+        return STEP_ERR_HIP;
+    }
+    const uint32_t k = (uint32_t)((long)k_total < E ? k_total : E);
+    dim3 grid(slices, B);
+    for (int d = 0; d < 3; ++d) {
+        tk_hist_kernel<<<grid, TK_THREADS, 0, st>>>(sim, E, k, d, w);
+        STEP_LAUNCH_CHECK("topk digit histogram");
+    }
+    tk_ties_kernel<<<grid, TK_THREADS, 0, st>>>(sim, E, k, w);
+    STEP_LAUNCH_CHECK("topk ties");
+    tk_mask_kernel<<<grid, TK_THREADS, 0, st>>>(sim, E, N, w, adj);
+    STEP_LAUNCH_CHECK("topk mask");
     return STEP_OK;
 }
 
@@ -249,14 +247,17 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
     }
     STEP_REQUIRE(F % 8 == 0, "knn_graph: feature length %d must be a multiple of 8", F);
     {
-        const int nt = cdiv(N, 128);
-        const int pairs = nt * (nt + 1) / 2;
-        int split = (1024 + pairs * B - 1) / (pairs * B);
-        const int chunks = cdiv(F, GBK);
-        if (split > chunks / 4) split = chunks / 4;
-        if (split < 1) split = 1;
-        gram_bf16_kernel<<<dim3(pairs, B, split), 256, 0, st>>>(hidden, N, F, split, sim);
-        STEP_LAUNCH_CHECK("gram_bf16");
+        // raw[b] = H[b] H[b]^T on the bf16 matrix cores: the staged GEMM (k-contiguous bf16 rows on both sides, 128x128
+        // tiles, split-K with f32 atomics into the zeroed output).  The full square is computed: the symmetric half would
+        // save MFMA work the kernel does not wait for (it streams H, 158 MB at PEMS04, and is latency / L2 bound).
+        StepGemm g;
+        memset(&g, 0, sizeof(g));
+        g.M = N; g.N = N; g.K = F; g.batch = B;
+        g.A = hidden; g.sam = F; g.sak = 1; g.sab = (long)N * F; g.a_bf16 = 1;
+        g.B = hidden; g.sbk = 1; g.sbn = F; g.sbb = (long)N * F; g.b_bf16 = 1;
+        g.C = sim; g.ldc = N; g.scn = 1; g.scb = (long)N * N;
+        g.alpha = 1.f; g.accumulate = 2; g.splitk = -1; g.compute_bf16 = 1;
+        STEP_TRY(step_gemm_launch(g, st));
     }
     dim3 grid(cdiv(N, 256) > 4 ? 4 : cdiv(N, 256), N, B);
     cosine_finalize_kernel<<<grid, 256, 0, st>>>(sim, sqnorm_part, N);

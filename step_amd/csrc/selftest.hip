@@ -40,7 +40,30 @@ __global__ void selftest_kernel(int32_t* out) {
     if (l == 0) out[7] = 0x600DC0DE;
 }
 
+// keep-mask streams of the encoder's dropout generator: stream (block, thread) is seeded like Dropper::seed and emits
+// `words` 32-bit draws = 4*words Bernoulli bytes.  gen 0: xorshift32 (6 VALU ops per word), gen 1: v_prng_b32 (1 op).
+__device__ __forceinline__ uint32_t st_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__global__ void dropout_stream_kernel(uint32_t base, int gen, int words, uint32_t* __restrict__ out) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t st = st_mix32(base + id * 0x9E3779B1u) | 1u;
+    for (int w = 0; w < words; ++w) {
+        if (gen == 0) { st ^= st << 13; st ^= st >> 17; st ^= st << 5; }
+        else st = __builtin_amdgcn_prng_b32(st);
+        out[(long)id * words + w] = st;
+    }
+}
+
 }  // namespace
+
+extern "C" int step_selftest_dropout_stream(uint32_t seed, int gen, int streams, int words, uint32_t* out, void* stream) {
+    STEP_REQUIRE(out && streams > 0 && streams % 64 == 0 && words > 0 && (gen == 0 || gen == 1), "selftest_dropout_stream: bad arguments");
+    dropout_stream_kernel<<<streams / 64, 64, 0, (hipStream_t)stream>>>(seed, gen, words, out);
+    STEP_LAUNCH_CHECK("step_selftest_dropout_stream");
+    return STEP_OK;
+}
 
 extern "C" int step_selftest_mfma(int32_t* out, void* stream) {
     STEP_REQUIRE(out != nullptr, "selftest: null output");

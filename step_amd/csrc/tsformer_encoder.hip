@@ -17,133 +17,9 @@
 //
 // MFMA work per token-layer: 221 184*1.33(q/k/v/o head padding 24->32 only) ... see DESIGN.md
 // for the flop accounting used by bench.py's roofline.
-#include "common.h"
-#include "step_internal.h"
-#include "tsformer_layout.h"
+#include "tsformer_device.h"
 
 namespace {
-
-struct EncArgs {
-    const float* series;
-    int S, L, P, depth, nkt;
-    const char* wpack;
-    uint16_t* hid_bf16;
-    float* hid_f32;
-    float* last_f32;
-    float* sqn;
-    float drop_p;
-    uint32_t seed;
-};
-
-#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ bf16x8 gfrag(const char* base, int frag, int lane) {
-    return *(const bf16x8*)(base + (long)frag * TSF_FRAG + lane * 16);
-}
-__device__ __forceinline__ bf16x8 lfrag(const char* lds, int frag, int lane) {
-    return *(const bf16x8*)(lds + frag * TSF_FRAG + lane * 16);
-}
-__device__ __forceinline__ bf16x8 pack_half(const f32x16& v, int s) {
-    float t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = v[8 * s + j];
-    return pack8(t);
-}
-
-// dropout keep-mask bits: a per-lane xorshift32 stream (6 full-rate VALU ops per 32 bits, no integer
-// multiplies in the hot loops) yields four 8-bit Bernoulli draws per step (p_eff = thresh/256; the
-// survivor scale uses p_eff, so the estimator stays unbiased).  The stream is re-seeded per
-// (sequence, layer, site, token) with a multiplicative hash, so results are launch-deterministic.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-struct Dropper {
-    uint32_t base;      // seed ^ per-(seq, layer, site) salt
-    uint32_t thresh;    // keep iff draw8 >= thresh
-    float scale;        // 1/(1-p_eff)
-    uint32_t st;        // xorshift state
-    __device__ __forceinline__ void seed(uint32_t elem_salt) { st = mix32(base + elem_salt * 0x9E3779B1u) | 1u; }
-    __device__ __forceinline__ uint32_t next() {
-        st ^= st << 13; st ^= st >> 17; st ^= st << 5;
-        return st;
-    }
-    // 16 accumulator registers of this lane; the stream must have been seeded by the caller
-    __device__ __forceinline__ void apply16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            const uint32_t r = next();
-            v[i] = ((r & 0xffu) >= thresh) ? v[i] * scale : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
-            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] * scale : 0.f;
-            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] * scale : 0.f;
-        }
-    }
-    // unscaled variant (the caller folds the survivor scale into a later multiply)
-    __device__ __forceinline__ void mask16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            const uint32_t r = next();
-            v[i] = ((r & 0xffu) >= thresh) ? v[i] : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] : 0.f;
-            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] : 0.f;
-            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] : 0.f;
-        }
-    }
-};
-
-// training-mode tail of a sub-layer: acc = dropout(acc) + x, with x taken from the bf16 operand
-// copy of the residual stream (the f32 copy is not kept live across the sub-layer)
-__device__ __forceinline__ void add_residual_bf16(f32x16 (&acc)[3], const bf16x8 (&xb)[6], Dropper& dr,
-                                                  uint32_t salt) {
-    dr.seed(salt);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        dr.apply16(acc[t]);
-        u32x4 lo = __builtin_bit_cast(u32x4, xb[2 * t]), hi = __builtin_bit_cast(u32x4, xb[2 * t + 1]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint32_t wl = lo[j >> 1], wh = hi[j >> 1];
-            acc[t][j] += bf16_bits_to_f32((j & 1) ? (wl >> 16) : (wl & 0xffffu));
-            acc[t][8 + j] += bf16_bits_to_f32((j & 1) ? (wh >> 16) : (wh & 0xffffu));
-        }
-    }
-}
-
-// LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest.
-// g / b point at this lane-half's 48 values (accumulator-register order).
-__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += a[t][i];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / 96.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[t][i] = (a[t][i] - mean) * rstd * gg[t * 16 + i] + bb[t * 16 + i];
-}
-
-// One 1 KB piece global -> LDS by the DMA path (no VGPR round trip, invisible to hipcc's waitcnt
-// bookkeeping: the kernel waits with an explicit vmcnt(0) at the next stage boundary).
-// lds_dst is wave-uniform; lane i's 16 bytes land at lds_dst + 16 i.
-__device__ __forceinline__ void dma_1k(const char* gsrc_lane, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc_lane), "s"(lds_dst)
-                 : "memory");
-}
-#define LDS_ADDR(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(p))
 
 template <int MAXW, bool DROP, bool PARK>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
@@ -272,6 +148,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(lfrag(blk, ks, lane), xb[ks], q);
                 qb[0] = pack_half(q, 0);
                 qb[1] = pack_half(q, 1);
+                // head-dim slots 25 / 26 (the head dim is 24 of 32) carry the softmax shift and the key-padding mask
+                // through the contraction: the key side holds (1, is_padding), the query side (-rowmax, -30000)
+                if (h == 0) qb[1][6] = (__bf16)(-30000.0f);
             }
             // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
             {
@@ -280,6 +159,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int i = 0; i < 16; ++i) kk[i] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) kk = MFMA_BF16(lfrag(blk, 6 + ks, lane), xb[ks], kk);
+                if (h == 0) { kk[13] = 1.0f; kk[14] = tok_ok ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
                 *(bf16x8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(kk, 0);
                 *(bf16x8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(kk, 1);
             }
@@ -297,70 +177,65 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes).  Software pipeline:
-            // the MFMAs of key tile kt+1 are issued before the VALU work on tile kt, so the matrix pipe and
-            // the vector ALU of this wave overlap (the last trip recomputes the final tile, 2 wasted MFMAs)
-            auto score_tile = [&](int kt, const f32x16& init) -> f32x16 {
-                f32x16 s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], init);
+            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes).  Software pipeline: the MFMAs
+            // of key tile kt+1 are issued before the VALU work on tile kt; padded keys score -30000 through slot 26 and
+            // never win.  (Unrolling by two to avoid the tile copy was measured 20 % SLOWER: profiles/r01_m_encoder_ab.md.)
+            f32x16 zero;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+            auto score_tile = [&](int kt) -> f32x16 {
+                f32x16 s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], zero);
                 return MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
             };
             float mx = -INFINITY;
             {
-                f32x16 zero;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-                f32x16 sc = score_tile(0, zero);
-#pragma unroll 1
-                for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt, zero);
-                    if (kt == nkt - 1) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
-                    }
+                auto fold = [&](const f32x16& sc) {
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[i]), sc[i + 1]);     // v_max3_f32
-                    sc = sn;
+                };
+                f32x16 sa = score_tile(0);
+#pragma unroll 1
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const f32x16 sb = score_tile(kt + 1 < nkt ? kt + 1 : kt);
+                    fold(sa);
+                    sa = sb;
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (h == 0) qb[1][5] = (__bf16)(-mx);        // slot 25: S - max comes out of the MFMA (bf16 rounding of max cancels)
 
-            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 accumulates the denominator), same pipeline;
-            // the subtraction of the row maximum rides in the MFMA accumulator (C = -max on every row)
+            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 of V^T is all ones: the denominator), same pipeline
             f32x16 o;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
-            float lsum = 0.f;
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            f32x2 lsum2 = {0.f, 0.f};
             if constexpr (drop) { dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1)); dr.seed((uint32_t)(tok * 2 + h)); }
             {
-                f32x16 nmx;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) nmx[i] = -mx;
-                f32x16 sc = score_tile(0, nmx);
-#pragma unroll 1
-                for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 sn = score_tile(kt + 1 < nkt ? kt + 1 : kt, nmx);
-                    bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
-                    if (kt == nkt - 1) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (kt * 32 + 4 * h + (i & 3) + 8 * (i >> 2) >= P) sc[i] = -INFINITY;
-                    }
+                auto consume = [&](f32x16& sc, int kt) {
+                    const bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
                     if constexpr (drop) {
                         // attention-prob dropout acts on the normalised probabilities: keep the denominator
-                        // dropout-free (VALU sum), mask the numerator only; the survivor scale is folded into 1/den
+                        // dropout-free (packed VALU sum), mask the numerator only; the survivor scale is folded into 1/den
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) lsum += sc[i];
+                        for (int i = 0; i < 16; i += 2) lsum2 += f32x2{sc[i], sc[i + 1]};         // v_pk_add_f32
                         dr.mask16(sc);
                     }
-                    bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
+                    const bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
                     o = MFMA_BF16(v0, p0, o);
                     o = MFMA_BF16(v1, p1, o);
-                    sc = sn;
+                };
+                f32x16 sa = score_tile(0);
+#pragma unroll 1
+                for (int kt = 0; kt < nkt; ++kt) {
+                    f32x16 sb = score_tile(kt + 1 < nkt ? kt + 1 : kt);
+                    consume(sa, kt);
+                    sa = sb;
                 }
             }
+            const float lsum = lsum2[0] + lsum2[1];
             float den;
             if constexpr (drop) {
                 den = (lsum + __shfl_xor(lsum, 32, 64)) * (1.0f / dr.scale);
@@ -417,7 +292,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(lfrag(blk, cc * 12 + ks, lane), xb[ks], hh);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) hh[i] = fmaxf(hh[i], 0.f);
+                for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
                 if constexpr (drop) dr.apply16(hh);
                 bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
 #pragma unroll

@@ -47,8 +47,9 @@ class _StepFunction(torch.autograd.Function):
         sim = _f32(B * N * N, dev).view(B, N, N)
         adj_knn = _f32(B * N * N, dev).view(B, N, N)
         dgl = model.discrete_graph_learning
+        kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
         L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, dgl.k * N, L.ptr(sim),
-               L.ptr(adj_knn), None, 0, st)
+               L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
         # ---- DGL: global feature, edge logits, Gumbel sample
         dt = dgl.native_tensors()
         bf = model.matmul_precision == "bf16"
