@@ -40,6 +40,22 @@ def synth_series(T, N, seed=0):
     return np.stack([ch0, ch1, ch2], -1).astype(np.float32)
 
 
+def pmc_traffic(config, B):
+    """HBM bytes per encoder launch from the committed rocprofv3 PMC passes (profiles/encoder_pmc.json, produced by
+    tools/pmc_encoder.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md "HBM").  A counter run cannot be nested inside this process, so the number is looked up for the
+    same config / batch; None when no matching measurement is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "encoder_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        ent = rec.get(f"{config}:B{B}")
+        return None if ent is None else {"hbm_bytes_per_launch": ent["read_bytes"] + ent["write_bytes"], "read_bytes": ent["read_bytes"],
+                                          "write_bytes": ent["write_bytes"], "source": ent["source"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def make_model(cfg, data):
     from step_amd import STEP
     N, L = cfg["N"], cfg["L"]
@@ -243,7 +259,7 @@ def main():
                                    "full train step (fwd+bwd+clip+Adam)", "global_batch": B * world,
                        "parallelism": f"dp{world}", "final_loss": float(loss)},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "ms_per_launch": enc_ms,
+                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(args.config, B), "ms_per_launch": enc_ms,
                          "algorithmic_flop_per_launch": flops},
         }
         if world == 1 and not args.no_cpu_baseline:

