@@ -684,8 +684,12 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
         bn_bwd_apply_kernel<8><<<grid, 256, 0, st>>>(d_a1, a1, st1, coef, T1);
         STEP_LAUNCH_CHECK("bn1_bwd_apply");
     }
-    conv_bwd_weight_kernel<1, 8><<<N, 256, 0, st>>>(d_a1, series_nt, nullptr, nullptr, grads->conv1_w, grads->conv1_b, T);
-    STEP_LAUNCH_CHECK("conv1_bwd_weight");
+    if (p->gemm_bf16) {
+        STEP_TRY(dgl_conv1_wgrad_mfma(d_a1, series_nt, wg_scratch, grads->conv1_w, grads->conv1_b, N, T, st));
+    } else {
+        conv_bwd_weight_kernel<1, 8><<<N, 256, 0, st>>>(d_a1, series_nt, nullptr, nullptr, grads->conv1_w, grads->conv1_b, T);
+        STEP_LAUNCH_CHECK("conv1_bwd_weight");
+    }
     return STEP_OK;
 }
 

@@ -242,19 +242,93 @@ __global__ __launch_bounds__(256) void conv2_wgrad_mfma_kernel(const float* __re
 }
 
 // dw / db += column sums of the per-workgroup partial rows (grid.y row slices, one atomic per slice and output)
-__global__ __launch_bounds__(256) void conv2_wgrad_reduce_kernel(const float* __restrict__ partial, int nrows, float* __restrict__ dw,
-                                                                 float* __restrict__ db) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nrows, int nout, int nw,
+                                                                float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float red[4][64];
     const int o = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     float s = 0.f;
-    if (o < WG_OUT)
-        for (int r = blockIdx.y * 4 + w; r < nrows; r += gridDim.y * 4) s += partial[(long)r * WG_OUT + o];
+    if (o < nout)
+        for (int r = blockIdx.y * 4 + w; r < nrows; r += gridDim.y * 4) s += partial[(long)r * nout + o];
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && o < WG_OUT) {
+    if (w == 0 && o < nout) {
         const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(o < CO * CI * KW ? &dw[o] : &db[o - CO * CI * KW], v);
+        atomicAdd(o < nw ? &dw[o] : &db[o - nw], v);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 wgrad
+// dw1[co][kk] += sum_{n,t} dz1[n][co][t] * x[n][t+kk],  db1[co] += sum dz1     (conv1: 1 -> 8 channels, no input affine)
+// Same scheme as conv2: m = co (8 of 16 rows), n = tap (10 of 16 columns), k = 32 time steps per MFMA.
+constexpr int C1 = 8;
+constexpr int W1_OUT = C1 * KW + C1;
+__global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                               float* __restrict__ partial, int T) {
+    constexpr int ZP = WG_SC + 8, XP = WG_SC + 16;
+    __shared__ __attribute__((aligned(16))) uint16_t zs[C1][ZP];
+    __shared__ __attribute__((aligned(16))) uint16_t x0[XP], x1[XP];        // x1[i] = x0[i + 1]
+    __shared__ float red[3][64][4];
+    __shared__ float redb[4][C1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
+    const int T1 = T - (KW - 1), tbeg = blockIdx.x * (WG_SC * WG_PASSES);
+    const int ln = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum[C1];
+#pragma unroll
+    for (int co = 0; co < C1; ++co) bsum[co] = 0.f;
+    for (int pass = 0; pass < WG_PASSES; ++pass) {
+        const int tp = tbeg + pass * WG_SC;
+        if (tp >= T1) break;
+        __syncthreads();
+        {
+            const int t = tp + tid;
+            float v[C1];
+#pragma unroll
+            for (int co = 0; co < C1; ++co) v[co] = t < T1 ? dz[((long)n * C1 + co) * T1 + t] : 0.f;
+#pragma unroll
+            for (int co = 0; co < C1; ++co) {
+                bsum[co] += v[co];
+                zs[co][tid] = (uint16_t)(cvt2(v[co], 0.f) & 0xffffu);
+            }
+            for (int tt = tid; tt < WG_SC + 10; tt += 256) {
+                const int tx = tp + tt;
+                const uint16_t hb = (uint16_t)(cvt2(tx < T ? x[(long)n * T + tx] : 0.f, 0.f) & 0xffffu);
+                x0[tt] = hb;
+                if (tt > 0) x1[tt - 1] = hb;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tb = 64 * wave + 32 * u + 8 * q;
+            uint4 av = *(const uint4*)&zs[ln & 7][tb];
+            if (ln >= C1) av = make_uint4(0u, 0u, 0u, 0u);
+            const int kk = ln < KW ? ln : 0;
+            const uint16_t* row = (kk & 1) ? x1 : x0;
+            const uint32_t* p = (const uint32_t*)(row + tb + (kk & ~1));
+            uint4 bv = make_uint4(p[0], p[1], p[2], p[3]);
+            if (ln >= KW) bv = make_uint4(0u, 0u, 0u, 0u);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(av), as_frag(bv), acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave - 1][lane][e] = acc[e];
+    }
+#pragma unroll
+    for (int co = 0; co < C1; ++co) {
+        const float sm = wave_sum(bsum[co]);
+        if (lane == 0) redb[wave][co] = sm;
+    }
+    __syncthreads();
+    float* out = partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * W1_OUT;
+    if (wave == 0 && q < 2 && ln < KW) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            out[(4 * q + e) * KW + ln] = acc[e] + red[0][lane][e] + red[1][lane][e] + red[2][lane][e];
+    }
+    if (tid < C1) out[C1 * KW + tid] = redb[0][tid] + redb[1][tid] + redb[2][tid] + redb[3][tid];
 }
 
 }  // namespace
@@ -286,7 +360,18 @@ int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, cons
     dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
     conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, sc, sh, scratch, T1);
     STEP_LAUNCH_CHECK("conv2_wgrad_mfma");
-    conv2_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, dw, db);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, dw, db);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
+    return STEP_OK;
+}
+
+// conv1 weight / bias gradient; scratch as for conv2 (dgl_conv2_wgrad_scratch_floats covers it: same grid, fewer outputs)
+int dgl_conv1_wgrad_mfma(const float* dz, const float* x, float* scratch, float* dw, float* db, int N, int T, hipStream_t st) {
+    const int T1 = T - (KW - 1);
+    dim3 grid(cdiv(T1, WG_SC * WG_PASSES), N);
+    conv1_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, x, scratch, T);
+    STEP_LAUNCH_CHECK("conv1_wgrad_mfma");
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(W1_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, W1_OUT, C1 * KW, dw, db);
+    STEP_LAUNCH_CHECK("conv1_wgrad_reduce");
     return STEP_OK;
 }

@@ -212,9 +212,13 @@ __global__ void softmax_relu_bwd_kernel(const float* __restrict__ M, const float
     dM[idx] = M[idx] > 0.f ? P[idx] * (dP[idx] - rdot[i]) : 0.f;
 }
 
-// gated-TCN weights [32,32,1,2] x2 -> Wcat[64 out][64 in] (in = tap*32 + c), bias[64]
-__global__ void pack_gate_kernel(const float* __restrict__ wf, const float* __restrict__ bf, const float* __restrict__ wg,
-                                 const float* __restrict__ bg, float* __restrict__ wcat, float* __restrict__ bcat) {
+// gated-TCN weights [32,32,1,2] x2 -> Wcat[64 out][64 in] (in = tap*32 + c), bias[64]; all 8 layers in one launch (grid.y)
+struct GatePtrs { float *wf[8], *bf[8], *wg[8], *bg[8]; };
+__global__ void pack_gate_kernel(GatePtrs P, float* __restrict__ wcat_all, float* __restrict__ bcat_all) {
+    const int L = blockIdx.y;
+    const float *wf = P.wf[L], *bf = P.bf[L], *wg = P.wg[L], *bg = P.bg[L];
+    float* wcat = wcat_all + L * 4096;
+    float* bcat = bcat_all + L * 64;
     int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < 64 * 64) {
         int o = idx / 64, k = idx % 64;
@@ -223,8 +227,11 @@ __global__ void pack_gate_kernel(const float* __restrict__ wf, const float* __re
     }
     if (idx < 64) bcat[idx] = idx < 32 ? bf[idx] : bg[idx - 32];
 }
-__global__ void unpack_gate_grad_kernel(const float* __restrict__ dwcat, const float* __restrict__ dbcat, float* __restrict__ dwf,
-                                        float* __restrict__ dbf, float* __restrict__ dwg, float* __restrict__ dbg) {
+__global__ void unpack_gate_grad_kernel(const float* __restrict__ dwcat_all, const float* __restrict__ dbcat_all, GatePtrs G) {
+    const int L = blockIdx.y;
+    const float* dwcat = dwcat_all + L * 4096;
+    const float* dbcat = dbcat_all + L * 64;
+    float *dwf = G.wf[L], *dbf = G.bf[L], *dwg = G.wg[L], *dbg = G.bg[L];
     int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < 64 * 64) {
         int o = idx / 64, k = idx % 64;
@@ -630,10 +637,12 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
                                                                                                S.PT16);
         STEP_LAUNCH_CHECK("stacks_to_bf16");
     }
-    for (int i = 0; i < NL; ++i) {
-        pack_gate_kernel<<<16, 256, 0, st>>>(p->filter_w[i], p->filter_b[i], p->gate_w[i], p->gate_b[i], W.wcat + i * 4096, W.bcat + i * 64);
+    {
+        GatePtrs gp;
+        for (int i = 0; i < NL; ++i) { gp.wf[i] = p->filter_w[i]; gp.bf[i] = p->filter_b[i]; gp.wg[i] = p->gate_w[i]; gp.bg[i] = p->gate_b[i]; }
+        pack_gate_kernel<<<dim3(16, NL), 256, 0, st>>>(gp, W.wcat, W.bcat);
+        STEP_LAUNCH_CHECK("pack_gate");
     }
-    STEP_LAUNCH_CHECK("pack_gate");
 
     for (int i = 0; i < NL; ++i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
@@ -708,9 +717,12 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     const long BN = (long)B * N;
     auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
-    for (int i = 0; i < NL; ++i)
-        pack_gate_kernel<<<16, 256, 0, st>>>(p->filter_w[i], p->filter_b[i], p->gate_w[i], p->gate_b[i], W.wcat + i * 4096, W.bcat + i * 64);
-    STEP_LAUNCH_CHECK("pack_gate");
+    {
+        GatePtrs gp;
+        for (int i = 0; i < NL; ++i) { gp.wf[i] = p->filter_w[i]; gp.bf[i] = p->filter_b[i]; gp.wg[i] = p->gate_w[i]; gp.bg[i] = p->gate_b[i]; }
+        pack_gate_kernel<<<dim3(16, NL), 256, 0, st>>>(gp, W.wcat, W.bcat);
+        STEP_LAUNCH_CHECK("pack_gate");
+    }
     STEP_TRY(zero(W.dwcat, NL * 4096, st));
     STEP_TRY(zero(W.dbcat, NL * 64, st));
     const long NN = (long)N * N;
@@ -817,9 +829,11 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         STEP_LAUNCH_CHECK("col2im");
         dx_next = dx;
     }
-    for (int i = 0; i < NL; ++i)
-        unpack_gate_grad_kernel<<<16, 256, 0, st>>>(W.dwcat + i * 4096, W.dbcat + i * 64, grads->filter_w[i], grads->filter_b[i],
-                                                    grads->gate_w[i], grads->gate_b[i]);
+    {
+        GatePtrs gg;
+        for (int i = 0; i < NL; ++i) { gg.wf[i] = grads->filter_w[i]; gg.bf[i] = grads->filter_b[i]; gg.wg[i] = grads->gate_w[i]; gg.bg[i] = grads->gate_b[i]; }
+        unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, st>>>(W.dwcat, W.dbcat, gg);
+    }
     start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx_next, grads->start_w, grads->start_b);
     STEP_LAUNCH_CHECK("start_conv_bwd");
 

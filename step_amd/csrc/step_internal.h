@@ -29,4 +29,5 @@ int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int
 long dgl_conv2_wgrad_scratch_floats(int N, int T1);
 int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
                          int T1, hipStream_t st);
+int dgl_conv1_wgrad_mfma(const float* dz, const float* x, float* scratch, float* dw, float* db, int N, int T, hipStream_t st);
 int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out, hipStream_t st);

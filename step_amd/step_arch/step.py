@@ -77,8 +77,8 @@ class _StepFunction(torch.autograd.Function):
                int(training), float(drop), model._next_seed(), BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), st)
         if training:
             with torch.no_grad():
-                for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:7]):
-                    m.num_batches_tracked += 1
+                # one multi-tensor launch instead of ten scalar ones
+                torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:7])], 1)
         ctx.model = model
         ctx.dims = (B, N, Cin, Ttr, float(drop))
         ctx.held = (hist, enc["last"], g, gsaved, esaved, wsaved)
