@@ -128,6 +128,11 @@ int step_dgl_global_forward(const float* series_nt, int N, int T, const StepDglP
                             float momentum, float* saved, float* work, float* g, void* stream);
 int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                              const float* dg, float* work, const StepDglParams* grads, void* stream);
+/* The same backward in two calls: phase 1 ends with the finished fc weight gradient (87 MB at PEMS04, the bulk of the
+   data-parallel all-reduce, which the caller starts while phase 2 -- conv / BatchNorm backward, same `work` -- runs);
+   phase 0 = both. */
+int step_dgl_global_backward_phase(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
+                             const float* dg, float* work, const StepDglParams* grads, int phase, void* stream);
 
 /* Edge logits + Gumbel-softmax hard sample (discrete_graph_learning.py:148-161, :11-45).
  *  g [N,100]; u f32 [B, N*N, 2] uniform noise as drawn by torch.rand (:12) or NULL for the

@@ -621,7 +621,16 @@ extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, con
 
 extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                                         const float* dg, float* work, const StepDglParams* grads, void* stream) {
-    STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18, "dgl_global_backward: bad arguments");
+    return step_dgl_global_backward_phase(series_nt, N, T, p, saved, dg, work, grads, 0, stream);
+}
+
+// phase 0: everything; phase 1: bn3 / fc backward up to the finished fc weight gradient (the 87 MB that dominate the
+// data-parallel all-reduce, which the caller can start right away); phase 2: the rest, with the same `work` buffer
+extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
+                                              const float* dg, float* work, const StepDglParams* grads, int phase, void* stream) {
+    STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18 && phase >= 0 && phase <= 2,
+                 "dgl_global_backward: bad arguments");
+    const bool do_fc = phase != 2, do_rest = phase != 1;
     hipStream_t st = (hipStream_t)stream;
     const int T1 = T - 9, T2 = T - 18;
     const long K = 16L * T2;
@@ -636,17 +645,20 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
     float* dgpreT = dgpre + (long)N * EMB;
     float* coef = dgpreT + (long)N * EMB;
     float* wg_scratch = coef + 256;
-    // BN3 + ReLU backward, fc bias gradient
-    bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT);
-    STEP_LAUNCH_CHECK("bn3_bwd");
-    // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
-    {
-        StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
-        gm.compute_bf16 = p->gemm_bf16;
-        STEP_TRY(step_gemm_launch(gm, st));
-        fc_wgrad_fixup_kernel<<<dim3(256, EMB), 256, 0, st>>>(wraw, dgpre, N, st2, 16, T2, K, grads->fc_w);
-        STEP_LAUNCH_CHECK("fc_wgrad_fixup");
+    if (do_fc) {
+        // BN3 + ReLU backward, fc bias gradient
+        bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT);
+        STEP_LAUNCH_CHECK("bn3_bwd");
+        // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
+        {
+            StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
+            gm.compute_bf16 = p->gemm_bf16;
+            STEP_TRY(step_gemm_launch(gm, st));
+            fc_wgrad_fixup_kernel<<<dim3(256, EMB), 256, 0, st>>>(wraw, dgpre, N, st2, 16, T2, K, grads->fc_w);
+            STEP_LAUNCH_CHECK("fc_wgrad_fixup");
+        }
     }
+    if (!do_rest) return STEP_OK;
     // d(BN2 output) = dgpre @ fc_w
     {
         StepGemm gm = gemm_desc(N, (int)K, EMB, dgpreT, 1, N, p->fc_w, K, 1, d_a2, K);     // A(m=n, k=o) = dgpreT[o][n]

@@ -101,6 +101,14 @@ flat = torch.arange(lay["total"], dtype=torch.float32) * (rank + 1)
 model._reduce_flat_grads(flat)
 want = torch.arange(lay["total"], dtype=torch.float32) * (sum(range(1, world + 1)) / world)
 assert torch.allclose(flat, want), (flat[:5], want[:5])
+# the backward's chunked form: the fc weight gradient (last in the layout) first, the rest afterwards
+assert lay["order"][-1] == "dgl.fc_w"
+fo, fn, _ = lay["items"]["dgl.fc_w"]
+flat = torch.arange(lay["total"], dtype=torch.float32) * (rank + 1)
+pending = model._reduce_begin(flat[fo:fo + fn])
+pending += model._reduce_begin(flat[:fo])
+model._reduce_finish(flat, pending)
+assert torch.allclose(flat[:fo + fn], want[:fo + fn])
 # weak-scaling shard check: per-rank window streams differ
 import numpy as np
 ts = np.random.default_rng(1234 + rank).integers(100, 1000, size=8)
