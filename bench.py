@@ -158,8 +158,8 @@ def pretrain_main(args, cfg, world, rank, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)          # >= 20 warm-up, >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="STEP_PEMS04", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -233,12 +233,16 @@ def main():
     for i in range(args.warmup):
         step(i)
     model.tsformer._events = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if world > 1:
         tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
@@ -258,6 +262,8 @@ def main():
                                    f"train series T={cfg['T_train']}, batch {B}/GPU, random-init weights, "
                                    "full train step (fwd+bwd+clip+Adam)", "global_batch": B * world,
                        "parallelism": f"dp{world}", "final_loss": float(loss)},
+            "step_ms": {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
+                        "p90": float(np.percentile(per_step, 90))},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,
                          "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(args.config, B), "ms_per_launch": enc_ms,
                          "algorithmic_flop_per_launch": flops},

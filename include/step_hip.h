@@ -85,6 +85,12 @@ int step_tsformer_encode(const float* series, int S, int L, const void* wpack, l
  * channel `ch` -> [B*N, L] f32.  Replaces the permute at tsformer.py:179 + `[..., [0]]` at
  * discrete_graph_learning.py:139. */
 int step_pack_long_history(const float* x, int B, int L, int N, int C, int ch, float* out, void* stream);
+/* Device-resident dataset, index-only loader (replaces ForecastingDataset.__getitem__ + collate + H2D,
+ * step/step_data/forecasting_dataset.py:52-71): data f32 [T, N, C] stays in HBM, t0 int64 [B] are the forecast origins.
+ *  long_series f32 [B*N, L]   channel ch of rows t0-L .. t0-1, in the encoder's layout (zero-filled when t0 < L, :66-67), or NULL
+ *  hist        f32 [B, H, N, C] rows t0-H .. t0-1, or NULL;  fut f32 [B, H, N, C] rows t0 .. t0+H-1, or NULL */
+int step_gather_windows(const float* data, int T, int N, int C, int ch, const long* t0, int B, int L, int H,
+                        float* long_series, float* hist, float* fut, void* stream);
 
 /* ---------------------------------------------------------------- kNN prior graph --------
  * Replaces batch_cosine_similarity (similarity.py:6-16) + get_k_nn_neighbor

@@ -10,4 +10,7 @@ def __getattr__(name):
     if name in ("STEP", "TSFormer", "GraphWaveNet", "DiscreteGraphLearning"):
         from . import step_arch
         return getattr(step_arch, name)
+    if name in ("LongHistoryRef", "DeviceWindowLoader"):          # device-resident dataset, index-only loader
+        from .step_arch import step
+        return getattr(step, name)
     raise AttributeError(name)

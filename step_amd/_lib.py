@@ -51,6 +51,7 @@ _SIGS = {
     "step_abi_version": (_i, []),
     "step_gemm": (_i, [ctypes.POINTER(StepGemm), _vp]),
     "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _u64, _vp]),
+    "step_gather_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "step_pack_long_history": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "step_knn_workspace_bytes": (_l, [_i, _i, _i]),
     "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),

@@ -360,6 +360,39 @@ __global__ __launch_bounds__(256) void pack_long_history_kernel(const float* __r
     }
 }
 
+// Same output as pack_long_history_kernel, read straight from the device-resident series [T][N][C]: sequence (b, n) is
+// channel ch of rows t0[b] - L .. t0[b] - 1 (windows that start before L rows exist are zero-filled, like the reference's
+// dataset does for them, forecasting_dataset.py:66-67).  No [B, L, N, C] tensor is ever materialised.
+__global__ __launch_bounds__(256) void gather_long_history_kernel(const float* __restrict__ data, int T, int N, int C, int ch,
+                                                                  const long* __restrict__ t0, int L, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long start = t0[b] - L;
+    const int l0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int l = l0 + r, n = n0 + tx;
+        const long t = start + l;
+        tile[r][tx] = (l < L && n < N && start >= 0 && t < T) ? data[(t * N + n) * C + ch] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, l = l0 + tx;
+        if (n < N && l < L) out[((long)b * N + n) * L + l] = tile[tx][r];
+    }
+}
+// hist[b][j][n][c] = data[t0[b] - H + j][n][c], fut[b][j][n][c] = data[t0[b] + j][n][c]   (H = horizon = 12)
+__global__ void gather_short_windows_kernel(const float* __restrict__ data, int T, int N, int C, const long* __restrict__ t0, int H,
+                                            float* __restrict__ hist, float* __restrict__ fut) {
+    const int b = blockIdx.y;
+    const long per = (long)H * N * C;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per) return;
+    const long th = t0[b] - H, tf = t0[b];
+    hist[b * per + idx] = (th >= 0 && th + H <= T) ? data[th * N * C + idx] : 0.f;
+    if (fut) fut[b * per + idx] = (tf >= 0 && tf + H <= T) ? data[tf * N * C + idx] : 0.f;
+}
+
 template <int MAXW, bool DROP, bool PARK>
 int launch_enc(const EncArgs& a, hipStream_t st) {
     size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
@@ -403,6 +436,22 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     if (a.nkt <= 11) return dr ? launch_enc<12, true, true>(a, st) : launch_enc<12, false, true>(a, st);
     if (a.nkt <= 12) return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
     return dr ? launch_enc<16, true, false>(a, st) : launch_enc<16, false, false>(a, st);
+}
+
+extern "C" int step_gather_windows(const float* data, int T, int N, int C, int ch, const long* t0, int B, int L, int H,
+                                   float* long_series, float* hist, float* fut, void* stream) {
+    STEP_REQUIRE(data && t0 && T > 0 && N > 0 && C > 0 && ch >= 0 && ch < C && B > 0 && L >= 0 && H > 0, "gather_windows: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (long_series) {
+        STEP_REQUIRE(L > 0, "gather_windows: long history length must be positive");
+        gather_long_history_kernel<<<dim3(cdiv(L, 32), cdiv(N, 32), B), 256, 0, st>>>(data, T, N, C, ch, t0, L, long_series);
+        STEP_LAUNCH_CHECK("gather_long_history");
+    }
+    if (hist) {
+        gather_short_windows_kernel<<<dim3(cdiv((long)H * N * C, 256), B), 256, 0, st>>>(data, T, N, C, t0, H, hist, fut);
+        STEP_LAUNCH_CHECK("gather_short_windows");
+    }
+    return STEP_OK;
 }
 
 extern "C" int step_pack_long_history(const float* x, int B, int L, int N, int C, int ch, float* out, void* stream) {

@@ -25,6 +25,40 @@ def _f32(n, device):
     return torch.empty(int(n), device=device, dtype=torch.float32)
 
 
+class LongHistoryRef:
+    """Stand-in for the ``long_history_data`` tensor [B, L, N, C] of a batch whose series lives on the device
+    (SURVEY 8f-1): ``data`` f32 [T, N, C] resident in HBM, ``t0`` int64 [B] forecast origins, ``length`` = L.  STEP.forward
+    accepts it in place of the tensor and gathers the encoder input directly (no 14.9 MB/window copy)."""
+
+    def __init__(self, data, t0, length):
+        assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 3 and data.is_contiguous()
+        assert t0.is_cuda and t0.dtype == torch.int64 and t0.dim() == 1
+        self.data, self.t0, self.length = data, t0, int(length)
+
+    @property
+    def shape(self):
+        return (self.t0.shape[0], self.length, self.data.shape[1], self.data.shape[2])
+
+
+class DeviceWindowLoader:
+    """Index-only loader over a device-resident series: yields (history_data [B,12,N,C], LongHistoryRef, future_data [B,12,N,C])
+    for a batch of forecast origins; one gather launch, nothing crosses PCIe."""
+
+    def __init__(self, data, long_len, horizon=12):
+        self.data = data.contiguous().float()
+        assert self.data.is_cuda
+        self.long_len, self.horizon = int(long_len), int(horizon)
+
+    def batch(self, t0):
+        t0 = torch.as_tensor(t0, dtype=torch.int64, device=self.data.device).contiguous()
+        B, (T, N, C), H = t0.shape[0], self.data.shape, self.horizon
+        hist = torch.empty(B, H, N, C, device=self.data.device)
+        fut = torch.empty(B, H, N, C, device=self.data.device)
+        _lib.call("step_gather_windows", _lib.ptr(self.data), T, N, C, 0, _lib.ptr(t0), B, 0, H, None, _lib.ptr(hist), _lib.ptr(fut),
+                  _lib.stream())
+        return hist, LongHistoryRef(self.data, t0, self.long_len), fut
+
+
 class _StepFunction(torch.autograd.Function):
     """Inputs: (model, hist [B,12,N,C], long_hist [B,L,N,C], u or None, *trainable tensors)."""
 
@@ -37,10 +71,15 @@ class _StepFunction(torch.autograd.Function):
         training = model.training
         st = L.stream()
         hist = hist.contiguous().float()
-        long_hist = long_hist.contiguous().float()
         # ---- TSFormer (frozen): [B,L,N,C] -> hidden bf16 [B*N, P, 96]
         series = _f32(B * N * Lh, dev).view(B * N, Lh)
-        L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
+        if isinstance(long_hist, LongHistoryRef):          # index-only loader: gather straight from the resident series
+            d = long_hist.data
+            L.call("step_gather_windows", L.ptr(d), d.shape[0], d.shape[1], d.shape[2], 0, L.ptr(long_hist.t0), B, Lh, 12,
+                   L.ptr(series), None, None, st)
+        else:
+            long_hist = long_hist.contiguous().float()
+            L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
         enc = model.tsformer.encode_series(series)
         P = Lh // 12
         # ---- kNN prior graph (no grad)
