@@ -241,7 +241,6 @@ constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64
 
 struct FastArgs {
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
-    int dbg;                           // tuning knobs (env STEP_GEMM_DBG): 1 no stores, 4/8 force 64/128 tiles, 32 general kernel
 };
 
 // no remap is encoded as lg = 30, stride = 0 (i >> 30 == 0): branch-free
@@ -497,7 +496,6 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     }
 
     float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
-    if ((fa.dbg & 1) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -582,11 +580,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
     const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, g.b_bf16, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog,
                                 &fa.b_nlog);
-    bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
+    const bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
                 !(g.a_rowsum && bmode == KC_BF16);
-    static const int dbg = getenv("STEP_GEMM_DBG") ? atoi(getenv("STEP_GEMM_DBG")) : 0;
-    fa.dbg = dbg;
-    if (dbg & 32) fast = false;
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
@@ -599,9 +594,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
     if (g.splitk > 1) STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2");
     STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
-    bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
-    if (dbg & 4) big = false;
-    if (dbg & 8) big = true;
+    const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
     if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
     STEP_TRY(step_gemm_rowsum_fallback(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
@@ -611,14 +604,12 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
 // Exact-f32 GEMM through the same staged pipeline (64 x 64 tiles).  Returns -1 when the operands do not qualify
 // (alignment / layout), in which case the caller falls back to the general kernels of gemm.hip.
 int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st) {
-    static const int dbg = getenv("STEP_GEMM_DBG") ? atoi(getenv("STEP_GEMM_DBG")) : 0;
-    if ((dbg & 64) || g.a_bf16 || g.b_bf16) return -1;
+    if (g.a_bf16 || g.b_bf16) return -1;
     FastArgs fa;
     int dummy;
     const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, 0, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog, &fa.b_nlog);
     if (amode < 0 || bmode < 0 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
-    fa.dbg = dbg;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;

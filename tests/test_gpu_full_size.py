@@ -1,0 +1,82 @@
+"""Full-size parity (BASELINE.json config C2 shapes: N=307 nodes, L=4032 steps -> P=336 patches, train series T=13 599):
+one training step of the native module, f32 matmul mode, dropout off, against the CPU oracle fed the device encoder's
+hidden states and the same Gumbel noise -- prediction, edge probabilities, loss and every gradient.  B=2 windows keep the
+oracle (torch CPU fp32) at a few seconds; nothing in the native path depends on B beyond the batch loops."""
+import numpy as np
+import pytest
+import torch
+
+import bench as Bn
+from oracle import step_oracle as O
+from tests.helpers import rel_l2, max_abs
+from tests.test_gpu_step import ref_name
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_size_training_step_parity(mode):
+    """mode "f32": exact contractions downstream of the encoder (tight); mode "bf16": what bench.py times -- hops, DGL conv and
+    fc on the bf16 matrix cores (tolerances of bf16 operand rounding, measured values in DESIGN.md section 2)."""
+    tight = mode == "f32"
+    cfg = dict(Bn.CONFIGS["STEP_PEMS04"])
+    N, L, Ttr, k = cfg["N"], cfg["L"], cfg["T_train"], cfg["k"]
+    B = 2
+    data = Bn.synth_series(cfg["T_all"], N)
+    model = Bn.make_model(cfg, data)
+    sd = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
+    model = model.cuda()
+    model.train()
+    model.matmul_precision = mode
+    model.backend.dropout = 0.0
+    model.tsformer.dropout_p = 0.0
+    gen = torch.Generator().manual_seed(5)
+    u = torch.rand(B, N * N, 2, generator=gen)
+    model._noise_override = u
+    d = torch.from_numpy(data)
+    ts = [L + 17, L + 17 + 301]
+    hist = torch.stack([d[a - 12:a] for a in ts]); fut = torch.stack([d[a:a + 12] for a in ts]); longh = torch.stack([d[a - L:a] for a in ts])
+    mean, std = 200.0, 150.0
+    pred, theta, knn, coef = model(history_data=hist.cuda(), long_history_data=longh.cuda(), future_data=None, batch_seen=0, epoch=1)
+    loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]].cuda(), mean, std), theta, knn, coef)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    P = L // 12
+    hid = model._last["hidden_bf16"].float().cpu().view(B, N, P, 96)
+    last = model._last["hidden_last"].cpu().view(B, N, 96)
+    p = {}
+    for kk, v in sd.items():
+        v = v.clone()
+        if v.is_floating_point() and not kk.startswith("tsformer.") and "running_" not in kk:
+            v.requires_grad_(True)
+        p[kk] = v
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    o_pred, o_theta, o_knn, o_coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, k, 1, training=True, hidden=hid, hidden_last=last)
+    o_loss = O.step_loss(O.rescale(o_pred, mean, std), O.rescale(fut[..., [0]], mean, std), o_theta, o_knn, o_coef)
+    o_loss.backward()
+
+    e_pred = rel_l2(pred.detach().cpu(), o_pred)
+    print(f"full size [{mode}]: pred rel-L2", e_pred, "theta max-abs", max_abs(theta.detach().cpu(), o_theta), "loss", float(loss), float(o_loss))
+    assert e_pred < (2e-3 if tight else 1e-2)
+    assert max_abs(theta.detach().cpu(), o_theta) < (2e-5 if tight else 5e-3)
+    assert float(loss) == pytest.approx(float(o_loss), rel=2e-3 if tight else 5e-3)
+    dk = (knn.cpu() != o_knn).sum().item()
+    print(f"full size [{mode}]: kNN entries differing from oracle(device hidden):", dk, "of", knn.numel())
+    assert dk <= 4 * B
+    errs = {}
+    for kname, t in dict(model._trainable()).items():
+        og = p[ref_name(kname)].grad
+        assert og is not None and t.grad is not None, kname
+        if float(og.abs().max()) < 1e-4:
+            assert max_abs(t.grad.cpu(), og) < 2e-4, kname
+            continue
+        errs[kname] = rel_l2(t.grad.cpu(), og)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    print(f"full size [{mode}]: worst gradient rel-L2:", [(a, round(b, 5)) for a, b in worst])
+    if tight:
+        assert max(errs.values()) < 2e-2, worst
+    num = sum(float(((dict(model._trainable())[a].grad.cpu() - p[ref_name(a)].grad) ** 2).sum()) for a in errs)
+    den = sum(float((p[ref_name(a)].grad ** 2).sum()) for a in errs)
+    print(f"full size [{mode}]: whole-gradient rel-L2", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < (5e-3 if tight else 5e-2)

@@ -1,4 +1,5 @@
-"""Micro-benchmark of the bf16 step_gemm on the production shapes (GPU box).  STEP_GEMM_DBG selects tuning knobs."""
+"""Micro-benchmark of step_gemm on the production shapes (GPU box): bf16 fc / hop GEMMs, and with the argument `f32` the exact-f32
+GraphWaveNet GEMMs.  Use STEP_HIP_LIB=<other build> for A/B comparisons."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from step_amd import _lib as L
@@ -42,9 +43,9 @@ sel = [a for a in sys.argv[1:] if a != 'f32'] or ([] if sys.argv[1:] else list(c
 for name in sel:
     f, nbytes = cases[name]
     us = timeit(f)
-    print(f"dbg={os.environ.get('STEP_GEMM_DBG', '0'):>3s} {name:16s} {us:8.1f} us  {nbytes / us / 1e6:7.2f} TB/s (algorithmic bytes)", flush=True)
+    print(f"{name:16s} {us:8.1f} us  {nbytes / us / 1e6:7.2f} TB/s (algorithmic bytes)", flush=True)
 
-# exact-f32 GEMMs of the GraphWaveNet layers (STEP_GEMM_DBG=64 disables the staged f32 kernel -> general kernels)
+# exact-f32 GEMMs of the GraphWaveNet layers
 if not sys.argv[1:] or "f32" in sys.argv[1:]:
     npos = 8 * 307 * 12
     x64 = torch.randn(npos, 64, device="cuda"); w64 = torch.randn(64, 64, device="cuda"); o64 = torch.empty(npos, 64, device="cuda")
@@ -64,4 +65,4 @@ if not sys.argv[1:] or "f32" in sys.argv[1:]:
     }
     for name, f in f32cases.items():
         us = timeit(f)
-        print(f"dbg={os.environ.get('STEP_GEMM_DBG', '0'):>3s} {name:26s} {us:8.1f} us", flush=True)
+        print(f"{name:26s} {us:8.1f} us", flush=True)

@@ -19,6 +19,6 @@ H = (torch.randn(B, 1, F, device="cuda") + 0.7 * torch.randn(B, N, F, device="cu
 sim = torch.empty(B, N, N, device="cuda"); adj = torch.empty(B, N, N, device="cuda")
 work = torch.empty(L.lib().step_knn_workspace_bytes(B, N, F), dtype=torch.uint8, device="cuda")
 f = lambda: L.call("step_knn_graph", L.ptr(H), None, B, N, F, k * N, L.ptr(sim), L.ptr(adj), L.ptr(work), work.numel(), L.stream())
-print(f"dbg={os.environ.get('STEP_GEMM_DBG','0')} knn_graph total {timeit(f):.1f} us")
+print(f"knn_graph total {timeit(f):.1f} us")
 g = lambda: L.call("step_topk_mask", L.ptr(sim), B, N, k * N, L.ptr(adj), L.ptr(work), work.numel(), L.stream())
 print(f"topk_mask {timeit(g):.1f} us")
