@@ -59,6 +59,11 @@ typedef struct StepGemm {
     /* optional: a_rowsum[m] += sum_k A(m,k)  (batch 1, alpha 1).  The bias gradient that accompanies a weight-gradient
        GEMM; the staged kernels get it from the matrix cores as one extra all-ones column of B. */
     float* a_rowsum;
+    /* optional column-block affine of the result: C(m,n) <- c_nscale[n / c_nperiod] * (alpha * A.B)(m,n)
+       + c_nshift[n / c_nperiod] * c_mvec[m]  (then accumulate / bias as usual).  Folds a BatchNorm affine of the B operand's
+       columns into a weight-gradient GEMM (the DGL fc weight gradient w.r.t. the normalised conv2 output). */
+    const float *c_nscale, *c_nshift, *c_mvec;
+    int c_nperiod;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 

@@ -1,5 +1,6 @@
 // Shared host/device helpers for libstep_hip (gfx950 / CDNA4 only).
 #pragma once
+#include "../../include/step_hip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -95,13 +96,28 @@ __device__ __forceinline__ float u32_to_unit(uint32_t x) { return (float)(x >> 8
 // mb + (e&3) + 8*(e>>2).  The accumulate mode is uniform, so it is branched on once per tile: the plain-store
 // and atomic paths issue their 16 memory operations back to back (no s_waitcnt in between), the read-modify-write
 // path issues its 16 loads first.
+// column-block affine of a result column (StepGemm.c_nscale / c_nshift / c_mvec): value <- cs * value + csh * mvec[row]
+struct GemmColAffine { float cs, csh; const float* mvec; };
+__device__ __forceinline__ GemmColAffine gemm_col_affine(const StepGemm& g, int gn) {
+    GemmColAffine a = {1.f, 0.f, nullptr};
+    if (g.c_nscale) { const int c = gn / g.c_nperiod; a.cs = g.c_nscale[c]; a.csh = g.c_nshift[c]; a.mvec = g.c_mvec; }
+    return a;
+}
+
 __device__ __forceinline__ void gemm_store_tile(const f32x16& acc, float* col, int mb, int M, long ldc, float alpha, int accumulate,
-                                                float bv, int relu) {
+                                                float bv, int relu, GemmColAffine ca = GemmColAffine{1.f, 0.f, nullptr}) {
+    float val[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int gm = mb + (e & 3) + 8 * (e >> 2);
+        val[e] = alpha * acc[e] * ca.cs;
+        if (ca.mvec) val[e] += ca.csh * (gm < M ? ca.mvec[gm] : 0.f);
+    }
     if (accumulate == 2) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int gm = mb + (e & 3) + 8 * (e >> 2);
-            if (gm < M) atomicAdd(col + (long)gm * ldc, alpha * acc[e]);
+            if (gm < M) atomicAdd(col + (long)gm * ldc, val[e]);
         }
     } else if (accumulate == 1) {
         float old[16];
@@ -113,7 +129,7 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16& acc, float* col, i
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int gm = mb + (e & 3) + 8 * (e >> 2);
-            float v = alpha * acc[e] + old[e] + bv;
+            float v = val[e] + old[e] + bv;
             if (relu) v = fmaxf(v, 0.f);
             if (gm < M) col[(long)gm * ldc] = v;
         }
@@ -121,7 +137,7 @@ __device__ __forceinline__ void gemm_store_tile(const f32x16& acc, float* col, i
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int gm = mb + (e & 3) + 8 * (e >> 2);
-            float v = alpha * acc[e] + bv;
+            float v = val[e] + bv;
             if (relu) v = fmaxf(v, 0.f);
             if (gm < M) col[(long)gm * ldc] = v;
         }

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void bn3_relu_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ stat,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ dbias, float* __restrict__ dgpre,
-                                                           float* __restrict__ dgpreT) {
+                                                           float* __restrict__ dgpreT, float* __restrict__ colsum) {
     __shared__ double r1[256], r2[256];
     const int j = blockIdx.x, tid = threadIdx.x;
     const float mean = stat[2 * EMB + j], rstd = stat[3 * EMB + j];
@@ -205,27 +205,7 @@ __global__ __launch_bounds__(256) void bn3_relu_bwd_kernel(const float* __restri
         if (tid < s) r1[tid] += r1[tid + s];
         __syncthreads();
     }
-    if (tid == 0) dbias[j] += (float)r1[0];
-}
-
-// dfc_w[o][k] += sc[c(k)] * raw[o][k] + sh[c(k)] * colsum[o],  c(k) = k / period
-__global__ __launch_bounds__(256) void fc_wgrad_fixup_kernel(const float* __restrict__ raw, const float* __restrict__ dgpre, int N,
-                                                             const float* __restrict__ stat, int C, int period, long K,
-                                                             float* __restrict__ dw) {
-    __shared__ float cs;
-    const int o = blockIdx.y;
-    if (threadIdx.x < 64) {
-        float s = 0.f;
-        for (int n = threadIdx.x; n < N; n += 64) s += dgpre[(long)n * EMB + o];
-        s = wave_sum(s);
-        if (threadIdx.x == 0) cs = s;
-    }
-    __syncthreads();
-    const float colsum = cs;
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < K; k += (long)gridDim.x * 256) {
-        int c = (int)(k / period);
-        dw[(long)o * K + k] += stat[c] * raw[(long)o * K + k] + stat[C + c] * colsum;
-    }
+    if (tid == 0) { dbias[j] += (float)r1[0]; colsum[j] = (float)r1[0]; }
 }
 
 // BatchNorm (over n, t per channel) backward, pass 1: S1 = sum dy, S2 = sum dy * xhat, per block partials
@@ -647,15 +627,17 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
     float* wg_scratch = coef + 256;
     if (do_fc) {
         // BN3 + ReLU backward, fc bias gradient
-        bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT);
+        float* colsum = coef + 128;          // column sums of dgpre [EMB] (coef holds 3 x 16 BatchNorm coefficients at most)
+        bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT, colsum);
         STEP_LAUNCH_CHECK("bn3_bwd");
         // fc weight gradient on the raw conv2 activation, then fold BN2's affine in
         {
-            StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
+            // d fc_w[o][k] += sc[c(k)] * (dgpre^T a2)[o][k] + sh[c(k)] * colsum(dgpre)[o]: BN2's affine rides in the GEMM epilogue
+            StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, grads->fc_w, K);
+            gm.accumulate = 1;
+            gm.c_nscale = st2; gm.c_nshift = st2 + 16; gm.c_nperiod = T2; gm.c_mvec = colsum;
             gm.compute_bf16 = p->gemm_bf16;
             STEP_TRY(step_gemm_launch(gm, st));
-            fc_wgrad_fixup_kernel<<<dim3(256, EMB), 256, 0, st>>>(wraw, dgpre, N, st2, 16, T2, K, grads->fc_w);
-            STEP_LAUNCH_CHECK("fc_wgrad_fixup");
         }
     }
     if (!do_rest) return STEP_OK;

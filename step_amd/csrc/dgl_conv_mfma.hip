@@ -170,34 +170,47 @@ __global__ __launch_bounds__(256) void conv2_wgrad_mfma_kernel(const float* __re
 #pragma unroll
     for (int co = 0; co < CO; ++co) bsum[co] = 0.f;
 
+    // software pipeline: the global loads of pass p+1 are in flight while pass p is converted, staged and multiplied
+    float v[CO], xa[CI], xb[CI];
+    auto fetch = [&](int tp) {           // dz (zero past T2) and the input window [tp, tp + 256 + 10) of this thread
+        const int t = tp + tid;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) v[co] = t < T2 ? dz[((long)n * CO + co) * T2 + t] : 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) xa[ci] = t < T1 ? a1[((long)n * CI + ci) * T1 + t] : 0.f;
+        const int t2 = tp + 256 + tid;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) xb[ci] = (tid < 10 && t2 < T1) ? a1[((long)n * CI + ci) * T1 + t2] : 0.f;
+    };
+    fetch(tbeg);
     for (int pass = 0; pass < WG_PASSES; ++pass) {
         const int tp = tbeg + pass * WG_SC;
         if (tp >= T2) break;
         __syncthreads();
-        {   // stage dz (zero past T2) and the affine input window [tp, tp + 256 + 10]
+        {
             const int t = tp + tid;
-            float v[CO];
-#pragma unroll
-            for (int co = 0; co < CO; ++co) v[co] = t < T2 ? dz[((long)n * CO + co) * T2 + t] : 0.f;
 #pragma unroll
             for (int co = 0; co < CO; ++co) {
                 bsum[co] += v[co];
                 zs[co][tid] = (uint16_t)(cvt2(v[co], 0.f) & 0xffffu);
             }
-            for (int tt = tid; tt < WG_SC + 10; tt += 256) {
-                const int tx = tp + tt;
-                float x[CI];
 #pragma unroll
-                for (int ci = 0; ci < CI; ++ci) x[ci] = tx < T1 ? a1[((long)n * CI + ci) * T1 + tx] * s8[ci] + h8[ci] : 0.f;
+            for (int ci = 0; ci < CI; ++ci) {
+                const uint16_t hb = (uint16_t)(cvt2(t < T1 ? xa[ci] * s8[ci] + h8[ci] : 0.f, 0.f) & 0xffffu);
+                x0[ci][tid] = hb;
+                if (tid > 0) x1[ci][tid - 1] = hb;
+            }
+            if (tid < 10) {
 #pragma unroll
                 for (int ci = 0; ci < CI; ++ci) {
-                    const uint16_t hb = (uint16_t)(cvt2(x[ci], 0.f) & 0xffffu);
-                    x0[ci][tt] = hb;
-                    if (tt > 0) x1[ci][tt - 1] = hb;
+                    const uint16_t hb = (uint16_t)(cvt2(t + 256 < T1 ? xb[ci] * s8[ci] + h8[ci] : 0.f, 0.f) & 0xffffu);
+                    x0[ci][tid + 256] = hb;
+                    x1[ci][tid + 255] = hb;
                 }
             }
         }
         __syncthreads();
+        if (pass + 1 < WG_PASSES && tp + WG_SC < T2) fetch(tp + WG_SC);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int tb = 64 * wave + 32 * u + 8 * q;          // first of this lane's 8 time steps
@@ -276,28 +289,36 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
     float bsum[C1];
 #pragma unroll
     for (int co = 0; co < C1; ++co) bsum[co] = 0.f;
+    float v[C1], xa, xb;
+    auto fetch = [&](int tp) {
+        const int t = tp + tid;
+#pragma unroll
+        for (int co = 0; co < C1; ++co) v[co] = t < T1 ? dz[((long)n * C1 + co) * T1 + t] : 0.f;
+        xa = t < T ? x[(long)n * T + t] : 0.f;
+        xb = (tid < 10 && t + 256 < T) ? x[(long)n * T + t + 256] : 0.f;
+    };
+    fetch(tbeg);
     for (int pass = 0; pass < WG_PASSES; ++pass) {
         const int tp = tbeg + pass * WG_SC;
         if (tp >= T1) break;
         __syncthreads();
         {
-            const int t = tp + tid;
-            float v[C1];
-#pragma unroll
-            for (int co = 0; co < C1; ++co) v[co] = t < T1 ? dz[((long)n * C1 + co) * T1 + t] : 0.f;
 #pragma unroll
             for (int co = 0; co < C1; ++co) {
                 bsum[co] += v[co];
                 zs[co][tid] = (uint16_t)(cvt2(v[co], 0.f) & 0xffffu);
             }
-            for (int tt = tid; tt < WG_SC + 10; tt += 256) {
-                const int tx = tp + tt;
-                const uint16_t hb = (uint16_t)(cvt2(tx < T ? x[(long)n * T + tx] : 0.f, 0.f) & 0xffffu);
-                x0[tt] = hb;
-                if (tt > 0) x1[tt - 1] = hb;
+            const uint16_t ha = (uint16_t)(cvt2(xa, 0.f) & 0xffffu);
+            x0[tid] = ha;
+            if (tid > 0) x1[tid - 1] = ha;
+            if (tid < 10) {
+                const uint16_t hb = (uint16_t)(cvt2(xb, 0.f) & 0xffffu);
+                x0[tid + 256] = hb;
+                x1[tid + 255] = hb;
             }
         }
         __syncthreads();
+        if (pass + 1 < WG_PASSES && tp + WG_SC < T1) fetch(tp + WG_SC);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int tb = 64 * wave + 32 * u + 8 * q;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32mfma_kernel(StepGemm g) {
             if (gn >= g.N) continue;
             const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
             const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
-            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu, gemm_col_affine(g, gn));
         }
 }
 
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(StepGemm g, DirectArgs
     if (!n_ok) return;
     const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
     const long ni = (long)(gn >> d.cn_sh) * g.c_nstride + (gn & d.cn_mask);
-    gemm_store_tile(acc, Cb + ni * g.scn, m0 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+    gemm_store_tile(acc, Cb + ni * g.scn, m0 + 4 * lk, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu, gemm_col_affine(g, gn));
 }
 
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }

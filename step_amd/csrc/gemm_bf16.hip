@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(StepGemm g) {
             if (gn >= g.N) continue;
             const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
             const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
-            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * h, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, m0 + wr * (TM * 32) + i * 32 + 4 * h, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu, gemm_col_affine(g, gn));
         }
 }
 
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             if (gn >= g.N) continue;
             const float bv = (g.bias != nullptr) ? g.bias[gn] : 0.f;
             const long ni = g.c_nblk ? (long)(gn / g.c_nblk) * g.c_nstride + (gn % g.c_nblk) : (long)gn;
-            gemm_store_tile(acc[i][j], Cb + ni * g.scn, mb, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu);
+            gemm_store_tile(acc[i][j], Cb + ni * g.scn, mb, g.M, g.ldc, g.alpha, g.accumulate, bv, g.relu, gemm_col_affine(g, gn));
         }
 }
 
