@@ -456,35 +456,37 @@ __global__ __launch_bounds__(256) void edge_dz_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restrict__ dz, const float* __restrict__ sndT,
                                                            const float* __restrict__ rcv, const float* __restrict__ wcat, int N,
                                                            float* __restrict__ drcv, float* __restrict__ dwcat, float* __restrict__ dbcat) {
-    __shared__ float sr[EMB], sw[EMB];
-    __shared__ float red[4][2 * EMB + 1];
-    const int i = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float sdz[];               // this receiver's dz row [N]
+    __shared__ float sr[EMB], sw[EMB], ra[EMB], rh[EMB];
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < EMB) { sr[tid] = rcv[(long)i * EMB + tid]; sw[tid] = wcat[tid] - wcat[EMB + tid]; }
+    float tot = 0.f;
+    for (int j = tid; j < N; j += 256) { const float d = dz[(long)i * N + j]; sdz[j] = d; tot += d; }
+    tot = wave_sum(tot);
+    if (lane == 0) red[wave] = tot;
     __syncthreads();
-    float sdz = 0.f;
-    for (int j = tid; j < N; j += 256) sdz += dz[(long)i * N + j];
-    sdz = wave_sum(sdz);
-    if ((tid & 63) == 0) red[tid >> 6][2 * EMB] = sdz;
-    for (int f = 0; f < EMB; ++f) {
-        float a = 0.f, h = 0.f;          // a -> drcv, h -> dwcat (sum dz * hid)
-        for (int j = tid; j < N; j += 256) {
-            float d = dz[(long)i * N + j];
-            float hid = sr[f] + sndT[(long)f * N + j];
+    // one feature per wave at a time (25 features per wave): a -> drcv, h -> dwcat (sum dz * hid)
+    for (int f = wave; f < EMB; f += 4) {
+        const float* srow = sndT + (long)f * N;
+        const float rf = sr[f];
+        float a = 0.f, h = 0.f;
+        for (int j = lane; j < N; j += 64) {
+            const float d = sdz[j];
+            const float hid = rf + srow[j];
             if (hid > 0.f) { a += d; h += d * hid; }
         }
         a = wave_sum(a); h = wave_sum(h);
-        if ((tid & 63) == 0) { red[tid >> 6][f] = a; red[tid >> 6][EMB + f] = h; }
+        if (lane == 0) { ra[f] = a; rh[f] = h; }
     }
     __syncthreads();
     if (tid < EMB) {
-        float a = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        float h = red[0][EMB + tid] + red[1][EMB + tid] + red[2][EMB + tid] + red[3][EMB + tid];
-        drcv[(long)i * EMB + tid] = a * sw[tid];
-        atomicAdd(&dwcat[tid], h);
-        atomicAdd(&dwcat[EMB + tid], -h);
+        drcv[(long)i * EMB + tid] = ra[tid] * sw[tid];
+        atomicAdd(&dwcat[tid], rh[tid]);
+        atomicAdd(&dwcat[EMB + tid], -rh[tid]);
     }
     if (tid == 0) {
-        float s = red[0][2 * EMB] + red[1][2 * EMB] + red[2][2 * EMB] + red[3][2 * EMB];
+        const float s = red[0] + red[1] + red[2] + red[3];
         atomicAdd(&dbcat[0], s);
         atomicAdd(&dbcat[1], -s);
     }
@@ -741,7 +743,7 @@ extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepD
     if (gx > 4096) gx = 4096;
     edge_dz_kernel<<<gx, 256, 0, st>>>(dtheta, dadj, theta, y0, B, N, 1.f / temperature, dz);
     STEP_LAUNCH_CHECK("edge_dz");
-    edge_bwd_row_kernel<<<N, 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
+    edge_bwd_row_kernel<<<N, 256, (size_t)N * sizeof(float), st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
     STEP_LAUNCH_CHECK("edge_bwd_row");
     edge_bwd_col_kernel<<<dim3(cdiv(N, 64), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
     STEP_LAUNCH_CHECK("edge_bwd_col");
