@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
-    ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="precision of the big GraphWaveNet/DGL contractions")
+    ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])

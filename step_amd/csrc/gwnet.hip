@@ -614,6 +614,7 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     Saved S = carve_saved(saved, B, N, use_drop);
     Work W = carve_work(work, B, N, false);
     const long BN = (long)B * N;
+    const int allbf16 = p->gemm_bf16;      // bf16 mode: every GEMM of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
 
     start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x_in[0]);
     STEP_LAUNCH_CHECK("start_conv");
@@ -652,14 +653,14 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         {   // pre = xcat @ Wcat^T + b
             StepGemm g = gemm_desc((int)npos, 64, 64, W.xcat, 64, 1, W.wcat + i * 4096, 1, 64, W.pre, 64);
             g.bias = W.bcat + i * 64;
-            STEP_TRY(step_gemm_launch(g, st));
+            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
         }
         gate_act_kernel<<<g1(npos * C), 256, 0, st>>>(W.pre, npos, S.tf[i], S.sg[i], S.cat[i]);
         STEP_LAUNCH_CHECK("gate_act");
         {   // skip[bn][:] (+)= Wskip z[bn][Tout-1]    (biases are summed once in the head)
             StepGemm g = gemm_desc((int)BN, CS, C, S.cat[i] + (long)(Tout - 1) * CAT, (long)Tout * CAT, 1, p->skip_w[i], 1, C, S.skip, CS);
             g.accumulate = i == 0 ? 0 : 1;
-            STEP_TRY(step_gemm_launch(g, st));
+            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
         }
         if (i == NL - 1) break;
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, p->gemm_bf16, st));      // slots 1,3,5 = P_s z
@@ -667,7 +668,7 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         {   // h = cat @ Wmix^T + b
             StepGemm g = gemm_desc((int)npos, C, CAT, S.cat[i], CAT, 1, p->gconv_w[i], 1, CAT, W.h, C);
             g.bias = p->gconv_b[i];
-            STEP_TRY(step_gemm_launch(g, st));
+            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
         }
         int nblk = (int)((npos + 7) / 8);
         if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
@@ -683,10 +684,10 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     {
         StepGemm g = gemm_desc((int)BN, CE, HID, hidden_last, HID, 1, p->fc_his0_w, 1, HID, S.h1, CE);
         g.bias = p->fc_his0_b; g.relu = 1;
-        STEP_TRY(step_gemm_launch(g, st));
+        g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
         StepGemm g2 = gemm_desc((int)BN, CS, CE, S.h1, CE, 1, p->fc_his2_w, 1, CE, S.h2, CS);
         g2.bias = p->fc_his2_b; g2.relu = 1;
-        STEP_TRY(step_gemm_launch(g2, st));
+        g2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g2, st));
         // sum of the 8 skip biases
         Ptr8 sb;
         for (int i = 0; i < NL; ++i) sb.p[i] = p->skip_b[i];
@@ -695,12 +696,12 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         STEP_LAUNCH_CHECK("head_combine");
         StepGemm g3 = gemm_desc((int)BN, CE, CS, S.xh, CS, 1, p->end1_w, 1, CS, S.e1, CE);
         g3.bias = p->end1_b; g3.relu = 1;
-        STEP_TRY(step_gemm_launch(g3, st));
+        g3.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g3, st));
         // pred[b][o][n] = e1[b,n,:] . W2[o,:] + b2[o]      (written directly as [B,12,N], step.py:65)
         StepGemm g4 = gemm_desc(N, OUT, CE, S.e1, CE, 1, p->end2_w, 1, CE, pred, 1);
         g4.batch = B; g4.sab = (long)N * CE; g4.scb = (long)OUT * N; g4.scn = N;
         g4.bias = p->end2_b;
-        STEP_TRY(step_gemm_launch(g4, st));
+        g4.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g4, st));
     }
     return STEP_OK;
 }
@@ -715,6 +716,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     Saved S = carve_saved((float*)saved, B, N, dropout != 0);
     Work W = carve_work(work, B, N, true);
     const long BN = (long)B * N;
+    const int allbf16 = p->gemm_bf16;
     auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
     {
@@ -744,9 +746,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
         gw1.accumulate = 2; gw1.splitk = split_for(BN);
         gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
-        STEP_TRY(step_gemm_launch(gw1, st));
+        gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, st));
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
-        STEP_TRY(step_gemm_launch(gx, st));
+        gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_xh, S.xh, BN * CS);       // = d skip = d h2 (pre-mask)
         {   // the 8 skip biases all receive colsum(d skip)
             STEP_TRY(zero(W.bsum, CS, st));
@@ -764,14 +766,14 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         StepGemm gw2 = gemm_desc(CS, CE, (int)BN, W.d_h2, 1, CS, S.h1, CE, 1, grads->fc_his2_w, CE);
         gw2.accumulate = 2; gw2.splitk = split_for(BN);
         gw2.a_rowsum = grads->fc_his2_b;
-        STEP_TRY(step_gemm_launch(gw2, st));
+        gw2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw2, st));
         StepGemm gh1 = gemm_desc((int)BN, CE, CS, W.d_h2, CS, 1, p->fc_his2_w, CE, 1, W.d_h1, CE);
-        STEP_TRY(step_gemm_launch(gh1, st));
+        gh1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gh1, st));
         relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_h1, S.h1, BN * CE);
         StepGemm gw0 = gemm_desc(CE, HID, (int)BN, W.d_h1, 1, CE, hidden_last, HID, 1, grads->fc_his0_w, HID);
         gw0.accumulate = 2; gw0.splitk = split_for(BN);
         gw0.a_rowsum = grads->fc_his0_b;
-        STEP_TRY(step_gemm_launch(gw0, st));
+        gw0.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw0, st));
     }
 
     // ---------------------------------------------------------------- WaveNet layers, reversed
@@ -792,9 +794,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = split_for(npos);
             gw.a_rowsum = grads->gconv_b[i];
-            STEP_TRY(step_gemm_launch(gw, st));
+            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
             StepGemm gd = gemm_desc((int)npos, CAT, C, W.dh, C, 1, p->gconv_w[i], CAT, 1, W.dcat, CAT);
-            STEP_TRY(step_gemm_launch(gd, st));
+            gd.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gd, st));
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 2, 1, 2, B, N, Tout, p->gemm_bf16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, p->gemm_bf16, st));      // dP += x1 (x) d_x2
@@ -807,10 +809,10 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         {
             StepGemm g = gemm_desc((int)BN, C, CS, W.d_xh, CS, 1, p->skip_w[i], C, 1, W.dcat + (long)(Tout - 1) * CAT, (long)Tout * CAT);
             g.accumulate = 1;
-            STEP_TRY(step_gemm_launch(g, st));
+            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
             StepGemm gw = gemm_desc(CS, C, (int)BN, W.d_xh, 1, CS, cat + (long)(Tout - 1) * CAT, (long)Tout * CAT, 1, grads->skip_w[i], C);
             gw.accumulate = 2; gw.splitk = split_for(BN);
-            STEP_TRY(step_gemm_launch(gw, st));
+            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
         }
         // gated TCN
         gate_bwd_kernel<<<g1(npos * C), 256, 0, st>>>(W.dcat, S.tf[i], S.sg[i], npos, W.dpre);
@@ -820,9 +822,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre, 1, 64, W.xcat, 64, 1, W.dwcat + i * 4096, 64);
             gw.accumulate = 2; gw.splitk = split_for(npos);
             gw.a_rowsum = W.dbcat + i * 64;
-            STEP_TRY(step_gemm_launch(gw, st));
+            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
             StepGemm gx = gemm_desc((int)npos, 64, 64, W.dpre, 64, 1, W.wcat + i * 4096, 64, 1, W.dxcat, 64);
-            STEP_TRY(step_gemm_launch(gx, st));
+            gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
         }
         float* dx = dxbuf[i & 1];
         col2im_kernel<<<g1(BN * Tin * C), 256, 0, st>>>(W.dxcat, i < NL - 1 ? W.dres : nullptr, BN, Tin, Tout, dil, dx);

@@ -91,7 +91,7 @@ class _StepFunction(torch.autograd.Function):
                L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
         # ---- DGL: global feature, edge logits, Gumbel sample
         dt = dgl.native_tensors()
-        bf = model.matmul_precision == "bf16"
+        bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
         dstruct = fill_dgl_struct(dt, bf)
         Ttr = dgl.train_length
         gsaved = _f32(L.lib().step_dgl_global_saved_floats(N, Ttr), dev)
@@ -140,7 +140,7 @@ class _StepFunction(torch.autograd.Function):
         views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
         gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
         dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
-        bf = model.matmul_precision == "bf16"
+        bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
         bstruct = fill_gwnet_struct(be.native_tensors(), bf)
         dstruct = fill_dgl_struct(dgl.native_tensors(), bf)
         dpred = dpred.contiguous().float().view(B, 12, N) if dpred is not None else torch.zeros(B, 12, N, device=dev)
@@ -185,7 +185,8 @@ class STEP(nn.Module):
         self.discrete_graph_learning = DiscreteGraphLearning(**dgl_args)
         self.gumbel_noise = "device"        # "torch_cpu": draw torch.rand on the host like the reference (:12)
         # "f32": every contraction outside the TSFormer on the exact-f32 matrix cores (tight parity with the oracle);
-        # "bf16": the diffusion hops / their adjoints and the DGL fc run on the bf16 matrix cores (BASELINE config "bf16")
+        # "bf16": every GEMM-shaped contraction of the GraphWaveNet and the DGL (hops, 1x1 / gate / mix / head layers and their
+        # weight gradients, DGL conv and fc) runs on the bf16 matrix cores with f32 accumulation (BASELINE config "bf16")
         self.matmul_precision = "f32"
         self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
         self._seed_ctr = 0

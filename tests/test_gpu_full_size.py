@@ -58,7 +58,6 @@ def test_full_size_training_step_parity(mode):
 
     e_pred = rel_l2(pred.detach().cpu(), o_pred)
     print(f"full size [{mode}]: pred rel-L2", e_pred, "theta max-abs", max_abs(theta.detach().cpu(), o_theta), "loss", float(loss), float(o_loss))
-    assert e_pred < (2e-3 if tight else 1e-2)
     assert max_abs(theta.detach().cpu(), o_theta) < (2e-5 if tight else 5e-3)
     assert float(loss) == pytest.approx(float(o_loss), rel=2e-3 if tight else 5e-3)
     dk = (knn.cpu() != o_knn).sum().item()
@@ -68,8 +67,8 @@ def test_full_size_training_step_parity(mode):
     for kname, t in dict(model._trainable()).items():
         og = p[ref_name(kname)].grad
         assert og is not None and t.grad is not None, kname
-        if float(og.abs().max()) < 1e-4:
-            assert max_abs(t.grad.cpu(), og) < 2e-4, kname
+        if float(og.abs().max()) < 1e-4:          # analytically zero (a bias in front of a train-mode BatchNorm): round-off only
+            assert max_abs(t.grad.cpu(), og) < (2e-4 if tight else 5e-3), kname
             continue
         errs[kname] = rel_l2(t.grad.cpu(), og)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
@@ -80,3 +79,4 @@ def test_full_size_training_step_parity(mode):
     den = sum(float((p[ref_name(a)].grad ** 2).sum()) for a in errs)
     print(f"full size [{mode}]: whole-gradient rel-L2", (num / den) ** 0.5)
     assert (num / den) ** 0.5 < (5e-3 if tight else 5e-2)
+    assert e_pred < (2e-3 if tight else 1e-2)

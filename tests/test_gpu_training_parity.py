@@ -91,7 +91,8 @@ def test_k_step_trajectory_and_h12_mae_parity(name, mode):
         assert losses == pytest.approx(o_losses, rel=8e-2)
         assert h12 == pytest.approx(o_h12, rel=6e-2)         # horizon-12 MAE after K steps (0.001-1.5 % observed)
     else:
-        assert losses[:3] == pytest.approx(o_losses[:3], rel=1.5e-2)
+        assert losses[:2] == pytest.approx(o_losses[:2], rel=5e-3)      # before / after one update
+        assert losses[:3] == pytest.approx(o_losses[:3], rel=4e-2)
         assert losses == pytest.approx(o_losses, rel=0.15)
         if name != "step_tiny":                              # 40 series: the single-horizon MAE is sample noise there
             assert h12 == pytest.approx(o_h12, rel=0.12)     # 0.7-2.3 % observed
