@@ -9,9 +9,13 @@
 // no data movement.  Inputs may be f32 or bf16 (bf16 is widened on the way into LDS, which
 // is how the cosine Gram matrix reads the TSFormer hidden states).
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN x 16, staged through LDS k-major so the
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32, staged through LDS k-major so the
 // MFMA operand read (lane l: A[i = l&31][k = l>>5]) is a conflict-free ds_read_b32.
 // Split-K (grid.z = batch*splitk) accumulates with f32 atomics.
+//
+// Dispatch (step_gemm_launch): compute_bf16 -> gemm_bf16.hip; otherwise the staged exact-f32 kernel of gemm_bf16.hip when the
+// operands are 16-byte aligned, else the kernels of this file (the direct-fragment kernel for short TN contractions such as
+// the f32-mode diffusion hops, the LDS-tiled kernel for the rest).
 #include "common.h"
 #include "step_internal.h"
 
@@ -442,6 +446,8 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
     if (g.scn == 0) g.scn = 1;
     if (g.a_rowsum)
         STEP_REQUIRE(g.batch == 1 && g.alpha == 1.f && !g.a_bf16 && !g.a_kscale, "step_gemm: a_rowsum needs batch 1, alpha 1, f32 A without affine");
+    if (g.c_nscale)
+        STEP_REQUIRE(g.c_nshift && g.c_mvec && g.c_nperiod > 0, "step_gemm: c_nscale needs c_nshift, c_mvec and a positive c_nperiod");
     if (g.compute_bf16) return step_gemm_bf16_launch(g, st);
     {
         const int rc = step_gemm_f32_fast_launch(g, st);

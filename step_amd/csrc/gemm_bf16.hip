@@ -1,12 +1,12 @@
-// bf16-MFMA variant of the generic strided-batched GEMM (same StepGemm descriptor, compute_bf16 = 1):
-// f32 (or bf16) operands in global memory, rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 with f32
-// accumulation, f32 output.  16x the matrix-pipe rate of the exact-f32 path; used for the big contractions of the
-// training step (diffusion hops with the N x N supports and their adjoints, the DGL fc forward/backward) when the
-// module runs in its bf16 matmul mode (BASELINE.json config C2 "bf16").
+// Matrix-core GEMM kernels of the generic strided-batched descriptor (StepGemm), two generations:
 //
-// LDS holds both operands ROW-MAJOR WITH k CONTIGUOUS (As[m][k], Bs[n][k], 80-byte pitch) so an MFMA operand
-// fragment (lane = row, 8 consecutive k) is one ds_read_b128.  The loader transposes when the global operand is
-// m- / n-contiguous (4 x ds_write_b16 per 16-byte global load) and packs 4 k into one 8-byte LDS write otherwise.
+//  1. gemm_bf16mfma_kernel -- general bf16 variant (compute_bf16 = 1) for arbitrary strides: f32 / bf16 operands rounded to
+//     bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16, f32 accumulation and output.  LDS holds both operands row-major with
+//     k contiguous (80-byte pitch); element-wise loads with runtime index arithmetic.  Now only the fallback for operands that
+//     are not 16-byte aligned.
+//  2. gemm_fast_kernel -- the staged pipeline every hot contraction of the training step runs on (see the block comment
+//     further down): 16-byte loads, BK = 64, double-buffered LDS, in bf16 (F32C = false) and exact-f32 (F32C = true) form.
+//     step_gemm_bf16_launch / step_gemm_f32_fast_launch pick it whenever the operand layouts qualify.
 #include "common.h"
 #include "step_internal.h"
 

@@ -309,3 +309,24 @@ def test_topk_mask_ties_and_order(L, Bn, N, k_total):
     work = torch.empty(L.lib().step_knn_workspace_bytes(Bn, N, 0), dtype=torch.uint8, device="cuda")
     L.call("step_topk_mask", L.ptr(sim.cuda()), Bn, N, k_total, L.ptr(adj), L.ptr(work), work.numel(), L.stream())
     assert torch.equal(adj.cpu(), want)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K,period", [(100, 16 * 37, 307, 37), (64, 8 * 52, 96, 52), (33, 5 * 30, 50, 30)])
+def test_gemm_column_block_affine(L, M, N, K, period, bf16):
+    """StepGemm.c_nscale / c_nshift / c_mvec: C(m,n) += sc[n / period] * (A.B)(m,n) + sh[n / period] * mvec[m] -- how the BatchNorm
+    affine of the conv2 output is folded into the DGL fc weight gradient (discrete_graph_learning.py:134 + autograd)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g)               # A(m,k) = A[k][m]  (m contiguous, like dgpre)
+    Bm = torch.randn(K, N, generator=g)              # B(k,n) n contiguous (like a2)
+    nch = N // period
+    sc, sh, mv = torch.randn(nch, generator=g), torch.randn(nch, generator=g), torch.randn(M, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = C0.clone().cuda()
+    L.gemm(A.cuda(), Bm.cuda(), C, M, N, K, 1, M, N, 1, N, accumulate=1, c_nscale=sc.cuda(), c_nshift=sh.cuda(), c_mvec=mv.cuda(),
+           c_nperiod=period, compute_bf16=bf16)
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+    raw = rnd(A).T @ rnd(Bm)
+    ch = torch.arange(N) // period
+    want = C0.double() + raw * sc.double()[ch][None, :] + mv.double()[:, None] * sh.double()[ch][None, :]
+    assert rel_l2(C.cpu(), want) < 2e-5
