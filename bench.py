@@ -116,6 +116,7 @@ def pretrain_main(args, cfg, world, rank, dev):
     random.seed(0)
     model = TSFormer(12, 1, 96, 4, 4, 0.1, Lh / 12, 0.75, 4, 1, mode="pre-train").to(dev)
     model.train()
+    model.matmul_precision = args.matmul
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=0.001, weight_decay=0, eps=1.0e-8, betas=(0.9, 0.95))
     dser = torch.from_numpy(data[:, :, :1]).to(dev)
@@ -150,7 +151,7 @@ def pretrain_main(args, cfg, world, rank, dev):
         print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": B * world * args.steps / dt,
                           "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic",
+                          "dtype": args.matmul, "data": "synthetic",
                           "config": {"workload": f"TSFormer_PEMS-BAY pre-train: N={N}, L={Lh} (P={Lh // 12}, 42 unmasked), batch {B}/GPU, "
                                                  "fwd+bwd+clip+Adam, exact-f32 unfused path", "final_loss": float(loss.detach())}}), flush=True)
 

@@ -94,23 +94,25 @@ def _empty(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+_BF16 = False        # operand precision of the pre-training GEMMs, set from TSFormer.matmul_precision by _PretrainFunction
+
+
 def _linear_fwd(x, w, b, relu=False):
-    """y[R,N] = x[R,K] @ w[N,K]^T + b   (step_gemm, f32 matrix cores)."""
+    """y[R,N] = x[R,K] @ w[N,K]^T + b   (step_gemm: exact-f32 matrix cores, or bf16 operands in the bf16 mode)."""
     R, K = x.shape
     N = w.shape[0]
     y = _empty(R, N, like=x)
-    _lib.gemm(x, w, y, R, N, K, K, 1, 1, K, N, bias=b, relu=relu)
+    _lib.gemm(x, w, y, R, N, K, K, 1, 1, K, N, bias=b, relu=relu, compute_bf16=_BF16)
     return y
 
 
 def _linear_bwd(dy, x, w, dw, db, dx=None, accumulate_dx=False):
-    """dw[N,K] += dy^T x ; db[N] += colsum(dy) ; dx[R,K] (=|+=) dy @ w."""
+    """dw[N,K] += dy^T x ; db[N] += colsum(dy) (as the all-ones column of the same GEMM) ; dx[R,K] (=|+=) dy @ w."""
     R, N = dy.shape
     K = x.shape[1]
-    _lib.gemm(dy, x, dw, N, K, R, 1, N, K, 1, K, accumulate=2, splitk=-1)
-    _lib.call("step_colsum", _lib.ptr(dy), R, N, N, _lib.ptr(db), _lib.stream())
+    _lib.gemm(dy, x, dw, N, K, R, 1, N, K, 1, K, accumulate=2, splitk=-1, a_rowsum=db, compute_bf16=_BF16)
     if dx is not None:
-        _lib.gemm(dy, w, dx, R, K, N, N, 1, K, 1, K, accumulate=1 if accumulate_dx else 0)
+        _lib.gemm(dy, w, dx, R, K, N, N, 1, K, 1, K, accumulate=1 if accumulate_dx else 0, compute_bf16=_BF16)
     return dx
 
 
@@ -121,6 +123,8 @@ class _PretrainFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, series, um, mk, *params):
+        global _BF16
+        _BF16 = model.matmul_precision == "bf16"
         L = _lib
         st = L.stream()
         P_ = dict(zip(model._pt_names, params))
@@ -234,9 +238,11 @@ class _PretrainFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dr):
+        global _BF16
         L = _lib
         st = L.stream()
         model, sv = ctx.model, ctx.saved
+        _BF16 = model.matmul_precision == "bf16"
         S, P, Pu, Pm = sv["dims"]
         p, seed = sv["p"], sv["seed"]
         P_ = {n: prm for n, prm in zip(model._pt_names, model._pt_params())}
@@ -293,6 +299,9 @@ class TSFormer(nn.Module):
             num_token, mask_ratio, encoder_depth, mode, mlp_ratio
         self.dropout_p = float(dropout)
         self.selected_feature = 0
+        # pre-training GEMMs: "f32" exact (parity default) or "bf16" operands with f32 accumulation; the fused forecasting encoder
+        # always runs bf16 operands
+        self.matmul_precision = "f32"
         self.encoder_norm = nn.LayerNorm(embed_dim)
         self.decoder_norm = nn.LayerNorm(embed_dim)
         self.patch_embedding = PatchEmbedding(patch_size, in_channel, embed_dim)

@@ -76,3 +76,30 @@ def test_pretrain_dropout_runs_and_is_replayable():
     model.dropout_p = 0.0
     clean, _ = model(history_data=x, future_data=None, batch_seen=0, epoch=1)
     assert rel_l2(outs[0][0].cpu(), clean.detach().cpu()) > 1e-3
+
+
+def test_pretrain_bf16_mode_close_to_f32_mode():
+    """matmul_precision="bf16": the linear layers of the pre-training step on bf16 operands (f32 accumulate); attention, LayerNorm
+    and the reductions stay f32.  Reconstruction and gradients against the exact-f32 mode of the same module."""
+    g = load_golden("tsformer_pretrain_tiny")
+    x = g["in.x"].cuda()
+    um, mk = g["in.unmasked"].tolist(), g["in.masked"].tolist()
+    res = {}
+    for mode in ("f32", "bf16"):
+        model = _model(g, x.shape[1])
+        model.train()
+        model.dropout_p = 0.0
+        model.matmul_precision = mode
+        model.mask.forward = lambda: (um, mk)
+        recon, label = model(history_data=x, future_data=None, batch_seen=0, epoch=1)
+        loss = O.masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (recon.detach().cpu(), float(loss), {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None})
+    e = rel_l2(res["bf16"][0], res["f32"][0])
+    num = sum(float(((res["bf16"][2][n] - res["f32"][2][n]) ** 2).sum()) for n in res["f32"][2])
+    den = sum(float((res["f32"][2][n] ** 2).sum()) for n in res["f32"][2])
+    print("pre-train bf16 vs f32 mode: recon rel-L2", e, "loss", res["bf16"][1], res["f32"][1], "whole-gradient rel-L2", (num / den) ** 0.5)
+    assert e < 2e-2
+    assert res["bf16"][1] == pytest.approx(res["f32"][1], rel=5e-3)
+    assert (num / den) ** 0.5 < 0.15         # masked-MAE gradients flip sign where reconstruction ~ label (8 % measured)
