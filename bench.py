@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="validation / test path (SURVEY 8f-4): eval-mode forward + metric under no_grad, no backward / optimizer")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -214,7 +216,16 @@ def main():
         batches.append((hist, longh, fut))
     mean, std = 200.0, 150.0
 
+    def eval_step(i):
+        hist, longh, fut = batches[i % len(batches)]
+        with torch.no_grad():
+            pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=None)
+            from step_amd.step_loss import masked_mae
+            return masked_mae(pred[..., :1] * std + mean, fut[..., :1] * std + mean, 0.0)       # base_tsf_runner.py:257-318
+
     def step(i, epoch=1):
+        if args.forward_only:
+            return eval_step(i)
         hist, longh, fut = batches[i % len(batches)]
         opt.zero_grad(set_to_none=True)
         pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
@@ -231,6 +242,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.forward_only:
+        model.eval()
     for i in range(args.warmup):
         step(i)
     model.tsformer._events = []
@@ -255,14 +268,16 @@ def main():
         flops = encoder_flops(cfg, B)
         ach = flops / (enc_ms * 1e-3) / 1e12
         out = {
-            "metric": "training windows/sec on PEMS04, horizon-12 MAE parity, 1/2/4/8 MI355X",
+            "metric": ("validation windows/sec (eval-mode forward + masked MAE)" if args.forward_only else
+                       "training windows/sec on PEMS04, horizon-12 MAE parity, 1/2/4/8 MI355X"),
             "value": B * world * args.steps / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.matmul == "bf16" else "bf16 (TSFormer) + f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N} nodes, long history L={Lh} (P={Lh // 12} patches), 12->12, "
                                    f"train series T={cfg['T_train']}, batch {B}/GPU, random-init weights, "
-                                   "full train step (fwd+bwd+clip+Adam)", "global_batch": B * world,
-                       "parallelism": f"dp{world}", "final_loss": float(loss)},
+                                   + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)"),
+                       "global_batch": B * world,
+                       "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
             "step_ms": {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
                         "p90": float(np.percentile(per_step, 90))},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,
