@@ -148,4 +148,4 @@ def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder"):
     pos = g("positional_encoding.position_embedding")[:P]              # [P, 96]
     out.extend(f32_bytes(np.stack([_lane_vec96(pos[p]) for p in range(P)])))         # [P,2,48]
     assert len(out) == total_bytes(depth, P), (len(out), total_bytes(depth, P))
-    return torch.frombuffer(bytes(out), dtype=torch.uint8).clone()
+    return torch.from_numpy(np.frombuffer(bytes(out), dtype=np.uint8).copy())
