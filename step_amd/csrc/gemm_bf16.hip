@@ -241,7 +241,14 @@ constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64
 
 struct FastArgs {
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
+    int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
 };
+
+// the LDS-staged epilogue pays off for large dense outputs only (two extra barriers and an LDS round trip per tile)
+static int wide_store_ok(const StepGemm& g) {
+    return g.accumulate != 2 && !g.a_rowsum && g.c_nblk == 0 && g.scn == 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && g.scb % 4 == 0 &&
+           g.scb1 % 4 == 0 && ((uintptr_t)g.C & 15) == 0 && (long)g.M * g.N * g.batch >= (4L << 20);
+}
 
 // no remap is encoded as lg = 30, stride = 0 (i >> 30 == 0): branch-free
 __device__ __forceinline__ long remap(int i, int lg, long stride) {
@@ -496,6 +503,44 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     }
 
     float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+    if (fa.wide_store) {
+        // Store / read-modify-write epilogue through LDS: the accumulator layout has 32 consecutive columns per wave
+        // instruction (128-byte runs); staged as a [BM][BN] f32 tile, every thread instead moves 16-byte pieces of whole rows
+        // (512-byte runs per wave instruction).  Used for the outputs that matter: the 267 MB d_a2 and the 87 MB fc gradient.
+        constexpr int TP = BN + 4;                          // padded row of the staging tile (floats)
+        static_assert(BM * TP * 4 <= 2 * BUF, "staging tile must fit in the operand buffers");
+        float* tile = (float*)lds;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cn = wc * (TN * 32) + j * 32 + r, gn = n0 + cn;
+                const GemmColAffine ca = gemm_col_affine(g, gn < g.N ? gn : 0);
+                const float bv = (g.bias != nullptr && gn < g.N) ? g.bias[gn] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rm = wr * (TM * 32) + i * 32 + 4 * h + (e & 3) + 8 * (e >> 2), gm = m0 + rm;
+                    float v = g.alpha * acc[i][j][e] * ca.cs + bv;
+                    if (ca.mvec) v += ca.csh * (gm < g.M ? ca.mvec[gm] : 0.f);
+                    tile[rm * TP + cn] = v;
+                }
+            }
+        __syncthreads();
+        constexpr int PIECES = BM * BN / 4;
+#pragma unroll 4
+        for (int pc = tid; pc < PIECES; pc += 256) {
+            const int rm = pc / (BN / 4), c4 = (pc % (BN / 4)) * 4;
+            const int gm = m0 + rm, gn = n0 + c4;
+            if (gm >= g.M || gn >= g.N) continue;                       // N % 4 == 0: a piece is inside or outside as a whole
+            float4 v = *(const float4*)(tile + rm * TP + c4);
+            float4* dst = (float4*)(Cb + (long)gm * g.ldc + gn);
+            if (g.accumulate == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *dst = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -582,6 +627,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
                                 &fa.b_nlog);
     const bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
                 !(g.a_rowsum && bmode == KC_BF16);
+    fa.wide_store = wide_store_ok(g);
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
@@ -610,6 +656,7 @@ int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st) {
     const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, 0, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog, &fa.b_nlog);
     if (amode < 0 || bmode < 0 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
+    fa.wide_store = wide_store_ok(g);
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;

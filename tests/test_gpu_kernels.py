@@ -330,3 +330,29 @@ def test_gemm_column_block_affine(L, M, N, K, period, bf16):
     ch = torch.arange(N) // period
     want = C0.double() + raw * sc.double()[ch][None, :] + mv.double()[:, None] * sh.double()[ch][None, :]
     assert rel_l2(C.cpu(), want) < 2e-5
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K,ta", [(2050, 16 * 129, 96, False), (307, 16 * 1004, 100, False), (100, 16 * 1004, 307, True)])
+def test_gemm_wide_store_epilogue(L, M, N, K, ta, bf16):
+    """Large dense outputs (>= 4 M elements, N % 4 == 0) leave the staged kernels through LDS in 16-byte row pieces: plain store with
+    bias + ReLU, and += with the column-block affine (the shapes of the DGL d_a2 / fc-gradient GEMMs, ragged M and N tails)."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+    raw = (rnd(A).T if ta else rnd(A)) @ rnd(Bm)
+    sam, sak = (1, M) if ta else (K, 1)
+    bias = torch.randn(N, generator=g)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    L.gemm(A.cuda(), Bm.cuda(), C, M, N, K, sam, sak, N, 1, N, bias=bias.cuda(), relu=True, alpha=0.5, compute_bf16=bf16)
+    assert rel_l2(C.cpu(), torch.relu(0.5 * raw + bias.double())) < 2e-5
+    period = N // 16
+    sc, sh, mv = torch.randn(16, generator=g), torch.randn(16, generator=g), torch.randn(M, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C2 = C0.clone().cuda()
+    L.gemm(A.cuda(), Bm.cuda(), C2, M, N, K, sam, sak, N, 1, N, accumulate=1, c_nscale=sc.cuda(), c_nshift=sh.cuda(), c_mvec=mv.cuda(),
+           c_nperiod=period, compute_bf16=bf16)
+    ch = torch.arange(N) // period
+    want = C0.double() + raw * sc.double()[ch][None, :] + mv.double()[:, None] * sh.double()[ch][None, :]
+    assert rel_l2(C2.cpu(), want) < 2e-5
