@@ -14,11 +14,16 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-B, N, F, k = 8, 307, 336 * 96, 10
-H = (torch.randn(B, 1, F, device="cuda") + 0.7 * torch.randn(B, N, F, device="cuda")).to(torch.bfloat16)
-sim = torch.empty(B, N, N, device="cuda"); adj = torch.empty(B, N, N, device="cuda")
-work = torch.empty(L.lib().step_knn_workspace_bytes(B, N, F), dtype=torch.uint8, device="cuda")
-f = lambda: L.call("step_knn_graph", L.ptr(H), None, B, N, F, k * N, L.ptr(sim), L.ptr(adj), L.ptr(work), work.numel(), L.stream())
-print(f"knn_graph total {timeit(f):.1f} us")
-g = lambda: L.call("step_topk_mask", L.ptr(sim), B, N, k * N, L.ptr(adj), L.ptr(work), work.numel(), L.stream())
-print(f"topk_mask {timeit(g):.1f} us")
+def main():
+    B, N, F, k = 8, 307, 336 * 96, 10
+    H = (torch.randn(B, 1, F, device="cuda") + 0.7 * torch.randn(B, N, F, device="cuda")).to(torch.bfloat16)
+    sim = torch.empty(B, N, N, device="cuda"); adj = torch.empty(B, N, N, device="cuda")
+    work = torch.empty(L.lib().step_knn_workspace_bytes(B, N, F), dtype=torch.uint8, device="cuda")
+    f = lambda: L.call("step_knn_graph", L.ptr(H), None, B, N, F, k * N, L.ptr(sim), L.ptr(adj), L.ptr(work), work.numel(), L.stream())
+    print(f"knn_graph total {timeit(f):.1f} us")
+    g = lambda: L.call("step_topk_mask", L.ptr(sim), B, N, k * N, L.ptr(adj), L.ptr(work), work.numel(), L.stream())
+    print(f"topk_mask {timeit(g):.1f} us")
+
+
+if __name__ == "__main__":
+    main()
