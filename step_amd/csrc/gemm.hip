@@ -432,7 +432,7 @@ int launch(const StepGemm& g, hipStream_t st) {
 
 }  // namespace
 
-int step_gemm_rowsum_fallback(StepGemm* g, hipStream_t st) {
+int step_gemm_rowsum_separate(StepGemm* g, hipStream_t st) {
     if (!g->a_rowsum) return STEP_OK;
     STEP_REQUIRE(g->sam == 1 && g->a_kblk == 0, "step_gemm: a_rowsum on the general kernels needs an m-contiguous A without k remap");
     STEP_TRY(step_colsum_launch((const float*)g->A, g->K, g->M, g->sak, g->a_rowsum, st));
@@ -453,7 +453,7 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
         const int rc = step_gemm_f32_fast_launch(g, st);
         if (rc != -1) return rc;
     }
-    STEP_TRY(step_gemm_rowsum_fallback(&g, st));
+    STEP_TRY(step_gemm_rowsum_separate(&g, st));
     if (g.splitk < 0 && direct_eligible(g)) g.splitk = 1;      // short contraction: the direct kernel, no split
     if (g.splitk < 0) {            // auto: enough workgroups to fill 256 CUs, at least 4 k-steps each
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");

@@ -642,7 +642,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
     const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
     if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
-    STEP_TRY(step_gemm_rowsum_fallback(&g, st));
+    STEP_TRY(step_gemm_rowsum_separate(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
     return launch_bf16<64, 64>(g, st);
 }

@@ -20,8 +20,8 @@ static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, 
     return g;
 }
 
-// general-kernel path of StepGemm.a_rowsum: a separate column-sum launch (needs A(m,k) = X[k*sak + m]); clears g->a_rowsum
-int step_gemm_rowsum_fallback(StepGemm* g, hipStream_t st);
+// StepGemm.a_rowsum on the general (unaligned-operand) kernels: a separate column-sum launch (needs A(m,k) = X[k*sak + m]); clears g->a_rowsum
+int step_gemm_rowsum_separate(StepGemm* g, hipStream_t st);
 // bf16 matrix-core conv2 stage of the DGL (dgl_conv_mfma.hip)
 int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
                        int N, int T1, int* nblk, hipStream_t st);
