@@ -120,12 +120,71 @@ print("rank", rank, "ok")
 """
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_data_parallel_flat_allreduce_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
+    for attempt in range(2):              # the rendezvous itself (a free port, gloo's full-mesh connect) gets one retry
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+        if all(p.returncode == 0 for p in procs):
+            break
+        if attempt == 0 and not any("AssertionError" in o for o in outs):
+            continue
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o
+
+
+def _null_call_names():
+    import ctypes
+    from step_amd import _lib
+    return sorted(n for n, (res, args) in _lib._SIGS.items()
+                  if res is ctypes.c_int and args and n not in ("step_abi_version",))
+
+
+@pytest.mark.parametrize("name", _null_call_names())
+def test_every_entry_point_rejects_null_arguments_before_touching_the_device(name):
+    """Error behaviour of the boundary (include/step_hip.h): a call with NULL buffers / zero sizes returns STEP_ERR_ARG (1) and
+    leaves a message naming the operation in step_last_error(); nothing is launched, so this runs without a GPU."""
+    import ctypes
+    from step_amd import _lib
+    lib = _lib.lib()
+    res, argtypes = _lib._SIGS[name]
+    zero = []
+    for t in argtypes:
+        if t in (ctypes.c_void_p,) or hasattr(t, "contents") or getattr(t, "_type_", None) not in ("i", "l", "f", "d", "I", "L", "Q", "q"):
+            zero.append(None)
+        elif t in (ctypes.c_float, ctypes.c_double):
+            zero.append(0.0)
+        else:
+            zero.append(0)
+    rc = getattr(lib, name)(*zero)
+    assert rc == 1, (name, rc)
+    msg = lib.step_last_error().decode()
+    assert len(msg) > 8, (name, msg)
+    with pytest.raises(RuntimeError, match="rc=1"):
+        _lib.check(rc, name)
+
+
+def test_workspace_size_queries_are_pure_host_functions():
+    from step_amd import _lib
+    lib = _lib.lib()
+    N, T, B = 307, 13599, 8
+    slices = (N * N + 4095) // 4096
+    assert lib.step_knn_workspace_bytes(B, N, 96 * 336) == B * (3 * 2048 + slices + 2) * 4
+    assert lib.step_dgl_edges_saved_floats(B, N) == 2 * N * 100 + N * N + 2 * B * N * N
+    assert lib.step_dgl_edges_work_floats(N) == N * N + 2 * N * 100
+    assert lib.step_dgl_global_saved_floats(N, T) > N * 8 * (T - 9)           # at least the conv1 activations
+    assert lib.step_dgl_global_work_floats(N, T, 1) >= lib.step_dgl_global_work_floats(N, T, 0)
+    assert lib.step_gwnet_work_floats(B, N, 1) >= lib.step_gwnet_work_floats(B, N, 0) > 0
+    assert lib.step_gwnet_saved_floats(B, N, 1) > lib.step_gwnet_saved_floats(B, N, 0) > 0
+    assert lib.step_gwnet_saved_floats(2 * B, N, 0) > lib.step_gwnet_saved_floats(B, N, 0)
+    assert lib.step_adam_work_floats() > 0
