@@ -5,6 +5,9 @@ byte offsets of csrc/tsformer_layout.h, MFMA 32x32x16 evaluated in (lane, slot) 
 fragment exchange between waves -- so that packing and index arithmetic can be checked on a
 machine without a GPU.  ``round_bf16=False`` keeps every operand in float64, which must agree
 with the oracle to round-off; ``True`` mimics the kernel's bf16 operand rounding.
+
+``OPERAND`` (module global, default bfloat16) is the 16-bit operand type: tools/encoder_precision_study.py switches it to
+float16 to price the same data flow with fp16 operand fragments (same MFMA rate, 3 more mantissa bits).
 """
 import numpy as np
 import torch
@@ -17,8 +20,12 @@ C = LANES % 32
 ROW = np.stack([(np.arange(16) & 3) + 8 * (np.arange(16) >> 2) + 4 * h for h in (0, 1)])   # [2,16]
 
 
+OPERAND = torch.bfloat16
+PEAK = {"abs": 0.0}                       # largest operand magnitude seen by pack_half (range check for a float16 variant)
+
+
 def bf16_round(a):
-    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(OPERAND).to(torch.float64).numpy()
 
 
 class Buf:
@@ -30,7 +37,7 @@ class Buf:
 
     def frag(self, off, idx):
         b = np.frombuffer(self.raw, dtype=np.int16, count=512, offset=off + idx * 1024)
-        return torch.from_numpy(b.copy()).view(torch.bfloat16).to(torch.float64).numpy().reshape(64, 8)
+        return torch.from_numpy(b.copy()).view(OPERAND).to(torch.float64).numpy().reshape(64, 8)
 
 
 def mfma(a, b, c):
@@ -55,6 +62,7 @@ def mfma_fast(a, b, c):
 
 def pack_half(v, s, rnd):
     x = v[:, 8 * s:8 * s + 8]
+    PEAK["abs"] = max(PEAK["abs"], float(np.abs(x[np.isfinite(x)]).max(initial=0.0)))
     return bf16_round(x) if rnd else x.copy()
 
 
