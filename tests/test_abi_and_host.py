@@ -123,6 +123,12 @@ ts = np.random.default_rng(1234 + rank).integers(100, 1000, size=8)
 gathered = [None] * world
 dist.all_gather_object(gathered, ts.tolist())
 assert gathered[0] != gathered[1]
+# bench.py's exchange step of the pre-training config (C3)
+import bench
+ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+ps[0].grad = torch.full((3, 5), float(rank + 1)); ps[1].grad = torch.arange(7.0) * (rank + 1)      # ps[2] has no gradient
+bench.average_grads(ps, world)
+assert torch.equal(ps[0].grad, torch.full((3, 5), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.0) * 1.5) and ps[2].grad is None
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
