@@ -5,6 +5,10 @@ Drop-in for the pair of torch calls the reference's training loop makes through 
 rule as ``torch.optim.Adam`` (L2 weight decay folded into the gradient, bias-corrected moments, eps added
 after the square root) preceded by ``torch.nn.utils.clip_grad_norm_``.  Parameters that receive no gradient
 (the reference leaves them at ``grad=None``, so torch's Adam skips them) are not part of the flat buffer.
+
+It consumes the flat gradient buffer of the LAST native backward (``model._flat_grad``): one backward per ``step()``, as in the
+reference's loop.  With gradient accumulation over several backwards use ``torch.optim.Adam`` on ``model.parameters()``
+(``bench.py --torch-optim``), which reads the accumulated ``.grad`` tensors.
 """
 import torch
 
