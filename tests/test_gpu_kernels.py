@@ -80,7 +80,7 @@ def _encode(L, series, packed, depth=4, f32=True, drop=0.0, seed=0):
     last = torch.empty(S, 96, device="cuda")
     sqn = torch.full((S, 16), float("nan"), device="cuda")
     pk = packed.cuda()
-    L.call("step_tsformer_encode", L.ptr(series), S, Lh, L.ptr(pk), pk.numel(), depth, L.ptr(hid16), L.ptr(hid32),
+    L.call("step_tsformer_encode", L.ptr(series), S, Lh, L.ptr(pk), pk.numel(), depth, 0, L.ptr(hid16), L.ptr(hid32),
            L.ptr(last), L.ptr(sqn), float(drop), int(seed), L.stream())
     torch.cuda.synchronize()
     return hid32, hid16, last, sqn
