@@ -104,6 +104,22 @@ def cpu_baseline(cfg, data, seed=0):
             "sample": f"2 windows (B=2) of the same workload, fwd+loss+bwd, {dt:.1f} s, torch CPU fp32 oracle"}
 
 
+def average_grads(params, world):
+    """Data-parallel exchange step of the pre-training bench: one all-reduce (mean) over the flattened gradients
+    (2.67 MB at C3), the job DistributedDataParallel does for easytorch in the reference."""
+    if world <= 1:
+        return
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat.mul_(1.0 / world)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
 def pretrain_main(args, cfg, world, rank, dev):
     """Config C3: one step = TSFormer masked pre-training forward + masked_mae + backward + clip(5.0) + Adam
     (reference step/TSFormer_PEMS-BAY.py:52-72), windows/s = sequences of L steps x N nodes per second."""
@@ -131,6 +147,7 @@ def pretrain_main(args, cfg, world, rank, dev):
         recon, label = model(history_data=batches[i % len(batches)], future_data=None, batch_seen=i, epoch=1)
         loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
         loss.backward()
+        average_grads(params, world)
         torch.nn.utils.clip_grad_norm_(params, max_norm=5.0)
         opt.step()
         return loss
@@ -147,13 +164,22 @@ def pretrain_main(args, cfg, world, rank, dev):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tdt)
     if rank == 0:
         print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": B * world * args.steps / dt,
                           "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": args.matmul, "data": "synthetic",
                           "config": {"workload": f"TSFormer_PEMS-BAY pre-train: N={N}, L={Lh} (P={Lh // 12}, 42 unmasked), batch {B}/GPU, "
-                                                 "fwd+bwd+clip+Adam, exact-f32 unfused path", "final_loss": float(loss.detach())}}), flush=True)
+                                                 "fwd+bwd" + ("+grad all-reduce" if world > 1 else "") + "+clip+Adam, unfused path, "
+                                                 + ("bf16 operands / f32 accumulate GEMMs" if args.matmul == "bf16" else "exact-f32 GEMMs"),
+                                     "global_batch": B * world, "parallelism": f"dp{world}",
+                                     "final_loss": float(loss.detach())}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main():

@@ -242,11 +242,24 @@ class STEP(nn.Module):
         self._flat_param = flat
         return flat
 
-    def enable_native_data_parallel(self, process_group=None):
-        """Average the flat gradient buffer over ranks with ONE RCCL all-reduce per step inside backward
-        (replaces DDP's bucketed reducer; do not also wrap the module in DistributedDataParallel)."""
+    def enable_native_data_parallel(self, process_group=None, sync_module_states=True):
+        """Average the flat gradient buffer over ranks inside backward (RCCL all-reduce of the flat buffer, in two asynchronous
+        chunks; replaces DDP's bucketed reducer -- do not also wrap the module in DistributedDataParallel).  Like DDP's
+        constructor, it first broadcasts rank 0's parameters and buffers (``sync_module_states``)."""
         import torch.distributed as dist
         self._process_group = process_group if process_group is not None else dist.group.WORLD
+        if sync_module_states and dist.get_world_size(self._process_group) > 1:
+            # what DistributedDataParallel does when it wraps a module: every rank starts from rank 0's parameters and buffers
+            src = dist.get_global_rank(self._process_group, 0)
+            with torch.no_grad():
+                for t in list(self.parameters()) + list(self.buffers()):
+                    d = t.detach()
+                    if d.is_contiguous():
+                        dist.broadcast(d, src, group=self._process_group)
+                    else:
+                        c = d.contiguous()
+                        dist.broadcast(c, src, group=self._process_group)
+                        d.copy_(c)
 
     def _reduce_begin(self, chunk):
         """Start the sum of one contiguous chunk of the flat gradient buffer over the data-parallel group (RCCL all-reduce on

@@ -95,7 +95,15 @@ from tests.test_abi_and_host import _tiny_model
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 model, g = _tiny_model()
-model.enable_native_data_parallel()
+torch.manual_seed(100 + rank)                      # ranks start from different parameters and BatchNorm statistics ...
+with torch.no_grad():
+    for t in list(model.parameters()) + [b for b in model.buffers() if b.is_floating_point()]:
+        t.add_(torch.randn_like(t))
+model.enable_native_data_parallel()                # ... and leave with rank 0's, like a DistributedDataParallel wrap
+state = torch.cat([t.detach().double().reshape(-1) for t in list(model.parameters()) + list(model.buffers())])
+both = [torch.empty_like(state) for _ in range(world)]
+dist.all_gather(both, state)
+assert torch.equal(both[0], both[1]) and torch.equal(both[rank], state)
 lay = model._grad_layout()
 flat = torch.arange(lay["total"], dtype=torch.float32) * (rank + 1)
 model._reduce_flat_grads(flat)
@@ -115,6 +123,12 @@ ts = np.random.default_rng(1234 + rank).integers(100, 1000, size=8)
 gathered = [None] * world
 dist.all_gather_object(gathered, ts.tolist())
 assert gathered[0] != gathered[1]
+# bench.py's exchange step of the pre-training config (C3)
+import bench
+ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
+ps[0].grad = torch.full((3, 5), float(rank + 1)); ps[1].grad = torch.arange(7.0) * (rank + 1)      # ps[2] has no gradient
+bench.average_grads(ps, world)
+assert torch.equal(ps[0].grad, torch.full((3, 5), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.0) * 1.5) and ps[2].grad is None
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
