@@ -58,6 +58,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+#ifndef TSF_DROPOUT_LCG
+#define TSF_DROPOUT_LCG 0          // 1: experimental 24-bit LCG keep-mask generator (A/B builds only, see below)
+#endif
+
+#if !TSF_DROPOUT_LCG
 struct Dropper {
     uint32_t base;      // seed ^ per-(seq, layer, site) salt
     uint32_t thresh;    // keep iff draw8 >= thresh
@@ -91,6 +96,39 @@ struct Dropper {
         }
     }
 };
+#else
+// Experimental generator (tools/dropout_generator_study.py): x <- x * 0x43FD45 + 0xC39EC3 mod 2^24 is ONE full-rate
+// v_mad_u32_u24 (which reads only bits 0..23 of x) and yields two Bernoulli bytes (bits 16..23, then 8..15): 0.5 VALU op
+// per draw instead of 1.5.  Inline asm because hipcc lowers __umul24 of an unmasked value to the quarter-rate v_mul_lo_u32.
+struct Dropper {
+    uint32_t base, thresh;
+    float scale;
+    uint32_t st;
+    __device__ __forceinline__ void seed(uint32_t elem_salt) { st = mix32(base + elem_salt * 0x9E3779B1u); }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t r;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(st), "s"(0x43FD45u), "v"(0xC39EC3u));
+        st = r;
+        return r;
+    }
+    __device__ __forceinline__ void apply16(f32x16& v) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const uint32_t r = next();
+            v[i] = (((r >> 16) & 0xffu) >= thresh) ? v[i] * scale : 0.f;
+            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
+        }
+    }
+    __device__ __forceinline__ void mask16(f32x16& v) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const uint32_t r = next();
+            v[i] = (((r >> 16) & 0xffu) >= thresh) ? v[i] : 0.f;
+            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] : 0.f;
+        }
+    }
+};
+#endif
 
 // training-mode tail of a sub-layer: acc = dropout(acc) + x, with x taken from the 16-bit operand
 // copy of the residual stream (the f32 copy is not kept live across the sub-layer)

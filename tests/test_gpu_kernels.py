@@ -261,10 +261,35 @@ def test_gemm_rowsum_column(L, M, N, K, lda, bf16):
     assert rel_l2(db.cpu(), 0.5 + rnd(dY).sum(0)) < 2e-5
 
 
-@pytest.mark.parametrize("gen", [0, pytest.param(1, marks=pytest.mark.xfail(reason="v_prng_b32 advances its LFSR by a few bits per call: bytes 4 and 8 draws apart are correlated (0.37 / 0.13); not used", strict=True))])
+def test_lcg24_generator_matches_its_cpu_statement(L):
+    """gen 2 (one v_mad_u32_u24 per step, draws = bits 16..23 then 8..15) is bit-identical to the numpy statement whose statistics
+    tools/dropout_generator_study.py evaluates."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dgs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                      "tools", "dropout_generator_study.py"))
+    dgs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dgs)
+    streams, words = 256, 64
+    out = torch.empty(streams, words, dtype=torch.int32, device="cuda")
+    L.call("step_selftest_dropout_stream", 0x1234567, 2, streams, words, L.ptr(out), L.stream())
+    torch.cuda.synchronize()
+    w = out.cpu().numpy().view(np.uint32)
+    by = np.stack([(w >> s) & 0xff for s in (0, 8, 16, 24)], -1).reshape(streams, words * 4).astype(np.uint8)
+    # the kernel seeds with mix32(...) | 1 (shared with the other generators); the LCG only sees the low 24 bits
+    st = (dgs.seeds(streams) & np.uint64(0xFFFFFF))
+    want = np.empty_like(by)
+    for i in range(words * 2):
+        st = (st * np.uint64(0x43FD45) + np.uint64(0xC39EC3)) & np.uint64(0xFFFFFF)
+        want[:, 2 * i] = (st >> np.uint64(16)) & np.uint64(0xFF)
+        want[:, 2 * i + 1] = (st >> np.uint64(8)) & np.uint64(0xFF)
+    assert np.array_equal(by, want)
+
+
+@pytest.mark.parametrize("gen", [0, pytest.param(1, marks=pytest.mark.xfail(reason="v_prng_b32 advances its LFSR by a few bits per call: bytes 4 and 8 draws apart are correlated (0.37 / 0.13); not used", strict=True)), 2])
 def test_dropout_generator_statistics(L, gen):
-    """Bernoulli bytes of the encoder's dropout generator (gen 0 xorshift32, gen 1 v_prng_b32): keep rate at threshold 26/256,
-    serial correlation inside a stream, correlation between neighbouring streams."""
+    """Bernoulli bytes of the encoder's dropout generator (gen 0 xorshift32, gen 1 v_prng_b32, gen 2 the experimental 24-bit LCG):
+    keep rate at threshold 26/256, serial correlation inside a stream, correlation between neighbouring streams."""
     streams, words = 4096, 256
     out = torch.empty(streams, words, dtype=torch.int32, device="cuda")
     L.call("step_selftest_dropout_stream", 0x1234567, gen, streams, words, L.ptr(out), L.stream())
