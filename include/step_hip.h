@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
+int step_abi_version(void);        /* 3: step_tsformer_encode(operand_f16); 2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
  * C[b](m,n) (op)= alpha * sum_k A[b](m,k) B[b](k,n) (+bias[n]) (relu), element strides.
@@ -74,8 +74,10 @@ int step_gemm(const StepGemm* g, void* stream);
  * patch.py:20-42, positional_encoding.py:13-35, transformer_layers.py:13-20.
  *
  *  series      f32 [S, L]            one contiguous row per sequence s=(b,n) (see step_pack_long_history)
- *  wpack       packed weights (step_amd/tsformer_pack.py documents the layout; bf16 MFMA
+ *  wpack       packed weights (step_amd/tsformer_pack.py documents the layout; 16-bit MFMA
  *              operand fragments + f32 vectors), built once per checkpoint
+ *  operand_f16 0: the fragments of wpack are bfloat16 (v_mfma_f32_32x32x16_bf16); 1: float16
+ *              (v_mfma_f32_32x32x16_f16, same rate, 3 more mantissa bits).  Must match how wpack was packed.
  *  hidden_bf16 bf16 [S, P, 96] or NULL
  *  hidden_f32  f32  [S, P, 96] or NULL   (parity tests)
  *  last_f32    f32  [S, 96]    or NULL   (state of the last patch = step.py:64)
@@ -83,7 +85,7 @@ int step_gemm(const StepGemm* g, void* stream);
  *  dropout_p   0 disables; otherwise inverted dropout at the reference's 1+4*depth sites
  */
 int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
-                         int depth, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
+                         int depth, int operand_f16, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
                          float* sqnorm_part, float dropout_p, uint64_t seed, void* stream);
 
 /* [B, L, N, C] f32 (the layout the reference DataLoader delivers, forecasting_dataset.py:62-71)

@@ -51,7 +51,7 @@ _SIGS = {
     "step_last_error": (ctypes.c_char_p, []),
     "step_abi_version": (_i, []),
     "step_gemm": (_i, [ctypes.POINTER(StepGemm), _vp]),
-    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _vp, _vp, _f, _u64, _vp]),
+    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _f, _u64, _vp]),
     "step_gather_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "step_pack_long_history": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "step_knn_workspace_bytes": (_l, [_i, _i, _i]),
@@ -95,7 +95,7 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def lib():

@@ -21,10 +21,12 @@
 
 namespace {
 
-template <int MAXW, bool DROP, bool PARK>
+template <int MAXW, bool DROP, bool PARK, bool F16>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
+    typedef typename Opnd<F16>::v8 op8;            // one MFMA operand: 8 x bfloat16 or 8 x float16
+    typedef typename Opnd<F16>::elem ope;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll 1
     for (int layer = 0; layer < A.depth; ++layer) {
         const uint32_t lsalt = seq_salt + (uint32_t)(layer + 1) * 0x632BE5ABu;
-        bf16x8 xb[6];
+        op8 xb[6];
         f32x16 acc[3];
 
         // the first head's stage is opened outside the loop so that the f32 residual stream xT is
@@ -116,10 +118,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         const float* tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(xT[t], 0); xb[2 * t + 1] = pack_half(xT[t], 1); }
+            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half<F16>(xT[t], 0); xb[2 * t + 1] = pack_half<F16>(xT[t], 1); }
             if constexpr (PARK) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) *(bf16x8*)(xpark + f * TSF_FRAG + lane * 16) = xb[f];
+                for (int f = 0; f < 6; ++f) *(op8*)(xpark + f * TSF_FRAG + lane * 16) = xb[f];
             }
             const float* bo = tail + 64 + h * 48;
 #pragma unroll
@@ -135,22 +137,22 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             }
             if constexpr (PARK) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) xb[f] = lfrag(xpark, f, lane);
+                for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
             }
             // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
-            bf16x8 qb[2];
+            op8 qb[2];
             {
                 f32x16 q;
                 const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) q = MFMA_BF16(lfrag(blk, ks, lane), xb[ks], q);
-                qb[0] = pack_half(q, 0);
-                qb[1] = pack_half(q, 1);
+                for (int ks = 0; ks < 6; ++ks) q = mfma16<F16>(lfrag<F16>(blk, ks, lane), xb[ks], q);
+                qb[0] = pack_half<F16>(q, 0);
+                qb[1] = pack_half<F16>(q, 1);
                 // head-dim slots 25 / 26 (the head dim is 24 of 32) carry the softmax shift and the key-padding mask
                 // through the contraction: the key side holds (1, is_padding), the query side (-rowmax, -30000)
-                if (h == 0) qb[1][6] = (__bf16)(-30000.0f);
+                if (h == 0) qb[1][6] = (ope)(-30000.0f);
             }
             // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
             {
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) kk[i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) kk = MFMA_BF16(lfrag(blk, 6 + ks, lane), xb[ks], kk);
+                for (int ks = 0; ks < 6; ++ks) kk = mfma16<F16>(lfrag<F16>(blk, 6 + ks, lane), xb[ks], kk);
                 if (h == 0) { kk[13] = 1.0f; kk[14] = tok_ok ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
-                *(bf16x8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(kk, 0);
-                *(bf16x8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(kk, 1);
+                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
             }
             // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T
             {
@@ -170,9 +172,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) vv = MFMA_BF16(xb[ks], lfrag(blk, 12 + ks, lane), vv);
-                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half(vv, 0);
-                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half(vv, 1);
+                for (int ks = 0; ks < 6; ++ks) vv = mfma16<F16>(xb[ks], lfrag<F16>(blk, 12 + ks, lane), vv);
+                *(op8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 0);
+                *(op8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 1);
             }
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) zero[i] = 0.f;
             auto score_tile = [&](int kt) -> f32x16 {
-                f32x16 s = MFMA_BF16(lfrag(kbuf, kt * 2, lane), qb[0], zero);
-                return MFMA_BF16(lfrag(kbuf, kt * 2 + 1, lane), qb[1], s);
+                f32x16 s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2, lane), qb[0], zero);
+                return mfma16<F16>(lfrag<F16>(kbuf, kt * 2 + 1, lane), qb[1], s);
             };
             float mx = -INFINITY;
             {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (h == 0) qb[1][5] = (__bf16)(-mx);        // slot 25: S - max comes out of the MFMA (bf16 rounding of max cancels)
+            if (h == 0) qb[1][5] = (ope)(-mx);        // slot 25: S - max comes out of the MFMA (bf16 rounding of max cancels)
 
             // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 of V^T is all ones: the denominator), same pipeline
             f32x16 o;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             if constexpr (drop) { dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1)); dr.seed((uint32_t)(tok * 2 + h)); }
             {
                 auto consume = [&](f32x16& sc, int kt) {
-                    const bf16x8 v0 = lfrag(vbuf, kt * 2, lane), v1 = lfrag(vbuf, kt * 2 + 1, lane);
+                    const op8 v0 = lfrag<F16>(vbuf, kt * 2, lane), v1 = lfrag<F16>(vbuf, kt * 2 + 1, lane);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
                     if constexpr (drop) {
@@ -223,9 +225,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                         for (int i = 0; i < 16; i += 2) lsum2 += f32x2{sc[i], sc[i + 1]};         // v_pk_add_f32
                         dr.mask16(sc);
                     }
-                    const bf16x8 p0 = pack_half(sc, 0), p1 = pack_half(sc, 1);
-                    o = MFMA_BF16(v0, p0, o);
-                    o = MFMA_BF16(v1, p1, o);
+                    const op8 p0 = pack_half<F16>(sc, 0), p1 = pack_half<F16>(sc, 1);
+                    o = mfma16<F16>(v0, p0, o);
+                    o = mfma16<F16>(v1, p1, o);
                 };
                 f32x16 sa = score_tile(0);
 #pragma unroll 1
@@ -245,12 +247,12 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             const float inv = 1.0f / den;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] *= inv;
-            bf16x8 ob0 = pack_half(o, 0), ob1 = pack_half(o, 1);
+            op8 ob0 = pack_half<F16>(o, 0), ob1 = pack_half<F16>(o, 1);
             // ---- out-projection of this head accumulates onto the residual
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                acc[t] = MFMA_BF16(lfrag(blk, 18 + t * 2, lane), ob0, acc[t]);
-                acc[t] = MFMA_BF16(lfrag(blk, 19 + t * 2, lane), ob1, acc[t]);
+                acc[t] = mfma16<F16>(lfrag<F16>(blk, 18 + t * 2, lane), ob0, acc[t]);
+                acc[t] = mfma16<F16>(lfrag<F16>(blk, 19 + t * 2, lane), ob1, acc[t]);
             }
         }  // heads
         if constexpr (drop) {
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             dr.base = lsalt ^ 0x51ED27u;
             if constexpr (PARK) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) xb[f] = lfrag(xpark, f, lane);
+                for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
             }
-            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 2 + h));
+            add_residual_op<F16>(acc, xb, dr, (uint32_t)(tok * 2 + h));
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
 
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half(acc[t], 0); xb[2 * t + 1] = pack_half(acc[t], 1); }
+            for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half<F16>(acc[t], 0); xb[2 * t + 1] = pack_half<F16>(acc[t], 1); }
             const float* b2 = tail + 64 + h * 48;
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -290,21 +292,21 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[i] = b1[i];
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) hh = MFMA_BF16(lfrag(blk, cc * 12 + ks, lane), xb[ks], hh);
+                for (int ks = 0; ks < 6; ++ks) hh = mfma16<F16>(lfrag<F16>(blk, cc * 12 + ks, lane), xb[ks], hh);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
                 if constexpr (drop) dr.apply16(hh);
-                bf16x8 hb0 = pack_half(hh, 0), hb1 = pack_half(hh, 1);
+                op8 hb0 = pack_half<F16>(hh, 0), hb1 = pack_half<F16>(hh, 1);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    acc[t] = MFMA_BF16(lfrag(blk, cc * 12 + 6 + t * 2, lane), hb0, acc[t]);
-                    acc[t] = MFMA_BF16(lfrag(blk, cc * 12 + 7 + t * 2, lane), hb1, acc[t]);
+                    acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 6 + t * 2, lane), hb0, acc[t]);
+                    acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 7 + t * 2, lane), hb1, acc[t]);
                 }
             }
         }
         if constexpr (drop) {
             dr.base = lsalt ^ 0x9E3779B9u;
-            add_residual_bf16(acc, xb, dr, (uint32_t)(tok * 2 + h));
+            add_residual_op<F16>(acc, xb, dr, (uint32_t)(tok * 2 + h));
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN2 params ride in the last ffn block
 #pragma unroll
@@ -393,12 +395,12 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
     if (fut) fut[b * per + idx] = (tf >= 0 && tf + H <= T) ? data[tf * N * C + idx] : 0.f;
 }
 
-template <int MAXW, bool DROP, bool PARK>
-int launch_enc(const EncArgs& a, hipStream_t st) {
+template <int MAXW, bool DROP, bool PARK, bool F16>
+int launch_enc_t(const EncArgs& a, hipStream_t st) {
     size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK>,
+        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
@@ -406,15 +408,19 @@ int launch_enc(const EncArgs& a, hipStream_t st) {
         }
         attr_set = true;
     }
-    tsformer_encoder_kernel<MAXW, DROP, PARK><<<a.S, a.nkt * 64, lds, st>>>(a);
+    tsformer_encoder_kernel<MAXW, DROP, PARK, F16><<<a.S, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
+}
+template <int MAXW, bool DROP, bool PARK>
+int launch_enc(const EncArgs& a, hipStream_t st) {
+    return a.f16 ? launch_enc_t<MAXW, DROP, PARK, true>(a, st) : launch_enc_t<MAXW, DROP, PARK, false>(a, st);
 }
 
 }  // namespace
 
 extern "C" int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
-                                    int depth, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
+                                    int depth, int operand_f16, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
                                     float* sqnorm_part, float dropout_p, uint64_t seed, void* stream) {
     STEP_REQUIRE(series && wpack, "tsformer_encode: null input");
     STEP_REQUIRE(S > 0 && L > 0 && L % TSF_PATCH == 0, "tsformer_encode: L=%d must be a positive multiple of %d", L, TSF_PATCH);
@@ -428,6 +434,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.series = series; a.S = S; a.L = L; a.P = P; a.depth = depth; a.nkt = (P + 31) / 32;
     a.wpack = (const char*)wpack; a.hid_bf16 = hidden_bf16; a.hid_f32 = hidden_f32; a.last_f32 = last_f32;
     a.sqn = sqnorm_part; a.drop_p = dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
+    a.f16 = operand_f16 != 0;
     hipStream_t st = (hipStream_t)stream;
     const bool dr = dropout_p > 0.f;
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)

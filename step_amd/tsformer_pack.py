@@ -62,9 +62,15 @@ def total_bytes(depth, P):
     return LAYER0 + depth * layer_bytes() + P * 2 * 48 * 4
 
 
-def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder"):
+OPERAND_DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder", operand="bf16"):
     """sd: mapping name -> tensor (reference TSFormer state_dict keys, optionally prefixed).
-    Returns a uint8 CPU tensor of ``total_bytes(depth, P)`` bytes (layout: csrc/tsformer_layout.h)."""
+    Returns a uint8 CPU tensor of ``total_bytes(depth, P)`` bytes (layout: csrc/tsformer_layout.h).
+    ``operand``: 16-bit type of the MFMA operand fragments, "bf16" or "f16" (same layout; header word 3 records it and the
+    kernel launch must be told the same, ``step_tsformer_encode(operand_f16=...)``)."""
+    odt = OPERAND_DTYPES[operand]
     g = lambda k: sd[prefix + k].detach().to(torch.float32).cpu().numpy()
     out = bytearray()
 
@@ -72,11 +78,11 @@ def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder"):
         return np.ascontiguousarray(a, dtype=np.float32).tobytes()
 
     def bf16_bytes(a):
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16)
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(odt)
         return t.view(torch.int16).numpy().tobytes()
 
     hdr = np.zeros(HDR // 4, dtype=np.int32)
-    hdr[0], hdr[1], hdr[2] = MAGIC, P, depth
+    hdr[0], hdr[1], hdr[2], hdr[3] = MAGIC, P, depth, int(operand == "f16")
     out.extend(hdr.tobytes())
     wpe = g("patch_embedding.input_embedding.weight")[:, 0, :, 0]        # [96, 12]
     out.extend(f32_bytes(np.stack([wpe[_lane_vec96(np.arange(96))[h]] for h in (0, 1)])))   # [2,48,12]

@@ -175,6 +175,24 @@ def test_step_eval_mode_matches_reference():
             assert torch.equal(model.state_dict()[kk[len("param."):]].cpu(), v)
 
 
+@pytest.mark.parametrize("operand,tol", [("bf16", 3e-2), ("f16", 6e-3)])
+def test_step_eval_mode_encoder_operand(operand, tol):
+    """The encoder's 16-bit operand type: float16 fragments bring the prediction error vs the reference's own output
+    (whose TSFormer is fp32) down by the factor the CPU emulation predicts (tools/encoder_precision_study.py)."""
+    g = load_golden("step_tiny_eval")
+    model = build_native(g)
+    model.eval()
+    model.tsformer.encoder_operand = operand
+    model._noise_override = g["in.u"]
+    hist, long_hist, fut = inputs_of(g)
+    with torch.no_grad():
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=None)
+    e = rel_l2(pred.cpu(), g["out.pred"])
+    print(operand, "pred rel-L2 vs reference", e)
+    assert e < tol
+    assert (knn.cpu() != g["out.knn"]).sum().item() <= 4
+
+
 def test_step_device_noise_and_dropout_run():
     """Perf-mode path: on-device Philox Gumbel noise + dropout in TSFormer and gcn."""
     g = load_golden("step_tiny")

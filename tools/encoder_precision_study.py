@@ -35,13 +35,8 @@ from tests.helpers import rel_l2                      # noqa: E402
 
 def packer_for(dtype_name):
     """The product packer with its 16-bit conversion retargeted (same fragment layout: both types are 2 bytes)."""
-    if dtype_name == "bfloat16":
-        return TP.pack_tsformer
-    src = open(TP.__file__).read()
-    assert src.count("torch.bfloat16") == 1
-    mod = types.ModuleType("tsformer_pack_" + dtype_name)
-    exec(compile(src.replace("torch.bfloat16", "torch." + dtype_name), TP.__file__, "exec"), mod.__dict__)
-    return mod.pack_tsformer
+    op = {"bfloat16": "bf16", "float16": "f16"}[dtype_name]
+    return lambda sd, P: TP.pack_tsformer(sd, P, operand=op)
 
 
 def main():
