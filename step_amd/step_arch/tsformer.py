@@ -300,7 +300,7 @@ class TSFormer(nn.Module):
         self.dropout_p = float(dropout)
         self.selected_feature = 0
         # pre-training GEMMs: "f32" exact (parity default) or "bf16" operands with f32 accumulation; the fused forecasting encoder
-        # always runs bf16 operands
+        # always runs 16-bit operands (encoder_operand below)
         self.matmul_precision = "f32"
         self.encoder_norm = nn.LayerNorm(embed_dim)
         self.decoder_norm = nn.LayerNorm(embed_dim)
@@ -319,8 +319,11 @@ class TSFormer(nn.Module):
         self._seed_ctr2 = 0
         self._packed = None
         self._packed_key = None
-        # 16-bit operand type of the fused forecasting encoder: "bf16" or "f16" (same MFMA rate; f16 cuts the hidden-state
-        # error vs the fp32 reference 4-7x, tools/encoder_precision_study.py)
+        # 16-bit operand type of the fused forecasting encoder: "bf16" (default) or "f16".  Same MFMA rate and kernel time; on
+        # MI355X float16 fragments bring the hidden-state error vs the fp32 reference from 1.2-1.9e-2 down to 2.2e-3 and the
+        # prediction error from 7.5e-3 to 8e-4 (profiles/r01_x_encoder_f16_lcg_ab.log, tests/test_gpu_kernels.py).  float16
+        # overflows at 65 504: operands on this path stay below ~200 (tools/encoder_precision_study.py).  "bf16" stays the default
+        # until the chaos-sensitive trajectory test has been re-calibrated on the f16 states.
         self.encoder_operand = "bf16"
         self._seed_counter = 0
         self._events = None          # bench.py: list collecting (start, end) events around the encoder launch

@@ -86,7 +86,7 @@ def _encode(L, series, packed, depth=4, f32=True, drop=0.0, seed=0, f16=0):
     return hid32, hid16, last, sqn
 
 
-@pytest.mark.parametrize("operand,tol", [("bf16", 2.5e-2), ("f16", 5e-3)])
+@pytest.mark.parametrize("operand,tol", [("bf16", 2.5e-2), ("f16", 7e-3)])
 @pytest.mark.parametrize("name", ["step_tiny", "step_small"])
 def test_encoder_matches_golden_hidden(L, name, operand, tol):
     from step_amd import tsformer_pack as TP
@@ -108,7 +108,7 @@ def test_encoder_matches_golden_hidden(L, name, operand, tol):
     assert rel_l2(sqn.cpu().double().sum(1), sq) < 1e-5
 
 
-@pytest.mark.parametrize("operand,tol", [("bf16", 2.5e-2), ("f16", 5e-3)])
+@pytest.mark.parametrize("operand,tol", [("bf16", 2.5e-2), ("f16", 7e-3)])
 @pytest.mark.parametrize("P", [40, 168, 336])
 def test_encoder_multi_wave(L, P, operand, tol):
     from step_amd import tsformer_pack as TP
