@@ -86,10 +86,13 @@ def test_k_step_trajectory_and_h12_mae_parity(name, mode):
     # differences (split-K atomics make even two runs of this module differ in the last bits) become O(lr) parameter
     # differences on near-zero gradients.  Tight on the first steps, a band afterwards; the single-step gradient parity
     # (test_gpu_step.py) and the full-size mode experiment (tools/mode_parity.py) are the sharp checks.
+    # Scale of the bands: the CPU oracle alone, fed states perturbed at the fp32 round-off level (1e-7), moves its 8-step losses by
+    # up to 2.3 % and its horizon-12 MAE by up to 3.5 % on step_small (tools/trajectory_sensitivity.py,
+    # profiles/r01_y_trajectory_sensitivity.txt); the late-step bands are ~3x that.
     if mode == "f32":
         assert losses[:3] == pytest.approx(o_losses[:3], rel=2e-3)
-        assert losses == pytest.approx(o_losses, rel=8e-2)
-        assert h12 == pytest.approx(o_h12, rel=6e-2)         # horizon-12 MAE after K steps (0.001-1.5 % observed)
+        assert losses == pytest.approx(o_losses, rel=0.10)
+        assert h12 == pytest.approx(o_h12, rel=0.10)         # horizon-12 MAE after K steps (0.001-1.5 % observed)
     else:
         assert losses[:2] == pytest.approx(o_losses[:2], rel=5e-3)      # before / after one update
         assert losses[:3] == pytest.approx(o_losses[:3], rel=4e-2)
