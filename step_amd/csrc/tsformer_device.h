@@ -58,6 +58,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+// Experimental (A/B builds only, default 0 = not emitted): raise the wave's issue priority while it feeds the matrix pipe.
+//   1: around the score / PV MFMAs of the two attention passes;  2: also around the QKV, out-projection and FFN MFMA chains.
+#ifndef TSF_SETPRIO
+#define TSF_SETPRIO 0
+#endif
+#define TSF_PRIO_ATTN(x) do { if (TSF_SETPRIO >= 1) __builtin_amdgcn_s_setprio(x); } while (0)
+#define TSF_PRIO_CHAIN(x) do { if (TSF_SETPRIO >= 2) __builtin_amdgcn_s_setprio(x); } while (0)
+
 #ifndef TSF_DROPOUT_LCG
 #define TSF_DROPOUT_LCG 0          // 1: experimental 24-bit LCG keep-mask generator (A/B builds only, see below)
 #endif

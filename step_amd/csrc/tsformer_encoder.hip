@@ -140,6 +140,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
             }
             // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
+            TSF_PRIO_CHAIN(1);
             op8 qb[2];
             {
                 f32x16 q;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 *(op8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 0);
                 *(op8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 1);
             }
+            TSF_PRIO_CHAIN(0);
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -186,8 +188,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) zero[i] = 0.f;
             auto score_tile = [&](int kt) -> f32x16 {
+                TSF_PRIO_ATTN(1);
                 f32x16 s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2, lane), qb[0], zero);
-                return mfma16<F16>(lfrag<F16>(kbuf, kt * 2 + 1, lane), qb[1], s);
+                s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2 + 1, lane), qb[1], s);
+                TSF_PRIO_ATTN(0);
+                return s;
             };
             float mx = -INFINITY;
             {
@@ -226,8 +231,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                         dr.mask16(sc);
                     }
                     const op8 p0 = pack_half<F16>(sc, 0), p1 = pack_half<F16>(sc, 1);
+                    TSF_PRIO_ATTN(1);
                     o = mfma16<F16>(v0, p0, o);
                     o = mfma16<F16>(v1, p1, o);
+                    TSF_PRIO_ATTN(0);
                 };
                 f32x16 sa = score_tile(0);
 #pragma unroll 1
@@ -249,11 +256,13 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             for (int i = 0; i < 16; ++i) o[i] *= inv;
             op8 ob0 = pack_half<F16>(o, 0), ob1 = pack_half<F16>(o, 1);
             // ---- out-projection of this head accumulates onto the residual
+            TSF_PRIO_CHAIN(1);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 acc[t] = mfma16<F16>(lfrag<F16>(blk, 18 + t * 2, lane), ob0, acc[t]);
                 acc[t] = mfma16<F16>(lfrag<F16>(blk, 19 + t * 2, lane), ob1, acc[t]);
             }
+            TSF_PRIO_CHAIN(0);
         }  // heads
         if constexpr (drop) {
             // dropout1 on (attention output + b_o); residual re-read from its bf16 operand copy
@@ -285,6 +294,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 blk = stage_begin(g);
                 tail = (const float*)(blk + TSF_TAIL);
             }
+            TSF_PRIO_CHAIN(1);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 f32x16 hh;
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 7 + t * 2, lane), hb1, acc[t]);
                 }
             }
+            TSF_PRIO_CHAIN(0);
         }
         if constexpr (drop) {
             dr.base = lsalt ^ 0x9E3779B9u;
