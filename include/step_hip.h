@@ -23,7 +23,8 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 3: step_tsformer_encode(operand_f16); 2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
+int step_abi_version(void);        /* 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+                                      2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
  * C[b](m,n) (op)= alpha * sum_k A[b](m,k) B[b](k,n) (+bias[n]) (relu), element strides.
@@ -76,17 +77,34 @@ int step_gemm(const StepGemm* g, void* stream);
  *  series      f32 [S, L]            one contiguous row per sequence s=(b,n) (see step_pack_long_history)
  *  wpack       packed weights (step_amd/tsformer_pack.py documents the layout; 16-bit MFMA
  *              operand fragments + f32 vectors), built once per checkpoint
- *  operand_f16 0: the fragments of wpack are bfloat16 (v_mfma_f32_32x32x16_bf16); 1: float16
- *              (v_mfma_f32_32x32x16_f16, same rate, 3 more mantissa bits).  Must match how wpack was packed.
+ *  flags       STEP_ENC_F16: the fragments of wpack are float16 (v_mfma_f32_32x32x16_f16; same rate as bfloat16, 3 more
+ *              mantissa bits; P and V of the attention stay bfloat16 for their exponent range) -- must match how wpack was
+ *              packed; 0: bfloat16 fragments.  STEP_ENC_ALWAYS_RESHIFT (tests): re-shift the online softmax on every new
+ *              running maximum instead of only when its head room is used up.
  *  hidden_bf16 bf16 [S, P, 96] or NULL
  *  hidden_f32  f32  [S, P, 96] or NULL   (parity tests)
  *  last_f32    f32  [S, 96]    or NULL   (state of the last patch = step.py:64)
  *  sqnorm_part f32  [S, 16]    or NULL   per-wave partial sums of hidden_bf16^2 (cosine norms)
- *  dropout_p   0 disables; otherwise inverted dropout at the reference's 1+4*depth sites
+ *  dropout_p   0 disables; otherwise inverted dropout at the reference's 1+4*depth sites (positional_encoding.py:32 and
+ *              torch.nn.TransformerEncoderLayer's attention-probability, dropout1, FFN and dropout2 sites), keep-masks taken
+ *              from drop_pool: pool_words (a power of two, >= 2 * step_tsformer_dropout_words(L, depth)) 64-bit words of
+ *              Bernoulli(1 - dropout_p) bits written by step_dropout_pool_fill(dropout_p) -- bit l of a word is lane l's
+ *              keep flag for one accumulator register.  Sequence s, layer l reads the step_tsformer_dropout_words() words
+ *              that start at word ((mix32(seed32 + s*0x9E3779B1 + (l+1)*0x632BE5AB) << 4) mod pool_words) (wrapping); the
+ *              layout inside that window is documented in csrc/tsformer_device.h and mirrored by tests/enc_dropout_host.py.
+ *              The pool is only read.  Refill it (new seed) before every training step.
  */
+#define STEP_ENC_F16 1
+#define STEP_ENC_ALWAYS_RESHIFT 2
 int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
-                         int depth, int operand_f16, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
-                         float* sqnorm_part, float dropout_p, uint64_t seed, void* stream);
+                         int depth, int flags, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
+                         float* sqnorm_part, float dropout_p, const uint64_t* drop_pool, long pool_words, uint64_t seed,
+                         void* stream);
+/* Keep-mask pool for the encoder's dropout: word w, bit l = (Philox4x32-10(counter = (w, w >> 32, l / 4, 0x5EEDD80F),
+ * key = (seed, seed >> 32))[l % 4] >= dropout_p * 2^32).  `words` must be a power of two >= 16.  Replaces the device
+ * generator draws of torch.nn.functional.dropout at the sites listed above. */
+int step_dropout_pool_fill(uint64_t* pool, long words, float dropout_p, uint64_t seed, void* stream);
+long step_tsformer_dropout_words(int L, int depth);       /* mask words one (sequence, layer) reads; 0 on bad arguments */
 
 /* [B, L, N, C] f32 (the layout the reference DataLoader delivers, forecasting_dataset.py:62-71)
  * channel `ch` -> [B*N, L] f32.  Replaces the permute at tsformer.py:179 + `[..., [0]]` at
@@ -248,9 +266,6 @@ int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const f
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on
  * (cdna_hip_programming.md section 3).  out: int32[8] failure counters, all zero when ok. */
 int step_selftest_mfma(int32_t* out, void* stream);
-/* raw 32-bit draws of the encoder's dropout mask generator (gen 0: xorshift32, gen 1: v_prng_b32), out[streams][words];
-   lets the tests measure keep rates and serial / cross-stream correlations of the Bernoulli bytes */
-int step_selftest_dropout_stream(uint32_t seed, int gen, int streams, int words, uint32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

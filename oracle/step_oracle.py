@@ -59,10 +59,18 @@ def batch_norm_eval(x, w, b, rm, rv, ch_dim, eps=BN_EPS):
 
 
 # ----------------------------------------------------------------------------- TSFormer
-def encoder_layer(h, p, pre):
+def _drop(x, mask, keep):
+    """torch.nn.functional.dropout with the realisation given: mask is 0/1 (1 = keep), survivors scaled by 1/keep."""
+    return x if mask is None else x * mask.to(x.dtype) / keep
+
+
+def encoder_layer(h, p, pre, drop=None, keep=1.0):
     """One post-norm encoder layer on h[S, P, 96] (S sequences).
     Restates torch.nn.TransformerEncoderLayer(d, 4, 4d, dropout) as instantiated at
-    step/step_arch/tsformer/transformer_layers.py:10-11 (norm_first=False, relu), dropout off."""
+    step/step_arch/tsformer/transformer_layers.py:10-11 (norm_first=False, relu).  ``drop`` = None (dropout off) or the
+    keep-masks of the layer's four dropout sites: attn[S,H,P,P] on the softmax output (F.multi_head_attention_forward),
+    drop1[S,P,96] on the attention block output, ffn[S,P,384] after the activation, drop2[S,P,96] on the FFN output."""
+    drop = drop or {}
     S, P, D = h.shape
     qkv = h @ p[pre + "self_attn.in_proj_weight"].T + p[pre + "self_attn.in_proj_bias"]
     q, k, v = qkv.split(D, dim=-1)
@@ -70,19 +78,20 @@ def encoder_layer(h, p, pre):
     k = k.reshape(S, P, HEADS, HDIM).transpose(1, 2)
     v = v.reshape(S, P, HEADS, HDIM).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(HDIM), dim=-1)
+    att = _drop(att, drop.get("attn"), keep)
     o = (att @ v).transpose(1, 2).reshape(S, P, D)
     o = o @ p[pre + "self_attn.out_proj.weight"].T + p[pre + "self_attn.out_proj.bias"]
-    h = layer_norm(h + o, p[pre + "norm1.weight"], p[pre + "norm1.bias"])
+    h = layer_norm(h + _drop(o, drop.get("drop1"), keep), p[pre + "norm1.weight"], p[pre + "norm1.bias"])
     f = torch.relu(h @ p[pre + "linear1.weight"].T + p[pre + "linear1.bias"])
-    f = f @ p[pre + "linear2.weight"].T + p[pre + "linear2.bias"]
-    return layer_norm(h + f, p[pre + "norm2.weight"], p[pre + "norm2.bias"])
+    f = _drop(f, drop.get("ffn"), keep) @ p[pre + "linear2.weight"].T + p[pre + "linear2.bias"]
+    return layer_norm(h + _drop(f, drop.get("drop2"), keep), p[pre + "norm2.weight"], p[pre + "norm2.bias"])
 
 
-def transformer_layers(h, p, pre, depth):
+def transformer_layers(h, p, pre, depth, drop_layers=None, keep=1.0):
     """transformer_layers.py:13-20: scale by sqrt(d) then ``depth`` layers."""
     h = h * math.sqrt(EMBED)
     for i in range(depth):
-        h = encoder_layer(h, p, f"{pre}transformer_encoder.layers.{i}.")
+        h = encoder_layer(h, p, f"{pre}transformer_encoder.layers.{i}.", None if drop_layers is None else drop_layers[i], keep)
     return h
 
 
@@ -95,15 +104,19 @@ def patch_embed(x, p, pre="tsformer."):
     return x.reshape(S, L // PATCH, PATCH) @ w.T + b
 
 
-def tsformer_encode(long_hist, p, pre="tsformer.", depth=4):
+def tsformer_encode(long_hist, p, pre="tsformer.", depth=4, drop=None, keep=1.0):
     """Forecasting-mode TSFormer (tsformer.py:71-105,179,190; positional_encoding.py:28-32).
-    long_hist[B, L, N] (channel 0 only) -> hidden[B, N, P, 96].  Dropout off."""
+    long_hist[B, L, N] (channel 0 only) -> hidden[B, N, P, 96].  ``drop`` = None (dropout off) or the keep-masks (tensors of
+    0/1, sequences in (b, n) order) of a training-mode forward, ``keep`` = 1 - p: {"pos": [S,P,96] (positional_encoding.py:32),
+    "layers": [per encoder layer the dict encoder_layer takes]}."""
     B, L, N = long_hist.shape
     x = long_hist.permute(0, 2, 1).reshape(B * N, L)
     h = patch_embed(x, p, pre)
     P = h.shape[1]
     h = h + p[pre + "positional_encoding.position_embedding"][:P]
-    h = transformer_layers(h, p, pre + "encoder.", depth)
+    if drop is not None:
+        h = _drop(h, drop["pos"], keep)
+    h = transformer_layers(h, p, pre + "encoder.", depth, None if drop is None else drop["layers"], keep)
     h = layer_norm(h, p[pre + "encoder_norm.weight"], p[pre + "encoder_norm.bias"])
     return h.reshape(B, N, P, EMBED)
 

@@ -51,14 +51,15 @@ _SIGS = {
     "step_last_error": (ctypes.c_char_p, []),
     "step_abi_version": (_i, []),
     "step_gemm": (_i, [ctypes.POINTER(StepGemm), _vp]),
-    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _f, _u64, _vp]),
+    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _l, _u64, _vp]),
+    "step_dropout_pool_fill": (_i, [_vp, _l, _f, _u64, _vp]),
+    "step_tsformer_dropout_words": (_l, [_i, _i]),
     "step_gather_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "step_pack_long_history": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "step_knn_workspace_bytes": (_l, [_i, _i, _i]),
     "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "step_topk_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp]),
     "step_selftest_mfma": (_i, [_vp, _vp]),
-    "step_selftest_dropout_stream": (_i, [ctypes.c_uint32, _i, _i, _i, _vp, _vp]),
     "step_dgl_global_saved_floats": (_l, [_i, _i]),
     "step_dgl_global_work_floats": (_l, [_i, _i, _i]),
     "step_dgl_global_forward": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp]),
@@ -95,7 +96,8 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
 
 
 def lib():

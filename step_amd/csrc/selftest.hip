@@ -40,39 +40,7 @@ __global__ void selftest_kernel(int32_t* out) {
     if (l == 0) out[7] = 0x600DC0DE;
 }
 
-// keep-mask streams of the encoder's dropout generator: stream (block, thread) is seeded like Dropper::seed and emits
-// `words` 32-bit draws = 4*words Bernoulli bytes.  gen 0: xorshift32 (6 VALU ops per word), gen 1: v_prng_b32 (1 op),
-// gen 2: the 24-bit LCG of the TSF_DROPOUT_LCG build (draw bytes packed in draw order).
-__device__ __forceinline__ uint32_t st_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x;
-}
-__global__ void dropout_stream_kernel(uint32_t base, int gen, int words, uint32_t* __restrict__ out) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t st = st_mix32(base + id * 0x9E3779B1u) | 1u;
-    for (int w = 0; w < words; ++w) {
-        if (gen == 0) { st ^= st << 13; st ^= st >> 17; st ^= st << 5; }
-        else if (gen == 1) st = __builtin_amdgcn_prng_b32(st);
-        else {       // gen 2: 24-bit LCG, one v_mad_u32_u24 per step; two draws (bits 16..23, 8..15) per step, two steps per word
-            uint32_t a, b;
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a) : "v"(st), "s"(0x43FD45u), "v"(0xC39EC3u));
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(b) : "v"(a), "s"(0x43FD45u), "v"(0xC39EC3u));
-            st = b;
-            out[(long)id * words + w] = ((a >> 16) & 0xffu) | (((a >> 8) & 0xffu) << 8) | (((b >> 16) & 0xffu) << 16) | (((b >> 8) & 0xffu) << 24);
-            continue;
-        }
-        out[(long)id * words + w] = st;
-    }
-}
-
 }  // namespace
-
-extern "C" int step_selftest_dropout_stream(uint32_t seed, int gen, int streams, int words, uint32_t* out, void* stream) {
-    STEP_REQUIRE(out && streams > 0 && streams % 64 == 0 && words > 0 && (gen >= 0 && gen <= 2), "selftest_dropout_stream: bad arguments");
-    dropout_stream_kernel<<<streams / 64, 64, 0, (hipStream_t)stream>>>(seed, gen, words, out);
-    STEP_LAUNCH_CHECK("step_selftest_dropout_stream");
-    return STEP_OK;
-}
 
 extern "C" int step_selftest_mfma(int32_t* out, void* stream) {
     STEP_REQUIRE(out != nullptr, "selftest: null output");

@@ -14,9 +14,12 @@ struct EncArgs {
     float* hid_f32;
     float* last_f32;
     float* sqn;
-    float drop_p;
+    float keep;                              // 1 - dropout probability (1 when dropout is off)
     uint32_t seed;
+    const unsigned long long* pool;          // Bernoulli(keep) lane-mask words (step_dropout_pool_fill); NULL when dropout is off
+    uint32_t pool_mask;                      // number of pool words - 1 (a power of two, multiple of 16)
     bool f16;          // operand fragments of wpack are float16 (else bfloat16)
+    bool always_rescale;                     // test hook: take the softmax re-shift path on every key tile
 };
 
 // The 16-bit operand type of the kernel is a template parameter: bfloat16 (v_mfma_f32_32x32x16_bf16) or float16
@@ -50,124 +53,97 @@ __device__ __forceinline__ typename Opnd<F16>::v8 pack_half(const f32x16& v, int
     }
 }
 
-// dropout keep-mask bits: a per-lane xorshift32 stream (6 full-rate VALU ops per 32 bits, no integer
-// multiplies in the hot loops) yields four 8-bit Bernoulli draws per step (p_eff = thresh/256; the
-// survivor scale uses p_eff, so the estimator stays unbiased).  The stream is re-seeded per
-// (sequence, layer, site, token) with a multiplicative hash, so results are launch-deterministic.
+// ---- dropout keep-masks ---------------------------------------------------------------------------------------------
+// A keep-mask is a 64-bit LANE mask per accumulator register: bit l of word i says whether lane l keeps register i.  The words
+// are not generated in this kernel: they are read with scalar loads (s_load_dwordx8/x16, no vector-ALU work at all) from a pool
+// of Bernoulli(keep) bits that step_dropout_pool_fill() regenerates from the step's seed (Philox4x32-10) before every launch,
+// and applied with ONE v_cndmask_b32 per element (the mask is the instruction's SGPR-pair operand).  Every (sequence, layer)
+// owns a contiguous window of the pool ("chunk") at a hashed, 16-word aligned offset; inside the chunk every site has its own
+// words, so no two elements of one (sequence, layer) ever share a bit (tests/enc_dropout_host.py mirrors this layout):
+//     attention probabilities  (head hd, query tile = wave, key tile kt)   ATT + ((hd*nkt + wave)*nkt + kt)*16 + reg
+//     FFN hidden units         (wave, chunk ch of 32 units)                FFN + (wave*12 + ch)*16 + reg
+//     dropout1 / dropout2      (wave, 32-feature block t)                  D1 / D2 + (wave*3 + t)*16 + reg
+// and chunk `depth` (one past the last layer) carries the positional-encoding dropout in its D1 words.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+struct DropLayout {
+    uint32_t ffn, d1, d2, words;            // word offsets inside a chunk, chunk length
+    __device__ __host__ explicit DropLayout(int nkt) {
+        ffn = 4u * nkt * nkt * 16u;
+        d1 = ffn + nkt * 12u * 16u;
+        d2 = d1 + nkt * 48u;
+        words = d2 + nkt * 48u;
+    }
+};
+__device__ __forceinline__ uint32_t drop_chunk_base(uint32_t seed, uint32_t seq, uint32_t layer, uint32_t pool_mask) {
+    return (mix32(seed + seq * 0x9E3779B1u + (layer + 1u) * 0x632BE5ABu) << 4) & pool_mask;
+}
+// The pool is read through the constant address space: that is what lets hipcc use scalar loads for it (a plain global
+// pointer inside the by-value argument struct is not provably unclobbered, and would be fetched with vector loads +
+// v_readfirstlane).  Nothing in this kernel writes the pool.
+typedef const __attribute__((address_space(4))) unsigned long long* mask_ptr;
+// v[i] = keep ? v[i] : 0 for the 16 accumulator registers of this lane; w is wave-uniform (scalar loads)
+__device__ __forceinline__ void keep16(f32x16& v, mask_ptr w) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __builtin_amdgcn_inverse_ballot_w64(w[i]) ? v[i] : 0.f;
+}
+
 // Experimental (A/B builds only, default 0 = not emitted): raise the wave's issue priority while it feeds the matrix pipe.
-//   1: around the score / PV MFMAs of the two attention passes;  2: also around the QKV, out-projection and FFN MFMA chains.
+//   1: around the score / PV MFMAs of the attention loop;  2: also around the QKV, out-projection and FFN MFMA chains.
 #ifndef TSF_SETPRIO
 #define TSF_SETPRIO 0
 #endif
 #define TSF_PRIO_ATTN(x) do { if (TSF_SETPRIO >= 1) __builtin_amdgcn_s_setprio(x); } while (0)
 #define TSF_PRIO_CHAIN(x) do { if (TSF_SETPRIO >= 2) __builtin_amdgcn_s_setprio(x); } while (0)
 
-#ifndef TSF_DROPOUT_LCG
-#define TSF_DROPOUT_LCG 0          // 1: experimental 24-bit LCG keep-mask generator (A/B builds only, see below)
-#endif
-
-#if !TSF_DROPOUT_LCG
-struct Dropper {
-    uint32_t base;      // seed ^ per-(seq, layer, site) salt
-    uint32_t thresh;    // keep iff draw8 >= thresh
-    float scale;        // 1/(1-p_eff)
-    uint32_t st;        // xorshift state
-    __device__ __forceinline__ void seed(uint32_t elem_salt) { st = mix32(base + elem_salt * 0x9E3779B1u) | 1u; }
-    __device__ __forceinline__ uint32_t next() {
-        st ^= st << 13; st ^= st >> 17; st ^= st << 5;
-        return st;
-    }
-    // 16 accumulator registers of this lane; the stream must have been seeded by the caller
-    __device__ __forceinline__ void apply16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            const uint32_t r = next();
-            v[i] = ((r & 0xffu) >= thresh) ? v[i] * scale : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
-            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] * scale : 0.f;
-            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] * scale : 0.f;
-        }
-    }
-    // unscaled variant (the caller folds the survivor scale into a later multiply)
-    __device__ __forceinline__ void mask16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            const uint32_t r = next();
-            v[i] = ((r & 0xffu) >= thresh) ? v[i] : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] : 0.f;
-            v[i + 2] = (((r >> 16) & 0xffu) >= thresh) ? v[i + 2] : 0.f;
-            v[i + 3] = ((r >> 24) >= thresh) ? v[i + 3] : 0.f;
-        }
-    }
-};
-#else
-// Experimental generator (tools/dropout_generator_study.py): x <- x * 0x43FD45 + 0xC39EC3 mod 2^24 is ONE full-rate
-// v_mad_u32_u24 (which reads only bits 0..23 of x) and yields two Bernoulli bytes (bits 16..23, then 8..15): 0.5 VALU op
-// per draw instead of 1.5.  Inline asm because hipcc lowers __umul24 of an unmasked value to the quarter-rate v_mul_lo_u32.
-struct Dropper {
-    uint32_t base, thresh;
-    float scale;
-    uint32_t st;
-    __device__ __forceinline__ void seed(uint32_t elem_salt) { st = mix32(base + elem_salt * 0x9E3779B1u); }
-    __device__ __forceinline__ uint32_t next() {
-        uint32_t r;
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(st), "s"(0x43FD45u), "v"(0xC39EC3u));
-        st = r;
-        return r;
-    }
-    __device__ __forceinline__ void apply16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const uint32_t r = next();
-            v[i] = (((r >> 16) & 0xffu) >= thresh) ? v[i] * scale : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] * scale : 0.f;
-        }
-    }
-    __device__ __forceinline__ void mask16(f32x16& v) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const uint32_t r = next();
-            v[i] = (((r >> 16) & 0xffu) >= thresh) ? v[i] : 0.f;
-            v[i + 1] = (((r >> 8) & 0xffu) >= thresh) ? v[i + 1] : 0.f;
-        }
-    }
-};
-#endif
-
-// training-mode tail of a sub-layer: acc = dropout(acc) + x, with x taken from the 16-bit operand
-// copy of the residual stream (the f32 copy is not kept live across the sub-layer)
+// training-mode tail of a sub-layer: acc = keep-mask(acc) * scale + x, with x taken from the 16-bit operand copy of the
+// residual stream (the f32 copy is not kept live across the sub-layer).  w[t]: the 16 mask words of 32-feature block t (each
+// 16-word group is contiguous in the pool; consecutive groups may wrap around its end).
 template <bool F16>
-__device__ __forceinline__ void add_residual_op(f32x16 (&acc)[3], const typename Opnd<F16>::v8 (&xb)[6], Dropper& dr,
-                                                uint32_t salt) {
-    dr.seed(salt);
+__device__ __forceinline__ void add_residual_op(f32x16 (&acc)[3], const typename Opnd<F16>::v8 (&xb)[6], const mask_ptr (&w)[3], float scale) {
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        dr.apply16(acc[t]);
+        float x[16];
         if constexpr (F16) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[t][j] += (float)xb[2 * t][j];
-                acc[t][8 + j] += (float)xb[2 * t + 1][j];
-            }
+            for (int j = 0; j < 8; ++j) { x[j] = (float)xb[2 * t][j]; x[8 + j] = (float)xb[2 * t + 1][j]; }
         } else {
             u32x4 lo = __builtin_bit_cast(u32x4, xb[2 * t]), hi = __builtin_bit_cast(u32x4, xb[2 * t + 1]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 uint32_t wl = lo[j >> 1], wh = hi[j >> 1];
-                acc[t][j] += bf16_bits_to_f32((j & 1) ? (wl >> 16) : (wl & 0xffffu));
-                acc[t][8 + j] += bf16_bits_to_f32((j & 1) ? (wh >> 16) : (wh & 0xffffu));
+                x[j] = bf16_bits_to_f32((j & 1) ? (wl >> 16) : (wl & 0xffffu));
+                x[8 + j] = bf16_bits_to_f32((j & 1) ? (wh >> 16) : (wh & 0xffffu));
             }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[t][i] = __builtin_amdgcn_inverse_ballot_w64(w[t][i]) ? __builtin_fmaf(acc[t][i], scale, x[i]) : x[i];
     }
+}
+
+// value of the 16-bit operand type nearest to x (what the MFMA will see when x is stored into an operand slot)
+template <bool F16>
+__device__ __forceinline__ float round_to_operand(float x) {
+    if constexpr (F16) return (float)(_Float16)fminf(fmaxf(x, -60000.f), 60000.f);
+    else return bf16_bits_to_f32(f32_to_bf16_bits(x));
+}
+// {x of lane & 31, x of (lane & 31) + 32} in every lane: one v_permlane32_swap, no LDS round trip
+__device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
 }
 
 // LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest.
 // g / b point at this lane-half's 48 values (accumulator-register order).
+#ifndef TSF_ABLATE
+#define TSF_ABLATE 0
+#endif
 __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
+    if (TSF_ABLATE & 128) return;
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t)

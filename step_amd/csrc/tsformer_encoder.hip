@@ -5,15 +5,30 @@
 // registers for the whole kernel: activations are kept TRANSPOSED ([feature][token], token =
 // lane & 31), weights are the MFMA A operand, and thanks to the k-slot map in
 // tsformer_layout.h every accumulator tile becomes the next MFMA's B operand by a plain
-// f32->bf16 pack.  Inter-wave traffic: the per-head K and V operand fragments (2 KB per key tile
+// f32->16-bit pack.  Inter-wave traffic: the per-head K and V operand fragments (2 KB per key tile
 // each) through LDS, and the weights, which every workgroup streams ONCE from L2 into a 2-slot
 // LDS ring (global_load_lds DMA, 25 KB stage blocks, prefetched one stage ahead) shared by all waves.
 //
-//   patch embed + pos-emb (f32 VALU)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> S^T = K Q^T
-//   -> exact two-pass softmax (exp2, scale folded into Wq) -> O^T = V^T P^T (row 24 of V is
-//   all-ones, so the softmax denominator falls out of the same MFMA) -> out-proj accumulates
-//   onto (x + b_o) ; LN1 ; FFN in 12 chunks of 32 hidden units, never leaving registers ;
-//   LN2 }  ->  encoder_norm  ->  hidden (bf16 and/or f32), last-patch state, squared norms.
+//   patch embed + pos-emb (f32 VALU)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> per key tile: S^T = K Q^T
+//   -> P = exp2(S - shift) -> O^T += V^T P^T  (ONE pass over the keys: online softmax, see below)
+//   -> out-proj accumulates onto (x + b_o) ; LN1 ; FFN in 12 chunks of 32 hidden units, never leaving
+//   registers ; LN2 }  ->  encoder_norm  ->  hidden (bf16 and/or f32), last-patch state, squared norms.
+//
+// Softmax.  The score tile comes out of the matrix cores already shifted: head-dim slot 25 (the head dim is 24 of 32)
+// carries (1 | -shift) through the contraction, slot 26 (is_padding | -30000) masks the padded keys.  `shift` is a per-query
+// running value kept TSF_BIAS = 60 (log2 units) ABOVE the largest score seen so far, so the probabilities of the leading keys
+// are ~2^-60 and a later key may exceed the running maximum by up to TSF_THR + TSF_BIAS = 160 before anything has to be
+// touched: P and V are bfloat16 operands (8 exponent bits) and O / the denominator are f32, so magnitudes up to 2^100 are
+// harmless and the common factor cancels in O / denominator.  Per key tile the only extra work over a plain exp2 is the
+// tile maximum (8 x v_max3_f32) and one compare; if any query of the wave saw a score above TSF_THR, the wave takes the
+// re-shift path (new shift, O and the denominator scaled by exp2(old - new), the score tiles in flight corrected).  The
+// first key tile always takes it (that sets the initial shift).  With the reference's sqrt(96) input scaling and default
+// initialisation the scores are in the hundreds, so this path does run (about once per head); tests force it on every
+// tile (flags bit 1) and on adversarial inputs.
+//
+// Dropout (training-mode TSFormer inside STEP, positional_encoding.py:32 and the four sites of each encoder layer): keep-masks
+// are lane masks fetched with scalar loads from the per-step pool (tsformer_device.h), one v_cndmask_b32 per element; all
+// survivor scales are folded into existing multiplies (sqrt(d), 1/denominator, the pre-scaled b2, the residual fma).
 //
 // MFMA work per token-layer: 221 184*1.33(q/k/v/o head padding 24->32 only) ... see DESIGN.md
 // for the flop accounting used by bench.py's roofline.
@@ -21,7 +36,17 @@
 
 namespace {
 
-template <int MAXW, bool DROP, bool PARK, bool F16>
+#define TSF_THR 100.0f
+#define TSF_BIAS 60.0f
+#ifndef TSF_ABLATE
+#define TSF_ABLATE 0        // timing experiments only (WRONG results): 1 no exp2, 2 no attention keep-masks, 4 no re-shift check, 16 no denominator adds,
+                            // 32 no key-tile loop at all, 64 one FFN stage instead of six, 128 no LayerNorm arithmetic
+#endif
+#ifndef TSF_MASK_EARLY
+#define TSF_MASK_EARLY 1    // fetch a tile's keep-mask words at the top of its step instead of next to their use
+#endif
+
+template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
@@ -36,16 +61,17 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     const bool tok_ok = tok < P;
     const int tokc = tok_ok ? tok : 0;
     const char* W = A.wpack;
-    Dropper dr;
-    dr.thresh = (uint32_t)(A.drop_p * 256.0f + 0.5f);
-    dr.scale = drop ? 256.0f / (256.0f - (float)dr.thresh) : 1.0f;
-    const uint32_t seq_salt = A.seed ^ ((uint32_t)seq * 0x7FEB352Du);
+    const mask_ptr pool = (mask_ptr)(uintptr_t)A.pool;
+    const uint32_t pmask = A.pool_mask;
+    const DropLayout dl(nkt);
+    const float keep = A.keep, inv_keep = 1.0f / A.keep;
+    auto mask_words = [&](uint32_t chunk, uint32_t off) -> mask_ptr { return pool + ((chunk + off) & pmask); };
 
     // LDS: [K frags nkt*2 KB][V frags nkt*2 KB][weight ring: 2 stage blocks of 25 KB]
     char* kbuf = smem;
     char* vbuf = smem + nkt * 2 * TSF_FRAG;
     char* ring = smem + nkt * 4 * TSF_FRAG;
-    // PARK: the bf16 operand copy of the residual stream (6 fragments per wave) lives in a wave-private LDS
+    // PARK: the 16-bit operand copy of the residual stream (6 fragments per wave) lives in a wave-private LDS
     // area while the attention loops run, which frees 24 VGPRs for the software-pipelined score tiles
     char* xpark = ring + 2 * TSF_BLOCK + wave * 6 * TSF_FRAG;
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(ring));
@@ -91,13 +117,13 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 acc += w2.x * xin[8] + w2.y * xin[9] + w2.z * xin[10] + w2.w * xin[11];
                 xT[t][i] = acc + pos[qd];
             }
-        if constexpr (drop) {
-            dr.base = seq_salt ^ 0xA511E9B3u;
-            dr.seed((uint32_t)(tok * 2 + h));
+        float sc = 9.797958971132712f;   // sqrt(96), transformer_layers.py:15
+        if constexpr (drop) {            // positional_encoding.py:32; the survivor scale rides on sqrt(d)
+            const uint32_t chunk = drop_chunk_base(A.seed, (uint32_t)seq, (uint32_t)A.depth, pmask);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) dr.apply16(xT[t]);
+            for (int t = 0; t < 3; ++t) keep16(xT[t], mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + t) * 16u));
+            sc *= inv_keep;
         }
-        const float sc = 9.797958971132712f;   // sqrt(96), transformer_layers.py:15
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -108,7 +134,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     int g = 0;                                  // global stage index (10 per layer)
 #pragma unroll 1
     for (int layer = 0; layer < A.depth; ++layer) {
-        const uint32_t lsalt = seq_salt + (uint32_t)(layer + 1) * 0x632BE5ABu;
+        const uint32_t chunk = drop ? drop_chunk_base(A.seed, (uint32_t)seq, (uint32_t)layer, pmask) : 0u;
         op8 xb[6];
         f32x16 acc[3];
 
@@ -152,8 +178,8 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 qb[0] = pack_half<F16>(q, 0);
                 qb[1] = pack_half<F16>(q, 1);
                 // head-dim slots 25 / 26 (the head dim is 24 of 32) carry the softmax shift and the key-padding mask
-                // through the contraction: the key side holds (1, is_padding), the query side (-rowmax, -30000)
-                if (h == 0) qb[1][6] = (ope)(-30000.0f);
+                // through the contraction: the key side holds (1, is_padding), the query side (-shift, -30000)
+                if (h == 0) { qb[1][5] = (ope)0.0f; qb[1][6] = (ope)(-30000.0f); }
             }
             // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
             {
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
                 *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
             }
-            // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T
+            // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T; always bfloat16 (like P): see the header
             {
                 f32x16 vv;
                 const float bv = tail[32 + c];
@@ -174,16 +200,14 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) vv = mfma16<F16>(xb[ks], lfrag<F16>(blk, 12 + ks, lane), vv);
-                *(op8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 0);
-                *(op8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(vv, 1);
+                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
             TSF_PRIO_CHAIN(0);
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-            // ---- pass 1: row maxima of S^T (keys on accumulator rows, queries on lanes).  Software pipeline: the MFMAs
-            // of key tile kt+1 are issued before the VALU work on tile kt; padded keys score -30000 through slot 26 and
-            // never win.  (Unrolling by two to avoid the tile copy was measured 20 % SLOWER: profiles/r01_m_encoder_ab.md.)
+            // ---- one pass over the key tiles: S^T = K Q^T - shift, P = exp2(S^T), O^T += V^T P^T
             f32x16 zero;
 #pragma unroll
             for (int i = 0; i < 16; ++i) zero[i] = 0.f;
@@ -194,60 +218,132 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 TSF_PRIO_ATTN(0);
                 return s;
             };
-            float mx = -INFINITY;
-            {
-                auto fold = [&](const f32x16& sc) {
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[i]), sc[i + 1]);     // v_max3_f32
-                };
-                f32x16 sa = score_tile(0);
-#pragma unroll 1
-                for (int kt = 0; kt < nkt; ++kt) {
-                    const f32x16 sb = score_tile(kt + 1 < nkt ? kt + 1 : kt);
-                    fold(sa);
-                    sa = sb;
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (h == 0) qb[1][5] = (ope)(-mx);        // slot 25: S - max comes out of the MFMA (bf16 rounding of max cancels)
-
-            // ---- pass 2: P = exp2(S - max), O^T += V^T P^T (row 24 of V^T is all ones: the denominator), same pipeline
             f32x16 o;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
             typedef __attribute__((ext_vector_type(2))) float f32x2;
-            f32x2 lsum2 = {0.f, 0.f};
-            if constexpr (drop) { dr.base = lsalt ^ (0x1000193u * (uint32_t)(hd + 1)); dr.seed((uint32_t)(tok * 2 + h)); }
-            {
-                auto consume = [&](f32x16& sc, int kt) {
-                    const op8 v0 = lfrag<F16>(vbuf, kt * 2, lane), v1 = lfrag<F16>(vbuf, kt * 2 + 1, lane);
+            f32x2 lsum2 = {0.f, 0.f}, lsum2b = {0.f, 0.f};
+            float shift = 0.f;                       // what slot 25 currently subtracts (a value of the operand type)
+            // test hook: re-shift whenever a tile holds a new running maximum (classic online softmax) instead of only
+            // when the head room is used up
+            const float thr = A.always_rescale ? -TSF_BIAS : TSF_THR;
+            const uint32_t att_off = (uint32_t)((hd * nkt + wave) * nkt) * 16u;
+
+            // Is a re-shift due?  (wave-uniform answer.)  tmax: this lane's largest score of the tile.
+            auto tile_max = [&](const f32x16& sc) -> float {          // two interleaved v_max3_f32 chains (dependency depth 5)
+                float m0 = fmaxf(fmaxf(sc[0], sc[1]), sc[2]), m1 = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+                m0 = fmaxf(fmaxf(m0, sc[6]), sc[7]);    m1 = fmaxf(fmaxf(m1, sc[8]), sc[9]);
+                m0 = fmaxf(fmaxf(m0, sc[10]), sc[11]);  m1 = fmaxf(fmaxf(m1, sc[12]), sc[13]);
+                return fmaxf(fmaxf(m0, sc[14]), fmaxf(m1, sc[15]));
+            };
+            // Re-shift: queries whose tile maximum exceeds the threshold (all queries on the first tile) move their shift to
+            // TSF_BIAS above that maximum; O and the denominator follow by exp2(old - new) and the tile itself, computed against
+            // the old shift, is corrected.  It runs BEFORE the next tile's score MFMAs are issued, so those see the new shift.
+            auto reshift = [&](f32x16& cur, float tmax, bool first) {
+                float lo, hi;
+                both_halves(tmax, lo, hi);
+                const float t = fmaxf(lo, hi);                        // maximum over the 32 keys of the tile, per query
+                const bool upd = first || t > thr;
+                const float ns = round_to_operand<F16>(shift + t + TSF_BIAS);
+                const float d = upd ? ns - shift : 0.f;               // exact: both are 16-bit-significand values; > 0 unless first
+                shift = upd ? ns : shift;
+                const float a = first ? 1.0f : __builtin_amdgcn_exp2f(-d);      // first tile: O and the denominator are still zero
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sc[i] = __builtin_amdgcn_exp2f(sc[i]);
-                    if constexpr (drop) {
-                        // attention-prob dropout acts on the normalised probabilities: keep the denominator
-                        // dropout-free (packed VALU sum), mask the numerator only; the survivor scale is folded into 1/den
+                for (int i = 0; i < 16; ++i) { o[i] *= a; cur[i] -= d; }
+                lsum2 *= a;
+                lsum2b *= a;
+                if (h == 0) qb[1][5] = (ope)(-shift);
+            };
+            // keep-mask words of one score tile, fetched at the top of the tile's step so that the scalar-load latency hides
+            // behind the tile maximum, the next tile's score MFMAs and the exponentials
+            struct TileMask { unsigned long long w[16]; };
+            auto load_mask = [&](int kt) -> TileMask {
+                TileMask m;
+                const mask_ptr mp = mask_words(chunk, att_off + (uint32_t)kt * 16u);
 #pragma unroll
-                        for (int i = 0; i < 16; i += 2) lsum2 += f32x2{sc[i], sc[i + 1]};         // v_pk_add_f32
-                        dr.mask16(sc);
+                for (int i = 0; i < 16; ++i) m.w[i] = mp[i];
+                return m;
+            };
+            // the tail of a tile's step: (drop: keep-masks), pack to bfloat16, O^T += V^T P^T
+            auto finish_tile = [&](f32x16& pr, int kt, const TileMask& tm) {
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                if constexpr (drop) {
+                    if (!(TSF_ABLATE & 2)) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? pr[i] : 0.f;
                     }
-                    const op8 p0 = pack_half<F16>(sc, 0), p1 = pack_half<F16>(sc, 1);
-                    TSF_PRIO_ATTN(1);
-                    o = mfma16<F16>(v0, p0, o);
-                    o = mfma16<F16>(v1, p1, o);
-                    TSF_PRIO_ATTN(0);
-                };
+                }
+                const bf16x8 p0 = pack_half<false>(pr, 0), p1 = pack_half<false>(pr, 1);
+                TSF_PRIO_ATTN(1);
+                o = mfma16<false>(v0, p0, o);
+                o = mfma16<false>(v1, p1, o);
+                TSF_PRIO_ATTN(0);
+            };
+            auto exp_tile = [&](f32x16& pr, const f32x16& sc) {
+                if (TSF_ABLATE & 1) { pr = sc; return; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(sc[i]);
+            };
+            // One key tile: decide / re-shift on `cur`, put the next tile's score MFMAs in flight, then the VALU work on `cur`.
+            auto tile_step = [&](f32x16& cur, f32x16& nxt, int kt) {
+                TileMask tm;
+                if constexpr (drop && TSF_MASK_EARLY) {
+                    tm = load_mask(kt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    if (!(TSF_ABLATE & 4)) {
+                        const float tmax = tile_max(cur);
+                        if (kt == 0 || __builtin_amdgcn_ballot_w64(tmax > thr) != 0) reshift(cur, tmax, kt == 0);
+                    } else if (kt == 0) {
+                        reshift(cur, tile_max(cur), true);
+                    }
+                    if (PIPE != 0 && kt + 1 < nkt) nxt = score_tile(kt + 1);
+                    if constexpr (drop && !TSF_MASK_EARLY) tm = load_mask(kt);
+                    exp_tile(cur, cur);
+                    if constexpr (drop) {
+                        if (!(TSF_ABLATE & 16)) {
+#pragma unroll
+                            for (int i = 0; i < 16; i += 4) {                          // v_pk_add_f32, two independent chains
+                                lsum2 += f32x2{cur[i], cur[i + 1]};
+                                lsum2b += f32x2{cur[i + 2], cur[i + 3]};
+                            }
+                        }
+                    }
+                    finish_tile(cur, kt, tm);
+                }
+            };
+            if (TSF_ABLATE & 32) {
+            } else if constexpr (PIPE == 2) {
+                // software pipeline over two alternating score tiles (no register copies)
+                f32x16 sa = score_tile(0), sb;
+                int kt = 0;
+#pragma unroll 1
+                for (; kt + 1 < nkt; kt += 2) {
+                    tile_step(sa, sb, kt);
+                    tile_step(sb, sa, kt + 1);
+                }
+                if (kt < nkt) tile_step(sa, sb, kt);
+            } else if constexpr (PIPE == 1) {
                 f32x16 sa = score_tile(0);
 #pragma unroll 1
                 for (int kt = 0; kt < nkt; ++kt) {
-                    f32x16 sb = score_tile(kt + 1 < nkt ? kt + 1 : kt);
-                    consume(sa, kt);
+                    f32x16 sb;
+                    tile_step(sa, sb, kt);
                     sa = sb;
                 }
+            } else {
+#pragma unroll 1
+                for (int kt = 0; kt < nkt; ++kt) {
+                    f32x16 sa = score_tile(kt);
+                    tile_step(sa, sa, kt);
+                }
             }
-            const float lsum = lsum2[0] + lsum2[1];
             float den;
             if constexpr (drop) {
-                den = (lsum + __shfl_xor(lsum, 32, 64)) * (1.0f / dr.scale);
+                float lo, hi;
+                both_halves((lsum2[0] + lsum2[1]) + (lsum2b[0] + lsum2b[1]), lo, hi);
+                den = (lo + hi) * keep;
             } else {
                 den = __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
             }
@@ -265,31 +361,33 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             TSF_PRIO_CHAIN(0);
         }  // heads
         if constexpr (drop) {
-            // dropout1 on (attention output + b_o); residual re-read from its bf16 operand copy
-            dr.base = lsalt ^ 0x51ED27u;
+            // dropout1 on (attention output + b_o); residual re-read from its 16-bit operand copy
             if constexpr (PARK) {
 #pragma unroll
                 for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
             }
-            add_residual_op<F16>(acc, xb, dr, (uint32_t)(tok * 2 + h));
+            const mask_ptr w1[3] = {mask_words(chunk, dl.d1 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 1) * 16u),
+                                    mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 2) * 16u)};
+            add_residual_op<F16>(acc, xb, w1, inv_keep);
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
-        if constexpr (drop) dr.base = lsalt ^ 0x2545F491u;
         blk = stage_begin(g);
         tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
             for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half<F16>(acc[t], 0); xb[2 * t + 1] = pack_half<F16>(acc[t], 1); }
             const float* b2 = tail + 64 + h * 48;
+            // training: the hidden-unit survivor scale is NOT applied per element; b2 is pre-multiplied by keep instead and the
+            // whole sub-layer output gets 1/keep^2 in the residual fma (one scale for the FFN dropout, one for dropout2)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : acc[t][i]) + b2[t * 16 + i];
+                for (int i = 0; i < 16; ++i) acc[t][i] = drop ? b2[t * 16 + i] * keep : acc[t][i] + b2[t * 16 + i];
         }
 #pragma unroll 1
-        for (int j = 0; j < 6; ++j, ++g) {
+        for (int j = 0; j < ((TSF_ABLATE & 64) ? 1 : 6); ++j, g += ((TSF_ABLATE & 64) ? 6 : 1)) {
             if (j > 0) {
                 blk = stage_begin(g);
                 tail = (const float*)(blk + TSF_TAIL);
@@ -305,7 +403,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int ks = 0; ks < 6; ++ks) hh = mfma16<F16>(lfrag<F16>(blk, cc * 12 + ks, lane), xb[ks], hh);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
-                if constexpr (drop) dr.apply16(hh);
+                if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
                 op8 hb0 = pack_half<F16>(hh, 0), hb1 = pack_half<F16>(hh, 1);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -316,8 +414,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             TSF_PRIO_CHAIN(0);
         }
         if constexpr (drop) {
-            dr.base = lsalt ^ 0x9E3779B9u;
-            add_residual_op<F16>(acc, xb, dr, (uint32_t)(tok * 2 + h));
+            const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 1) * 16u),
+                                    mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 2) * 16u)};
+            add_residual_op<F16>(acc, xb, w2, inv_keep * inv_keep);
         }
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN2 params ride in the last ffn block
 #pragma unroll
@@ -406,20 +505,21 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
     if (fut) fut[b * per + idx] = (tf >= 0 && tf + H <= T) ? data[tf * N * C + idx] : 0.f;
 }
 
+#ifndef TSF_PIPE
+#define TSF_PIPE 2          // attention loop schedule (A/B knob): 0 plain, 1 next tile's score MFMAs in flight during this tile's
+#endif                      // VALU work (one tile copy per iteration), 2 the same over two alternating tiles (no copies)
+
 template <int MAXW, bool DROP, bool PARK, bool F16>
 int launch_enc_t(const EncArgs& a, hipStream_t st) {
     size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-            return STEP_ERR_HIP;
-        }
-        attr_set = true;
+    // per launch, not once per process: the attribute is per device and setting it is cheap
+    hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+        return STEP_ERR_HIP;
     }
-    tsformer_encoder_kernel<MAXW, DROP, PARK, F16><<<a.S, a.nkt * 64, lds, st>>>(a);
+    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE><<<a.S, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
 }
@@ -428,11 +528,43 @@ int launch_enc(const EncArgs& a, hipStream_t st) {
     return a.f16 ? launch_enc_t<MAXW, DROP, PARK, true>(a, st) : launch_enc_t<MAXW, DROP, PARK, false>(a, st);
 }
 
+// ---------------------------------------------------------------------------------------
+// Dropout pool: word w = 64 Bernoulli(keep) bits, bit l <- Philox4x32-10(counter (w, l / 4), key seed) word l % 4 >= drop * 2^32.
+__global__ __launch_bounds__(256) void dropout_pool_kernel(unsigned long long* __restrict__ pool, long words, uint32_t thresh,
+                                                           uint32_t k0, uint32_t k1) {
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per word, one lane per bit
+    if (w >= words) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t r[4];
+    philox4x32((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)(lane >> 2), 0x5EEDD80Fu, k0, k1, r);
+    const uint32_t x = r[lane & 3];
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(x >= thresh);
+    if (lane == 0) pool[w] = m;
+}
+
 }  // namespace
 
+extern "C" int step_dropout_pool_fill(uint64_t* pool, long words, float dropout_p, uint64_t seed, void* stream) {
+    STEP_REQUIRE(pool, "dropout_pool_fill: null pool");
+    STEP_REQUIRE(words >= 16 && (words & (words - 1)) == 0, "dropout_pool_fill: %ld words is not a power of two >= 16", words);
+    STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_pool_fill: bad dropout %f", dropout_p);
+    const uint32_t thresh = (uint32_t)((double)dropout_p * 4294967296.0);
+    dropout_pool_kernel<<<cdiv(words, 4), 256, 0, (hipStream_t)stream>>>((unsigned long long*)pool, words, thresh, (uint32_t)seed,
+                                                                         (uint32_t)(seed >> 32));
+    STEP_LAUNCH_CHECK("step_dropout_pool_fill");
+    return STEP_OK;
+}
+
+extern "C" long step_tsformer_dropout_words(int L, int depth) {
+    if (L <= 0 || L % TSF_PATCH != 0 || depth < 1) return 0;
+    const int nkt = (L / TSF_PATCH + 31) / 32;
+    return (long)DropLayout(nkt).words;
+}
+
 extern "C" int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
-                                    int depth, int operand_f16, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
-                                    float* sqnorm_part, float dropout_p, uint64_t seed, void* stream) {
+                                    int depth, int flags, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
+                                    float* sqnorm_part, float dropout_p, const uint64_t* drop_pool, long pool_words, uint64_t seed,
+                                    void* stream) {
     STEP_REQUIRE(series && wpack, "tsformer_encode: null input");
     STEP_REQUIRE(S > 0 && L > 0 && L % TSF_PATCH == 0, "tsformer_encode: L=%d must be a positive multiple of %d", L, TSF_PATCH);
     const int P = L / TSF_PATCH;
@@ -441,13 +573,24 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     STEP_REQUIRE(wpack_bytes >= TSF_TOTAL_BYTES(depth, P), "tsformer_encode: packed weights too small (%ld < %ld)",
                  wpack_bytes, (long)TSF_TOTAL_BYTES(depth, P));
     STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "tsformer_encode: bad dropout %f", dropout_p);
+    STEP_REQUIRE((flags & ~3) == 0, "tsformer_encode: unknown flag bits 0x%x", flags);
+    const bool dr = dropout_p > 0.f;
     EncArgs a;
     a.series = series; a.S = S; a.L = L; a.P = P; a.depth = depth; a.nkt = (P + 31) / 32;
+    if (dr) {
+        STEP_REQUIRE(drop_pool, "tsformer_encode: dropout needs a keep-mask pool (step_dropout_pool_fill)");
+        STEP_REQUIRE(pool_words >= 16 && (pool_words & (pool_words - 1)) == 0 && pool_words <= (1L << 31),
+                     "tsformer_encode: pool of %ld words is not a power of two in [16, 2^31]", pool_words);
+        STEP_REQUIRE(pool_words >= 2 * (long)DropLayout(a.nkt).words, "tsformer_encode: pool of %ld words is smaller than two chunks of %ld",
+                     pool_words, (long)DropLayout(a.nkt).words);
+    }
     a.wpack = (const char*)wpack; a.hid_bf16 = hidden_bf16; a.hid_f32 = hidden_f32; a.last_f32 = last_f32;
-    a.sqn = sqnorm_part; a.drop_p = dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
-    a.f16 = operand_f16 != 0;
+    a.sqn = sqnorm_part; a.keep = 1.0f - dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
+    a.pool = dr ? (const unsigned long long*)drop_pool : nullptr;
+    a.pool_mask = dr ? (uint32_t)(pool_words - 1) : 0u;
+    a.f16 = (flags & STEP_ENC_F16) != 0;
+    a.always_rescale = (flags & STEP_ENC_ALWAYS_RESHIFT) != 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool dr = dropout_p > 0.f;
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
     if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);
     if (a.nkt <= 8) return dr ? launch_enc<8, true, true>(a, st) : launch_enc<8, false, true>(a, st);

@@ -319,13 +319,19 @@ class TSFormer(nn.Module):
         self._seed_ctr2 = 0
         self._packed = None
         self._packed_key = None
-        # 16-bit operand type of the fused forecasting encoder: "bf16" (default) or "f16".  Same MFMA rate and kernel time; on
-        # MI355X float16 fragments bring the hidden-state error vs the fp32 reference from 1.2-1.9e-2 down to 2.2e-3 and the
-        # prediction error from 7.5e-3 to 8e-4 (profiles/r01_x_encoder_f16_lcg_ab.log, tests/test_gpu_kernels.py).  float16
-        # overflows at 65 504: operands on this path stay below ~200 (tools/encoder_precision_study.py).  "bf16" stays the default
-        # until the chaos-sensitive trajectory test has been re-calibrated on the f16 states.
-        self.encoder_operand = "bf16"
+        # 16-bit operand type of the fused forecasting encoder: "f16" (default) or "bf16".  Same MFMA rate and kernel time; on
+        # MI355X float16 fragments bring the hidden-state error vs the fp32 reference from 1.2-1.9e-2 (bf16) down to 2.2e-3 and
+        # the prediction error from 7.5e-3 to 8e-4 (profiles/r01_x_encoder_f16_lcg_ab.log, tests/test_gpu_kernels.py).  float16
+        # overflows at 65 504: operands on this path stay below ~200 (tools/encoder_precision_study.py); the attention
+        # probabilities and V, which need exponent range rather than mantissa, are bfloat16 in both modes.
+        self.encoder_operand = "f16"
         self._seed_counter = 0
+        # training-mode dropout: pool of Bernoulli(1 - p) keep bits the encoder kernel reads its lane masks from, refilled from
+        # the step's seed before every launch (step_dropout_pool_fill); 2^18 words = 2 MB stay resident in every XCD's L2
+        self.dropout_pool_words = 1 << 18
+        self._drop_pool = None
+        self._pool_override = None          # tests: int64 cuda tensor of keep-mask words used instead of the Philox fill
+        self.encoder_debug_flags = 0        # tests: _lib.ENC_ALWAYS_RESHIFT
         self._events = None          # bench.py: list collecting (start, end) events around the encoder launch
 
     # ------------------------------------------------------------------ packed operand cache
@@ -339,6 +345,21 @@ class TSFormer(nn.Module):
             self._packed = pack_tsformer(sd, P, depth=self.encoder_depth, operand=self.encoder_operand).to(device)
             self._packed_key = key
         return self._packed
+
+    def dropout_pool(self, device, drop, seed, L):
+        """The keep-mask pool for this launch: (int64 tensor viewed as 64-bit words, number of words).  ``_pool_override``
+        (tests) supplies the bits instead of the Philox fill, so a test can reproduce every mask on the host."""
+        if self._pool_override is not None:
+            pool = self._pool_override
+            return pool, pool.numel()
+        need = 2 * _lib.lib().step_tsformer_dropout_words(int(L), self.encoder_depth)
+        words = self.dropout_pool_words
+        while words < need:
+            words *= 2
+        if self._drop_pool is None or self._drop_pool.numel() != words or self._drop_pool.device != device:
+            self._drop_pool = torch.empty(words, dtype=torch.int64, device=device)
+        _lib.call("step_dropout_pool_fill", _lib.ptr(self._drop_pool), words, float(drop), int(seed), _lib.stream())
+        return self._drop_pool, words
 
     # ------------------------------------------------------------------ device entry points
     def encode_series(self, series, want_f32=False, want_bf16=True):
@@ -358,12 +379,16 @@ class TSFormer(nn.Module):
         drop = self.dropout_p if self.training else 0.0
         self._seed_counter += 1
         seed = (torch.initial_seed() * 1000003 + self._seed_counter) & ((1 << 63) - 1) if drop > 0 else 0
+        pool, pool_words = None, 0
+        if drop > 0:
+            pool, pool_words = self.dropout_pool(series.device, drop, seed, L)
         if self._events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        flags = (_lib.ENC_F16 if self.encoder_operand == "f16" else 0) | self.encoder_debug_flags
         _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
-                  int(self.encoder_operand == "f16"), _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
-                  _lib.ptr(out["sqnorm"]), float(drop), int(seed), _lib.stream())
+                  flags, _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
+                  _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.stream())
         if self._events is not None:
             ev[1].record()
             self._events.append(ev)

@@ -13,6 +13,10 @@ import numpy as np
 import torch
 
 from step_amd import tsformer_pack as TP
+from tests import enc_dropout_host as DH
+
+THR, BIAS = 100.0, 60.0          # TSF_THR / TSF_BIAS of csrc/tsformer_encoder.hip
+STATS = {"reshifts": 0, "tiles": 0}
 
 LANES = np.arange(64)
 H = LANES // 32
@@ -24,8 +28,16 @@ OPERAND = torch.bfloat16
 PEAK = {"abs": 0.0}                       # largest operand magnitude seen by pack_half (range check for a float16 variant)
 
 
-def bf16_round(a):
-    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(OPERAND).to(torch.float64).numpy()
+def bf16_round(a, dt=None):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dt or OPERAND).to(torch.float64).numpy()
+
+
+def round_to_operand(x):
+    """csrc/tsformer_device.h round_to_operand: nearest value of the operand type (float16 clamps at +-60000)."""
+    x = np.asarray(x, dtype=np.float64)
+    if OPERAND == torch.float16:
+        x = np.clip(x, -60000.0, 60000.0)
+    return bf16_round(x)
 
 
 class Buf:
@@ -60,10 +72,16 @@ def mfma_fast(a, b, c):
     return d
 
 
-def pack_half(v, s, rnd):
+def pack_half(v, s, rnd, dt=None):
     x = v[:, 8 * s:8 * s + 8]
     PEAK["abs"] = max(PEAK["abs"], float(np.abs(x[np.isfinite(x)]).max(initial=0.0)))
-    return bf16_round(x) if rnd else x.copy()
+    return bf16_round(x, dt) if rnd else x.copy()
+
+
+def lane_bits(pool, start):
+    """keep bits of the 16 mask words at `start`: [64 lanes, 16 registers]."""
+    b = DH._tile_bits(pool, start)                       # [reg, half, column]
+    return b.transpose(1, 2, 0).reshape(64, 16).astype(np.float64)
 
 
 def layer_norm(acc, g, b):
@@ -80,11 +98,23 @@ def layer_norm(acc, g, b):
     return d * rstd[None, :, None] * gg + bb
 
 
-def encode_sequence(series, packed, P, depth, round_bf16=True):
-    """series: [L] float; returns hidden [P, 96] (float64)."""
+def encode_sequence(series, packed, P, depth, round_bf16=True, drop=None, always_reshift=False):
+    """series: [L] float; returns hidden [P, 96] (float64).
+    drop: None or dict(pool=uint64 array, seed=64-bit seed argument of step_tsformer_encode, seq=sequence index, keep=1-p):
+    training-mode dropout with the kernel's keep-mask words."""
     B = Buf(packed)
     rnd = round_bf16
     nkt = (P + 31) // 32
+    BF = torch.bfloat16
+    thr = -BIAS if always_reshift else THR
+    if drop is not None:
+        pool = np.asarray(drop["pool"]).view(np.uint64)
+        keep = float(drop["keep"])
+        dl = DH.DropLayout(nkt)
+        s32 = DH.seed32(int(drop["seed"]))
+        cbase = lambda layer: DH.chunk_base(s32, int(drop["seq"]), layer, pool.shape[0])
+    else:
+        keep = 1.0
     LB = TP.layer_bytes()
     G_WPE = TP.HDR
     G_BPE = G_WPE + 2 * 48 * 12 * 4
@@ -101,8 +131,13 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
         tokc = np.where(ok, tok, 0)
         xin = np.where(ok[:, None], series[tokc[:, None] * 12 + np.arange(12)[None, :]], 0.0)     # [64,12]
         pos = np.stack([B.f32(POS + (int(tokc[l]) * 2 + int(H[l])) * 48 * 4, 48) for l in range(64)])
-        e = np.einsum("lqj,lj->lq", wpe[H], xin) + bpe[H] + pos                                  # [64,48]
-        xT.append((e * np.sqrt(96.0)).reshape(64, 3, 16).transpose(1, 0, 2).copy())              # [3,64,16]
+        e = (np.einsum("lqj,lj->lq", wpe[H], xin) + bpe[H] + pos).reshape(64, 3, 16).transpose(1, 0, 2).copy()   # [3,64,16]
+        sc = np.sqrt(96.0)
+        if drop is not None:
+            for t in range(3):
+                e[t] = e[t] * lane_bits(pool, cbase(depth) + dl.d1 + (w * 3 + t) * 16)
+            sc = sc / keep
+        xT.append(e * sc)
     for layer in range(depth):
         base = L0 + layer * LB
         hblk = lambda hd: base + hd * TP.BLOCK                       # head stage block
@@ -110,7 +145,8 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
         tailf = lambda blk, off, n: B.f32(blk + TP.TAIL + off * 4, n)
         xb = [[pack_half(xT[w][t], s, rnd) for t in range(3) for s in range(2)] for w in range(nkt)]
         bo = tailf(hblk(0), 64, 96).reshape(2, 48)
-        acc = [xT[w] + bo[H].reshape(64, 3, 16).transpose(1, 0, 2) for w in range(nkt)]
+        acc = [(xT[w] if drop is None else 0.0) + bo[H].reshape(64, 3, 16).transpose(1, 0, 2) for w in range(nkt)]
+        xop = lambda frs: np.stack([np.concatenate([frs[2 * t], frs[2 * t + 1]], axis=1) for t in range(3)])   # operand copy -> [3,64,16]
         for hd in range(4):
             kf, vf, qb = {}, {}, []
             bq = tailf(hblk(hd), 0, 32).reshape(2, 16)
@@ -126,23 +162,39 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
                 qb.append([pack_half(q, 0, rnd), pack_half(q, 1, rnd)])
                 for s in range(2):
                     kf[(w, s)] = pack_half(kk, s, rnd)
-                    vf[(w, s)] = pack_half(vv, s, rnd)
+                    vf[(w, s)] = pack_half(vv, s, rnd, BF)           # V and P are bfloat16 in both operand modes
             for w in range(nkt):
                 def scores(kt):
                     s_ = mfma_fast(kf[(kt, 0)], qb[w][0], np.zeros((64, 16)))
                     s_ = mfma_fast(kf[(kt, 1)], qb[w][1], s_)
                     key = kt * 32 + ROW[H]                                # [64,16]
-                    return np.where(key >= P, -np.inf, s_)
-                mx = np.full(64, -np.inf)
-                for kt in range(nkt):
-                    mx = np.maximum(mx, scores(kt).max(axis=1))
-                mx = np.maximum(mx, mx[LANES ^ 32])
+                    return np.where(key >= P, s_ - 30000.0, s_)          # slot 26: (is_padding | -30000)
+                # one pass, online softmax: `shift` rides through the score MFMA (slot 25), see the kernel header
+                shift = np.zeros(64)
                 ov = np.zeros((64, 16))
+                lsum = np.zeros(64)
                 for kt in range(nkt):
-                    p = np.exp2(scores(kt) - mx[:, None])
-                    ov = mfma_fast(vf[(kt, 0)], pack_half(p, 0, rnd), ov)
-                    ov = mfma_fast(vf[(kt, 1)], pack_half(p, 1, rnd), ov)
-                den = ov[C, 12]
+                    sc = scores(kt) - shift[:, None]
+                    tmax = sc.max(axis=1)
+                    STATS["tiles"] += 1
+                    if kt == 0 or bool((tmax > thr).any()):
+                        STATS["reshifts"] += kt > 0
+                        t = np.maximum(tmax, tmax[LANES ^ 32])
+                        upd = (t > thr) | (kt == 0)
+                        ns = round_to_operand(shift + t + BIAS) if rnd else shift + t + BIAS
+                        d = np.where(upd, ns - shift, 0.0)
+                        shift = np.where(upd, ns, shift)
+                        a = np.ones(64) if kt == 0 else np.exp2(-d)
+                        ov = ov * a[:, None]
+                        lsum = lsum * a
+                        sc = sc - d[:, None]
+                    p = np.exp2(sc)
+                    if drop is not None:
+                        lsum = lsum + p.sum(axis=1)
+                        p = p * lane_bits(pool, cbase(layer) + ((hd * nkt + w) * nkt + kt) * 16)
+                    ov = mfma_fast(vf[(kt, 0)], pack_half(p, 0, rnd, BF), ov)
+                    ov = mfma_fast(vf[(kt, 1)], pack_half(p, 1, rnd, BF), ov)
+                den = ov[C, 12] if drop is None else (lsum + lsum[LANES ^ 32]) * keep
                 ov = ov / den[:, None]
                 ob = [pack_half(ov, 0, rnd), pack_half(ov, 1, rnd)]
                 for t in range(3):
@@ -152,9 +204,13 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
         g2, b2n = tailf(fblk(5), 64, 96).reshape(2, 48), tailf(fblk(5), 160, 96).reshape(2, 48)
         b2 = tailf(fblk(0), 64, 96).reshape(2, 48)
         for w in range(nkt):
+            if drop is not None:           # dropout1 on (attention output + b_o), residual from its 16-bit operand copy
+                m1 = np.stack([lane_bits(pool, cbase(layer) + dl.d1 + (w * 3 + t) * 16) for t in range(3)])
+                acc[w] = np.where(m1 > 0, acc[w] / keep, 0.0) + xop(xb[w])
             x1 = layer_norm(acc[w], g1, b1n)
             xbw = [pack_half(x1[t], s, rnd) for t in range(3) for s in range(2)]
-            a2 = x1 + b2[H].reshape(64, 3, 16).transpose(1, 0, 2)
+            b2l = b2[H].reshape(64, 3, 16).transpose(1, 0, 2)
+            a2 = x1 + b2l if drop is None else b2l * keep
             for ch in range(12):
                 j, cc = ch // 2, ch % 2
                 b1 = tailf(fblk(j), cc * 32, 32).reshape(2, 16)
@@ -162,10 +218,15 @@ def encode_sequence(series, packed, P, depth, round_bf16=True):
                 for ks in range(6):
                     hh = mfma_fast(B.frag(fblk(j), cc * 12 + ks), xbw[ks], hh)
                 hh = np.maximum(hh + b1[H], 0.0)
+                if drop is not None:
+                    hh = hh * lane_bits(pool, cbase(layer) + dl.ffn + (w * 12 + ch) * 16)
                 hb = [pack_half(hh, 0, rnd), pack_half(hh, 1, rnd)]
                 for t in range(3):
                     for s in range(2):
                         a2[t] = mfma_fast(B.frag(fblk(j), cc * 12 + 6 + t * 2 + s), hb[s], a2[t])
+            if drop is not None:           # FFN-dropout and dropout2 survivor scales in one multiply, residual from the operand copy
+                m2 = np.stack([lane_bits(pool, cbase(layer) + dl.d2 + (w * 3 + t) * 16) for t in range(3)])
+                a2 = np.where(m2 > 0, a2 / (keep * keep), 0.0) + xop(xbw)
             xT[w] = layer_norm(a2, g2, b2n)
     ng, nb = B.f32(G_NG, 96).reshape(2, 48), B.f32(G_NB, 96).reshape(2, 48)
     hidden = np.zeros((P, 96))

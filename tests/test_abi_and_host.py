@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/step_hip.h but not exported"
     assert set(_lib.exported_symbols()) == declared, set(_lib.exported_symbols()) ^ declared
-    assert lib.step_abi_version() == 3
+    assert lib.step_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_error_reporting_without_compute():
@@ -202,3 +202,16 @@ def test_workspace_size_queries_are_pure_host_functions():
     assert lib.step_gwnet_saved_floats(B, N, 1) > lib.step_gwnet_saved_floats(B, N, 0) > 0
     assert lib.step_gwnet_saved_floats(2 * B, N, 0) > lib.step_gwnet_saved_floats(B, N, 0)
     assert lib.step_adam_work_floats() > 0
+
+
+def test_mask_generator_seeded_matches_reference():
+    """T3 (tsformer/mask.py:15-28): python random.shuffle of range(P), first 75 % masked, both lists sorted.  The golden
+    lists were drawn by the reference's MaskGenerator after random.seed(4) (tools/make_golden.py run_pretrain_case)."""
+    import random
+    from step_amd.step_arch.tsformer import MaskGenerator
+    g = load_golden("tsformer_pretrain_tiny")
+    P = (g["in.x"].shape[1]) // 12
+    random.seed(4)
+    um, mk = MaskGenerator(P, 0.75)()
+    assert um == g["in.unmasked"].tolist() and mk == g["in.masked"].tolist()
+    assert sorted(um + mk) == list(range(P)) and len(mk) == int(P * 0.75)

@@ -55,3 +55,87 @@ def test_emulated_kernel_multi_wave(operand):
     want = O.tsformer_encode(x, p).reshape(2, L // 12, 96)
     got = encode_sequence(x[0, :, 1].double().numpy(), packed, L // 12, 4, round_bf16=True)
     assert rel_l2(torch.from_numpy(got), want[1]) < TOL[operand][1]
+
+
+def _random_pool(words, keep, seed):
+    rng = np.random.default_rng(seed)
+    bits = (rng.random((words, 64)) < keep).astype(np.uint64)
+    return (bits << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+
+
+def _masks_to_torch(m):
+    t = torch.from_numpy
+    return {"pos": t(m["pos"]), "layers": [{k: t(v) for k, v in L.items()} for L in m["layers"]]}
+
+
+@pytest.mark.parametrize("P", [8, 40])
+def test_emulated_dropout_matches_oracle_with_host_masks(P):
+    """Training-mode dropout: the emulated kernel consumes the keep-mask words exactly like csrc/tsformer_encoder.hip (word
+    offsets, lane / register maps, survivor scales folded into sqrt(d), 1/denominator, b2 and the residual fma); the oracle
+    replays the dense masks tests/enc_dropout_host.py builds from the same pool through an independent index map.  With
+    exact (unrounded) operands the two must agree to round-off -- except for the residual stream, which the kernel re-reads
+    from its 16-bit operand copy in training mode; rnd=False keeps that copy exact too."""
+    from tests import enc_dropout_host as DH
+    g = load_golden("step_tiny")
+    p = params_of(g, requires_grad=False)
+    rng = np.random.default_rng(P)
+    S, L = 3, P * 12
+    x = torch.tensor(rng.normal(size=(1, L, S)), dtype=torch.float32)
+    sd = {k[len("tsformer."):]: v for k, v in p.items() if k.startswith("tsformer.")}
+    packed = TP.pack_tsformer(sd, P, operand="f16")
+    keep, seed = 0.9, 0x1234_5678_9ABC_DEF1
+    nkt = (P + 31) // 32
+    pool = _random_pool(1 << 12 if nkt == 1 else 1 << 13, keep, 7)
+    assert pool.shape[0] >= 2 * DH.DropLayout(nkt).words
+    masks = DH.encoder_masks(pool, seed, S, P)
+    for k in ("pos",):
+        assert abs(masks[k].mean() - keep) < 0.02
+    assert abs(masks["layers"][1]["attn"].mean() - keep) < 0.02
+    pd = {k: v.double() for k, v in p.items()}
+    want = O.tsformer_encode(x.double(), pd, drop=_masks_to_torch(masks), keep=keep).reshape(S, P, 96)
+    nodrop = O.tsformer_encode(x.double(), pd).reshape(S, P, 96)
+    E.OPERAND = torch.float16
+    try:
+        for s in range(S):
+            got = encode_sequence(x[0, :, s].double().numpy(), packed, P, 4, round_bf16=False,
+                                  drop=dict(pool=pool, seed=seed, seq=s, keep=keep))
+            # weights are float16-rounded in the packed buffer, activations exact: same band as the dropout-free check above
+            err = rel_l2(torch.from_numpy(got), want[s])
+            assert err < TOL["f16"][0], (s, err)
+            assert rel_l2(torch.from_numpy(got), nodrop[s]) > 10 * err
+    finally:
+        E.OPERAND = torch.bfloat16
+
+
+def test_emulated_online_softmax_reshift_paths():
+    """The single-pass softmax with a biased running shift: weights scaled up so that scores reach the thousands and the
+    running maximum jumps by more than the head room between key tiles (the re-shift path then runs on later tiles, not only
+    on the first), plus the test mode that re-shifts on every new maximum.  In exact arithmetic the result does not depend on
+    when the shift moves: the two schedules must agree to round-off, and both must match the exact softmax of the oracle up
+    to the rounding of the packed weights (amplified by the x16 scores)."""
+    g = load_golden("step_tiny")
+    p = params_of(g, requires_grad=False)
+    rng = np.random.default_rng(11)
+    P = 72
+    L = P * 12
+    x = torch.tensor(rng.normal(size=(1, L, 1)) * np.linspace(0.2, 3.0, L)[None, :, None], dtype=torch.float32)
+    p = dict(p)
+    for l in range(4):
+        k = f"tsformer.encoder.transformer_encoder.layers.{l}.self_attn.in_proj_weight"
+        p[k] = p[k] * 4.0                                   # scores x16
+    sd = {k[len("tsformer."):]: v for k, v in p.items() if k.startswith("tsformer.")}
+    packed = TP.pack_tsformer(sd, P, operand="f16")
+    want = O.tsformer_encode(x.double(), {k: v.double() for k, v in p.items()}).reshape(P, 96)
+    E.OPERAND = torch.float16
+    got, counts = {}, {}
+    try:
+        for always in (False, True):
+            E.STATS.update(reshifts=0, tiles=0)
+            got[always] = encode_sequence(x[0, :, 0].double().numpy(), packed, P, 4, round_bf16=False, always_reshift=always)
+            counts[always] = E.STATS["reshifts"]
+    finally:
+        E.OPERAND = torch.bfloat16
+    assert counts[False] > 0, "the input does not exercise the re-shift path"
+    assert counts[True] > counts[False]
+    assert rel_l2(torch.from_numpy(got[False]), torch.from_numpy(got[True])) < 1e-9
+    assert rel_l2(torch.from_numpy(got[False]), want) < 16 * TOL["f16"][0]

@@ -102,3 +102,25 @@ def test_pretrain_matches_reference():
             assert err < 5e-3, (k, err)
             n += 1
     assert n > 50
+
+
+def _dropout_masks_of(g):
+    t = lambda a: torch.from_numpy(a.astype("float32"))
+    return {"pos": t(g["mask.pos"]),
+            "layers": [{k: t(g[f"mask.{l}.{k}"]) for k in ("attn", "drop1", "ffn", "drop2")} for l in range(4)]}
+
+
+def test_training_mode_dropout_sites_match_reference():
+    """The reference TSFormer in train mode with every dropout realisation recorded (tools/make_golden.py run_dropout_case):
+    the oracle replaying those masks must reproduce its hidden states, i.e. the five kinds of dropout sites
+    (positional_encoding.py:32; attention probabilities, dropout1, FFN, dropout2 of each encoder layer) sit where the
+    reference's do and scale survivors the same way."""
+    g = load_golden("tsformer_dropout_tiny")
+    N, L, B = [int(x) for x in g["meta"]]
+    p = {"tsformer." + k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}
+    keep = 1.0 - float(g["meta.p"])
+    x = g["in.x"][..., 0]
+    h = O.tsformer_encode(x, p, drop=_dropout_masks_of(g), keep=keep)
+    assert max_abs(h, g["out.hidden"]) < 1e-4
+    # the masks matter: without them the states differ visibly
+    assert rel_l2(O.tsformer_encode(x, p), g["out.hidden"]) > 0.05

@@ -1,6 +1,11 @@
-// Standalone A/B harness for the fused TSFormer encoder (no torch, no python): dlopen a libstep_hip build (ABI 3), check the
-// hidden states of 12 full-length sequences against the CPU oracle for bf16 and f16 operand fragments, time the kernel at the
-// PEMS04 launch size (S=2456, P=336) with and without dropout, and dump the selftest stream of a dropout generator.
+// Standalone A/B harness for the fused TSFormer encoder (no torch, no python).  Usage:
+//     ./enc_ab tag1=./libenc_tag1.so tag2=./libenc_tag2.so ...
+// Every library is a build of csrc/tsformer_encoder.hip + errors.cpp (ABI 4; an ABI 3 build -- the round-1 kernel -- is
+// accepted too and called through its old signature, so the previous kernel can be timed on the same box).
+// Per library: hidden states of 12 full-length sequences against the CPU oracle (dropout off, bf16 and f16 operand fragments;
+// the re-shift-on-every-maximum test mode), training-mode dropout against the oracle replaying the same keep-mask pool
+// (files written by tools/enc_ab_prepare.py), run-to-run determinism.  Then timing at the PEMS04 launch size (S=2456, P=336)
+// in INTERLEAVED rounds over all libraries (cdna_hip_programming.md 5.4 rule 24), with and without dropout.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <math.h>
@@ -8,10 +13,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <string>
 #include <vector>
 
-typedef int (*enc_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, uint64_t, void*);
-typedef int (*dump_fn)(uint32_t, int, int, int, uint32_t*, void*);
+typedef int (*enc4_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, const uint64_t*, long,
+                       uint64_t, void*);
+typedef int (*enc3_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, uint64_t, void*);
+typedef int (*fill_fn)(uint64_t*, long, float, uint64_t, void*);
 typedef const char* (*err_fn)(void);
 typedef int (*abi_fn)(void);
 
@@ -27,29 +36,65 @@ static std::vector<char> slurp(const char* path) {
     return b;
 }
 
+struct Lib {
+    std::string tag;
+    int abi;
+    enc4_fn e4; enc3_fn e3; fill_fn fill; err_fn err;
+    // unified call: flags bit0 f16, bit1 always-reshift (ABI 4 only)
+    int run(const float* x, int S, int L, const void* pk, long pkb, int flags, uint16_t* h16, float* h32, float* last, float* sqn, float p,
+            const uint64_t* pool, long words, uint64_t seed, hipStream_t st) const {
+        if (abi >= 4) return e4(x, S, L, pk, pkb, 4, flags, h16, h32, last, sqn, p, pool, words, seed, st);
+        return e3(x, S, L, pk, pkb, 4, flags & 1, h16, h32, last, sqn, p, seed, st);
+    }
+};
+
+static double rel_l2(const float* got, const float* want, size_t n, int* nan) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!(got[i] == got[i])) ++*nan;
+        double d = (double)got[i] - want[i]; num += d * d; den += (double)want[i] * want[i];
+    }
+    return sqrt(num / den);
+}
+
 int main(int argc, char** argv) {
-    const char* libpath = argv[1];
-    const char* tag = argv[2];
-    const int dump_gen = argc > 3 ? atoi(argv[3]) : -1;
-    void* h = dlopen(libpath, RTLD_NOW);
-    if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
-    enc_fn enc = (enc_fn)dlsym(h, "step_tsformer_encode");
-    dump_fn dump = (dump_fn)dlsym(h, "step_selftest_dropout_stream");
-    err_fn lasterr = (err_fn)dlsym(h, "step_last_error");
-    abi_fn abi = (abi_fn)dlsym(h, "step_abi_version");
-    if (!enc || !dump || !lasterr || !abi) { printf("missing symbol\n"); return 1; }
-    printf("[%s] abi %d\n", tag, abi());
-    if (abi() != 3) { printf("needs an ABI 3 build\n"); return 1; }
-    const int P = 336, L = 12 * P, S0 = 12, S = 2456, depth = 4;
-    std::vector<char> series = slurp("series_small.bin"), want = slurp("want_hidden.bin");
+    std::vector<Lib> libs;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        size_t eq = a.find('=');
+        if (eq == std::string::npos) { printf("argument %s is not tag=path\n", argv[i]); return 1; }
+        Lib l; l.tag = a.substr(0, eq);
+        void* h = dlopen(a.substr(eq + 1).c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
+        abi_fn abi = (abi_fn)dlsym(h, "step_abi_version");
+        l.err = (err_fn)dlsym(h, "step_last_error");
+        if (!abi || !l.err) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
+        l.abi = abi();
+        l.e4 = (enc4_fn)dlsym(h, "step_tsformer_encode"); l.e3 = (enc3_fn)l.e4;
+        l.fill = (fill_fn)dlsym(h, "step_dropout_pool_fill");
+        if (!l.e4 || (l.abi >= 4 && !l.fill)) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
+        printf("[%s] abi %d\n", l.tag.c_str(), l.abi);
+        libs.push_back(l);
+    }
+    if (libs.empty()) { printf("no libraries\n"); return 1; }
+    const int P = 336, L = 12 * P, S0 = 12, S = 2456;
+    std::vector<char> series = slurp("series_small.bin"), want = slurp("want_hidden.bin"), wantd = slurp("want_hidden_drop.bin");
+    std::vector<char> poolf = slurp("drop_pool.bin"), seedf = slurp("drop_seed.bin");
     std::vector<char> pack[2] = {slurp("pack_bf16.bin"), slurp("pack_f16.bin")};
+    const long pool_words = (long)poolf.size() / 8;
+    uint64_t drop_seed; memcpy(&drop_seed, seedf.data(), 8);
     hipStream_t st;
     HIPCK(hipStreamCreate(&st));
     float *d_series, *d_hid32, *d_last, *d_sqn, *d_big;
     uint16_t* d_hid16;
+    uint64_t *d_pool, *d_pool2;
     void* d_pack[2];
     HIPCK(hipMalloc(&d_series, series.size()));
     HIPCK(hipMemcpy(d_series, series.data(), series.size(), hipMemcpyHostToDevice));
+    HIPCK(hipMalloc(&d_pool, poolf.size()));
+    HIPCK(hipMemcpy(d_pool, poolf.data(), poolf.size(), hipMemcpyHostToDevice));
+    const long words2 = 1L << 18;
+    HIPCK(hipMalloc(&d_pool2, words2 * 8));
     for (int k = 0; k < 2; ++k) {
         HIPCK(hipMalloc(&d_pack[k], pack[k].size()));
         HIPCK(hipMemcpy(d_pack[k], pack[k].data(), pack[k].size(), hipMemcpyHostToDevice));
@@ -58,34 +103,42 @@ int main(int argc, char** argv) {
     HIPCK(hipMalloc(&d_hid16, (size_t)S * P * 96 * 2));
     HIPCK(hipMalloc(&d_last, (size_t)S * 96 * 4));
     HIPCK(hipMalloc(&d_sqn, (size_t)S * 16 * 4));
-    // ---- correctness vs the CPU oracle, dropout off
-    std::vector<float> got((size_t)S0 * P * 96);
+    const size_t n0 = (size_t)S0 * P * 96;
+    std::vector<float> got(n0), again(n0);
     const float* w = (const float*)want.data();
-    for (int k = 0; k < 2; ++k) {
-        HIPCK(hipMemset(d_hid32, 0xff, got.size() * 4));
-        int rc = enc(d_series, S0, L, d_pack[k], (long)pack[k].size(), depth, k, d_hid16, d_hid32, d_last, d_sqn, 0.f, 0, st);
-        if (rc) { printf("encode failed: %s\n", lasterr()); return 1; }
-        HIPCK(hipStreamSynchronize(st));
-        HIPCK(hipMemcpy(got.data(), d_hid32, got.size() * 4, hipMemcpyDeviceToHost));
-        double num = 0, den = 0, worst = 0; int nan = 0;
-        for (int s = 0; s < S0; ++s) {
-            double n1 = 0, d1 = 0;
-            for (long i = (long)s * P * 96; i < (long)(s + 1) * P * 96; ++i) {
-                if (!(got[i] == got[i])) ++nan;
-                double d = (double)got[i] - w[i]; n1 += d * d; d1 += (double)w[i] * w[i];
+    const float* wd = (const float*)wantd.data();
+    // ---------------------------------------------------------------- correctness
+    for (const Lib& l : libs) {
+        const char* tag = l.tag.c_str();
+        for (int k = 0; k < 2; ++k)
+            for (int fl = 0; fl < (l.abi >= 4 ? 2 : 1); ++fl) {
+                HIPCK(hipMemset(d_hid32, 0xff, n0 * 4));
+                int rc = l.run(d_series, S0, L, d_pack[k], (long)pack[k].size(), k | (fl << 1), d_hid16, d_hid32, d_last, d_sqn, 0.f, nullptr, 0, 0, st);
+                if (rc) { printf("[%s] encode failed: %s\n", tag, l.err()); return 1; }
+                HIPCK(hipStreamSynchronize(st));
+                HIPCK(hipMemcpy(got.data(), d_hid32, n0 * 4, hipMemcpyDeviceToHost));
+                int nan = 0;
+                double e = rel_l2(got.data(), w, n0, &nan);
+                rc = l.run(d_series, S0, L, d_pack[k], (long)pack[k].size(), k | (fl << 1), d_hid16, d_hid32, d_last, d_sqn, 0.f, nullptr, 0, 0, st);
+                HIPCK(hipStreamSynchronize(st));
+                HIPCK(hipMemcpy(again.data(), d_hid32, n0 * 4, hipMemcpyDeviceToHost));
+                printf("[%s] operand %s%s: hidden rel-L2 vs oracle %.3e (NaN %d), deterministic %d\n", tag, k ? "f16 " : "bf16",
+                       fl ? " re-shift on every maximum" : "", e, nan, (int)(memcmp(again.data(), got.data(), n0 * 4) == 0));
             }
-            num += n1; den += d1;
-            if (sqrt(n1 / d1) > worst) worst = sqrt(n1 / d1);
-        }
-        printf("[%s] operand %s: hidden rel-L2 vs oracle %.3e (worst sequence %.3e, NaN %d)\n", tag, k ? "f16 " : "bf16", sqrt(num / den), worst, nan);
-        // run-to-run determinism
-        std::vector<float> again(got.size());
-        rc = enc(d_series, S0, L, d_pack[k], (long)pack[k].size(), depth, k, d_hid16, d_hid32, d_last, d_sqn, 0.f, 0, st);
-        HIPCK(hipStreamSynchronize(st));
-        HIPCK(hipMemcpy(again.data(), d_hid32, got.size() * 4, hipMemcpyDeviceToHost));
-        printf("[%s] operand %s: deterministic %d\n", tag, k ? "f16 " : "bf16", (int)(memcmp(again.data(), got.data(), got.size() * 4) == 0));
+        if (l.abi >= 4)
+            for (int k = 0; k < 2; ++k) {
+                HIPCK(hipMemset(d_hid32, 0xff, n0 * 4));
+                int rc = l.run(d_series, S0, L, d_pack[k], (long)pack[k].size(), k, d_hid16, d_hid32, d_last, d_sqn, 0.1f, d_pool, pool_words, drop_seed, st);
+                if (rc) { printf("[%s] encode failed: %s\n", tag, l.err()); return 1; }
+                HIPCK(hipStreamSynchronize(st));
+                HIPCK(hipMemcpy(got.data(), d_hid32, n0 * 4, hipMemcpyDeviceToHost));
+                int nan = 0;
+                double e = rel_l2(got.data(), wd, n0, &nan), pert = rel_l2(wd, w, n0, &nan);
+                printf("[%s] operand %s DROPOUT 0.1, pool from file: hidden rel-L2 vs oracle replaying the same masks %.3e (NaN %d; dropout moves the states by %.3f)\n",
+                       tag, k ? "f16 " : "bf16", e, nan, pert);
+            }
     }
-    // ---- timing at the PEMS04 launch size
+    // ---------------------------------------------------------------- timing at the PEMS04 launch size, interleaved rounds
     std::vector<float> big((size_t)S * L);
     uint32_t x = 12345u;
     for (size_t i = 0; i < big.size(); ++i) { x = x * 1664525u + 1013904223u; big[i] = ((x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 3.0f; }
@@ -93,44 +146,43 @@ int main(int argc, char** argv) {
     HIPCK(hipMemcpy(d_big, big.data(), big.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-    for (int k = 0; k < 2; ++k)
-        for (int dr = 0; dr < 2; ++dr) {
-            const float p = dr ? 0.1f : 0.f;
-            for (int i = 0; i < 3; ++i) enc(d_big, S, L, d_pack[k], (long)pack[k].size(), depth, k, d_hid16, nullptr, d_last, d_sqn, p, 7 + i, st);
-            HIPCK(hipStreamSynchronize(st));
-            float best = 1e9f, sum = 0.f;
-            const int reps = 10;
-            for (int i = 0; i < reps; ++i) {
-                HIPCK(hipEventRecord(e0, st));
-                int rc = enc(d_big, S, L, d_pack[k], (long)pack[k].size(), depth, k, d_hid16, nullptr, d_last, d_sqn, p, 100 + i, st);
-                HIPCK(hipEventRecord(e1, st));
-                HIPCK(hipEventSynchronize(e1));
-                if (rc) { printf("encode failed: %s\n", lasterr()); return 1; }
-                float ms; HIPCK(hipEventElapsedTime(&ms, e0, e1));
-                sum += ms; if (ms < best) best = ms;
+    const int rounds = 7;
+    const double flop = (double)S * P * (4.0 * (221184 + 384.0 * P) + 2304);
+    for (int mode = 0; mode < 3; ++mode) {          // 0: f16 no dropout, 1: f16 dropout, 2: bf16 dropout
+        const int k = mode == 2 ? 0 : 1;
+        const float p = mode == 0 ? 0.f : 0.1f;
+        std::vector<std::vector<float>> t(libs.size());
+        for (int r = -1; r < rounds; ++r)             // round -1 = warm-up
+            for (size_t li = 0; li < libs.size(); ++li) {
+                const Lib& l = libs[li];
+                if (p > 0 && l.abi >= 4) { int rc = l.fill(d_pool2, words2, p, 77 + r, st); if (rc) { printf("fill failed: %s\n", l.err()); return 1; } }
+                for (int rep = 0; rep < 3; ++rep) {
+                    HIPCK(hipEventRecord(e0, st));
+                    int rc = l.run(d_big, S, L, d_pack[k], (long)pack[k].size(), k, d_hid16, nullptr, d_last, d_sqn, p, d_pool2, words2, 100 + r * 3 + rep, st);
+                    HIPCK(hipEventRecord(e1, st));
+                    HIPCK(hipEventSynchronize(e1));
+                    if (rc) { printf("[%s] encode failed: %s\n", l.tag.c_str(), l.err()); return 1; }
+                    float ms; HIPCK(hipEventElapsedTime(&ms, e0, e1));
+                    if (r >= 0) t[li].push_back(ms);
+                }
             }
-            // sanity of the dropout-on output: mean squared hidden of the first sequences must be ~1 per feature (LayerNorm output)
+        for (size_t li = 0; li < libs.size(); ++li) {
+            std::vector<float> v = t[li];
+            std::sort(v.begin(), v.end());
+            const float med = v[v.size() / 2];
             std::vector<uint16_t> hb((size_t)64 * P * 96);
             HIPCK(hipMemcpy(hb.data(), d_hid16, hb.size() * 2, hipMemcpyDeviceToHost));
-            double ss = 0; int bad = 0;
-            for (size_t i = 0; i < hb.size(); ++i) { uint32_t u = (uint32_t)hb[i] << 16; float f; memcpy(&f, &u, 4); if (!(f == f) || fabsf(f) > 1e4f) ++bad; ss += (double)f * f; }
-            printf("[%s] operand %s dropout %.1f: %.3f ms avg, %.3f ms best (S=%d P=%d); hidden mean-square %.4f, non-finite %d\n", tag,
-                   k ? "f16 " : "bf16", p, sum / reps, best, S, P, ss / hb.size(), bad);
+            printf("[%s] %s dropout %.1f: median %.3f ms, min %.3f, max %.3f (%zu launches, S=%d P=%d) = %.1f TFLOP/s algorithmic, %.1f %% of 2.5 PF\n",
+                   libs[li].tag.c_str(), k ? "f16 " : "bf16", p, med, v.front(), v.back(), v.size(), S, P, flop / med / 1e9, flop / med / 1e9 / 25.0);
         }
-    // ---- generator dump
-    if (dump_gen >= 0) {
-        const int streams = 4096, words = 256;
-        uint32_t* d_out;
-        HIPCK(hipMalloc(&d_out, (size_t)streams * words * 4));
-        int rc = dump(0x1234567u, dump_gen, streams, words, d_out, st);
-        if (rc) { printf("dump failed: %s\n", lasterr()); return 1; }
-        HIPCK(hipStreamSynchronize(st));
-        std::vector<uint32_t> o((size_t)streams * words);
-        HIPCK(hipMemcpy(o.data(), d_out, o.size() * 4, hipMemcpyDeviceToHost));
-        char name[256];
-        snprintf(name, sizeof(name), "../gpurun_out/dropout_stream_gen%d.bin", dump_gen);
-        FILE* f = fopen(name, "wb");
-        if (f) { fwrite(o.data(), 4, o.size(), f); fclose(f); printf("[%s] wrote %s\n", tag, name); }
+    }
+    // sanity of the last dropout-on output of the last library: LayerNorm output, mean square ~1 per feature
+    {
+        std::vector<uint16_t> hb((size_t)64 * P * 96);
+        HIPCK(hipMemcpy(hb.data(), d_hid16, hb.size() * 2, hipMemcpyDeviceToHost));
+        double ss = 0; int bad = 0;
+        for (size_t i = 0; i < hb.size(); ++i) { uint32_t u = (uint32_t)hb[i] << 16; float f; memcpy(&f, &u, 4); if (!(f == f) || fabsf(f) > 1e4f) ++bad; ss += (double)f * f; }
+        printf("last dropout-on launch: hidden mean-square %.4f, non-finite %d\n", ss / hb.size(), bad);
     }
     return 0;
 }

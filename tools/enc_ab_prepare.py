@@ -1,17 +1,18 @@
-"""Stage the torch-free encoder A/B harness (tools/enc_ab.cpp) for a GPU box: packed weights (bf16 and f16 fragments), 12
-full-length series, the CPU oracle's hidden states, the harness binary and the library builds to compare, all under
-scratch_ab/ (git-ignored, shipped by gpurun).  A gpurun call of the harness costs ~20-45 s of GPU budget including the box:
+"""Stage the torch-free encoder A/B harness (tools/enc_ab.cpp) for a GPU box under scratch_ab/ (git-ignored, shipped by gpurun):
+packed weights (bf16 and f16 fragments), 12 full-length series, the CPU oracle's hidden states without dropout and with the
+dropout masks of a keep-mask pool (drop_pool.bin / drop_seed.bin, masks rebuilt on the host by tests/enc_dropout_host.py), the
+harness binary, and one small library per variant (csrc/tsformer_encoder.hip + errors.cpp only, so a variant builds in ~15 s):
 
-    python tools/enc_ab_prepare.py                     # default build  -> scratch_ab/libstep_default.so
-    python tools/enc_ab_prepare.py lcg -DTSF_DROPOUT_LCG=1    # + a variant build -> scratch_ab/libstep_lcg.so
-    gpurun --timeout 120 -- 'mkdir -p gpurun_out && cd scratch_ab && ./enc_ab ./libstep_default.so default 0; ./enc_ab ./libstep_lcg.so lcg 2'
+    python tools/enc_ab_prepare.py default pipe0:-DTSF_PIPE=0 pipe1:-DTSF_PIPE=1 prio1:-DTSF_SETPRIO=1 old@HEAD~3
+    gpurun --timeout 300 -- 'cd scratch_ab && ./enc_ab default=./libenc_default.so pipe0=./libenc_pipe0.so ... > ../gpurun_out/enc_ab.log'
 
-Third harness argument: generator whose selftest stream is dumped to gpurun_out/dropout_stream_gen<k>.bin (-1 / absent: none).
+`name:-Dflag[,-Dflag]` = extra defines; `name@rev` = the sources of git revision `rev` (an ABI 3 kernel is called through its old
+signature, which lets the previous round's kernel be timed in the same process).
 """
 import os
-import shutil
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import torch
@@ -19,12 +20,37 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "scratch_ab")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def build_variant(name, defines, rev=None):
+    lib = os.path.join(OUT, f"libenc_{name}.so")
+    with tempfile.TemporaryDirectory() as tmp:
+        if rev is None:
+            csrc = os.path.join(ROOT, "step_amd", "csrc")
+        else:                           # check the revision's csrc/ and include/ out into a scratch tree
+            for d in ("step_amd/csrc", "include"):
+                os.makedirs(os.path.join(tmp, d), exist_ok=True)
+                files = subprocess.check_output(["git", "-C", ROOT, "ls-tree", "--name-only", rev, d + "/"]).decode().split()
+                for f in files:
+                    with open(os.path.join(tmp, f), "wb") as fh:
+                        fh.write(subprocess.check_output(["git", "-C", ROOT, "show", f"{rev}:{f}"]))
+            csrc = os.path.join(tmp, "step_amd", "csrc")
+        objs = []
+        for src in ("tsformer_encoder.hip", "errors.cpp"):
+            o = os.path.join(tmp, src + ".o")
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *defines, "-c",
+                                   os.path.join(csrc, src), "-o", o])
+            objs.append(o)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 def main():
     from oracle import step_oracle as O
-    from step_amd import build as B, tsformer_pack as TP
+    from step_amd import tsformer_pack as TP
     from step_amd.step_arch.tsformer import TSFormer
+    from tests import enc_dropout_host as DH
     os.makedirs(OUT, exist_ok=True)
     P, S0 = 336, 12
     L = 12 * P
@@ -43,18 +69,31 @@ def main():
     t = np.arange(L)
     series = np.stack([np.sin(2 * np.pi * t / 288 + rng.uniform(0, 6)) * rng.uniform(0.5, 1.5) + 0.3 * np.sin(2 * np.pi * t / 2016)
                        + 0.25 * rng.standard_normal(L) for _ in range(S0)]).astype(np.float32)
-    want = O.tsformer_encode(torch.from_numpy(series.T.copy())[None], p).reshape(S0, P, 96).numpy().astype(np.float32)
+    x = torch.from_numpy(series.T.copy())[None]
+    want = O.tsformer_encode(x, p).reshape(S0, P, 96).numpy().astype(np.float32)
+    # dropout: a host-made pool, the dense masks the kernel will take from it, the oracle replaying them
+    keep, seed, words = 0.9, 0x5EED_0123_4567_89AB, 1 << 16
+    bits = (rng.random((words, 64)) < keep).astype(np.uint64)
+    pool = (bits << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+    masks = DH.encoder_masks(pool, seed, S0, P)
+    tt = torch.from_numpy
+    md = {"pos": tt(masks["pos"]), "layers": [{k: tt(v) for k, v in Lr.items()} for Lr in masks["layers"]]}
+    wantd = O.tsformer_encode(x, p, drop=md, keep=keep).reshape(S0, P, 96).numpy().astype(np.float32)
     series.tofile(os.path.join(OUT, "series_small.bin"))
     want.tofile(os.path.join(OUT, "want_hidden.bin"))
+    wantd.tofile(os.path.join(OUT, "want_hidden_drop.bin"))
+    pool.tofile(os.path.join(OUT, "drop_pool.bin"))
+    np.array([seed], dtype=np.uint64).tofile(os.path.join(OUT, "drop_seed.bin"))
     for op in ("bf16", "f16"):
         TP.pack_tsformer(sd, P, operand=op).numpy().tofile(os.path.join(OUT, f"pack_{op}.bin"))
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-o", os.path.join(OUT, "enc_ab"), os.path.join(ROOT, "tools", "enc_ab.cpp"), "-ldl"])
-    shutil.copy(B.build(verbose=False), os.path.join(OUT, "libstep_default.so"))
-    if len(sys.argv) > 2:
-        name = sys.argv[1]
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), name, *sys.argv[2:]])
-        shutil.copy(os.path.join(B.HERE, f"libstep_hip_{name}.so"), os.path.join(OUT, f"libstep_{name}.so"))
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-o", os.path.join(OUT, "enc_ab"), os.path.join(ROOT, "tools", "enc_ab.cpp"), "-ldl"])
+    for spec in sys.argv[1:] or ["default"]:
+        if "@" in spec:
+            name, rev = spec.split("@", 1)
+            print(build_variant(name, [], rev))
+        else:
+            name, _, d = spec.partition(":")
+            print(build_variant(name, [x for x in d.split(",") if x]))
     print(sorted(os.listdir(OUT)))
 
 

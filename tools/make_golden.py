@@ -9,7 +9,8 @@ Runs only in the build container (needs /root/reference).  The reference's arith
     read files from the cwd (discrete_graph_learning.py:55-57,61,73; step.py:27-35).
     The attributes set here are exactly the ones those constructors set.
   * dropout probabilities are set to 0 so the only random draw left is the Gumbel noise
-    (`torch.rand`, discrete_graph_learning.py:12), which is recorded and stored.
+    (`torch.rand`, discrete_graph_learning.py:12), which is recorded and stored; the one case that keeps dropout on
+    (run_dropout_case) records every mask instead.
 
 Usage:  python tools/make_golden.py            (writes tests/golden/step_tiny.npz, ...)
 """
@@ -228,6 +229,66 @@ def run_pretrain_case(ref, name, N, L, B, seed):
     print(name, "loss", float(loss), tuple(recon.shape))
 
 
+def run_dropout_case(ref, name, N, L, B, seed, p_drop=0.1):
+    """Training-mode forward of the reference TSFormer (forecasting mode) with every dropout realisation recorded.
+    torch.nn.functional.dropout is wrapped (same arithmetic: x * mask / (1 - p)) so the masks can be stored, and
+    torch.nn.functional.scaled_dot_product_attention -- the call F.multi_head_attention_forward makes for
+    need_weights=False -- is replaced by its documented definition softmax(q k^T / sqrt(d)) -> dropout -> @ v, the only way to
+    observe the attention-probability masks.  Everything else is the reference's unmodified code in train mode."""
+    import math
+    import torch.nn.functional as F
+    _, TSFormer, _, _, _, _, _ = ref
+    rng = np.random.default_rng(seed)
+    series = synth_series(L + 32, N, rng)
+    targs = dict(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=p_drop,
+                 num_token=L / 12, mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode="forecasting")
+    model = TSFormer(**targs)
+    params = synth_params(model.state_dict(), rng)
+    model.load_state_dict(params)
+    model.train()
+    data = torch.from_numpy(series)
+    ts = rng.integers(L, L + 32, size=B)
+    x = torch.stack([data[t - L:t] for t in ts])[..., [0]]
+    masks = []
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+
+    def rec_dropout(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return inp
+        m = (torch.rand_like(inp) >= p)
+        masks.append(m.clone())
+        return inp * m.to(inp.dtype) / (1.0 - p)
+
+    def explicit_sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, **kw):
+        assert attn_mask is None and not is_causal
+        w = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(q.shape[-1]), dim=-1)
+        return rec_dropout(w, dropout_p, True) @ v
+    torch.manual_seed(seed)
+    F.dropout, F.scaled_dot_product_attention = rec_dropout, explicit_sdpa
+    try:
+        with torch.no_grad():
+            hidden = model(x)
+    finally:
+        F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+    S, P = B * N, L // 12
+    assert len(masks) == 1 + 4 * 4, len(masks)
+    out = {"in.x": x, "out.hidden": hidden, "meta": np.array([N, L, B]), "meta.p": np.float64(p_drop)}
+    # positional_encoding.py:32 sees [B, N, P, d]; the encoder layers run seq-first [P, S, d] (transformer_layers.py:14-17),
+    # attention weights are [S * heads (batch-major), P, P] -> store everything sequence-major
+    out["mask.pos"] = masks[0].reshape(S, P, 96)
+    for l in range(4):
+        a, d1, f, d2 = masks[1 + 4 * l: 5 + 4 * l]
+        out[f"mask.{l}.attn"] = a.reshape(S, 4, P, P)
+        out[f"mask.{l}.drop1"] = d1.permute(1, 0, 2)
+        out[f"mask.{l}.ffn"] = f.permute(1, 0, 2)
+        out[f"mask.{l}.drop2"] = d2.permute(1, 0, 2)
+    for n_, _ in model.named_parameters():
+        out["param." + n_] = params[n_]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k_: (v_.detach().numpy() if torch.is_tensor(v_) else v_) for k_, v_ in out.items()})
+    print(name, "hidden", tuple(hidden.shape), "keep rates", [round(float(m.float().mean()), 3) for m in masks[:5]])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -236,3 +297,4 @@ if __name__ == "__main__":
     run_step_case(ref, "step_small", N=37, L=288, T_train=200, B=3, k=4, epoch=7, seed=2)
     run_step_case(ref, "step_tiny_eval", N=20, L=96, T_train=120, B=2, k=3, epoch=None, seed=3, training=False)
     run_pretrain_case(ref, "tsformer_pretrain_tiny", N=9, L=192, B=2, seed=4)
+    run_dropout_case(ref, "tsformer_dropout_tiny", N=5, L=96, B=2, seed=5)

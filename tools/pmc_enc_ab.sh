@@ -1,0 +1,36 @@
+#!/bin/bash
+# PMC passes (rocprofv3, counters only -- no trace domains besides the kernel trace) over the torch-free encoder harness for
+# one library of scratch_ab/ (default: default).  Run on the GPU box via gpurun; writes gpurun_out/pmc_ab_<tag>_*.
+#   usage: tools/pmc_enc_ab.sh [tag]
+tag=${1:-default}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+run() { # name, counters...
+  name=$1; shift
+  (cd scratch_ab && rocprofv3 --kernel-trace --pmc "$@" -d ../gpurun_out/pmc_ab_${tag}_$name -o p -- ./enc_ab $tag=./libenc_$tag.so > ../gpurun_out/pmc_ab_${tag}_$name.log 2>&1)
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES
+run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F32
+run sq3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+if [ "$2" == "mem" ]; then
+run mem1 FETCH_SIZE
+run mem2 WRITE_SIZE GRBM_GUI_ACTIVE
+fi
+python - "$tag" <<'PY'
+import sqlite3, glob, sys
+tag = sys.argv[1]
+out = open(f"gpurun_out/pmc_ab_{tag}_summary.txt", "w")
+for d in sorted(glob.glob(f'gpurun_out/pmc_ab_{tag}_*/')):
+    for db in glob.glob(d + '**/*.db', recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        try:
+            rows = cur.execute("""select s.kernel_name, p.name, sum(e.value), count(distinct d.id) from rocpd_pmc_event e
+               join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id
+               join rocpd_info_kernel_symbol s on d.kernel_id = s.id where s.kernel_name like '%tsformer_encoder%' and d.grid_size > 1000000
+               group by s.kernel_name, p.name""").fetchall()
+        except Exception as ex:
+            print(db, "query failed", ex); continue
+        for r in rows:
+            line = f"{d.split('/')[-2]:28s} {r[0][44:70]:26s} {r[1]:30s} per-dispatch {r[2] / r[3]:16.0f}  ({r[3]} dispatches)"
+            print(line); out.write(line + "\n")
+PY
