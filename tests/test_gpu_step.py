@@ -257,7 +257,9 @@ def test_fused_adam_clip_matches_torch():
 
 
 def test_native_step_loss_matches_reference_loss():
-    from step_amd.step_loss import step_loss_native, step_loss
+    """The fused loss kernel (value + both gradients) against the ORACLE's step_loss (oracle/step_oracle.py, pinned to the
+    reference's step_loss / masked_mae by tests/test_oracle_golden.py), evaluated on the CPU."""
+    from step_amd.step_loss import step_loss_native
     g = torch.Generator().manual_seed(5)
     B, N = 3, 23
     pred = (torch.randn(B, 12, N, 1, generator=g) * 150 + 200).cuda().requires_grad_(True)
@@ -266,15 +268,17 @@ def test_native_step_loss_matches_reference_loss():
     real = real.cuda()
     theta = torch.rand(B, N, N, generator=g).clamp(1e-4, 1 - 1e-4).cuda().requires_grad_(True)
     prior = (torch.rand(B, N, N, generator=g) < 0.1).float().cuda()
+    pred_c = pred.detach().cpu().requires_grad_(True)
+    theta_c = theta.detach().cpu().requires_grad_(True)
     for coef in (1.0, 0.5, 0):
-        l_ref = step_loss(pred, real, theta, prior, coef, null_val=0.0)
-        gp, gt = torch.autograd.grad(l_ref, [pred, theta], allow_unused=True)
+        l_ref = O.step_loss(pred_c, real.cpu(), theta_c, prior.cpu(), coef, null_val=0.0)
+        gp, gt = torch.autograd.grad(l_ref, [pred_c, theta_c], allow_unused=True)
         l_nat = step_loss_native(pred, real, theta, prior, coef, null_val=0.0)
         np_, nt_ = torch.autograd.grad(l_nat * 2.0, [pred, theta], allow_unused=True)
         assert float(l_nat) == pytest.approx(float(l_ref), rel=1e-5)
-        assert rel_l2(np_.cpu() / 2.0, gp.cpu()) < 1e-5
+        assert rel_l2(np_.cpu() / 2.0, gp) < 1e-5
         if coef:
-            assert rel_l2(nt_.cpu() / 2.0, gt.cpu()) < 1e-5
+            assert rel_l2(nt_.cpu() / 2.0, gt) < 1e-5
         else:
             assert float(nt_.abs().max()) == 0.0
 
@@ -355,3 +359,63 @@ def test_device_window_loader_matches_tensor_inputs():
     # SURVEY appendix A.3), so only its number of selected edges is compared.
     assert (a[2][:3] != b[2][:3]).sum().item() <= 6
     assert abs(float(a[2][3].sum() - b[2][3].sum())) <= N
+
+
+@pytest.mark.parametrize("name", ["step_tiny", "step_small"])
+def test_step_training_parity_with_gcn_dropout_masks(name):
+    """F.dropout(0.3) after every gcn (graphwavenet/model.py:47): the native forward keeps its keep-masks (already scaled by
+    1/0.7) for the backward; the test reads them back (step_gwnet_saved_offset item 0) and the oracle replays the same
+    realisation -- prediction, loss and every gradient of the dropout-on training step must agree like the dropout-off ones."""
+    import step_amd._lib as L
+    g = load_golden(name)
+    N, Lh, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    model = build_native(g)
+    model.train()
+    model.tsformer.dropout_p = 0.0            # the encoder's dropout has its own mask-exact test (test_gpu_kernels.py)
+    assert model.backend.dropout == pytest.approx(0.3)
+    model._noise_override = g["in.u"]
+    hist, long_hist, fut = inputs_of(g)
+    pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=epoch)
+    loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+    loss.backward()
+    torch.cuda.synchronize()
+    saved = model._last["saved_gwnet"].cpu()
+    touts = [12, 10, 9, 7, 6, 4, 3]
+    masks, rates = [], []
+    for i, To in enumerate(touts):
+        off = L.lib().step_gwnet_saved_offset(B, N, 1, 0, i)
+        m = saved[off:off + B * N * To * 32].view(B, N, To, 32)
+        vals = torch.unique(m)
+        assert set(round(float(v), 5) for v in vals) <= {0.0, round(1 / 0.7, 5)}, vals
+        rates.append(float((m > 0).float().mean()))
+        masks.append(m.permute(0, 3, 1, 2).contiguous())          # [b][n][t][c] -> the oracle's [B, C, N, T]
+    n_el = sum(mk.numel() for mk in masks)
+    rate = sum(r * mk.numel() for r, mk in zip(rates, masks)) / n_el
+    assert abs(rate - 0.7) < 5 * (0.21 / n_el) ** 0.5 + 1e-3, (rate, rates)
+    masks.append(None)
+    P = Lh // 12
+    hid = model._last["hidden_bf16"].float().cpu().view(B, N, P, 96)
+    p = params_of(g)
+    o_pred, o_theta, o_knn, o_coef = O.step_forward(g["in.hist"], g["in.long_hist0"].unsqueeze(-1), g["in.node_feats"], p, g["in.u"],
+                                                    k, epoch, training=True, hidden=hid, drop_masks=masks,
+                                                    hidden_last=model._last["hidden_last"].cpu().view(B, N, 96))
+    o_loss = O.step_loss(O.rescale(o_pred, mean, std), O.rescale(g["in.future"][..., [0]], mean, std), o_theta, o_knn, o_coef)
+    o_loss.backward()
+    nodrop, _, _, _ = O.step_forward(g["in.hist"], g["in.long_hist0"].unsqueeze(-1), g["in.node_feats"], params_of(g), g["in.u"],
+                                     k, epoch, training=True, hidden=hid, hidden_last=model._last["hidden_last"].cpu().view(B, N, 96))
+    e_pred, moved = rel_l2(pred.detach().cpu(), o_pred), rel_l2(o_pred, nodrop)
+    worst, wname = 0.0, ""
+    for kname, t in dict(model._trainable()).items():
+        og = p[ref_name(kname)].grad
+        if float(og.abs().max()) < 1e-4:
+            assert max_abs(t.grad.cpu(), og) < 2e-4, kname
+            continue
+        e = rel_l2(t.grad.cpu(), og)
+        if e > worst:
+            worst, wname = e, kname
+    print(f"{name} gcn dropout on (keep rate {rate:.4f}): pred rel-L2 vs oracle with the same masks {e_pred:.2e} (dropout moves the prediction by "
+          f"{moved:.3f}), loss {float(loss):.5f} vs {float(o_loss):.5f}, worst gradient {wname} {worst:.2e}")
+    assert e_pred < 2e-3 and moved > 20 * e_pred
+    assert float(loss) == pytest.approx(float(o_loss), rel=2e-3)
+    assert worst < 1e-2

@@ -1,107 +1,220 @@
-"""Training-trajectory and horizon-12 MAE parity (BASELINE.json metric: "... horizon-12 MAE parity"):
-K optimizer steps of the native STEP module versus K steps of the CPU oracle on the same windows, the same
-Gumbel noise and the same torch.optim.Adam + clip_grad_norm_, dropout off.  The frozen TSFormer's hidden
-states are constant over training, so the oracle is fed the device encoder's states (tight comparison) and,
-separately, its own fp32 states (the bf16-encoder effect on the forecast error)."""
+"""Multi-step training parity of the native STEP module against the CPU oracle (BASELINE.json metric: "... horizon-12 MAE
+parity"), same windows, same Gumbel noise, same torch.optim.Adam + clip_grad_norm_ (step/STEP_PEMS04.py:90-106), dropout off.
+
+Two optimisers started from the same point separate step by step even when both are exact: Adam turns round-off sized
+gradient differences into O(lr) parameter differences, and every flipped Gumbel arg-max / kNN cut is a discrete event.  The
+tests are therefore built so that their tolerances do not depend on that realisation:
+
+* lock-step: the oracle drives the trajectory, the native module is re-synchronised to the oracle's parameters before every
+  step, and loss / sampled graph / prior graph / whole gradient / BatchNorm statistics are compared at every point of a real
+  trajectory -- tight, fixed tolerances;
+* free-running: both run freely; while all discrete decisions have been identical the losses must agree to 2 %, afterwards
+  to the larger of 2 % and three times the oracle's OWN divergence under a 1e-6 relative perturbation of its inputs;
+* horizon-12 MAE: 200 free-running steps with learning-rate decay on a mid-size problem (N=64, P=168 tokens, batch 4; the
+  oracle uses its own fp32 TSFormer states), held-out horizon-12 masked MAE within +-2 % of the oracle's mean (the oracle's
+  own run-to-run spread under round-off sized perturbations is 0.5 % there; without the decay it is 2.5 %).
+"""
 import numpy as np
 import pytest
 import torch
 
 from oracle import step_oracle as O
+from tests import train_problem as TPb
 from tests.helpers import load_golden, params_of, rel_l2
 from tests.test_gpu_step import build_native, inputs_of, ref_name
 
 pytestmark = pytest.mark.gpu
 K_STEPS = 8
+TOL = {"f32": dict(loss=1e-3, grad=5e-3, flips=0), "bf16": dict(loss=1e-2, grad=1e-1, flips=None)}
 
 
-def _h12_mae(pred, fut, mean, std):
-    return float(O.masked_mae(O.rescale(pred[:, 11], mean, std), O.rescale(fut[:, 11, :, [0]], mean, std), 0.0))
-
-
-def _oracle_run(g, hidden, hidden_last, noises):
-    N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
-    mean, std = [float(x) for x in g["meta.scaler"]]
-    p = params_of(g)
-    train = [v for kk, v in p.items() if v.requires_grad]
-    opt = torch.optim.Adam(train, lr=2e-3, weight_decay=1e-5, eps=1e-8)
-    losses = []
-    for it in range(K_STEPS):
-        opt.zero_grad(set_to_none=True)
-        stats = {}
-        pred, theta, knn, coef = O.step_forward(g["in.hist"], g["in.long_hist0"].unsqueeze(-1), g["in.node_feats"], p, noises[it], k, 1,
-                                                training=True, stats=stats, hidden=hidden, hidden_last=hidden_last)
-        loss = O.step_loss(O.rescale(pred, mean, std), O.rescale(g["in.future"][..., [0]], mean, std), theta, knn, coef)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
-        opt.step()
-        losses.append(float(loss))
-    with torch.no_grad():
-        pred, _, _, _ = O.step_forward(g["in.hist"], g["in.long_hist0"].unsqueeze(-1), g["in.node_feats"], p, noises[0], k, 1,
-                                       training=True, hidden=hidden, hidden_last=hidden_last)
-    return losses, _h12_mae(pred, g["in.future"], mean, std)
-
-
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["step_tiny", "step_small"])
-def test_k_step_trajectory_and_h12_mae_parity(name, mode):
-    """mode "f32": every contraction outside the TSFormer exact (tight); mode "bf16" (what bench.py times): diffusion hops,
-    DGL conv2 and fc on the bf16 matrix cores -- the trajectory must stay within a few % of the fp32 oracle's."""
+def _golden_setup(name, mode):
     g = load_golden(name)
     N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
-    mean, std = [float(x) for x in g["meta.scaler"]]
-    gen = torch.Generator().manual_seed(11)
-    noises = [torch.rand(B, N * N, 2, generator=gen) for _ in range(K_STEPS)]
     model = build_native(g)
     model.train()
     model.matmul_precision = mode
     model.backend.dropout = 0.0
     model.tsformer.dropout_p = 0.0
+    gen = torch.Generator().manual_seed(11)
+    noises = [torch.rand(B, N * N, 2, generator=gen) for _ in range(K_STEPS)]
+    return g, model, noises
+
+
+def _native_step(g, model, u, it):
+    mean, std = [float(x) for x in g["meta.scaler"]]
     hist, long_hist, fut = inputs_of(g)
+    model._noise_override = u
+    model.zero_grad(set_to_none=True)
+    pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
+    loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+    loss.backward()
+    return float(loss.detach()), knn.detach().cpu(), model._last["sampled_adj"].detach().cpu()
+
+
+def _oracle_step(g, p, u, hidden, hidden_last):
+    N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    stats, aux = {}, {}
+    pred, theta, knn, coef = O.step_forward(g["in.hist"], g["in.long_hist0"].unsqueeze(-1), g["in.node_feats"], p, u, k, 1,
+                                            training=True, stats=stats, hidden=hidden, hidden_last=hidden_last, aux=aux)
+    loss = O.step_loss(O.rescale(pred, mean, std), O.rescale(g["in.future"][..., [0]], mean, std), theta, knn, coef)
+    loss.backward()
+    return loss, stats, knn, aux["sampled_adj"]
+
+
+def _device_hidden(g, model):
+    N, L, T, B = [int(x) for x in g["meta"][:4]]
+    return (model._last["hidden_bf16"].float().cpu().view(B, N, L // 12, 96), model._last["hidden_last"].cpu().view(B, N, 96))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["step_tiny", "step_small"])
+def test_trajectory_lockstep(name, mode):
+    """K optimizer steps of the oracle; before every step the native module takes over the oracle's parameters and BatchNorm
+    buffers, then both evaluate the same minibatch with the same Gumbel noise."""
+    g, model, noises = _golden_setup(name, mode)
+    tol = TOL[mode]
+    p = params_of(g)
+    train = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(train, lr=2e-3, weight_decay=1e-5, eps=1e-8)
+    names = {k: ref_name(k) for k, _ in model._trainable()}
+    worst = dict(loss=0.0, grad=0.0, flips=0, knn=0, bn=0.0)
+    for it in range(K_STEPS):
+        model.load_state_dict({k: v.detach() for k, v in p.items()}, strict=True)          # oracle -> native
+        loss_n, knn_n, adj_n = _native_step(g, model, noises[it], it)
+        hid, last = _device_hidden(g, model)
+        opt.zero_grad(set_to_none=True)
+        loss_o, stats, knn_o, adj_o = _oracle_step(g, p, noises[it], hid, last)
+        flips = int((adj_n != adj_o).sum())
+        num = den = 0.0
+        for kname, t in model._trainable():
+            rg = p[names[kname]].grad
+            if rg is None:
+                assert t.grad is None or float(t.grad.abs().max()) == 0.0, kname
+                continue
+            num += float((t.grad.cpu().double() - rg.double()).pow(2).sum())
+            den += float(rg.double().pow(2).sum())
+        ge = (num / den) ** 0.5
+        le = abs(loss_n - float(loss_o)) / abs(float(loss_o))
+        worst["loss"], worst["grad"] = max(worst["loss"], le), max(worst["grad"], ge)
+        worst["flips"], worst["knn"] = max(worst["flips"], flips), max(worst["knn"], int((knn_n != knn_o).sum()))
+        assert le < tol["loss"], (it, loss_n, float(loss_o))
+        assert ge < tol["grad"], (it, ge)
+        assert int((knn_n != knn_o).sum()) <= 4, it                       # ties at the top-k cut only
+        if tol["flips"] is not None:
+            assert flips <= tol["flips"], (it, flips)                     # same logits to 1e-6, same noise -> same arg-max
+        else:
+            assert flips <= 0.002 * adj_o.numel() + 2, (it, flips)
+        torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
+        opt.step()
+        TPb.update_running_stats(p, stats)
+        sd_n = model.state_dict()
+        for kk in p:                                                      # native running statistics after its own step
+            if "running_" in kk and not kk.startswith("backend.bn.7") and not kk.startswith("tsformer."):
+                worst["bn"] = max(worst["bn"], rel_l2(sd_n[kk].cpu(), p[kk]))
+    print(f"{name} {mode} lock-step over {K_STEPS} steps: worst loss rel {worst['loss']:.2e}, whole-gradient rel-L2 {worst['grad']:.2e}, "
+          f"Gumbel flips {worst['flips']}, kNN differences {worst['knn']}, running-stat rel-L2 {worst['bn']:.2e}")
+    assert worst["bn"] < (5e-3 if mode == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_trajectory_free_running(mode):
+    name = "step_small"
+    g, model, noises = _golden_setup(name, mode)
     params = [q for q in model.parameters() if q.requires_grad]
     opt = torch.optim.Adam(params, lr=2e-3, weight_decay=1e-5, eps=1e-8)
-    losses = []
+    losses, graphs = [], []
     for it in range(K_STEPS):
+        loss, knn, adj = _native_step(g, model, noises[it], it)
+        if it == 0:
+            hid, last = _device_hidden(g, model)
+        torch.nn.utils.clip_grad_norm_(params, 3.0)
+        opt.step()
+        losses.append(loss)
+        graphs.append((knn, adj))
+
+    def oracle_run(perturb):
+        p = params_of(g)
+        train = [v for v in p.values() if v.requires_grad]
+        o = torch.optim.Adam(train, lr=2e-3, weight_decay=1e-5, eps=1e-8)
+        out, gr = [], []
+        for it in range(K_STEPS):
+            h, l = hid, last
+            if perturb:
+                gen = torch.Generator().manual_seed(500 + it)
+                h = hid * (1 + perturb * torch.randn(hid.shape, generator=gen))
+                l = h[:, :, -1, :]
+            o.zero_grad(set_to_none=True)
+            loss, stats, knn, adj = _oracle_step(g, p, noises[it], h, l)
+            torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
+            o.step()
+            TPb.update_running_stats(p, stats)
+            out.append(float(loss.detach()))
+            gr.append((knn, adj))
+        return out, gr
+    o_losses, o_graphs = oracle_run(0.0)
+    p_losses, _ = oracle_run(1e-6)
+    same = True
+    report = []
+    for it in range(K_STEPS):
+        same = same and bool((graphs[it][1] == o_graphs[it][1]).all()) and int((graphs[it][0] != o_graphs[it][0]).sum()) <= 4
+        own = abs(p_losses[it] - o_losses[it]) / abs(o_losses[it])
+        band = 2e-2 if same else max(2e-2, 3 * own)
+        d = abs(losses[it] - o_losses[it]) / abs(o_losses[it])
+        report.append((it, same, round(d, 5), round(own, 5)))
+        assert d < band, (it, same, losses[it], o_losses[it], own)
+    print(name, mode, "free-running (step, decisions identical so far, |native - oracle| / oracle, oracle's own 1e-6 divergence):", report)
+
+
+# ---------------------------------------------------------------------------------------------- horizon-12 MAE after 200 steps
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_h12_mae_parity(mode):
+    """N1: 200 free-running optimizer steps (Adam 2e-3 with a MultiStepLR-style decay at steps 120 / 160, clip 3.0, same
+    minibatches and Gumbel noise) on N=64 nodes x 168 tokens, batch 4, then an eval-mode forward on 64 held-out windows.
+    The oracle side (its own fp32 TSFormer states) was run in the build container six times with round-off sized input
+    perturbations (tools/make_n1_golden.py -> tests/golden/n1_oracle.npz): horizon-12 masked MAE 38.79 +- 0.53 %, all
+    horizons 38.38 +- 0.16 %.  The native module must land within 2 % (horizon 12) / 1 % (all horizons) of the oracle's mean."""
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "n1_oracle.npz"))
+    N, L, T_train, steps, B, k = [int(x) for x in z["cfg"]]
+    runs = z["runs"]
+    o_h12, o_mae, o_tail = runs[:, 1].mean(), runs[:, 2].mean(), runs[:, 3].mean()
+    prob = TPb.Problem(N, L, T_train)
+    model = TPb.build_native(N, L, T_train, prob.series, k=k).cuda()
+    model.train()
+    model.matmul_precision = mode
+    model.backend.dropout = 0.0
+    model.tsformer.dropout_p = 0.0
+    params = [q for q in model.parameters() if q.requires_grad]
+    opt = torch.optim.Adam(params, lr=TPb.LR0, weight_decay=1e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(TPb.LR_MILESTONES), gamma=TPb.LR_GAMMA)
+    schedule, noises = prob.schedule(steps, B), prob.noises(steps, B)
+    losses = []
+    for it, ts in enumerate(schedule):
+        assert opt.param_groups[0]["lr"] == pytest.approx(TPb.lr_at(it))
+        hist, longh, fut = [x.cuda() for x in prob.batch(ts)]
         model._noise_override = noises[it]
         opt.zero_grad(set_to_none=True)
-        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
-        loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=it, epoch=1)
+        loss = O.step_loss(O.rescale(pred[..., [0]], prob.mean, prob.std), O.rescale(fut[..., [0]], prob.mean, prob.std), theta, knn, coef)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 3.0)
         opt.step()
-        losses.append(float(loss))
-    model._noise_override = noises[0]
+        sched.step()
+        losses.append(float(loss.detach()))
+    model.eval()
+    model._noise_override = torch.rand(len(prob.eval_t), N * N, 2, generator=torch.Generator().manual_seed(999))
+    hist, longh, fut = [x.cuda() for x in prob.batch(prob.eval_t)]
     with torch.no_grad():
-        pred, _, _, _ = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=1)
-    h12 = _h12_mae(pred.cpu(), g["in.future"], mean, std)
-    hid = model._last["hidden_bf16"].float().cpu().view(B, N, L // 12, 96)
-    last = model._last["hidden_last"].cpu().view(B, N, 96)
-    o_losses, o_h12 = _oracle_run(g, hid, last, noises)
-    print(name, mode, "native losses", [round(x, 3) for x in losses])
-    print(name, "oracle losses", [round(x, 3) for x in o_losses])
-    print(name, "H12 MAE native", h12, "oracle(device hidden)", o_h12)
-    # Adam turns round-off sized gradient differences into O(lr) parameter differences (sign-like updates), so two
-    # correct implementations drift apart step by step; the first steps must agree tightly, the later ones to a few %
-    # Under Adam the trajectories of two correct implementations separate step by step: round-off sized gradient
-    # differences (split-K atomics make even two runs of this module differ in the last bits) become O(lr) parameter
-    # differences on near-zero gradients.  Tight on the first steps, a band afterwards; the single-step gradient parity
-    # (test_gpu_step.py) and the full-size mode experiment (tools/mode_parity.py) are the sharp checks.
-    # Scale of the bands: the CPU oracle alone, fed states perturbed at the fp32 round-off level (1e-7), moves its 8-step losses by
-    # up to 2.3 % and its horizon-12 MAE by up to 3.5 % on step_small (tools/trajectory_sensitivity.py,
-    # profiles/r01_y_trajectory_sensitivity.txt); the late-step bands are ~3x that.
-    if mode == "f32":
-        assert losses[:3] == pytest.approx(o_losses[:3], rel=2e-3)
-        assert losses == pytest.approx(o_losses, rel=0.10)
-        assert h12 == pytest.approx(o_h12, rel=0.10)         # horizon-12 MAE after K steps (0.001-1.5 % observed)
-    else:
-        assert losses[:2] == pytest.approx(o_losses[:2], rel=5e-3)      # before / after one update
-        assert losses[:3] == pytest.approx(o_losses[:3], rel=4e-2)
-        assert losses == pytest.approx(o_losses, rel=0.15)
-        if name != "step_tiny":                              # 40 series: the single-horizon MAE is sample noise there
-            assert h12 == pytest.approx(o_h12, rel=0.12)     # 0.7-2.3 % observed
-    f_losses, f_h12 = _oracle_run(g, None, None, noises)     # oracle with its own fp32 TSFormer
-    print(name, "oracle(fp32 hidden) losses", [round(x, 3) for x in f_losses], "H12 MAE", f_h12)
-    assert losses[:3] == pytest.approx(f_losses[:3], rel=2e-2)
-    assert losses == pytest.approx(f_losses, rel=0.12)      # two correct runs whose inputs differ by the bf16 encoder error (1-2 %)
-    # the single-horizon MAE of B*N <= 111 series after 8 chaotic Adam steps is dominated by sample noise
-    # (it moves by tens of % between two fp32 runs that differ by 1 % in one input); reported, not asserted
+        pred, _, _, _ = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=0, epoch=None)
+    pr, fu = O.rescale(pred[..., [0]].cpu(), prob.mean, prob.std), O.rescale(fut[..., [0]].cpu(), prob.mean, prob.std)
+    h12, mae = float(O.masked_mae(pr[:, 11], fu[:, 11], 0.0)), float(O.masked_mae(pr, fu, 0.0))
+    tail = float(np.mean(losses[-20:]))
+    print(f"N1 [{mode}] {steps} steps, N={N} P={L // 12} B={B}: training loss {losses[0]:.3f} -> {tail:.3f} (oracle {float(z['first_loss']):.3f} -> {o_tail:.3f}); "
+          f"held-out horizon-12 MAE native {h12:.4f} vs oracle {o_h12:.4f} +- {100 * runs[:, 1].std() / o_h12:.2f} % ({(h12 / o_h12 - 1) * 100:+.2f} %), "
+          f"all horizons {mae:.4f} vs {o_mae:.4f} +- {100 * runs[:, 2].std() / o_mae:.2f} % ({(mae / o_mae - 1) * 100:+.2f} %)")
+    assert losses[0] == pytest.approx(float(z["first_loss"]), rel=5e-3)
+    assert tail < 0.6 * losses[0]                                   # it trains
+    assert tail == pytest.approx(o_tail, rel=2e-2)
+    assert h12 == pytest.approx(o_h12, rel=2e-2)
+    assert mae == pytest.approx(o_mae, rel=1e-2)

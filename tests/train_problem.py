@@ -1,0 +1,144 @@
+"""A mid-size synthetic forecasting problem and an oracle-side trainer (TEST INFRASTRUCTURE) for the multi-step parity tests:
+series the model can actually learn (daily + fast sinusoid per node, noise), a pool of training windows, held-out windows,
+and K optimizer steps of the CPU oracle with the reference's optimizer settings (step/STEP_PEMS04.py:90-106: Adam lr 2e-3,
+weight_decay 1e-5, eps 1e-8; clip_grad_norm_ 3.0) on rescaled outputs (base_tsf_runner.py:240-250).  The TSFormer is frozen
+(step.py:34-35), so the oracle's fp32 hidden states are computed once per window."""
+import numpy as np
+import torch
+
+from oracle import step_oracle as O
+
+BN_MOMENTUM = 0.1
+
+
+def make_series(N, T_all, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T_all, dtype=np.float32)[:, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, N)).astype(np.float32)
+    amp = rng.uniform(0.5, 1.5, (1, N)).astype(np.float32)
+    ch0 = amp * np.sin(2 * np.pi * t / 288.0 + phase) + 0.3 * np.sin(2 * np.pi * t / 37.0 + 2 * phase) \
+        + 0.3 * rng.standard_normal((T_all, N), dtype=np.float32)
+    ch1 = np.broadcast_to((t % 288) / 288.0, (T_all, N))
+    ch2 = np.broadcast_to((t // 288) % 7, (T_all, N))
+    return np.stack([ch0, ch1, ch2], -1).astype(np.float32)
+
+
+def model_args(N, L):
+    targs = dict(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=L / 12,
+                 mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode="forecasting")
+    bargs = dict(num_nodes=N, support_len=2, dropout=0.3, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=2, out_dim=12,
+                 residual_channels=32, dilation_channels=32, skip_channels=256, end_channels=512, kernel_size=2, blocks=4, layers=2)
+    return targs, bargs
+
+
+def build_native(N, L, T_train, series, k=10, seed=0):
+    """step_amd.STEP on the CPU with torch's default initialisation (seeded); the caller moves it to the GPU."""
+    from step_amd import STEP
+    targs, bargs = model_args(N, L)
+    torch.manual_seed(seed)
+    return STEP("SYNTH", None, targs, bargs, dict(dataset_name="SYNTH", k=k, input_seq_len=12, output_seq_len=12,
+                                                  data=series[:T_train], train_length=T_train, tsformer_tokens=L // 12))
+
+
+class Problem:
+    def __init__(self, N=64, L=2016, T_train=1200, n_train=64, n_eval=64, seed=0):
+        self.N, self.L, self.T_train = N, L, T_train
+        self.series = make_series(N, L + 1500, seed)
+        self.data = torch.from_numpy(self.series)
+        rng = np.random.default_rng(seed + 1)
+        ts = list(range(L, self.series.shape[0] - 12, 5))
+        rng.shuffle(ts)
+        self.train_t, self.eval_t = ts[:n_train], ts[n_train:n_train + n_eval]
+        self.mean, self.std = 200.0, 150.0          # the scaler of the synthetic datasets
+
+    def batch(self, ts):
+        d = self.data
+        return (torch.stack([d[t - 12:t] for t in ts]), torch.stack([d[t - self.L:t] for t in ts]), torch.stack([d[t:t + 12] for t in ts]))
+
+    def schedule(self, steps, B, seed=5):
+        rng = np.random.default_rng(seed)
+        return [[self.train_t[i] for i in rng.choice(len(self.train_t), B, replace=False)] for _ in range(steps)]
+
+    def noises(self, steps, B, seed=3):
+        gen = torch.Generator().manual_seed(seed)
+        return [torch.rand(B, self.N * self.N, 2, generator=gen) for _ in range(steps)]
+
+    def oracle_hidden(self, sd, ts):
+        """fp32 oracle TSFormer states of the given windows: dict t -> [N, P, 96]."""
+        out = {}
+        with torch.no_grad():
+            for t in ts:
+                out[t] = O.tsformer_encode(self.data[t - self.L:t, :, 0][None], sd)[0]
+        return out
+
+
+def trainable(sd):
+    p = {k: v.detach().clone() for k, v in sd.items()}
+    for k, v in p.items():
+        if v.is_floating_point() and not k.startswith("tsformer.") and "running_" not in k:
+            v.requires_grad_(True)
+    return p
+
+
+def update_running_stats(p, stats):
+    """what torch.nn.BatchNorm does in train mode (momentum 0.1, unbiased variance), for the oracle's functional BN"""
+    with torch.no_grad():
+        for name, (mu, var) in stats.items():
+            pre = "backend." if name.startswith("bn.") else "discrete_graph_learning."
+            p[pre + name + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mu)
+            p[pre + name + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var)
+
+
+def oracle_step(prob, p, ts, hidden, u, k, epoch=1, aux=None):
+    """forward + step_loss + backward of the oracle on one minibatch; returns (loss, stats)."""
+    hist, _, fut = prob.batch(ts)
+    hid = torch.stack([hidden[t] for t in ts])
+    stats = {}
+    pred, theta, knn, coef = O.step_forward(hist, torch.zeros(len(ts), prob.L, prob.N, 1), prob.data[:prob.T_train, :, 0], p, u, k, epoch,
+                                            training=True, stats=stats, hidden=hid, hidden_last=hid[:, :, -1, :], aux=aux)
+    if aux is not None:
+        aux["knn"] = knn
+    loss = O.step_loss(O.rescale(pred, prob.mean, prob.std), O.rescale(fut[..., [0]], prob.mean, prob.std), theta, knn, coef)
+    loss.backward()
+    return loss, stats
+
+
+def oracle_eval(prob, p, hidden, u, k):
+    """eval-mode forward (running statistics) on the held-out windows -> (horizon-12 masked MAE, all-horizon masked MAE), rescaled"""
+    hist, _, fut = prob.batch(prob.eval_t)
+    hid = torch.stack([hidden[t] for t in prob.eval_t])
+    with torch.no_grad():
+        pred, _, _, _ = O.step_forward(hist, torch.zeros(len(prob.eval_t), prob.L, prob.N, 1), prob.data[:prob.T_train, :, 0], p, u, k, None,
+                                       training=False, hidden=hid, hidden_last=hid[:, :, -1, :])
+    pr, fu = O.rescale(pred, prob.mean, prob.std), O.rescale(fut[..., [0]], prob.mean, prob.std)
+    return float(O.masked_mae(pr[:, 11], fu[:, 11], 0.0)), float(O.masked_mae(pr, fu, 0.0))
+
+
+LR0, LR_MILESTONES, LR_GAMMA = 2e-3, (120, 160), 0.25     # MultiStepLR like the reference configs (STEP_PEMS04.py:98-102), in steps
+
+
+def lr_at(it, decay=True):
+    return LR0 * LR_GAMMA ** sum(it >= m for m in LR_MILESTONES) if decay else LR0
+
+
+def oracle_train(prob, sd, hidden, schedule, noises, k=10, perturb=0.0, lr_decay=False):
+    """K free-running optimizer steps; returns (losses, final parameter dict).  perturb: relative Gaussian perturbation of the
+    hidden states per step (the oracle's own sensitivity to round-off sized input changes)."""
+    p = trainable(sd)
+    train = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(train, lr=LR0, weight_decay=1e-5, eps=1e-8)
+    losses = []
+    for it, ts in enumerate(schedule):
+        for grp in opt.param_groups:
+            grp["lr"] = lr_at(it, lr_decay)
+        hid = hidden
+        if perturb:
+            g = torch.Generator().manual_seed(1000 + it)
+            hid = {t: hidden[t] * (1 + perturb * torch.randn(hidden[t].shape, generator=g)) for t in ts}
+        opt.zero_grad(set_to_none=True)
+        loss, stats = oracle_step(prob, p, ts, hid, noises[it], k)
+        torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
+        opt.step()
+        update_running_stats(p, stats)
+        losses.append(float(loss.detach()))
+    return losses, p
