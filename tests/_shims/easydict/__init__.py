@@ -1,0 +1,21 @@
+"""Minimal EasyDict: a dict whose keys are also attributes, recursively (what the reference configs use)."""
+
+
+class EasyDict(dict):
+    def __init__(self, d=None, **kwargs):
+        super().__init__()
+        for k, v in {**(d or {}), **kwargs}.items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, EasyDict):
+            v = EasyDict(v)
+        super().__setitem__(k, v)
+
+    __setattr__ = __setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)

@@ -1,0 +1,74 @@
+"""Shared pieces of the drop-in tests (TEST INFRASTRUCTURE): a scratch working directory holding exactly the files the
+reference reads with cwd-relative paths --
+
+    datasets/<DS>/data_in12_out12.pkl   {"processed_data": float32 [T, N, 3]}          discrete_graph_learning.py:57, dataset
+    datasets/<DS>/index_in12_out12.pkl  {"train" | "valid" | "test": [(t-12, t, t+12)]}  forecasting_dataset.py:29
+    datasets/<DS>/scaler_in12_out12.pkl {"func": "re_standard_transform", "args": {"mean", "std"}}   base_tsf_runner.py:40
+    tsformer_ckpt/TSFormer_<DS>.pt      {"model_state_dict": TSFormer(mode="pre-train").state_dict()}   step.py:31-32
+
+-- and the model keyword arguments of the reference's config files (step/STEP_<DS>.py), restated so that the GPU box, which
+has no /root/reference, can build the same module.  Everything is synthetic and seeded."""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+DATASETS = {   # name: (nodes, series length, long-history length) -- scripts/data_preparation/*/generate_training_data.py
+    "METR-LA": (207, 34272, 288 * 7),
+    "PEMS04": (307, 16992, 288 * 7 * 2),
+}
+MEAN, STD = 200.0, 150.0
+
+
+def synth_series(T, N, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float32)[:, None]
+    phase = rng.uniform(0, 2 * np.pi, (1, N)).astype(np.float32)
+    ch0 = np.sin(2 * np.pi * t / 288.0 + phase) + 0.5 * rng.standard_normal((T, N), dtype=np.float32)
+    ch1 = np.broadcast_to((t % 288) / 288.0, (T, N))
+    ch2 = np.broadcast_to((t // 288) % 7, (T, N))
+    return np.stack([ch0, ch1, ch2], -1).astype(np.float32)
+
+
+def model_param(ds):
+    """CFG.MODEL.PARAM of step/STEP_<DS>.py (STEP_METR-LA.py:41-82, STEP_PEMS04.py:41-81)."""
+    N, _, L = DATASETS[ds]
+    return {
+        "dataset_name": ds,
+        "pre_trained_tsformer_path": f"tsformer_ckpt/TSFormer_{ds}.pt",
+        "tsformer_args": {"patch_size": 12, "in_channel": 1, "embed_dim": 96, "num_heads": 4, "mlp_ratio": 4, "dropout": 0.1,
+                          "num_token": L / 12, "mask_ratio": 0.75, "encoder_depth": 4, "decoder_depth": 1, "mode": "forecasting"},
+        "backend_args": {"num_nodes": N, "support_len": 2, "dropout": 0.3, "gcn_bool": True, "addaptadj": True, "aptinit": None,
+                         "in_dim": 2, "out_dim": 12, "residual_channels": 32, "dilation_channels": 32, "skip_channels": 256,
+                         "end_channels": 512, "kernel_size": 2, "blocks": 4, "layers": 2},
+        "dgl_args": {"dataset_name": ds, "k": 10, "input_seq_len": 12, "output_seq_len": 12},
+    }
+
+
+def train_origins(ds, n=6, seed=0):
+    """a few forecast origins with a full long history (t >= L)"""
+    N, T, L = DATASETS[ds]
+    rng = np.random.default_rng(seed + 17)
+    return sorted(int(t) for t in rng.choice(np.arange(L, T - 12), n, replace=False))
+
+
+def make_workspace(root, ds="METR-LA", seed=0):
+    """Write the four files under `root`; returns the series [T, N, 3]."""
+    from step_amd.step_arch.tsformer import TSFormer
+    N, T, L = DATASETS[ds]
+    series = synth_series(T, N, seed)
+    d = os.path.join(root, "datasets", ds)
+    os.makedirs(d, exist_ok=True)
+    os.makedirs(os.path.join(root, "tsformer_ckpt"), exist_ok=True)
+    with open(os.path.join(d, "data_in12_out12.pkl"), "wb") as f:
+        pickle.dump({"processed_data": series}, f)
+    idx = [(t - 12, t, t + 12) for t in train_origins(ds, seed=seed)]
+    with open(os.path.join(d, "index_in12_out12.pkl"), "wb") as f:
+        pickle.dump({"train": idx, "valid": idx[:2], "test": idx[:2]}, f)
+    with open(os.path.join(d, "scaler_in12_out12.pkl"), "wb") as f:
+        pickle.dump({"func": "re_standard_transform", "args": {"mean": MEAN, "std": STD}}, f)
+    torch.manual_seed(seed)
+    a = dict(model_param(ds)["tsformer_args"], mode="pre-train")
+    torch.save({"model_state_dict": TSFormer(**a).state_dict()}, os.path.join(root, "tsformer_ckpt", f"TSFormer_{ds}.pt"))
+    return series
