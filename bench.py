@@ -22,7 +22,7 @@ CONFIGS = {
     # name: (nodes, long-history length L, train_length, total series length, batch per GPU)
     "STEP_PEMS04": dict(N=307, L=288 * 7 * 2, T_train=13599, T_all=16992, B=8, k=10),
     "STEP_PEMS07": dict(N=883, L=288 * 7, T_train=16513, T_all=28224, B=4, k=10),
-    "STEP_METR-LA": dict(N=207, L=288 * 7, T_train=23990, T_all=34272, B=2, k=10),
+    "STEP_METR-LA": dict(N=207, L=288 * 7, T_train=23990, T_all=34272, B=2, k=10, train_ratio=0.7),
     "SYNTH_4096": dict(N=4096, L=288 * 7, T_train=16513, T_all=28224, B=1, k=10),      # BASELINE config 5 (N-scaling stress)
     # BASELINE config 3: masked pre-training of TSFormer (reference step/TSFormer_PEMS-BAY.py: B=16... batch per GPU)
     "TSFormer_PEMS-BAY": dict(N=325, L=288 * 7, T_train=36482, T_all=52116, B=16, k=0, pretrain=True),
@@ -42,16 +42,17 @@ def synth_series(T, N, seed=0):
 
 def pmc_traffic(config, B):
     """HBM bytes per encoder launch from the committed rocprofv3 PMC passes (profiles/encoder_pmc.json, produced by
-    tools/pmc_encoder.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md "HBM").  A counter run cannot be nested inside this process, so the number is looked up for the
-    same config / batch; None when no matching measurement is committed."""
+    tools/pmc_enc_ab.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md "HBM").  A counter run cannot be nested inside this process, so the number is NOT a measurement of
+    this run: it is looked up for the same kernel / config / batch and labelled "static": true; None when no matching
+    measurement is committed."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "encoder_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         ent = rec.get(f"{config}:B{B}")
         return None if ent is None else {"hbm_bytes_per_launch": ent["read_bytes"] + ent["write_bytes"], "read_bytes": ent["read_bytes"],
-                                          "write_bytes": ent["write_bytes"], "source": ent["source"]}
+                                          "write_bytes": ent["write_bytes"], "static": True, "source": ent["source"]}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -77,10 +78,12 @@ def encoder_flops(cfg, B):
 
 
 def cpu_baseline(cfg, data, seed=0):
-    """The CPU oracle (restatement of the reference algorithm, kind "port") timed on this host's cores on ONE
-    training window of the same workload (forward + step_loss + backward)."""
+    """The CPU oracle (restatement of the reference algorithm, kind "port") timed on this host's cores on a bounded sample of
+    the same workload: full training steps (forward + step_loss + backward + clip_grad_norm_ + Adam) of ONE window each --
+    one warm-up and three timed steps on all cores (median reported), then one step with two threads, the thread count the
+    reference ships with (step/run.py:10 torch.set_num_threads(2)).  The reference itself cannot run on the GPU box
+    (no /root/reference there); its own CPU timing, taken in the build container, is profiles/r02_cpu_reference_baseline.json."""
     from oracle import step_oracle as O
-    from tests.helpers import rel_l2  # noqa: F401
     torch.manual_seed(seed)
     N, L, Ttr = cfg["N"], cfg["L"], cfg["T_train"]
     model = make_model(cfg, data)
@@ -88,20 +91,33 @@ def cpu_baseline(cfg, data, seed=0):
     for k, v in p.items():
         if v.is_floating_point() and not k.startswith("tsformer.") and "running_" not in k:
             v.requires_grad_(True)
+    train = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(train, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)
     d = torch.from_numpy(data)
-    t = L + 17
-    ts = [t, t + 301]
-    hist = torch.stack([d[a - 12:a] for a in ts]); fut = torch.stack([d[a:a + 12] for a in ts]); longh = torch.stack([d[a - L:a] for a in ts])
-    u = torch.rand(2, N * N, 2)
+
+    def one_step(i):
+        t = L + 17 + 301 * i
+        hist, fut, longh = d[t - 12:t][None], d[t:t + 12][None], d[t - L:t][None]
+        u = torch.rand(1, N * N, 2)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, cfg["k"], 1, training=True)
+        loss = O.step_loss(O.rescale(pred, 200.0, 150.0), O.rescale(fut[..., [0]], 200.0, 150.0), theta, knn, coef)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
+        opt.step()
+        return time.perf_counter() - t0
     cores = min(os.cpu_count() or 1, 32)          # torch CPU ops stop scaling (and oversubscribe) beyond a few tens of threads
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    pred, theta, knn, coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, cfg["k"], 1, training=True)
-    loss = O.step_loss(O.rescale(pred, 200.0, 150.0), O.rescale(fut[..., [0]], 200.0, 150.0), theta, knn, coef)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": 2.0 / dt, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"2 windows (B=2) of the same workload, fwd+loss+bwd, {dt:.1f} s, torch CPU fp32 oracle"}
+    one_step(0)
+    ts = sorted(one_step(1 + i) for i in range(3))
+    torch.set_num_threads(2)
+    t2 = one_step(4)
+    torch.set_num_threads(cores)
+    return {"value": 1.0 / ts[1], "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"full training steps (fwd+loss+bwd+clip+Adam) of 1 window of the same workload, torch CPU fp32 oracle: 1 warm-up + 3 timed "
+                      f"on {cores} threads ({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median reported), 1 step on 2 threads ({t2:.1f} s)",
+            "two_threads": {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}}
 
 
 def average_grads(params, world):
@@ -190,6 +206,7 @@ def main():
     ap.add_argument("--config", default="STEP_PEMS04", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loader-figure", action="store_true", help="skip the second timed loop through the device-resident window loader")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -278,6 +295,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     model.tsformer._events = []
+    if world > 1:
+        model._reduce_wait_ms = []
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
@@ -287,6 +306,8 @@ def main():
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        model.collect_reduce_waits()
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if world > 1:
         tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -295,6 +316,71 @@ def main():
     ev = model.tsformer._events
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
     model.tsformer._events = None
+    # ---- second figure: the same step fed by the index-only loader over the device-resident series, forecast
+    # origins drawn over the WHOLE training split -- including the windows that start before a full long history exists
+    # (all-zero history, forecasting_dataset.py:66-67: 39 % of PEMS04's training windows) -- gather launches inside the timed region
+    loader_fig = None
+    if not args.forward_only and not args.no_loader_figure:
+        from step_amd.step_arch.step import DeviceWindowLoader
+        loader = DeviceWindowLoader(dser, Lh)
+        n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
+        lrng = np.random.default_rng(4321 + rank)
+        nl = max(args.steps // 2, 10)
+        origins = [torch.from_numpy(lrng.integers(12, 12 + n_train, size=B)).to(dev) for _ in range(nl + 3)]
+        zero_frac = float(np.mean([float((o < Lh).float().mean()) for o in origins[3:]]))
+
+        def loader_step(i):
+            hist, ref, fut = loader.batch(origins[i])
+            opt.zero_grad(set_to_none=True)
+            pred, theta, knn, coef = model(history_data=hist, long_history_data=ref, future_data=None, batch_seen=i, epoch=1)
+            loss = step_loss(pred[..., :1] * std + mean, fut[..., :1] * std + mean, theta, knn, coef, null_val=0.0)
+            loss.backward()
+            if args.torch_optim:
+                torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)
+            opt.step()
+        for i in range(3):
+            loader_step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(nl):
+            loader_step(3 + i)
+        barrier()
+        dtl = time.perf_counter() - t1
+        if world > 1:
+            tdl = torch.tensor([dtl], device=dev, dtype=torch.float64)
+            dist.all_reduce(tdl, op=dist.ReduceOp.MAX)
+            dtl = float(tdl)
+        loader_fig = {"value": B * world * nl / dtl, "unit": "windows/s", "ms_per_step": dtl / nl * 1e3, "steps": nl,
+                      "zero_history_fraction": zero_frac,
+                      "what": "same training step, windows gathered on the device from the resident series by forecast origin "
+                              "(step_gather_windows, LongHistoryRef), origins uniform over the training split"}
+    # ---- data-parallel exchange: the flat-gradient all-reduce alone (isolated) and the part of it the step does not hide
+    comm = None
+    if world > 1 and not args.forward_only:
+        lay = model._grad_layout()
+        fo, fn, _ = lay["items"]["dgl.fc_w"]
+        buf = torch.zeros(lay["total"], device=dev)
+        reps = 5
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(buf[fo:fo + fn]); dist.all_reduce(buf[:fo])
+        e1.record()
+        torch.cuda.synchronize()
+        iso = e0.elapsed_time(e1) / reps
+        exposed = float(np.mean(model._reduce_wait_ms)) if model._reduce_wait_ms else float("nan")
+        t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t_ex) for _ in range(world)]
+        dist.all_gather(gathered, t_ex)
+        comm = {"allreduce_bytes": int(lay["total"] * 4), "chunks": [int(fn * 4), int(fo * 4)],
+                "per_rank_allreduce_ms_isolated": [float(g[0]) for g in gathered],
+                "per_rank_exposed_wait_ms": [float(g[1]) for g in gathered],
+                "overlap_fraction": [float(1.0 - g[1] / g[0]) if float(g[0]) > 0 else None for g in gathered],
+                "what": "isolated = the two chunked all-reduces of the flat gradient alone; exposed = time the compute stream waits "
+                        "for them at the end of backward (events around the waits), averaged over the timed steps"}
     if rank == 0:
         flops = encoder_flops(cfg, B)
         ach = flops / (enc_ms * 1e-3) / 1e12
@@ -315,6 +401,10 @@ def main():
                          "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(args.config, B), "ms_per_launch": enc_ms,
                          "algorithmic_flop_per_launch": flops},
         }
+        if loader_fig is not None:
+            out["device_loader"] = loader_fig
+        if comm is not None:
+            out["data_parallel"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, data)
         print(json.dumps(out), flush=True)

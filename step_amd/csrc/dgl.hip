@@ -535,6 +535,36 @@ int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out,
     return STEP_OK;
 }
 
+// Small scratch block of the backward (floats): [0,128) BatchNorm coefficients, [128,256) column sums of dgpre, [256,288) the two
+// per-channel sums of the fused BatchNorm2 backward, [288,288+1296) this step's raw conv2 weight-gradient sums (fused BatchNorm1)
+constexpr int DGL_SMALL = 256 + 64 + 1344;
+
+// Fused BatchNorm backward (no pass over the activations): coefficients from per-channel sums that come out of the
+// weight-gradient contractions.  With dy = d(BatchNorm output), xhat the normalised input:
+//     S1 = sum dy,  S2 = sum dy * xhat   ->   dbeta += S1, dgamma += S2, coef = [S1/count | S2/count | gamma*rstd]
+// BatchNorm2 (behind the fc): dy = dgpre fc_w is never materialised; the dW GEMM epilogue (GemmFused.dotw) supplies
+//     dots[2c] = sum_{o,k in c} fc_w[o,k] (dgpre^T a2)[o,k],  dots[2c+1] = sum_{o,k in c} fc_w[o,k] colsum(dgpre)[o] = S1,
+//     S2 = rstd_c (dots[2c] - mean_c S1).
+__global__ void bn2_fused_coef_kernel(const float* __restrict__ dots, const float* __restrict__ stat, const float* __restrict__ gamma,
+                                      double count, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    constexpr int C = 16;
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const float S1 = dots[2 * c + 1];
+    const float S2 = stat[3 * C + c] * (dots[2 * c] - stat[2 * C + c] * S1);
+    dgamma[c] += S2;
+    dbeta[c] += S1;
+    coef[c] = (float)(S1 / count);
+    coef[C + c] = (float)(S2 / count);
+    coef[2 * C + c] = gamma[c] * stat[3 * C + c];
+}
+
+// STEP_DGL_LEGACY_BN=1 in the environment keeps the three-pass BatchNorm backward (A/B measurements, debugging)
+static bool dgl_legacy_bn_backward() {
+    const char* e = getenv("STEP_DGL_LEGACY_BN");
+    return e && e[0] == '1';
+}
+
 // =========================================================================================== C ABI
 extern "C" long step_dgl_global_saved_floats(int N, int T) {
     long T1 = T - 9, T2 = T - 18;
@@ -545,7 +575,7 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
     if (!backward) return part;
-    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + 256 + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
+    return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + DGL_SMALL + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
 static void carve_saved(float* saved, int N, int T, float** a1, float** a2, float** gpre, float** st1, float** st2, float** st3) {
@@ -626,7 +656,11 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
     float* dgpre = wraw + (long)EMB * K;
     float* dgpreT = dgpre + (long)N * EMB;
     float* coef = dgpreT + (long)N * EMB;
-    float* wg_scratch = coef + 256;
+    float* dots = coef + 256;            // written by phase 1 (dW GEMM epilogue), read by phase 2
+    float* graw = coef + 320;
+    float* wg_scratch = coef + DGL_SMALL;
+    // BatchNorm2 backward without its two passes over d_a2 / a2 (1.3 GB at PEMS04): needs a tile to span at most two channels
+    const bool fuse2 = T2 >= 128 && !dgl_legacy_bn_backward();
     if (do_fc) {
         // BN3 + ReLU backward, fc bias gradient
         float* colsum = coef + 128;          // column sums of dgpre [EMB] (coef holds 3 x 16 BatchNorm coefficients at most)
@@ -639,19 +673,32 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
             gm.accumulate = 1;
             gm.c_nscale = st2; gm.c_nshift = st2 + 16; gm.c_nperiod = T2; gm.c_mvec = colsum;
             gm.compute_bf16 = p->gemm_bf16;
-            STEP_TRY(step_gemm_launch(gm, st));
+            if (fuse2) {
+                if (hipMemsetAsync(dots, 0, 32 * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+                GemmFused fu = {p->fc_w, dots, nullptr, nullptr, nullptr, 16, T2};
+                STEP_TRY(step_gemm_launch_fused(gm, fu, st));
+            } else {
+                STEP_TRY(step_gemm_launch(gm, st));
+            }
         }
     }
     if (!do_rest) return STEP_OK;
     // d(BN2 output) = dgpre @ fc_w
     {
         StepGemm gm = gemm_desc(N, (int)K, EMB, dgpreT, 1, N, p->fc_w, K, 1, d_a2, K);     // A(m=n, k=o) = dgpreT[o][n]
-        if (p->gemm_bf16) { gm.A = dgpre; gm.sam = EMB; gm.sak = 1; }                      // LDS-staged path: k-contiguous rows
+        if (p->gemm_bf16 || fuse2) { gm.A = dgpre; gm.sam = EMB; gm.sak = 1; }             // LDS-staged path: k-contiguous rows
         gm.compute_bf16 = p->gemm_bf16;
-        STEP_TRY(step_gemm_launch(gm, st));
+        if (fuse2) {       // coefficients from the sums of phase 1, BatchNorm2 backward + ReLU mask in the GEMM's epilogue: writes dz2
+            bn2_fused_coef_kernel<<<1, 64, 0, st>>>(dots, st2, p->bn2_w, (double)N * T2, grads->bn2_w, grads->bn2_b, coef);
+            STEP_LAUNCH_CHECK("bn2_fused_coef");
+            GemmFused fu = {nullptr, nullptr, a2, coef, st2, 16, T2};
+            STEP_TRY(step_gemm_launch_fused(gm, fu, st));
+        } else {
+            STEP_TRY(step_gemm_launch(gm, st));
+        }
     }
     // BN2 backward (+ReLU mask) in place -> dz2
-    {
+    if (!fuse2) {
         dim3 grid(cdiv(T2, 1024), 16, N);
         bn_bwd_reduce_kernel<16><<<grid, 256, 0, st>>>(d_a2, a2, st2, T2, partial);
         STEP_LAUNCH_CHECK("bn2_bwd_reduce");
@@ -661,9 +708,16 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
         STEP_LAUNCH_CHECK("bn2_bwd_apply");
     }
     // conv2 backward: weights (BN1 affine folded into the input read) and data
-    if (p->gemm_bf16) {
+    // bf16 mode: BatchNorm1's backward is fused as well -- its sums come out of the conv2 weight-gradient contraction, its
+    // transform rides in the epilogue of the conv2 data gradient (no pass over d_a1 / a1)
+    const bool fuse1 = p->gemm_bf16 && !dgl_legacy_bn_backward();
+    if (fuse1) {
+        STEP_TRY(dgl_conv2_wgrad_bn1_mfma(d_a2, a1, st1, p->conv2_w, p->bn1_w, p->bn1_b, wg_scratch, graw, grads->conv2_w, grads->conv2_b,
+                                          grads->bn1_w, grads->bn1_b, coef + 64, N, T1, st));
+        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, a1, coef + 64, st1, st));
+    } else if (p->gemm_bf16) {
         STEP_TRY(dgl_conv2_wgrad_mfma(d_a2, a1, st1, st1 + 8, wg_scratch, grads->conv2_w, grads->conv2_b, N, T1, st));
-        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, st));
+        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, nullptr, nullptr, nullptr, st));
     } else {
         conv_bwd_weight_kernel<8, 16><<<N, 256, 0, st>>>(d_a2, a1, st1, st1 + 8, grads->conv2_w, grads->conv2_b, T1);
         STEP_LAUNCH_CHECK("conv2_bwd_weight");
@@ -671,7 +725,7 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
         STEP_LAUNCH_CHECK("conv2_bwd_data");
     }
     // BN1 backward in place -> dz1
-    {
+    if (!fuse1) {
         dim3 grid(cdiv(T1, 1024), 8, N);
         bn_bwd_reduce_kernel<8><<<grid, 256, 0, st>>>(d_a1, a1, st1, T1, partial);
         STEP_LAUNCH_CHECK("bn1_bwd_reduce");

@@ -97,8 +97,11 @@ __global__ __launch_bounds__(256) void conv2_fwd_mfma_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------ dgrad
 // d_a1[n][ci][t] = sum_{co,kk} w[co][ci][kk] * dz[n][co][t-kk]      (dz = 0 outside [0, T2))
 // k index = kk*16 + co (five 32-wide steps); rows m = ci (8 of the 16 MFMA rows are used).
+// bnx != nullptr: fused BatchNorm1 backward -- what is stored is dz1 = [x > 0] * coef[2C+c] * (d_a1 - coef[c] - (x - mean_c) * rstd_c * coef[C+c])
+// with x = bnx (= a1, laid out like din), coef = [m1 | m2 | gamma*rstd], stat = [scale | shift | mean | rstd], C = 8.
 __global__ __launch_bounds__(256) void conv2_dgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ w,
-                                                               float* __restrict__ din, int T1) {
+                                                               float* __restrict__ din, int T1, const float* __restrict__ bnx,
+                                                               const float* __restrict__ coef, const float* __restrict__ stat) {
     __shared__ uint4 zs[FW_TT + 16][2];           // [t - (t0 - 9)][16 co] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
     const int T2 = T1 - (KW - 1), t0 = blockIdx.x * FW_TT;
@@ -133,8 +136,19 @@ __global__ __launch_bounds__(256) void conv2_dgrad_mfma_kernel(const float* __re
         }
         const int t = t0 + tb + ln;
         if (t < T1 && q < 2) {
+            if (bnx) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) din[((long)n * CI + 4 * q + e) * T1 + t] = acc[e];
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    const long idx = ((long)n * CI + c) * T1 + t;
+                    const float x = bnx[idx];
+                    const float v = coef[2 * CI + c] * (acc[e] - coef[c] - (x - stat[2 * CI + c]) * stat[3 * CI + c] * coef[CI + c]);
+                    din[idx] = x > 0.f ? v : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) din[((long)n * CI + 4 * q + e) * T1 + t] = acc[e];
+            }
         }
     }
 }
@@ -147,9 +161,12 @@ constexpr int WG_SC = 256;               // time steps staged per pass
 constexpr int WG_PASSES = 14;            // passes per workgroup (3584 steps)
 constexpr int WG_OUT = CO * CI * KW + CO;
 
+// xhat != 0: the input is read NORMALISED (sc / sh then point at BatchNorm1's [scale | shift | mean | rstd] block and
+// (a1 - mean) * rstd is used): the result is G'[co][ci][kk] = sum dz * xhat, from which conv2_wgrad_finish_kernel forms both the
+// weight gradient gamma * G' + beta * db and BatchNorm1's backward sums.
 __global__ __launch_bounds__(256) void conv2_wgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ a1,
                                                                const float* __restrict__ sc, const float* __restrict__ sh,
-                                                               float* __restrict__ partial, int T1) {
+                                                               float* __restrict__ partial, int T1, int xhat) {
     constexpr int ZP = WG_SC + 8;        // bf16 elements per row (16-byte multiple)
     constexpr int XP = WG_SC + 16;
     __shared__ __attribute__((aligned(16))) uint16_t zs[CO][ZP];
@@ -161,7 +178,10 @@ __global__ __launch_bounds__(256) void conv2_wgrad_mfma_kernel(const float* __re
     const int ln = lane & 15, q = lane >> 4;
     float s8[CI], h8[CI];
 #pragma unroll
-    for (int ci = 0; ci < CI; ++ci) { s8[ci] = sc[ci]; h8[ci] = sh[ci]; }
+    for (int ci = 0; ci < CI; ++ci) {
+        if (xhat) { s8[ci] = sc[3 * CI + ci]; h8[ci] = -sc[2 * CI + ci] * sc[3 * CI + ci]; }
+        else { s8[ci] = sc[ci]; h8[ci] = sh[ci]; }
+    }
 
     f32x4 acc[5];
 #pragma unroll
@@ -270,6 +290,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// Fused BatchNorm1 backward, coefficient step (one block).  graw = this step's sums over nodes and time
+// G'[co][ci][kk] = sum dz2 * xhat1 (1280 numbers) followed by db2[co] = sum dz2 (16).  With y1 = gamma xhat1 + beta the input of conv2:
+//     d conv2_w = gamma[ci] G' + beta[ci] db2[co],  d conv2_b = db2,
+//     S1[ci] = sum d_y1 = sum_{co,kk} w[co][ci][kk] db2[co],   S2[ci] = sum d_y1 xhat1 = sum_{co,kk} w[co][ci][kk] G'[co][ci][kk]
+// (exact: d_y1 is the full correlation of dz2 with w, every dz2 element meets every tap inside the valid range), hence
+// BatchNorm1's dbeta += S1, dgamma += S2 and coef = [S1/count | S2/count | gamma*rstd] without a pass over d_a1 and a1.
+__global__ __launch_bounds__(256) void conv2_wgrad_finish_kernel(const float* __restrict__ graw, const float* __restrict__ w,
+                                                                 const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, double count, float* __restrict__ dw,
+                                                                 float* __restrict__ db, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ float r1[CI][32], r2[CI][32];
+    const int tid = threadIdx.x;
+    const int ci = tid >> 5, sub = tid & 31;                 // 8 channels x 32 threads, 5 (co, kk) pairs each
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = sub; i < CO * KW; i += 32) {
+        const int co = i / KW, kk = i % KW;
+        const int idx = (co * CI + ci) * KW + kk;
+        const float g = graw[idx], d = graw[CO * CI * KW + co], wv = w[idx];
+        dw[idx] += gamma[ci] * g + beta[ci] * d;
+        s1 += wv * d;
+        s2 += wv * g;
+    }
+    r1[ci][sub] = s1; r2[ci][sub] = s2;
+    if (tid < CO) db[tid] += graw[CO * CI * KW + tid];
+    __syncthreads();
+    if (tid < CI) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < 32; ++i) { a += r1[tid][i]; b += r2[tid][i]; }
+        dbeta[tid] += a;
+        dgamma[tid] += b;
+        coef[tid] = (float)(a / count);
+        coef[CI + tid] = (float)(b / count);
+        coef[2 * CI + tid] = gamma[tid] * stat[3 * CI + tid];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ conv1 wgrad
 // dw1[co][kk] += sum_{n,t} dz1[n][co][t] * x[n][t+kk],  db1[co] += sum dz1     (conv1: 1 -> 8 channels, no input affine)
 // Same scheme as conv2: m = co (8 of 16 rows), n = tap (10 of 16 columns), k = 32 time steps per MFMA.
@@ -364,8 +421,9 @@ int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const fl
     return STEP_OK;
 }
 
-int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, hipStream_t st) {
-    conv2_dgrad_mfma_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>(dz, w, din, T1);
+int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, const float* bnx, const float* coef, const float* stat,
+                         hipStream_t st) {
+    conv2_dgrad_mfma_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>(dz, w, din, T1, bnx, coef, stat);
     STEP_LAUNCH_CHECK("conv2_dgrad_mfma");
     return STEP_OK;
 }
@@ -379,10 +437,27 @@ int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, cons
                          int T1, hipStream_t st) {
     const int T2 = T1 - (KW - 1);
     dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
-    conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, sc, sh, scratch, T1);
+    conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, sc, sh, scratch, T1, 0);
     STEP_LAUNCH_CHECK("conv2_wgrad_mfma");
     conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, dw, db);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
+    return STEP_OK;
+}
+
+// conv2 weight / bias gradient together with the fused BatchNorm1 backward's coefficient step (see conv2_wgrad_finish_kernel):
+// stat1 = BatchNorm1's [scale | shift | mean | rstd], graw = 1296 floats of scratch, coef1 out (24 floats)
+int dgl_conv2_wgrad_bn1_mfma(const float* dz, const float* a1, const float* stat1, const float* w, const float* gamma1, const float* beta1,
+                             float* scratch, float* graw, float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, int N, int T1,
+                             hipStream_t st) {
+    const int T2 = T1 - (KW - 1);
+    dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
+    if (hipMemsetAsync(graw, 0, WG_OUT * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+    conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, stat1, nullptr, scratch, T1, 1);
+    STEP_LAUNCH_CHECK("conv2_wgrad_mfma(xhat)");
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
+    STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
+    conv2_wgrad_finish_kernel<<<1, 256, 0, st>>>(graw, w, stat1, gamma1, beta1, (double)N * T1, dw, db, dgamma1, dbeta1, coef1);
+    STEP_LAUNCH_CHECK("conv2_wgrad_finish");
     return STEP_OK;
 }
 

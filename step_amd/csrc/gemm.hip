@@ -479,6 +479,18 @@ int step_gemm_launch(StepGemm g, hipStream_t st) {
     return launch<128, 128, 2, 2>(g, st);
 }
 
+int step_gemm_launch_fused(StepGemm g, const GemmFused& fused, hipStream_t st) {
+    STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0 && g.batch == 1 && g.A && g.B && g.C, "step_gemm(fused): bad descriptor");
+    STEP_REQUIRE(fused.channels > 0 && fused.period > 0 && (long)fused.channels * fused.period == g.N, "step_gemm(fused): N != channels * period");
+    if (g.scn == 0) g.scn = 1;
+    if (g.splitk < 1) g.splitk = 1;
+    if (g.c_nscale) STEP_REQUIRE(g.c_nshift && g.c_mvec && g.c_nperiod == fused.period, "step_gemm(fused): column affine must use the same period");
+    if (g.compute_bf16) return step_gemm_bf16_launch(g, st, &fused);
+    const int rc = step_gemm_f32_fast_launch(g, st, &fused);
+    if (rc == -1) { step_set_error("step_gemm(fused): operands do not qualify for the staged path"); return STEP_ERR_ARG; }
+    return rc;
+}
+
 extern "C" int step_gemm(const StepGemm* g, void* stream) {
     STEP_REQUIRE(g != nullptr, "step_gemm: null descriptor");
     return step_gemm_launch(*g, (hipStream_t)stream);

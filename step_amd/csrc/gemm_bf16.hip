@@ -242,12 +242,13 @@ constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64
 struct FastArgs {
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
     int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
+    GemmFused fu;                      // fused epilogues of the DGL fc backward (step_internal.h); all-null = off
 };
 
 // the LDS-staged epilogue pays off for large dense outputs only (two extra barriers and an LDS round trip per tile)
-static int wide_store_ok(const StepGemm& g) {
+static int wide_store_ok(const StepGemm& g, bool force = false) {
     return g.accumulate != 2 && !g.a_rowsum && g.c_nblk == 0 && g.scn == 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && g.scb % 4 == 0 &&
-           g.scb1 % 4 == 0 && ((uintptr_t)g.C & 15) == 0 && (long)g.M * g.N * g.batch >= (4L << 20);
+           g.scb1 % 4 == 0 && ((uintptr_t)g.C & 15) == 0 && (force || (long)g.M * g.N * g.batch >= (4L << 20));
 }
 
 // no remap is encoded as lg = 30, stride = 0 (i >> 30 == 0): branch-free
@@ -503,6 +504,85 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     }
 
     float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+    if (fa.wide_store && (fa.fu.dotw || fa.fu.bnx)) {
+        // Wide-store epilogue with the fused pieces of the DGL BatchNorm2 backward (GemmFused, step_internal.h).  The RAW
+        // alpha * A.B tile is staged; the column-block affine, the per-channel reductions against W and the BatchNorm-backward
+        // transform run in the piece loop, where a thread holds 4 consecutive columns of one row.  A tile spans at most two
+        // channels (period >= BN, checked on the host).
+        constexpr int TP = BN + 4;
+        static_assert(BM * TP * 4 <= 2 * BUF, "staging tile must fit in the operand buffers");
+        __shared__ float fred[4][4];
+        float* tile = (float*)lds;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cn = wc * (TN * 32) + j * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rm = wr * (TM * 32) + i * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+                    tile[rm * TP + cn] = g.alpha * acc[i][j][e];
+                }
+            }
+        __syncthreads();
+        const GemmFused& fu = fa.fu;
+        const int c_lo = n0 / fu.period, nb = (c_lo + 1) * fu.period, C = fu.channels;
+        float cs[2] = {1.f, 1.f}, csh[2] = {0.f, 0.f}, kk[2], m1[2], m2r[2], mu[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c_lo + j < C ? c_lo + j : C - 1;
+            if (g.c_nscale) { cs[j] = g.c_nscale[c]; csh[j] = g.c_nshift[c]; }
+            if (fu.bnx) { m1[j] = fu.bncoef[c]; m2r[j] = fu.bncoef[C + c] * fu.bnstat[3 * C + c]; kk[j] = fu.bncoef[2 * C + c]; mu[j] = fu.bnstat[2 * C + c]; }
+        }
+        float dw[2] = {0.f, 0.f}, dm[2] = {0.f, 0.f};
+        constexpr int PIECES = BM * BN / 4;
+#pragma unroll 2
+        for (int pc = tid; pc < PIECES; pc += 256) {
+            const int rm = pc / (BN / 4), c4 = (pc % (BN / 4)) * 4;
+            const int gm = m0 + rm, gn = n0 + c4;
+            if (gm >= g.M || gn >= g.N) continue;
+            const float4 t4 = *(const float4*)(tile + rm * TP + c4);
+            float v[4] = {t4.x, t4.y, t4.z, t4.w};
+            const long off = (long)gm * g.ldc + gn;
+            const float mv = g.c_mvec ? g.c_mvec[gm] : 0.f;
+            if (fu.dotw) {
+                const float4 w4 = *(const float4*)(fu.dotw + off);
+                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; dw[j] += w[i] * v[i]; dm[j] += w[i] * mv; }
+            }
+            if (g.c_nscale) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; v[i] = v[i] * cs[j] + csh[j] * mv; }
+            }
+            if (fu.bnx) {
+                const float4 x4 = *(const float4*)(fu.bnx + off);
+                const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = gn + i >= nb;
+                    v[i] = x[i] > 0.f ? kk[j] * (v[i] - m1[j] - (x[i] - mu[j]) * m2r[j]) : 0.f;
+                }
+            }
+            float4* dst = (float4*)(Cb + off);
+            float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+            if (g.accumulate == 1) { const float4 o = *dst; o4.x += o.x; o4.y += o.y; o4.z += o.z; o4.w += o.w; }
+            *dst = o4;
+        }
+        if (fu.dotw) {
+            float q4[4] = {dw[0], dm[0], dw[1], dm[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q4[i] = wave_sum(q4[i]);
+            if (lane == 0) { fred[wave][0] = q4[0]; fred[wave][1] = q4[1]; fred[wave][2] = q4[2]; fred[wave][3] = q4[3]; }
+            __syncthreads();
+            if (tid < 4) {
+                const int c = c_lo + (tid >> 1);
+                if (c < C) atomicAdd(fu.dots + 2 * c + (tid & 1), fred[0][tid] + fred[1][tid] + fred[2][tid] + fred[3][tid]);
+            }
+        }
+        return;
+    }
     if (fa.wide_store) {
         // Store / read-modify-write epilogue through LDS: the accumulator layout has 32 consecutive columns per wave
         // instruction (128-byte runs); staged as a [BM][BN] f32 tile, every thread instead moves 16-byte pieces of whole rows
@@ -619,15 +699,19 @@ int launch_bf16(const StepGemm& g, hipStream_t st) {
 
 }  // namespace
 
-int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
+int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     FastArgs fa;
+    memset(&fa.fu, 0, sizeof(fa.fu));
+    if (fused) fa.fu = *fused;
     int dummy;
     const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, g.b_bf16, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog,
                                 &fa.b_nlog);
     const bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
                 !(g.a_rowsum && bmode == KC_BF16);
-    fa.wide_store = wide_store_ok(g);
+    fa.wide_store = wide_store_ok(g, fused != nullptr);
+    if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 && fused->period >= 128,
+                            "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
@@ -649,14 +733,17 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st) {
 
 // Exact-f32 GEMM through the same staged pipeline (64 x 64 tiles).  Returns -1 when the operands do not qualify
 // (alignment / layout), in which case the caller falls back to the general kernels of gemm.hip.
-int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st) {
+int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     if (g.a_bf16 || g.b_bf16) return -1;
     FastArgs fa;
+    memset(&fa.fu, 0, sizeof(fa.fu));
+    if (fused) fa.fu = *fused;
     int dummy;
     const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, 0, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog, &fa.b_nlog);
     if (amode < 0 || bmode < 0 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
-    fa.wide_store = wide_store_ok(g);
+    fa.wide_store = wide_store_ok(g, fused != nullptr);
+    if (fused && !(fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 && fused->period >= 128)) return -1;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         long tiles = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;

@@ -3,9 +3,24 @@
 #include <hip/hip_runtime.h>
 #include "../../include/step_hip.h"
 
+// Fused epilogues of the DiscreteGraphLearning fc backward, internal to the library (wide-store epilogue of the staged GEMM).
+// The result C [M, N] has `channels` column blocks of `period` columns (N = channels * period).
+//   dotw / dots: dots[2c] += sum_{m, n in block c} W[m][n] * (alpha A.B)[m][n],  dots[2c+1] += sum W[m][n] * c_mvec[m]
+//                (W laid out like C).  With A.B = dgpre^T a2 and W = fc.weight these are the two sums the BatchNorm2 backward needs
+//                (sum dy, sum dy*xhat over nodes and time) without ever materialising dy = dgpre fc.weight -- see dgl.hip.
+//   bnx ...:     the stored value becomes the BatchNorm-backward of the result, masked by the ReLU in front of the BatchNorm:
+//                C = x > 0 ? coef[2C+c] * (v - coef[c] - (x - stat[2C+c]) * stat[3C+c] * coef[C+c]) : 0,  x = bnx[m][n] (laid out like C)
+//                coef = [m1 | m2 | gamma*rstd], stat = [scale | shift | mean | rstd], C = channels.
+struct GemmFused {
+    const float* dotw; float* dots;
+    const float* bnx; const float* bncoef; const float* bnstat;
+    int channels, period;
+};
+
 int step_gemm_launch(StepGemm g, hipStream_t st);
-int step_gemm_bf16_launch(StepGemm g, hipStream_t st);
-int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st);      // -1: operands do not qualify
+int step_gemm_launch_fused(StepGemm g, const GemmFused& fused, hipStream_t st);      // STEP_ERR_ARG (message set) when the operands do not qualify
+int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused = nullptr);
+int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused = nullptr);      // -1: operands do not qualify
 
 // convenience builder for the common dense cases (f32 operands, batch 1)
 static inline StepGemm gemm_desc(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbk,
@@ -25,7 +40,11 @@ int step_gemm_rowsum_separate(StepGemm* g, hipStream_t st);
 // bf16 matrix-core conv2 stage of the DGL (dgl_conv_mfma.hip)
 int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
                        int N, int T1, int* nblk, hipStream_t st);
-int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, hipStream_t st);
+int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, const float* bnx, const float* coef, const float* stat,
+                         hipStream_t st);
+int dgl_conv2_wgrad_bn1_mfma(const float* dz, const float* a1, const float* stat1, const float* w, const float* gamma1, const float* beta1,
+                             float* scratch, float* graw, float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, int N, int T1,
+                             hipStream_t st);
 long dgl_conv2_wgrad_scratch_floats(int N, int T1);
 int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
                          int T1, hipStream_t st);

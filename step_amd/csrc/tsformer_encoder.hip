@@ -530,16 +530,20 @@ int launch_enc(const EncArgs& a, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------
 // Dropout pool: word w = 64 Bernoulli(keep) bits, bit l <- Philox4x32-10(counter (w, l / 4), key seed) word l % 4 >= drop * 2^32.
+// One thread per Philox call (4 bits), 16 threads per word; the nibbles are OR-combined with four xor-shuffles.
 __global__ __launch_bounds__(256) void dropout_pool_kernel(unsigned long long* __restrict__ pool, long words, uint32_t thresh,
                                                            uint32_t k0, uint32_t k1) {
-    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per word, one lane per bit
-    if (w >= words) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t r[4];
-    philox4x32((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)(lane >> 2), 0x5EEDD80Fu, k0, k1, r);
-    const uint32_t x = r[lane & 3];
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(x >= thresh);
-    if (lane == 0) pool[w] = m;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long w = id >> 4;
+    const int q = (int)(id & 15);
+    uint32_t r[4] = {0u, 0u, 0u, 0u};
+    if (w < words) philox4x32((uint32_t)w, (uint32_t)(w >> 32), (uint32_t)q, 0x5EEDD80Fu, k0, k1, r);
+    const uint32_t nib = (r[0] >= thresh ? 1u : 0u) | (r[1] >= thresh ? 2u : 0u) | (r[2] >= thresh ? 4u : 0u) | (r[3] >= thresh ? 8u : 0u);
+    unsigned long long m = (unsigned long long)nib << (4 * q);
+    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { lo |= __shfl_xor(lo, o, 64); hi |= __shfl_xor(hi, o, 64); }
+    if (q == 0 && w < words) pool[w] = ((unsigned long long)hi << 32) | lo;
 }
 
 }  // namespace
@@ -549,7 +553,7 @@ extern "C" int step_dropout_pool_fill(uint64_t* pool, long words, float dropout_
     STEP_REQUIRE(words >= 16 && (words & (words - 1)) == 0, "dropout_pool_fill: %ld words is not a power of two >= 16", words);
     STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_pool_fill: bad dropout %f", dropout_p);
     const uint32_t thresh = (uint32_t)((double)dropout_p * 4294967296.0);
-    dropout_pool_kernel<<<cdiv(words, 4), 256, 0, (hipStream_t)stream>>>((unsigned long long*)pool, words, thresh, (uint32_t)seed,
+    dropout_pool_kernel<<<cdiv(words, 16), 256, 0, (hipStream_t)stream>>>((unsigned long long*)pool, words, thresh, (uint32_t)seed,
                                                                          (uint32_t)(seed >> 32));
     STEP_LAUNCH_CHECK("step_dropout_pool_fill");
     return STEP_OK;

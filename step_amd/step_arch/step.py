@@ -195,6 +195,8 @@ class STEP(nn.Module):
         self._last = {}
         self._flat_param = None
         self._flat_grad = None
+        self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
+        self._reduce_events = []
 
     def load_pre_trained_model(self):
         """step.py:27-35: load {"model_state_dict": ...} and freeze."""
@@ -272,13 +274,29 @@ class STEP(nn.Module):
         return [dist.all_reduce(chunk, group=self._process_group, async_op=True)]
 
     def _reduce_finish(self, flat, pending):
-        """Wait for the chunks and turn the sums into means."""
+        """Wait for the chunks and turn the sums into means.  With ``_reduce_wait_ms`` set to a list (bench.py), the time the
+        compute stream spends waiting for the collectives is recorded with events (read after a synchronize)."""
         if not pending:
             return
         import torch.distributed as dist
+        timed = self._reduce_wait_ms is not None and flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in pending:
             w.wait()
+        if timed:
+            e1.record()
+            self._reduce_events.append((e0, e1))
         flat.mul_(1.0 / dist.get_world_size(self._process_group))
+
+    def collect_reduce_waits(self):
+        """ms the compute stream waited for the gradient all-reduce in each backward since the last call (needs a synchronize)."""
+        out = [a.elapsed_time(b) for a, b in self._reduce_events]
+        self._reduce_events = []
+        if self._reduce_wait_ms is not None:
+            self._reduce_wait_ms.extend(out)
+        return out
 
     def _reduce_flat_grads(self, flat):
         self._reduce_finish(flat, self._reduce_begin(flat))

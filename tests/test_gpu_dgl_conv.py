@@ -78,3 +78,42 @@ def test_dgl_global_bf16_mode_vs_f32_mode(N, T):
     for k in ("conv2_w", "conv1_w", "fc_w"):
         assert errs[k] < 0.12, errs
     assert max(errs.values()) < 0.3, errs
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("N,T", [(150, 2100), (64, 4000)])
+def test_dgl_fused_batchnorm_backward_matches_three_pass(N, T, bf16, monkeypatch):
+    """The BatchNorm backward passes are fused away (dgl.hip: the two per-channel sums come out of the weight-gradient
+    contractions -- exactly, see conv2_wgrad_finish_kernel / bn2_fused_coef_kernel --, the transform rides in the epilogue of the
+    kernel that produces the incoming gradient).  STEP_DGL_LEGACY_BN=1 keeps the three-pass form (reduce, finalize, apply):
+    same gradients up to summation order in exact-f32 mode, up to the bf16 rounding of the two sums in bf16 mode."""
+    from step_amd import _lib as L
+    from step_amd.step_arch.discrete_graph_learning import fill_dgl_struct
+    gen = torch.Generator().manual_seed(N + T)
+    tt = torch.arange(T, dtype=torch.float32)
+    series = (torch.sin(2 * 3.14159265 * tt[None, :] / 288.0 + 6.28 * torch.rand(N, 1, generator=gen)) + 0.3 * torch.randn(N, T, generator=gen)).cuda()
+    K = 16 * (T - 18)
+    t = {"conv1_w": torch.randn(8, 1, 10, generator=gen) * 0.3, "conv1_b": torch.randn(8, generator=gen) * 0.1,
+         "conv2_w": torch.randn(16, 8, 10, generator=gen) * 0.1, "conv2_b": torch.randn(16, generator=gen) * 0.1,
+         "fc_w": torch.randn(100, K, generator=gen) * (1.0 / K ** 0.5), "fc_b": torch.randn(100, generator=gen) * 0.1,
+         "bn1_w": torch.rand(8, generator=gen) + 0.5, "bn1_b": torch.randn(8, generator=gen) * 0.1,
+         "bn2_w": torch.rand(16, generator=gen) + 0.5, "bn2_b": torch.randn(16, generator=gen) * 0.1,
+         "bn3_w": torch.rand(100, generator=gen) + 0.5, "bn3_b": torch.randn(100, generator=gen) * 0.1,
+         "bn1_rm": torch.zeros(8), "bn1_rv": torch.ones(8), "bn2_rm": torch.zeros(16), "bn2_rv": torch.ones(16),
+         "bn3_rm": torch.zeros(100), "bn3_rv": torch.ones(100),
+         "fc_out_w": torch.zeros(100, 200), "fc_out_b": torch.zeros(100), "fc_cat_w": torch.zeros(2, 100), "fc_cat_b": torch.zeros(2)}
+    t = {k: v.cuda().contiguous() for k, v in t.items()}
+    trainable = {k: v for k, v in t.items() if not (k.endswith("_rm") or k.endswith("_rv"))}
+    dg = torch.randn(N, 100, generator=gen).cuda()
+    monkeypatch.setenv("STEP_DGL_LEGACY_BN", "1")
+    _, legacy = _run(L, series, t, trainable, dg, bf16, fill_dgl_struct)
+    monkeypatch.setenv("STEP_DGL_LEGACY_BN", "0")
+    _, fused = _run(L, series, t, trainable, dg, bf16, fill_dgl_struct)
+    errs = {k: rel_l2(fused[k].cpu(), legacy[k].cpu()) for k in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "bn1_w", "bn1_b", "bn2_w", "bn2_b", "fc_w")}
+    print(f"N={N} T={T} bf16={bf16}: fused vs three-pass BatchNorm backward, gradient rel-L2:", {k: f"{v:.1e}" for k, v in errs.items()})
+    if not bf16:
+        assert max(errs.values()) < 5e-4, errs
+    else:
+        for k in ("conv1_w", "conv2_w", "fc_w", "bn1_w", "bn2_w"):
+            assert errs[k] < 5e-2, errs
+        assert max(errs.values()) < 0.3, errs

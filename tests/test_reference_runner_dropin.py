@@ -161,7 +161,8 @@ def test_reference_runner_trains_native_module(workspace):
                     n.startswith("backend.gconv.7") or n.startswith("discrete_graph_learning.fc_mean")}
     assert moved == set(before) - dead
     rec = {"dataset": DS, "origins": origins[:4], "losses": losses, "train_MAE_first": mae0, "cl_length": 1, "gumbel_seed": GUMBEL_SEED,
-           "init_seed": 0, "optimizer": {"lr": 0.002, "weight_decay": 1.0e-5, "eps": 1.0e-8, "max_norm": 3.0}}
+           "init_seed": 0, "optimizer": dict(cfg.TRAIN.OPTIM.PARAM, max_norm=cfg.TRAIN.CLIP_GRAD_PARAM["max_norm"])}
+    assert cfg.TRAIN.OPTIM.TYPE == "Adam" and rec["optimizer"] == {"lr": 0.005, "weight_decay": 1.0e-5, "eps": 1.0e-8, "max_norm": 3.0}
     if os.environ.get("STEP_WRITE_GOLDEN") == "1":
         with open(GOLDEN, "w") as f:
             json.dump(rec, f, indent=1)
