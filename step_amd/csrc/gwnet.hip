@@ -212,20 +212,39 @@ __global__ void softmax_relu_bwd_kernel(const float* __restrict__ M, const float
     dM[idx] = M[idx] > 0.f ? P[idx] * (dP[idx] - rdot[i]) : 0.f;
 }
 
-// gated-TCN weights [32,32,1,2] x2 -> Wcat[64 out][64 in] (in = tap*32 + c), bias[64]; all 8 layers in one launch (grid.y)
+// Weight packing, one launch: gated-TCN weights [32,32,1,2] x2 -> Wcat[64 out][64 in] (in = tap*32 + c) + its transpose,
+// bias[64] (blocks [0, 128): layer = block / 16); the 8 skip convolutions as one [256 out][8*32 in] matrix and the sum of
+// their biases (blocks [128, 384): one output row each); the 7 gcn mix weights transposed [224][32] (blocks [384, 580)).
 struct GatePtrs { float *wf[8], *bf[8], *wg[8], *bg[8]; };
-__global__ void pack_gate_kernel(GatePtrs P, float* __restrict__ wcat_all, float* __restrict__ bcat_all) {
-    const int L = blockIdx.y;
-    const float *wf = P.wf[L], *bf = P.bf[L], *wg = P.wg[L], *bg = P.bg[L];
-    float* wcat = wcat_all + L * 4096;
-    float* bcat = bcat_all + L * 64;
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < 64 * 64) {
-        int o = idx / 64, k = idx % 64;
-        const float* src = o < 32 ? wf : wg;
-        wcat[idx] = src[(((o & 31) * 32) + (k & 31)) * 2 + (k >> 5)];
+struct SkipPtrs { float *w[8], *b[8]; };
+struct MixPtrs { const float* w[7]; };
+__global__ __launch_bounds__(256) void pack_weights_kernel(GatePtrs P, SkipPtrs K, MixPtrs M, float* __restrict__ wcat_all,
+                                                           float* __restrict__ wcatT_all, float* __restrict__ bcat_all,
+                                                           float* __restrict__ wskip, float* __restrict__ bsum, float* __restrict__ wmixT) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk < 128) {
+        const int L = blk >> 4;
+        const int idx = (blk & 15) * 256 + tid;
+        const int o = idx / 64, k = idx % 64;
+        const float v = (o < 32 ? P.wf[L] : P.wg[L])[(((o & 31) * 32) + (k & 31)) * 2 + (k >> 5)];
+        wcat_all[L * 4096 + idx] = v;
+        wcatT_all[L * 4096 + k * 64 + o] = v;
+        if (idx < 64) bcat_all[L * 64 + idx] = idx < 32 ? P.bf[L][idx] : P.bg[L][idx - 32];
+    } else if (blk < 384) {
+        const int o = blk - 128, k = tid;
+        wskip[o * CS + k] = K.w[k >> 5][o * C + (k & 31)];
+        if (o == 0) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += K.b[i][k];
+            bsum[k] = sum;
+        }
+    } else {
+        const int L = (blk - 384) / 28;
+        const int idx = ((blk - 384) % 28) * 256 + tid;             // = c * 224 + j
+        const int c = idx / CAT, j = idx % CAT;
+        wmixT[L * (C * CAT) + j * C + c] = M.w[L][idx];
     }
-    if (idx < 64) bcat[idx] = idx < 32 ? bf[idx] : bg[idx - 32];
 }
 __global__ void unpack_gate_grad_kernel(const float* __restrict__ dwcat_all, const float* __restrict__ dbcat_all, GatePtrs G) {
     const int L = blockIdx.y;
@@ -240,182 +259,419 @@ __global__ void unpack_gate_grad_kernel(const float* __restrict__ dwcat_all, con
     }
     if (idx < 64) { if (idx < 32) dbf[idx] += dbcat[idx]; else dbg[idx - 32] += dbcat[idx]; }
 }
-// xcat[(bn,t)][tap*32 + c] = x[bn][t + tap*dil][c]
-__global__ void im2col_kernel(const float* __restrict__ x, long BN, int Tin, int Tout, int dil, float* __restrict__ xcat) {
+// ---------------------------------------------------------------------------- fused layer kernels
+// The input of layer i >= 1 is BatchNorm_{i-1}(y_{i-1}) and is never materialised: every consumer applies the two per-channel
+// numbers scale / shift on the fly (stat == nullptr: layer 0, the start conv's output as is).
+struct XIn { const float* src; const float* stat; };
+
+// Operand loads of the register-fed MFMA tiles.  A lane needs 8 of the 16 (32x32x16 tile, two lanes per row) or 32 (16x16x32
+// tile, four lanes per row) k values of a step; WHICH 8 is free as long as both operands agree, so the lanes of a row take
+// interleaved 16-byte pieces: one load instruction then covers 32 (64) contiguous bytes per row instead of scattered pieces.
+//   half h    of a 16-float chunk: floats [4h, 4h+4) and [8+4h, 8+4h+4)      -> element j is float 4h + (j&3) + 8(j>>2)
+//   quarter g of a 32-float chunk: floats [4g, 4g+4) and [16+4g, 16+4g+4)    -> element j is float 4g + (j&3) + 16(j>>2)
+__device__ __forceinline__ void load8h(const float* chunk, int h, float* v) {
+    const float4 a = *(const float4*)(chunk + 4 * h), b = *(const float4*)(chunk + 8 + 4 * h);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8q(const float* chunk, int g, float* v) {
+    const float4 a = *(const float4*)(chunk + 4 * g), b = *(const float4*)(chunk + 16 + 4 * g);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8h(float* chunk, int h, const float* v) {
+    *(float4*)(chunk + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(chunk + 8 + 4 * h) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ int chan8h(int q, int h, int j) { return 16 * q + 4 * h + (j & 3) + 8 * (j >> 2); }
+
+// One 16-deep step of a 32x32 tile product (lane l: row / column l & 31, half l >> 5).  bf16 mode: one v_mfma_f32_32x32x16_bf16
+// (operands rounded to nearest even, like step_gemm's bf16 path); f32 mode: eight v_mfma_f32_32x32x2_f32, step s contracting
+// element s of both halves.
+template <bool BF16>
+__device__ __forceinline__ void mma16(f32x16& acc, const float* a, const float* b) {
+    if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(a), pack8(b), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+}
+// 32-deep step of a 16x16 tile (lane l: row / column l & 15, quarter l >> 4): v_mfma_f32_16x16x32_bf16 / eight
+// v_mfma_f32_16x16x4_f32; result D[m = 4 (l >> 4) + e][n = l & 15].
+template <bool BF16>
+__device__ __forceinline__ void mma32_16(f32x4& acc, const float* a, const float* b) {
+    if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack8(a), pack8(b), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+    }
+}
+
+// BatchNorm sums without finalize launches and without grid-wide synchronisation inside a kernel: the producing kernel adds
+// its 64 block sums (f32) to f64 accumulators [NCOPY][64] with native f64 atomics (copy = block % NCOPY spreads the
+// contention; the order-dependence of a few hundred f64 additions is ~1e-13 relative, far below the f32 numbers derived
+// from them), and every block of the CONSUMING kernel turns the sums into the 2 x 32 numbers it needs in its prologue
+// (block 0 also stores what later kernels and the backward read, and updates the running statistics exactly once).
+constexpr int NCOPY = 16;
+__device__ __forceinline__ void add_block_sums(double* acc, const float* blocksum64) {
+    if (threadIdx.x < 64) unsafeAtomicAdd(acc + (blockIdx.x % NCOPY) * 64 + threadIdx.x, (double)blocksum64[threadIdx.x]);
+}
+__device__ __forceinline__ double gather_sum(const double* acc, int i) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < NCOPY; ++k) a += acc[k * 64 + i];
+    return a;
+}
+// channel-last BN statistics -> st[128] = scale, shift, mean, rstd in LDS (model.py:212; running stats in train mode)
+struct BnFwd { const float *gamma, *beta; float *rm, *rv; int training; float momentum; float* stat; double count; const double* sums; };
+__device__ __forceinline__ void bn_fwd_stats(const BnFwd& bn, float* st) {
+    __shared__ double tot[64];
+    if (bn.training && threadIdx.x < 64) tot[threadIdx.x] = gather_sum(bn.sums, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        double mean, var;
+        if (bn.training) {
+            mean = tot[c] / bn.count;
+            var = fmax(tot[32 + c] / bn.count - mean * mean, 0.0);
+        } else {
+            mean = bn.rm[c]; var = bn.rv[c];
+        }
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float sc = bn.gamma[c] * rstd, sh = bn.beta[c] - (float)mean * sc;
+        st[c] = sc; st[32 + c] = sh; st[64 + c] = (float)mean; st[96 + c] = rstd;
+        if (blockIdx.x == 0) {
+            bn.stat[c] = sc; bn.stat[32 + c] = sh; bn.stat[64 + c] = (float)mean; bn.stat[96 + c] = rstd;
+            if (bn.training) {
+                bn.rm[c] = (1.f - bn.momentum) * bn.rm[c] + bn.momentum * (float)mean;
+                bn.rv[c] = (1.f - bn.momentum) * bn.rv[c] + bn.momentum * (float)(var * bn.count / fmax(bn.count - 1.0, 1.0));
+            }
+        }
+    }
+    __syncthreads();
+}
+// BN backward sums S1 = sum dy, S2 = sum dy*xhat -> co[96] = [S1/count | S2/count | gamma*rstd] in LDS; block 0 adds the
+// gradients of gamma / beta
+struct BnBwd { const float *gamma, *stat; float *dgamma, *dbeta; double count; const double* sums; };
+__device__ __forceinline__ void bn_bwd_coef(const BnBwd& bn, float* co) {
+    __shared__ double tot[64];
+    if (threadIdx.x < 64) tot[threadIdx.x] = gather_sum(bn.sums, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        co[c] = (float)(tot[c] / bn.count); co[32 + c] = (float)(tot[32 + c] / bn.count); co[64 + c] = bn.gamma[c] * bn.stat[96 + c];
+        if (blockIdx.x == 0) { bn.dgamma[c] += (float)tot[32 + c]; bn.dbeta[c] += (float)tot[c]; }
+    }
+    __syncthreads();
+}
+
+// Gated TCN of one layer (model.py:183-189) in one kernel: the two-tap dilated filter / gate convolutions as one 64 -> 64
+// contraction per position (k = tap*32 + c, read straight from the layer input: no im2col), tanh * sigmoid, z into slot 0
+// of the gcn buffer, and the last time step's z into column block `layer` of zlast [BN][8*32] (the skip convolutions only
+// matter there -- they are applied to all 8 layers at once in the head).  Layers >= 1 finalise the previous layer's
+// BatchNorm statistics in the prologue (bn.stat != nullptr) and apply them to what they read.  One wave = 32 positions.
+template <bool BF16>
+__global__ __launch_bounds__(256) void tcn_fwd_kernel(const float* __restrict__ src, BnFwd bn, long npos, int Tin, int Tout, int dil,
+                                                      const float* __restrict__ wcat, const float* __restrict__ bcat,
+                                                      float* __restrict__ tf, float* __restrict__ sg, float* __restrict__ cat,
+                                                      float* __restrict__ zlast, int layer) {
+    __shared__ float st[128];
+    if (bn.stat) bn_fwd_stats(bn, st);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= npos) return;
+    long p = r0 + col;
+    if (p >= npos) p = npos - 1;
+    const long bn_ = p / Tout;
+    const long xrow = bn_ * Tin + (p - bn_ * Tout);
+    float a[4][8], bf[4][8], bg[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // k = 16 q + ... = tap*32 + c
+        load8h(src + (xrow + (q >> 1) * dil) * C + 16 * (q & 1), h, a[q]);
+        load8h(wcat + col * 64 + 16 * q, h, bf[q]);
+        load8h(wcat + (32 + col) * 64 + 16 * q, h, bg[q]);
+    }
+    if (bn.stat) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int c = chan8h(q & 1, h, j); a[q][j] = a[q][j] * st[c] + st[32 + c]; }
+    }
+    f32x16 af, ag;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { af[e] = 0.f; ag[e] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mma16<BF16>(af, a[q], bf[q]); mma16<BF16>(ag, a[q], bg[q]); }
+    const float b_f = bcat[col], b_g = bcat[32 + col];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const long pe = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (pe >= npos) continue;
+        const float f = tanhf(af[e] + b_f);
+        const float g = 1.f / (1.f + __expf(-(ag[e] + b_g)));
+        tf[pe * C + col] = f; sg[pe * C + col] = g;
+        cat[pe * CAT + col] = f * g;
+        const long bne = pe / Tout;
+        if (pe - bne * Tout == Tout - 1) zlast[bne * CS + layer * C + col] = f * g;
+    }
+}
+
+// gcn mix of one layer: h = cat @ Wmix^T + b (224 -> 32), dropout, + residual x_in[t + dil] (model.py:36-47,206-212),
+// y written once, BatchNorm sums added to `sums`.  One wave = 16 positions x 32 channels (two 16x16 tiles), every operand
+// load of the 224-deep contraction issued before the first MFMA; one Philox call yields the keep decisions of a lane's four
+// positions of one channel.
+template <bool BF16>
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ cat, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, XIn x, long npos, int Tin, int Tout, int dil,
+                                                      float drop_p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer,
+                                                      float* __restrict__ mask, float* __restrict__ y, double* __restrict__ sums) {
+    __shared__ float red[4][64];
+    __shared__ float bsum[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, kg = lane >> 4;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 16;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (r0 < npos) {
+        long p = r0 + ln;
+        if (p >= npos) p = npos - 1;
+        float a[7][8], b0[7][8], b1[7][8];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            load8q(cat + p * CAT + 32 * s, kg, a[s]);
+            load8q(w + ln * CAT + 32 * s, kg, b0[s]);
+            load8q(w + (16 + ln) * CAT + 32 * s, kg, b1[s]);
+        }
+        // residual rows of this lane's 4 positions (clamped; stores are guarded below)
+        float res[2][4];
+        long pe[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            long q = r0 + 4 * kg + e;
+            pe[e] = q;
+            if (q >= npos) q = npos - 1;
+            const long bne = q / Tout;
+            const float* rsrc = x.src + (bne * Tin + (q - bne * Tout) + dil) * C;
+            res[0][e] = rsrc[ln]; res[1][e] = rsrc[16 + ln];
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 7; ++s) { mma32_16<BF16>(acc[0], a[s], b0[s]); mma32_16<BF16>(acc[1], a[s], b1[s]); }
+        const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int col = 16 * half + ln;
+            const float bv = bias[col];
+            const float xs = x.stat ? x.stat[col] : 1.f, xh = x.stat ? x.stat[32 + col] : 0.f;
+            uint32_t r[4] = {0u, 0u, 0u, 0u};
+            if (drop_p > 0.f) {
+                const long i0 = pe[0] * C + col;
+                philox4x32((uint32_t)i0, (uint32_t)(i0 >> 32), layer, 0xD409u, seed_lo, seed_hi, r);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (pe[e] >= npos) continue;
+                const long idx = pe[e] * C + col;
+                float m = 1.f;
+                if (drop_p > 0.f) {
+                    m = u32_to_unit(r[e]) >= drop_p ? keep_scale : 0.f;
+                    mask[idx] = m;
+                }
+                const float v = (acc[half][e] + bv) * m + (res[half][e] * xs + xh);
+                y[idx] = v;
+                s1[half] += v; s2[half] += v * v;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            s1[half] += __shfl_xor(s1[half], 16, 64); s2[half] += __shfl_xor(s2[half], 16, 64);
+            s1[half] += __shfl_xor(s1[half], 32, 64); s2[half] += __shfl_xor(s2[half], 32, 64);
+        }
+    }
+    if (kg == 0) { red[wave][ln] = s1[0]; red[wave][16 + ln] = s1[1]; red[wave][32 + ln] = s2[0]; red[wave][48 + ln] = s2[1]; }
+    __syncthreads();
+    if (threadIdx.x < 64) bsum[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+    add_block_sums(sums, bsum);
+}
+
+// Backward of BatchNorm_i + dropout + mix data gradient in one kernel (coefficients from the sums the previous backward
+// kernel left, see bn_bwd_coef):
+//   d = gamma*rstd * (dy - m1 - xhat m2)  (-> dres: the residual branch's gradient),  dh = d * mask,  dcat = dh @ Wmix (32 -> 224)
+// dh is kept for the weight-gradient GEMM.  One wave = 32 positions; wT = Wmix transposed [224][32].
+template <bool BF16>
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, BnBwd bn,
+                                                      const float* __restrict__ mask, const float* __restrict__ wT, long npos,
+                                                      float* __restrict__ dres, float* __restrict__ dh, float* __restrict__ dcat) {
+    __shared__ float co[96];
+    bn_bwd_coef(bn, co);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+    const long r0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= npos) return;
+    const long p = r0 + col;
+    const bool ok = p < npos;
+    float a[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, y8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (ok) {
+            load8h(dy + p * C + 16 * q, h, d8); load8h(y + p * C + 16 * q, h, y8);
+            if (mask) load8h(mask + p * C + 16 * q, h, m8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chan8h(q, h, j);
+            const float xhat = (y8[j] - bn.stat[64 + c]) * bn.stat[96 + c];
+            const float d = ok ? co[64 + c] * (d8[j] - co[c] - xhat * co[32 + c]) : 0.f;
+            d8[j] = d;
+            a[q][j] = d * m8[j];
+        }
+        if (ok) { store8h(dres + p * C + 16 * q, h, d8); store8h(dh + p * C + 16 * q, h, a[q]); }
+    }
+#pragma unroll
+    for (int slot = 0; slot < 7; ++slot) {
+        float b[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) load8h(wT + (slot * C + col) * C + 16 * q, h, b[q]);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) mma16<BF16>(acc, a[q], b[q]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long pe = r0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (pe < npos) dcat[pe * CAT + slot * C + col] = acc[e];
+        }
+    }
+}
+
+// Backward of the gated TCN of one layer in one kernel.  A workgroup owns G = 64 / Tout whole (b, n) pairs:
+//   dz = dcat slot 0 (+ d_zlast at the last time step: the skip branch),  dpre = [dz g (1 - f^2) | dz f g (1 - g)]  (kept for
+//   the weight-gradient GEMM),  dxcat = dpre @ Wcat (64 -> 64, tile kept in LDS),  then the transposed im2col
+//   dx[bn][t'][c] = [t' < Tout] dxcat[t'][c] + [t' >= dil] (dxcat[t'-dil][32+c] + dres[t'-dil][c])
+// and, dx being the gradient of BatchNorm_{layer-1}'s output, that BatchNorm's backward sums (xhat from yprev / statprev)
+// added to `sums`.  dcat == nullptr: last layer (gradient from the skip branch only).  wcatT = Wcat transposed [64 n][64 k].
+// Wave w: rows 32 (w & 1) of the tile, output columns 32 (w >> 1).
+constexpr int TB_ROWS = 64;
+template <bool BF16>
+__global__ __launch_bounds__(256) void tcn_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ dzlast, int layer,
+                                                      const float* __restrict__ tf, const float* __restrict__ sg,
+                                                      const float* __restrict__ wcatT, const float* __restrict__ dres, long BN, int Tin,
+                                                      int Tout, int dil, float* __restrict__ dpre, float* __restrict__ dx,
+                                                      const float* __restrict__ yprev, const float* __restrict__ statprev,
+                                                      double* __restrict__ sums) {
+    __shared__ float dxs[TB_ROWS][65];
+    __shared__ float red[8][64];
+    __shared__ float bsum[64];
+    const int G = TB_ROWS / Tout, R = G * Tout;
+    const long bn0 = (long)blockIdx.x * G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+    {
+        const int nt = wave >> 1;
+        const int r = (wave & 1) * 32 + col;                 // row of the tile
+        const long bnr = bn0 + r / Tout;
+        const bool ok = r < R && bnr < BN;
+        const long p = bn0 * Tout + r;
+        const bool lastt = ok && (r % Tout == Tout - 1);
+        float b[4][8];                                       // B[k = part*32 + c][n] = Wcat[k][n]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load8h(wcatT + (32 * nt + col) * 64 + 16 * q, h, b[q]);
+        float dp[2][2][8];                                   // [part filter | gate][16-channel chunk][j]
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, f8[8], g8[8];
+            if (ok) {
+                if (dcat) load8h(dcat + p * CAT + 16 * qc, h, dz);
+                load8h(tf + p * C + 16 * qc, h, f8); load8h(sg + p * C + 16 * qc, h, g8);
+                if (lastt) {
+                    float s8[8];
+                    load8h(dzlast + bnr * CS + layer * C + 16 * qc, h, s8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dz[j] += s8[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dp[0][qc][j] = ok ? dz[j] * g8[j] * (1.f - f8[j] * f8[j]) : 0.f;
+                dp[1][qc][j] = ok ? dz[j] * f8[j] * g8[j] * (1.f - g8[j]) : 0.f;
+            }
+            if (ok) store8h(dpre + p * 64 + 32 * nt + 16 * qc, h, dp[nt][qc]);     // wave pair (w, w + 2) shares the rows: each stores one part
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mma16<BF16>(acc, dp[q >> 1][q & 1], b[q]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dxs[(wave & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h][32 * nt + col] = acc[e];
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, jg = threadIdx.x >> 5;
+    float s1 = 0.f, s2 = 0.f;
+    const float mean = statprev ? statprev[64 + c] : 0.f, rstd = statprev ? statprev[96 + c] : 0.f;
+    const int njt = G * Tin;
+    for (int j0 = 0; j0 < njt; j0 += 32) {                   // 4 (bn, t') pairs per thread and pass, their loads issued together
+        float dr[4], yv[4], v[4];
+        long o[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 8 * u + jg;
+            const int g = j / Tin, t = j - g * Tin;
+            const long bnr = bn0 + g;
+            valid[u] = j < njt && bnr < BN;
+            const long bc = valid[u] ? bnr : 0;
+            const int tc = valid[u] ? t : 0;
+            o[u] = (bc * Tin + tc) * C + c;
+            const bool tap1 = valid[u] && tc >= dil;
+            dr[u] = (dres && tap1) ? dres[(bc * Tout + tc - dil) * C + c] : 0.f;
+            yv[u] = yprev ? yprev[o[u]] : 0.f;
+            float x = 0.f;
+            if (valid[u] && tc < Tout) x += dxs[g * Tout + tc][c];
+            if (tap1) x += dxs[g * Tout + tc - dil][32 + c];
+            v[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!valid[u]) continue;
+            const float x = v[u] + dr[u];
+            dx[o[u]] = x;
+            s1 += x; s2 += x * (yv[u] - mean) * rstd;
+        }
+    }
+    if (!yprev) return;
+    red[jg][c] = s1; red[jg][32 + c] = s2;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += red[r][threadIdx.x];
+        bsum[threadIdx.x] = a;
+    }
+    __syncthreads();
+    add_block_sums(sums, bsum);
+}
+
+// xcat[(bn,t)][tap*32 + c] = x[bn][t + tap*dil][c]   (operand of the gated-TCN weight gradient)
+__global__ void im2col_kernel(XIn x, long BN, int Tin, int Tout, int dil, float* __restrict__ xcat) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= BN * Tout * 64) return;
     int k = idx % 64, t = (idx / 64) % Tout;
     long bn = idx / (64L * Tout);
-    xcat[idx] = x[(bn * Tin + t + (k >> 5) * dil) * C + (k & 31)];
+    float v = x.src[(bn * Tin + t + (k >> 5) * dil) * C + (k & 31)];
+    if (x.stat) v = v * x.stat[k & 31] + x.stat[32 + (k & 31)];
+    xcat[idx] = v;
 }
-// pre[pos][64] -> tf = tanh, sg = sigmoid, z = tf*sg into cat slot 0
-__global__ void gate_act_kernel(const float* __restrict__ pre, long npos, float* __restrict__ tf, float* __restrict__ sg,
-                                float* __restrict__ cat) {
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= npos * C) return;
-    long p = idx / C;
-    int c = idx % C;
-    float f = tanhf(pre[p * 64 + c]);
-    float g = 1.f / (1.f + __expf(-pre[p * 64 + 32 + c]));
-    tf[idx] = f; sg[idx] = g;
-    cat[p * CAT + c] = f * g;
+__global__ void unpack_skip_grad_kernel(const float* __restrict__ dwskip, SkipPtrs G) {
+    const int o = blockIdx.x, k = threadIdx.x;
+    G.w[k >> 5][o * C + (k & 31)] += dwskip[o * CS + k];
 }
-__global__ void gate_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ tf, const float* __restrict__ sg,
-                                long npos, float* __restrict__ dpre) {
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= npos * C) return;
-    long p = idx / C;
-    int c = idx % C;
-    float dz = dcat[p * CAT + c], f = tf[idx], g = sg[idx];
-    dpre[p * 64 + c] = dz * g * (1.f - f * f);
-    dpre[p * 64 + 32 + c] = dz * f * g * (1.f - g);
-}
-// dx[bn][t'][c] = [t' < Tout] dxcat[(bn,t')][c] + [t' >= dil] (dxcat[(bn,t'-dil)][32+c] + dres[(bn,t'-dil)][c])
-__global__ void col2im_kernel(const float* __restrict__ dxcat, const float* __restrict__ dres, long BN, int Tin, int Tout, int dil,
-                              float* __restrict__ dx) {
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= BN * Tin * C) return;
-    int c = idx % C, t = (idx / C) % Tin;
-    long bn = idx / ((long)C * Tin);
-    float v = 0.f;
-    if (t < Tout) v += dxcat[(bn * Tout + t) * 64 + c];
-    if (t >= dil) {
-        long q = bn * Tout + (t - dil);
-        v += dxcat[q * 64 + 32 + c];
-        if (dres) v += dres[q * C + c];
-    }
-    dx[idx] = v;
-}
-// y = dropout(h) + x_in[t + dil];  BN partial sums.  block = 256 threads = 8 positions x 32 channels, grid-stride
-__global__ __launch_bounds__(256) void mix_post_kernel(const float* __restrict__ h, const float* __restrict__ xin, long BN, int Tin,
-                                                       int Tout, int dil, float drop_p, uint32_t seed_lo, uint32_t seed_hi,
-                                                       uint32_t layer, float* __restrict__ mask, float* __restrict__ y,
-                                                       float* __restrict__ partial) {
-    __shared__ float red[8][64];
-    const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;
-    const long npos = BN * Tout;
-    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (long p = (long)blockIdx.x * 8 + sub; p < npos; p += (long)gridDim.x * 8) {
-        long bn = p / Tout;
-        int t = p % Tout;
-        float m = 1.f;
-        if (drop_p > 0.f) {
-            uint32_t r[4];
-            long e = p * C + c;
-            philox4x32((uint32_t)e, (uint32_t)(e >> 32), layer, 0xD409u, seed_lo, seed_hi, r);
-            m = u32_to_unit(r[0]) >= drop_p ? keep_scale : 0.f;
-            mask[p * C + c] = m;
-        }
-        float v = h[p * C + c] * m + xin[(bn * Tin + t + dil) * C + c];
-        y[p * C + c] = v;
-        s1 += v; s2 += v * v;
-    }
-    red[sub][c] = s1; red[sub][32 + c] = s2;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float a = 0.f;
-        for (int r = 0; r < 8; ++r) a += red[r][threadIdx.x];
-        partial[(long)blockIdx.x * 64 + threadIdx.x] = a;
-    }
-}
-// channel-last BN statistics -> stat [4][32] = scale, shift, mean, rstd (+ running stats)
-__global__ __launch_bounds__(1024) void bn_cl_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ rm, float* __restrict__ rv, int training,
-                                                             float momentum, float* __restrict__ stat) {
-    __shared__ double ra[32][32], rq[32][32];
-    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;      // 1024 threads: 32 partial sums per channel
-    double a = 0.0, q = 0.0;
-    if (training)
-        for (int i = part; i < nblk; i += 32) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
-    ra[part][c] = a; rq[part][c] = q;
-    __syncthreads();
-    if (part != 0) return;
-    double mean, var;
-    if (training) {
-        for (int r = 1; r < 32; ++r) { a += ra[r][c]; q += rq[r][c]; }
-        mean = a / count;
-        var = fmax(q / count - mean * mean, 0.0);
-        rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
-        rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(var * count / fmax(count - 1.0, 1.0));
-    } else {
-        mean = rm[c]; var = rv[c];
-    }
-    float rstd = (float)(1.0 / sqrt(var + 1e-5));
-    float sc = gamma[c] * rstd;
-    stat[c] = sc; stat[32 + c] = beta[c] - (float)mean * sc; stat[64 + c] = (float)mean; stat[96 + c] = rstd;
-}
-__global__ void bn_cl_apply_kernel(const float* __restrict__ y, long n, const float* __restrict__ stat, float* __restrict__ out) {
+// xh = relu(skip + h2)   (skip already carries the sum of the 8 skip-conv biases)
+__global__ void head_combine_kernel(const float* __restrict__ skip, const float* __restrict__ h2, long n, float* __restrict__ xh) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
-    int c = idx % C;
-    out[idx] = y[idx] * stat[c] + stat[32 + c];
+    xh[idx] = fmaxf(skip[idx] + h2[idx], 0.f);
 }
-// BN backward (channel-last): partial S1 = sum dy, S2 = sum dy*xhat
-__global__ __launch_bounds__(256) void bn_cl_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y, long npos,
-                                                               const float* __restrict__ stat, float* __restrict__ partial) {
-    __shared__ float red[8][64];
-    const int c = threadIdx.x & 31, sub = threadIdx.x >> 5;
-    const float mean = stat[64 + c], rstd = stat[96 + c];
-    float s1 = 0.f, s2 = 0.f;
-    for (long p = (long)blockIdx.x * 8 + sub; p < npos; p += (long)gridDim.x * 8) {
-        float d = dy[p * C + c];
-        s1 += d; s2 += d * (y[p * C + c] - mean) * rstd;
-    }
-    red[sub][c] = s1; red[sub][32 + c] = s2;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float a = 0.f;
-        for (int r = 0; r < 8; ++r) a += red[r][threadIdx.x];
-        partial[(long)blockIdx.x * 64 + threadIdx.x] = a;
-    }
-}
-__global__ __launch_bounds__(1024) void bn_cl_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, double count,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ stat,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 float* __restrict__ coef) {
-    __shared__ double ra[32][32], rq[32][32];
-    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
-    double a = 0.0, q = 0.0;
-    for (int i = part; i < nblk; i += 32) { a += partial[(long)i * 64 + c]; q += partial[(long)i * 64 + 32 + c]; }
-    ra[part][c] = a; rq[part][c] = q;
-    __syncthreads();
-    if (part != 0) return;
-    for (int r = 1; r < 32; ++r) { a += ra[r][c]; q += rq[r][c]; }
-    dgamma[c] += (float)q; dbeta[c] += (float)a;
-    coef[c] = (float)(a / count); coef[32 + c] = (float)(q / count); coef[64 + c] = gamma[c] * stat[96 + c];
-}
-// dpre = k (dy - m1 - xhat m2);  dh = dpre * mask
-__global__ void bn_cl_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, long n, const float* __restrict__ stat,
-                                       const float* __restrict__ coef, const float* __restrict__ mask, float* __restrict__ dpre,
-                                       float* __restrict__ dh) {
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    int c = idx % C;
-    float xh = (y[idx] - stat[64 + c]) * stat[96 + c];
-    float d = coef[64 + c] * (dy[idx] - coef[c] - xh * coef[32 + c]);
-    dpre[idx] = d;
-    dh[idx] = mask ? d * mask[idx] : d;
-}
-// xh = relu(skip + bias_sum + h2)
-__global__ void head_combine_kernel(const float* __restrict__ skip, const float* __restrict__ bsum, const float* __restrict__ h2,
-                                    long n, float* __restrict__ xh) {
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    xh[idx] = fmaxf(skip[idx] + bsum[idx % CS] + h2[idx], 0.f);
-}
-struct Ptr8 { const float* p[8]; };
 struct MPtr8 { float* p[8]; };
-// out[i] = sum of the 8 skip-conv biases
-__global__ void sum8_kernel(float* __restrict__ out, Ptr8 srcs, int n) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += srcs.p[k][i];
-    out[i] = s;
-}
 // dst_k[i] += v[i] for the 8 skip-conv bias gradients
 __global__ void add_to8_kernel(MPtr8 dst, const float* __restrict__ v, int n) {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -459,7 +715,7 @@ struct Carver {
 static inline int n8(int N) { return (N + 7) & ~7; }
 
 struct Saved {
-    float *x_in[NL], *cat[NL], *tf[NL], *sg[NL], *y[NL], *mask[NL], *bnstat[NL];
+    float *x0, *cat[NL], *tf[NL], *sg[NL], *y[NL], *mask[NL], *bnstat[NL], *zlast;     // x0: start conv output; layer i >= 1 reads BN(y[i-1])
     float *Pstk, *PTstk, *Pa, *Madp, *rs, *cs;      // stacks: [3 supports f,b,a][B][N][N]
     uint16_t *P16, *PT16;                           // bf16 copies, rows zero-padded to N8 = roundup(N, 8) (bf16 hop operands)
     float *skip, *h1, *h2, *xh, *e1;
@@ -469,8 +725,9 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
     Carver cv(base);
     Saved s;
     const long BN = (long)B * N;
+    s.x0 = cv.take(BN * TIN[0] * C);
+    s.zlast = cv.take(BN * CS);
     for (int i = 0; i < NL; ++i) {
-        s.x_in[i] = cv.take(BN * TIN[i] * C);
         s.cat[i] = cv.take(BN * TOUT[i] * CAT);
         s.tf[i] = cv.take(BN * TOUT[i] * C);
         s.sg[i] = cv.take(BN * TOUT[i] * C);
@@ -495,30 +752,31 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
     return s;
 }
 struct Work {
-    float *wcat, *bcat, *dwcat, *dbcat;       // [8][64][64], [8][64]
-    float *xcat, *pre, *h, *partial, *bsum;
-    float *dcat, *dpre, *dxcat, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb, *coef;
+    float *wcat, *wcatT, *bcat, *wskip, *wmixT, *dwcat, *dbcat, *dwskip;       // [8][64][64] x2, [8][64], [256][256], [7][224][32]; d* and acc64 contiguous (one memset)
+    double* acc64;             // [7 BatchNorms][NCOPY][64] f64 accumulators of the in-kernel BatchNorm sums
+    float *xcat, *bsum;
+    float *dcat, *dpre, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
     float *d_e1, *d_xh, *d_h2, *d_h1;
     long total;
 };
-constexpr int BN_BLOCKS = 512;
 Work carve_work(float* base, int B, int N, bool backward) {
     Carver cv(base);
     Work w;
     const long BN = (long)B * N;
     w.wcat = cv.take(NL * 64 * 64);
+    w.wcatT = cv.take(NL * 64 * 64);
     w.bcat = cv.take(NL * 64);
+    w.wskip = cv.take(CS * CS);
+    w.wmixT = cv.take(7 * C * CAT);
     w.dwcat = cv.take(NL * 64 * 64);
     w.dbcat = cv.take(NL * 64);
-    w.xcat = cv.take(BN * 12 * 64);
-    w.pre = cv.take(BN * 12 * 64);
-    w.h = cv.take(BN * 12 * C);
-    w.partial = cv.take((long)BN_BLOCKS * 64);
+    w.dwskip = cv.take(CS * CS);
+    w.acc64 = (double*)cv.take(2L * 7 * NCOPY * 64);
+    w.xcat = backward ? cv.take(BN * 12 * 64) : nullptr;
     w.bsum = cv.take(CS);
     if (backward) {
         w.dcat = cv.take(BN * 12 * CAT);
         w.dpre = cv.take(BN * 12 * 64);
-        w.dxcat = cv.take(BN * 12 * 64);
         w.dh = cv.take(BN * 12 * C);
         w.dres = cv.take(BN * 12 * C);
         w.dxa = cv.take(BN * 13 * C);
@@ -529,7 +787,6 @@ Work carve_work(float* base, int B, int N, bool backward) {
         w.dM = cv.take((long)N * N);
         w.rf = cv.take(BN > N ? BN : N);
         w.rb = cv.take(BN);
-        w.coef = cv.take(128);
         w.d_e1 = cv.take(BN * CE);
         w.d_xh = cv.take(BN * CS);
         w.d_h2 = cv.take(BN * CS);
@@ -604,6 +861,48 @@ extern "C" long step_gwnet_saved_offset(int B, int N, int dropout, int item, int
     return p ? (long)(p - (float*)16) : -1;
 }
 
+template <bool BF16>
+static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const Work& W, int B, int N, bool training, float drop_p,
+                                uint64_t seed, float momentum, hipStream_t st) {
+    const long BN = (long)B * N;
+    for (int i = 0; i < NL; ++i) {
+        const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
+        const long npos = BN * Tout;
+        // statistics of BatchNorm_{i-1} (sums left by mix_fwd of the previous layer), finalised by this layer's first kernel
+        BnFwd bn = {nullptr, nullptr, nullptr, nullptr, training ? 1 : 0, momentum, nullptr, (double)BN * Tin, nullptr};
+        if (i > 0) {
+            bn.gamma = p->bn_w[i - 1]; bn.beta = p->bn_b[i - 1]; bn.rm = p->bn_rm[i - 1]; bn.rv = p->bn_rv[i - 1];
+            bn.stat = S.bnstat[i - 1]; bn.sums = W.acc64 + (long)(i - 1) * NCOPY * 64;
+        }
+        tcn_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(i == 0 ? S.x0 : S.y[i - 1], bn, npos, Tin, Tout, dil, W.wcat + i * 4096,
+                                                                        W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
+        STEP_LAUNCH_CHECK("tcn_fwd");
+        if (i == NL - 1) break;
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, st));      // slots 1,3,5 = P_s z
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, st));      // slots 2,4,6 = P_s (P_s z)
+        const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
+        mix_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 64), 256, 0, st>>>(S.cat[i], p->gconv_w[i], p->gconv_b[i], xin, npos, Tin, Tout, dil, drop_p,
+                                                                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, S.mask[i], S.y[i],
+                                                                       W.acc64 + (long)i * NCOPY * 64);
+        STEP_LAUNCH_CHECK("mix_fwd");
+    }
+    return STEP_OK;
+}
+
+static int pack_weights(const StepGwnetParams* p, const Work& W, hipStream_t st) {
+    GatePtrs gp;
+    SkipPtrs sp;
+    MixPtrs mp;
+    for (int i = 0; i < NL; ++i) {
+        gp.wf[i] = p->filter_w[i]; gp.bf[i] = p->filter_b[i]; gp.wg[i] = p->gate_w[i]; gp.bg[i] = p->gate_b[i];
+        sp.w[i] = p->skip_w[i]; sp.b[i] = p->skip_b[i];
+        if (i < NL - 1) mp.w[i] = p->gconv_w[i];
+    }
+    pack_weights_kernel<<<384 + 7 * 28, 256, 0, st>>>(gp, sp, mp, W.wcat, W.wcatT, W.bcat, W.wskip, W.bsum, W.wmixT);
+    STEP_LAUNCH_CHECK("pack_weights");
+    return STEP_OK;
+}
+
 extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                                   const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                                   float* saved, float* work, float* pred, void* stream) {
@@ -614,9 +913,10 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     Saved S = carve_saved(saved, B, N, use_drop);
     Work W = carve_work(work, B, N, false);
     const long BN = (long)B * N;
-    const int allbf16 = p->gemm_bf16;      // bf16 mode: every GEMM of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
+    const int allbf16 = p->gemm_bf16;      // bf16 mode: every contraction of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
 
-    start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x_in[0]);
+    STEP_TRY(zero((float*)W.acc64, 2L * 7 * NCOPY * 64, st));
+    start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
     STEP_LAUNCH_CHECK("start_conv");
     // supports (model.py:160-166)
     row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs);
@@ -638,48 +938,13 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
                                                                                                S.PT16);
         STEP_LAUNCH_CHECK("stacks_to_bf16");
     }
-    {
-        GatePtrs gp;
-        for (int i = 0; i < NL; ++i) { gp.wf[i] = p->filter_w[i]; gp.bf[i] = p->filter_b[i]; gp.wg[i] = p->gate_w[i]; gp.bg[i] = p->gate_b[i]; }
-        pack_gate_kernel<<<dim3(16, NL), 256, 0, st>>>(gp, W.wcat, W.bcat);
-        STEP_LAUNCH_CHECK("pack_gate");
-    }
+    STEP_TRY(pack_weights(p, W, st));
 
-    for (int i = 0; i < NL; ++i) {
-        const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
-        const long npos = BN * Tout;
-        im2col_kernel<<<g1(npos * 64), 256, 0, st>>>(S.x_in[i], BN, Tin, Tout, dil, W.xcat);
-        STEP_LAUNCH_CHECK("im2col");
-        {   // pre = xcat @ Wcat^T + b
-            StepGemm g = gemm_desc((int)npos, 64, 64, W.xcat, 64, 1, W.wcat + i * 4096, 1, 64, W.pre, 64);
-            g.bias = W.bcat + i * 64;
-            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
-        }
-        gate_act_kernel<<<g1(npos * C), 256, 0, st>>>(W.pre, npos, S.tf[i], S.sg[i], S.cat[i]);
-        STEP_LAUNCH_CHECK("gate_act");
-        {   // skip[bn][:] (+)= Wskip z[bn][Tout-1]    (biases are summed once in the head)
-            StepGemm g = gemm_desc((int)BN, CS, C, S.cat[i] + (long)(Tout - 1) * CAT, (long)Tout * CAT, 1, p->skip_w[i], 1, C, S.skip, CS);
-            g.accumulate = i == 0 ? 0 : 1;
-            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
-        }
-        if (i == NL - 1) break;
-        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, p->gemm_bf16, st));      // slots 1,3,5 = P_s z
-        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, p->gemm_bf16, st));      // slots 2,4,6 = P_s (P_s z)
-        {   // h = cat @ Wmix^T + b
-            StepGemm g = gemm_desc((int)npos, C, CAT, S.cat[i], CAT, 1, p->gconv_w[i], 1, CAT, W.h, C);
-            g.bias = p->gconv_b[i];
-            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
-        }
-        int nblk = (int)((npos + 7) / 8);
-        if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
-        mix_post_kernel<<<nblk, 256, 0, st>>>(W.h, S.x_in[i], BN, Tin, Tout, dil, use_drop ? dropout_p : 0.f, (uint32_t)seed,
-                                              (uint32_t)(seed >> 32), (uint32_t)i, S.mask[i], S.y[i], W.partial);
-        STEP_LAUNCH_CHECK("mix_post");
-        bn_cl_finalize_kernel<<<1, 1024, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], training,
-                                                momentum, S.bnstat[i]);
-        bn_cl_apply_kernel<<<g1(npos * C), 256, 0, st>>>(S.y[i], npos * C, S.bnstat[i], S.x_in[i + 1]);
-        STEP_LAUNCH_CHECK("bn_apply");
-    }
+    // 8 layers: gated TCN (one kernel), two diffusion hops (the three supports per launch), gcn mix + dropout + residual + BatchNorm
+    // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
+    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
+    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
+
     // head (model.py:215-220)
     {
         StepGemm g = gemm_desc((int)BN, CE, HID, hidden_last, HID, 1, p->fc_his0_w, 1, HID, S.h1, CE);
@@ -688,11 +953,11 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
         StepGemm g2 = gemm_desc((int)BN, CS, CE, S.h1, CE, 1, p->fc_his2_w, 1, CE, S.h2, CS);
         g2.bias = p->fc_his2_b; g2.relu = 1;
         g2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g2, st));
-        // sum of the 8 skip biases
-        Ptr8 sb;
-        for (int i = 0; i < NL; ++i) sb.p[i] = p->skip_b[i];
-        sum8_kernel<<<1, 256, 0, st>>>(W.bsum, sb, CS);
-        head_combine_kernel<<<g1(BN * CS), 256, 0, st>>>(S.skip, W.bsum, S.h2, BN * CS, S.xh);
+        // skip = sum_i Wskip_i z_i[last step] + sum_i b_i: the 8 skip convolutions as one K = 256 contraction
+        StepGemm gs = gemm_desc((int)BN, CS, CS, S.zlast, CS, 1, W.wskip, 1, CS, S.skip, CS);
+        gs.bias = W.bsum;
+        gs.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gs, st));
+        head_combine_kernel<<<g1(BN * CS), 256, 0, st>>>(S.skip, S.h2, BN * CS, S.xh);
         STEP_LAUNCH_CHECK("head_combine");
         StepGemm g3 = gemm_desc((int)BN, CE, CS, S.xh, CS, 1, p->end1_w, 1, CS, S.e1, CE);
         g3.bias = p->end1_b; g3.relu = 1;
@@ -706,6 +971,52 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     return STEP_OK;
 }
 
+template <bool BF16>
+static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams* grads, const Saved& S, const Work& W, int B, int N,
+                                 float** dx0, hipStream_t st) {
+    const long BN = (long)B * N;
+    float* dx_next = nullptr;
+    float* dxbuf[2] = {W.dxa, W.dxb};
+    for (int i = NL - 1; i >= 0; --i) {
+        const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
+        const long npos = BN * Tout;
+        const float* cat = S.cat[i];
+        if (i < NL - 1) {
+            // BatchNorm_i backward (sums left by the previous iteration's tcn_bwd) + dropout + mix data gradient
+            const BnBwd bn = {p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
+            mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh,
+                                                                            W.dcat);
+            STEP_LAUNCH_CHECK("mix_bwd");
+            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
+            gw.accumulate = 2; gw.splitk = -1;
+            gw.a_rowsum = grads->gconv_b[i];
+            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, st));
+            // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
+            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, BF16, st));      // dP += x1 (x) d_x2
+            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, BF16, st));      // dP += z  (x) d_x1
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
+        }
+        // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
+        float* dx = dxbuf[i & 1];
+        tcn_bwd_kernel<BF16><<<(unsigned)cdiv(BN, TB_ROWS / Tout), 256, 0, st>>>(i < NL - 1 ? W.dcat : nullptr, W.dskip, i, S.tf[i], S.sg[i],
+                                                                                W.wcatT + i * 4096, i < NL - 1 ? W.dres : nullptr, BN, Tin, Tout, dil,
+                                                                                W.dpre, dx, i > 0 ? S.y[i - 1] : nullptr,
+                                                                                i > 0 ? S.bnstat[i - 1] : nullptr,
+                                                                                i > 0 ? W.acc64 + (long)(i - 1) * NCOPY * 64 : nullptr);
+        STEP_LAUNCH_CHECK("tcn_bwd");
+        const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
+        im2col_kernel<<<g1(npos * 64), 256, 0, st>>>(xin, BN, Tin, Tout, dil, W.xcat);
+        STEP_LAUNCH_CHECK("im2col");
+        StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre, 1, 64, W.xcat, 64, 1, W.dwcat + i * 4096, 64);
+        gw.accumulate = 2; gw.splitk = -1;
+        gw.a_rowsum = W.dbcat + i * 64;
+        gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, st));
+        dx_next = dx;
+    }
+    *dx0 = dx_next;
+    return STEP_OK;
+}
 
 extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                                    const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
@@ -719,14 +1030,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     const int allbf16 = p->gemm_bf16;
     auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
-    {
-        GatePtrs gp;
-        for (int i = 0; i < NL; ++i) { gp.wf[i] = p->filter_w[i]; gp.bf[i] = p->filter_b[i]; gp.wg[i] = p->gate_w[i]; gp.bg[i] = p->gate_b[i]; }
-        pack_gate_kernel<<<dim3(16, NL), 256, 0, st>>>(gp, W.wcat, W.bcat);
-        STEP_LAUNCH_CHECK("pack_gate");
-    }
-    STEP_TRY(zero(W.dwcat, NL * 4096, st));
-    STEP_TRY(zero(W.dbcat, NL * 64, st));
+    STEP_TRY(pack_weights(p, W, st));
+    STEP_TRY(zero(W.dwcat, (long)((float*)W.acc64 - W.dwcat) + 2L * 7 * NCOPY * 64, st));       // dwcat, dbcat, dwskip, acc64
     const long NN = (long)N * N;
     STEP_TRY(zero(W.dPstk, 3L * B * NN, st));
 
@@ -757,6 +1062,13 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             for (int i = 0; i < NL; ++i) gb.p[i] = grads->skip_b[i];
             add_to8_kernel<<<1, 256, 0, st>>>(gb, W.bsum, CS);
         }
+        {   // the 8 skip convolutions: d zlast = d skip @ Wskip (every layer's last-step gradient), dWskip = d skip^T zlast
+            StepGemm gz = gemm_desc((int)BN, CS, CS, W.d_xh, CS, 1, W.wskip, CS, 1, W.dskip, CS);
+            gz.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gz, st));
+            StepGemm gws = gemm_desc(CS, CS, (int)BN, W.d_xh, 1, CS, S.zlast, CS, 1, W.dwskip, CS);
+            gws.accumulate = 2; gws.splitk = split_for(BN);
+            gws.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gws, st));
+        }
         // fc_his
         if (hipMemcpyAsync(W.d_h2, W.d_xh, (size_t)BN * CS * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
             step_set_error("gwnet_backward: copy failed");
@@ -777,66 +1089,20 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     }
 
     // ---------------------------------------------------------------- WaveNet layers, reversed
-    float* dx_next = nullptr;
-    float* dxbuf[2] = {W.dxa, W.dxb};
-    for (int i = NL - 1; i >= 0; --i) {
-        const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
-        const long npos = BN * Tout;
-        const float* cat = S.cat[i];
-        if (i < NL - 1) {
-            int nblk = (int)((npos + 7) / 8);
-            if (nblk > BN_BLOCKS) nblk = BN_BLOCKS;
-            bn_cl_bwd_reduce_kernel<<<nblk, 256, 0, st>>>(dx_next, S.y[i], npos, S.bnstat[i], W.partial);
-            bn_cl_bwd_finalize_kernel<<<1, 1024, 0, st>>>(W.partial, nblk, (double)npos, p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], W.coef);
-            bn_cl_bwd_apply_kernel<<<g1(npos * C), 256, 0, st>>>(dx_next, S.y[i], npos * C, S.bnstat[i], W.coef, S.mask[i], W.dres, W.dh);
-            STEP_LAUNCH_CHECK("bn_bwd");
-            // mix (gconv.i.mlp) gradients
-            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
-            gw.accumulate = 2; gw.splitk = split_for(npos);
-            gw.a_rowsum = grads->gconv_b[i];
-            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
-            StepGemm gd = gemm_desc((int)npos, CAT, C, W.dh, C, 1, p->gconv_w[i], CAT, 1, W.dcat, CAT);
-            gd.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gd, st));
-            // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 2, 1, 2, B, N, Tout, p->gemm_bf16, st));          // d_x1 += P (d_x2)
-            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, p->gemm_bf16, st));      // dP += x1 (x) d_x2
-            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, p->gemm_bf16, st));      // dP += z  (x) d_x1
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 1, 0, 0, B, N, Tout, p->gemm_bf16, st));          // d_z  += sum_s P_s (d_x1_s)
-        } else {
-            STEP_TRY(zero(W.dcat, npos * CAT, st));
-        }
-        // skip connection: gradient enters z at the last time index only
-        {
-            StepGemm g = gemm_desc((int)BN, C, CS, W.d_xh, CS, 1, p->skip_w[i], C, 1, W.dcat + (long)(Tout - 1) * CAT, (long)Tout * CAT);
-            g.accumulate = 1;
-            g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
-            StepGemm gw = gemm_desc(CS, C, (int)BN, W.d_xh, 1, CS, cat + (long)(Tout - 1) * CAT, (long)Tout * CAT, 1, grads->skip_w[i], C);
-            gw.accumulate = 2; gw.splitk = split_for(BN);
-            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
-        }
-        // gated TCN
-        gate_bwd_kernel<<<g1(npos * C), 256, 0, st>>>(W.dcat, S.tf[i], S.sg[i], npos, W.dpre);
-        im2col_kernel<<<g1(npos * 64), 256, 0, st>>>(S.x_in[i], BN, Tin, Tout, dil, W.xcat);
-        STEP_LAUNCH_CHECK("gate_bwd");
-        {
-            StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre, 1, 64, W.xcat, 64, 1, W.dwcat + i * 4096, 64);
-            gw.accumulate = 2; gw.splitk = split_for(npos);
-            gw.a_rowsum = W.dbcat + i * 64;
-            gw.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw, st));
-            StepGemm gx = gemm_desc((int)npos, 64, 64, W.dpre, 64, 1, W.wcat + i * 4096, 64, 1, W.dxcat, 64);
-            gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
-        }
-        float* dx = dxbuf[i & 1];
-        col2im_kernel<<<g1(BN * Tin * C), 256, 0, st>>>(W.dxcat, i < NL - 1 ? W.dres : nullptr, BN, Tin, Tout, dil, dx);
-        STEP_LAUNCH_CHECK("col2im");
-        dx_next = dx;
-    }
+    float* dx0 = nullptr;
+    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st));
+    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st));
     {
         GatePtrs gg;
-        for (int i = 0; i < NL; ++i) { gg.wf[i] = grads->filter_w[i]; gg.bf[i] = grads->filter_b[i]; gg.wg[i] = grads->gate_w[i]; gg.bg[i] = grads->gate_b[i]; }
+        SkipPtrs sg;
+        for (int i = 0; i < NL; ++i) {
+            gg.wf[i] = grads->filter_w[i]; gg.bf[i] = grads->filter_b[i]; gg.wg[i] = grads->gate_w[i]; gg.bg[i] = grads->gate_b[i];
+            sg.w[i] = grads->skip_w[i]; sg.b[i] = nullptr;
+        }
         unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, st>>>(W.dwcat, W.dbcat, gg);
+        unpack_skip_grad_kernel<<<CS, CS, 0, st>>>(W.dwskip, sg);
     }
-    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx_next, grads->start_w, grads->start_b);
+    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);
     STEP_LAUNCH_CHECK("start_conv_bwd");
 
     // ---------------------------------------------------------------- supports
