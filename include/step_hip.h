@@ -208,6 +208,12 @@ long step_gwnet_saved_offset(int B, int N, int dropout, int item, int layer);
 int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                        const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                        float* saved, float* work, float* pred, void* stream);
+/* The same in two calls, so that the caller can run the part that does not depend on the TSFormer on another stream while
+ * the encoder is busy: phase 1 = supports + the 8 WaveNet layers (hidden_last / pred unused), phase 2 = head (hist / adj
+ * unused; same saved / work buffers, after phase 1 in stream order), phase 0 = both. */
+int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
+                             const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
+                             float* saved, float* work, float* pred, int phase, void* stream);
 /* dpred [B,12,N] -> parameter gradients (+=) and dadj [B,N,N] (gradient w.r.t. the sampled adjacency,
  * through both random-walk normalisations, model.py:121-130,160). */
 int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,

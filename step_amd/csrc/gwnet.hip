@@ -906,8 +906,17 @@ static int pack_weights(const StepGwnetParams* p, const Work& W, hipStream_t st)
 extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                                   const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                                   float* saved, float* work, float* pred, void* stream) {
-    STEP_REQUIRE(hist && hidden_last && adj && p && saved && work && pred, "gwnet_forward: null argument");
+    return step_gwnet_forward_phase(hist, B, N, Cin, hidden_last, adj, p, training, dropout_p, seed, momentum, saved, work, pred, 0, stream);
+}
+
+extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
+                                        const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
+                                        float* saved, float* work, float* pred, int phase, void* stream) {
+    STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 2, "gwnet_forward: null argument / bad phase");
+    STEP_REQUIRE(phase == 2 || (hist && adj), "gwnet_forward: the layer phase needs hist and adj");
+    STEP_REQUIRE(phase == 1 || (hidden_last && pred), "gwnet_forward: the head phase needs hidden_last and pred");
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_forward: bad sizes B=%d N=%d C=%d", B, N, Cin);
+    const bool do_layers = phase != 2, do_head = phase != 1;
     hipStream_t st = (hipStream_t)stream;
     const bool use_drop = training && dropout_p > 0.f;
     Saved S = carve_saved(saved, B, N, use_drop);
@@ -915,6 +924,7 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     const long BN = (long)B * N;
     const int allbf16 = p->gemm_bf16;      // bf16 mode: every contraction of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
 
+    if (do_layers) {
     STEP_TRY(zero((float*)W.acc64, 2L * 7 * NCOPY * 64, st));
     start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
     STEP_LAUNCH_CHECK("start_conv");
@@ -944,9 +954,10 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
     // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
     if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
     else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
+    }
 
-    // head (model.py:215-220)
-    {
+    // head (model.py:215-220): the only part that needs the TSFormer's hidden state
+    if (do_head) {
         StepGemm g = gemm_desc((int)BN, CE, HID, hidden_last, HID, 1, p->fc_his0_w, 1, HID, S.h1, CE);
         g.bias = p->fc_his0_b; g.relu = 1;
         g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));

@@ -8,6 +8,7 @@ parameters through one ``torch.autograd.Function`` whose forward/backward only l
 kernels through the C ABI (PyTorch supplies device memory, the stream and ``.grad`` plumbing).
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -80,40 +81,62 @@ class _StepFunction(torch.autograd.Function):
         else:
             long_hist = long_hist.contiguous().float()
             L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
-        enc = model.tsformer.encode_series(series)
+        # Everything up to the GraphWaveNet head is independent of the (frozen) TSFormer: the DGL's global feature, the edge
+        # logits, the Gumbel sample and the 8 WaveNet layers only need the train series, the short history and the weights.
+        # They are queued on a second stream next to the encoder: its workgroups keep the compute units busy while that chain of
+        # small, latency-bound kernels advances.  Buffers are allocated on the main stream and outlive the join below.
         P = Lh // 12
-        # ---- kNN prior graph (no grad)
-        sim = _f32(B * N * N, dev).view(B, N, N)
-        adj_knn = _f32(B * N * N, dev).view(B, N, N)
-        dgl = model.discrete_graph_learning
-        kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
-        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, dgl.k * N, L.ptr(sim),
-               L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
-        # ---- DGL: global feature, edge logits, Gumbel sample
+        dgl, be = model.discrete_graph_learning, model.backend
         dt = dgl.native_tensors()
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
         dstruct = fill_dgl_struct(dt, bf)
+        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
         Ttr = dgl.train_length
+        drop = be.dropout if training else 0.0
+        sim = _f32(B * N * N, dev).view(B, N, N)
+        adj_knn = _f32(B * N * N, dev).view(B, N, N)
+        kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
         gsaved = _f32(L.lib().step_dgl_global_saved_floats(N, Ttr), dev)
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 0), dev)
         g = _f32(N * 100, dev).view(N, 100)
-        L.call("step_dgl_global_forward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
-               L.ptr(gsaved), L.ptr(gwork), L.ptr(g), st)
         esaved = _f32(L.lib().step_dgl_edges_saved_floats(B, N), dev)
         theta = _f32(B * N * N, dev).view(B, N, N)
         adj = _f32(B * N * N, dev).view(B, N, N)
-        seed = model._next_seed()
-        L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
-               TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), st)
-        # ---- GraphWaveNet
-        be = model.backend
-        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
-        drop = be.dropout if training else 0.0
         wsaved = _f32(L.lib().step_gwnet_saved_floats(B, N, int(drop > 0)), dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 0), dev)
         pred = _f32(B * 12 * N, dev).view(B, 12, N)
-        L.call("step_gwnet_forward", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), L.ptr(adj), ctypes.byref(bstruct),
-               int(training), float(drop), model._next_seed(), BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), st)
+        seed, seed_gw = model._next_seed(), model._next_seed()
+        side = model._side_stream(dev) if model.overlap_streams else None
+        main = torch.cuda.current_stream()
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)              # inputs, weights (the previous optimizer step) and the noise are ordered before this point
+
+        def graph_and_layers(sst):
+            L.call("step_dgl_global_forward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
+                   L.ptr(gsaved), L.ptr(gwork), L.ptr(g), sst)
+            L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
+                   TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), sst)
+            L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct), int(training),
+                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, sst)
+
+        # ---- TSFormer (frozen) and the kNN prior graph (no grad) on the main stream
+        enc = model.tsformer.encode_series(series)
+        if side is not None:
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                graph_and_layers(L.stream())
+                joined = torch.cuda.Event()
+                joined.record(side)
+        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, dgl.k * N, L.ptr(sim),
+               L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
+        if side is not None:
+            main.wait_event(joined)
+        else:
+            graph_and_layers(st)
+        # ---- GraphWaveNet head: the only consumer of the TSFormer's last hidden state
+        L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), None, ctypes.byref(bstruct), int(training),
+               float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), 2, st)
         if training:
             with torch.no_grad():
                 # one multi-tensor launch instead of ten scalar ones
@@ -195,6 +218,8 @@ class STEP(nn.Module):
         self._last = {}
         self._flat_param = None
         self._flat_grad = None
+        self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
+        self._side = {}
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
         self._reduce_events = []
 
@@ -207,6 +232,12 @@ class STEP(nn.Module):
             p.requires_grad = False
 
     # ------------------------------------------------------------------ helpers
+    def _side_stream(self, dev):
+        key = (dev.type, dev.index)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
     def _next_seed(self):
         self._seed_ctr += 1
         return (torch.initial_seed() * 2654435761 + self._seed_ctr * 40503) & ((1 << 63) - 1)
