@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--forward-only", action="store_true",
                     help="validation / test path (SURVEY 8f-4): eval-mode forward + metric under no_grad, no backward / optimizer")
+    ap.add_argument("--no-shard", action="store_true", help="--gpus > 1: keep the whole graph learner (and fc.weight) on every rank")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -245,7 +246,9 @@ def main():
         model.backend.dropout = 0.0
         model.tsformer.dropout_p = 0.0
     if world > 1:
-        model.enable_native_data_parallel()
+        # each rank keeps one time slice of the graph learner's global branch and of fc.weight (bf16 mode)
+        model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim)
+    sharded = model.discrete_graph_learning._shard is not None
     params = [p for p in model.parameters() if p.requires_grad]
     if args.torch_optim:
         opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)    # step/STEP_PEMS04.py:90-96
@@ -362,12 +365,14 @@ def main():
         buf = torch.zeros(lay["total"], device=dev)
         reps = 5
         for _ in range(2):
-            dist.all_reduce(buf)
+            dist.all_reduce(buf[:fo])          # (with time slices the fc chunk has a different length on every rank and is never reduced)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            dist.all_reduce(buf[fo:fo + fn]); dist.all_reduce(buf[:fo])
+            if not sharded:
+                dist.all_reduce(buf[fo:fo + fn])
+            dist.all_reduce(buf[:fo])
         e1.record()
         torch.cuda.synchronize()
         iso = e0.elapsed_time(e1) / reps
@@ -375,7 +380,8 @@ def main():
         t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(t_ex) for _ in range(world)]
         dist.all_gather(gathered, t_ex)
-        comm = {"allreduce_bytes": int(lay["total"] * 4), "chunks": [int(fn * 4), int(fo * 4)],
+        comm = {"allreduce_bytes": int((fo if sharded else lay["total"]) * 4), "chunks": [int(fo * 4)] if sharded else [int(fn * 4), int(fo * 4)],
+                "graph_learner_time_slices": bool(sharded),
                 "per_rank_allreduce_ms_isolated": [float(g[0]) for g in gathered],
                 "per_rank_exposed_wait_ms": [float(g[1]) for g in gathered],
                 "overlap_fraction": [float(1.0 - g[1] / g[0]) if float(g[0]) > 0 else None for g in gathered],
@@ -394,7 +400,8 @@ def main():
                                    f"train series T={cfg['T_train']}, batch {B}/GPU, random-init weights, "
                                    + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)"),
                        "global_batch": B * world,
-                       "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
+                       "parallelism": f"dp{world}" + (" + graph-learner time slices (fc.weight sharded)" if sharded else ""),
+                       "final_loss": float(loss.detach())},
             "step_ms": {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
                         "p90": float(np.percentile(per_step, 90))},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,

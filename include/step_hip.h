@@ -165,6 +165,24 @@ int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDgl
 int step_dgl_global_backward_phase(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                              const float* dg, float* work, const StepDglParams* grads, int phase, void* stream);
 
+/* Time slice of the global feature for data-parallel ranks (the fc weight is 98 % of the gradient bytes
+ * and the conv / fc work is identical on every rank).  Rank r owns conv2-output columns [a, b) of the T-18: it gets the series
+ * columns [a, b+18) as series_slice [N, Ts = b-a+18] and the weight columns fc.weight.view(100,16,T-18)[:, :, a:b] as p->fc_w
+ * [100, 16*(b-a)], and runs the same kernels on that smaller problem.  What couples the slices is reduced by the CALLER between
+ * the phases (sum over the ranks): the BatchNorm1/2 sums `sums` (f64: [0,16) after phase 1, [16,48) after phase 2), the partial
+ * fc product gpre (step_dgl_global_offset item 2, after phase 3); backward: the 32 "dots" (item 10, after phase 1) and the 1296
+ * "graw" (item 11, after phase 3).  own1 = conv1-output columns of the slice this rank owns (b-a, or b-a+9 on the last rank: the
+ * other 9 are halo shared with the next rank); count1 / count2 = N*(T-9) / N*(T-18) of the WHOLE series.  The results equal the
+ * unsliced forward / backward up to summation order.  bf16 contraction mode only (the fused BatchNorm backward). */
+typedef struct StepDglShard { int own1; double count1, count2; } StepDglShard;
+int step_dgl_global_forward_shard(const float* series_slice, int N, int Ts, const StepDglParams* p, int training, float momentum,
+                                  float* saved, float* work, double* sums, float* g, const StepDglShard* shard, int phase,
+                                  void* stream);
+int step_dgl_global_backward_shard(const float* series_slice, int N, int Ts, const StepDglParams* p, const float* saved,
+                                   const float* dg, float* work, const StepDglParams* grads, const StepDglShard* shard, int phase,
+                                   void* stream);
+long step_dgl_global_offset(int N, int T, int item);
+
 /* Edge logits + Gumbel-softmax hard sample (discrete_graph_learning.py:148-161, :11-45).
  *  g [N,100]; u f32 [B, N*N, 2] uniform noise as drawn by torch.rand (:12) or NULL for the
  *  on-device Philox stream keyed by seed.  Outputs theta[B,N,N] = softmax(logits)[...,0]
@@ -262,6 +280,11 @@ long step_adam_work_floats(void);
 int step_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float max_norm, float* work, float* out_norm,
                    void* stream);
+/* The same with extra_sumsq (device scalar, NULL = 0): the sum of squares of gradient elements held by OTHER ranks (the fc weight
+ * slices of a sharded graph learner), so that every rank clips with the norm of the whole model. */
+int step_adam_clip_sharded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
+                           float* work, float* out_norm, void* stream);
 /* step_loss = masked_mae(pred, real, null_val) + coef * BCELoss(theta, prior)  (step/step_loss/step_loss.py:5-16,
  * basicts/metrics/mae.py:5-28; pred/real are the RESCALED tensors the runner passes, base_tsf_runner.py:240-250).
  * Writes the scalar loss and d loss/d pred, d loss/d theta.  work: 3 doubles of scratch. */

@@ -45,6 +45,13 @@ class StepGwnetParams(ctypes.Structure):
 
 
 _PD = ctypes.POINTER(StepDglParams)
+
+
+class StepDglShard(ctypes.Structure):
+    _fields_ = [("own1", ctypes.c_int), ("count1", ctypes.c_double), ("count2", ctypes.c_double)]
+
+
+_PS = ctypes.POINTER(StepDglShard)
 _PG = ctypes.POINTER(StepGwnetParams)
 
 _SIGS = {
@@ -65,6 +72,9 @@ _SIGS = {
     "step_dgl_global_forward": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp]),
     "step_dgl_global_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _PD, _vp]),
     "step_dgl_global_backward_phase": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _PD, _i, _vp]),
+    "step_dgl_global_forward_shard": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp, _PS, _i, _vp]),
+    "step_dgl_global_backward_shard": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _PD, _PS, _i, _vp]),
+    "step_dgl_global_offset": (_l, [_i, _i, _i]),
     "step_dgl_edges_saved_floats": (_l, [_i, _i]),
     "step_dgl_edges_work_floats": (_l, [_i]),
     "step_dgl_edges_forward": (_i, [_vp, _i, _i, _PD, _vp, _u64, _f, _vp, _vp, _vp, _vp]),
@@ -92,6 +102,7 @@ _SIGS = {
     "step_loss_fwd_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
+    "step_adam_clip_sharded": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

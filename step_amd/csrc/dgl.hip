@@ -25,7 +25,7 @@ template <int CI, int CO, int TPT>
 __global__ __launch_bounds__(256) void conv_relu_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                             const float* __restrict__ b, const float* __restrict__ in_sc,
                                                             const float* __restrict__ in_sh, float* __restrict__ out,
-                                                            float* __restrict__ partial, int Tin) {
+                                                            float* __restrict__ partial, int Tin, int stat_limit) {
     __shared__ __attribute__((aligned(16))) float ws[CI * KW * CO];   // [ci][k][co]
     __shared__ float red[4][2 * CO];
     const int tid = threadIdx.x, n = blockIdx.y;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_relu_fwd_kernel(const float* __restr
             if (t0 + j < Tout) {
                 float v = fmaxf(acc[co][j], 0.f);
                 dst[j] = v;
-                s1[co] += v; s2[co] += v * v;
+                if (t0 + j < stat_limit) { s1[co] += v; s2[co] += v * v; }     // columns >= stat_limit: halo owned by the next time slice
             }
         }
     }
@@ -122,6 +122,40 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         stat[2 * C + c] = (float)mean;
         stat[3 * C + c] = rstd;
     }
+}
+
+// Time-sliced variant (data-parallel ranks each own a time slice, see step_dgl_global_forward_shard): the per-block partials
+// are first reduced to f64 sums [2C] -- summed over the ranks by the caller -- and the statistics come from those sums.
+__global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ partial, int nblk, int C, double* __restrict__ sums) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int i = tid; i < nblk; i += 256) { a += partial[(long)i * 2 * C + c]; q += partial[(long)i * 2 * C + C + c]; }
+    r1[tid] = a; r2[tid] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) { sums[c] = r1[0]; sums[C + c] = r2[0]; }
+}
+__global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                        int training, float momentum, float* __restrict__ stat) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = sums[c] / count;
+        var = fmax(sums[C + c] / count - mean * mean, 0.0);
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * count / fmax(count - 1.0, 1.0));
+    } else {
+        mean = rmean[c]; var = rvar[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = gamma[c] * rstd;
+    stat[c] = sc; stat[C + c] = beta[c] - (float)mean * sc; stat[2 * C + c] = (float)mean; stat[3 * C + c] = rstd;
 }
 
 // gpre[n][j] += bias[j]   (in place; the value saved for backward is fc(x)+b)
@@ -588,48 +622,94 @@ static void carve_saved(float* saved, int N, int T, float** a1, float** a2, floa
     *st3 = saved;
 }
 
-extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, const StepDglParams* p, int training,
-                                       float momentum, float* saved, float* work, float* g, void* stream) {
-    STEP_REQUIRE(series_nt && p && saved && work && g && N > 0 && T > 18, "dgl_global_forward: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+// Forward in up to four phases.  shard == nullptr: the whole series on this device (phase must be 0).  With a shard the caller
+// sums `sums` (after phases 1 and 2) and gpre (after phase 3) over the ranks between the calls:
+//   1: conv1 + its BatchNorm sums -> sums[0..16)            2: BatchNorm1 statistics, conv2 + sums -> sums[16..48)
+//   3: BatchNorm2 statistics, partial fc product -> gpre     4: + bias, ReLU, BatchNorm3 -> g
+static int dgl_global_forward_impl(const float* series_nt, int N, int T, const StepDglParams* p, int training, float momentum,
+                                   float* saved, float* work, double* sums, float* g, const StepDglShard* shard, int phase,
+                                   hipStream_t st) {
     const int T1 = T - 9, T2 = T - 18;
     float *a1, *a2, *gpre, *st1, *st2, *st3;
     carve_saved(saved, N, T, &a1, &a2, &gpre, &st1, &st2, &st3);
     float* partial = work;
-    {
+    const bool all = phase == 0;
+    const double count1 = shard ? shard->count1 : (double)N * T1, count2 = shard ? shard->count2 : (double)N * T2;
+    if (all || phase == 1) {
         dim3 grid(cdiv(T1, 256 * 4), N);
-        conv_relu_fwd_kernel<1, 8, 4><<<grid, 256, 0, st>>>(series_nt, p->conv1_w, p->conv1_b, nullptr, nullptr, a1, partial, T);
+        conv_relu_fwd_kernel<1, 8, 4><<<grid, 256, 0, st>>>(series_nt, p->conv1_w, p->conv1_b, nullptr, nullptr, a1, partial, T,
+                                                            shard ? shard->own1 : T1);
         STEP_LAUNCH_CHECK("conv1");
-        bn_finalize_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, (double)N * T1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv,
-                                              training, momentum, st1);
+        if (shard) bn_sums_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, sums);
+        else bn_finalize_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training,
+                                                   momentum, st1);
         STEP_LAUNCH_CHECK("bn1");
     }
-    {
+    if (all || phase == 2) {
+        if (shard) bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1);
         int nblk;
         if (p->gemm_bf16) {
             STEP_TRY(dgl_conv2_fwd_mfma(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
         } else {
             dim3 grid(cdiv(T2, 256 * 4), N);
-            conv_relu_fwd_kernel<8, 16, 4><<<grid, 256, 0, st>>>(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, T1);
+            conv_relu_fwd_kernel<8, 16, 4><<<grid, 256, 0, st>>>(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, T1, T2);
             STEP_LAUNCH_CHECK("conv2");
             nblk = grid.x * grid.y;
         }
-        bn_finalize_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, (double)N * T2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv,
-                                               training, momentum, st2);
+        if (shard) bn_sums_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, sums + 16);
+        else bn_finalize_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, count2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, training, momentum,
+                                                    st2);
         STEP_LAUNCH_CHECK("bn2");
     }
-    const long K = 16L * T2;
-    if (hipMemsetAsync(gpre, 0, (size_t)N * EMB * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
-    StepGemm gm = gemm_desc(N, EMB, (int)K, a2, K, 1, p->fc_w, 1, K, gpre, EMB);
-    gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
-    gm.accumulate = 2;
-    gm.splitk = -1;
-    gm.compute_bf16 = p->gemm_bf16;
-    STEP_TRY(step_gemm_launch(gm, st));
-    fc_post_bn3_kernel<<<EMB, 256, 0, st>>>(gpre, p->fc_b, N, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, training, momentum, st3, g);
-    STEP_LAUNCH_CHECK("fc_post_bn3");
+    if (all || phase == 3) {
+        if (shard) bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums + 16, 16, count2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, training, momentum, st2);
+        const long K = 16L * T2;
+        if (hipMemsetAsync(gpre, 0, (size_t)N * EMB * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+        StepGemm gm = gemm_desc(N, EMB, (int)K, a2, K, 1, p->fc_w, 1, K, gpre, EMB);
+        gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
+        gm.accumulate = 2;
+        gm.splitk = -1;
+        gm.compute_bf16 = p->gemm_bf16;
+        STEP_TRY(step_gemm_launch(gm, st));
+    }
+    if (all || phase == 4) {
+        fc_post_bn3_kernel<<<EMB, 256, 0, st>>>(gpre, p->fc_b, N, p->bn3_w, p->bn3_b, p->bn3_rm, p->bn3_rv, training, momentum, st3, g);
+        STEP_LAUNCH_CHECK("fc_post_bn3");
+    }
     return STEP_OK;
 }
+
+extern "C" int step_dgl_global_forward(const float* series_nt, int N, int T, const StepDglParams* p, int training,
+                                       float momentum, float* saved, float* work, float* g, void* stream) {
+    STEP_REQUIRE(series_nt && p && saved && work && g && N > 0 && T > 18, "dgl_global_forward: bad arguments");
+    return dgl_global_forward_impl(series_nt, N, T, p, training, momentum, saved, work, nullptr, g, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int step_dgl_global_forward_shard(const float* series_slice, int N, int Ts, const StepDglParams* p, int training,
+                                             float momentum, float* saved, float* work, double* sums, float* g,
+                                             const StepDglShard* shard, int phase, void* stream) {
+    STEP_REQUIRE(series_slice && p && saved && work && sums && g && shard && N > 0 && Ts > 18 && phase >= 1 && phase <= 4,
+                 "dgl_global_forward_shard: bad arguments");
+    STEP_REQUIRE(shard->own1 > 0 && shard->own1 <= Ts - 9 && shard->count1 > 0 && shard->count2 > 0, "dgl_global_forward_shard: bad shard");
+    return dgl_global_forward_impl(series_slice, N, Ts, p, training, momentum, saved, work, sums, g, shard, phase, (hipStream_t)stream);
+}
+
+// float offset of an item inside `saved` (item 0: a1, 1: a2, 2: gpre [N,100]) / inside the backward `work` (item 10: the 32 BatchNorm2
+// sums "dots", 11: the 1296 raw conv2 weight-gradient sums "graw") -- what a sharded caller reduces over the ranks
+extern "C" long step_dgl_global_offset(int N, int T, int item) {
+    const long T1 = T - 9, T2 = T - 18;
+    if (item == 0) return 0;
+    if (item == 1) return (long)N * 8 * T1;
+    if (item == 2) return (long)N * 8 * T1 + (long)N * 16 * T2;
+    const long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
+    const long coef = (nb1 > nb2 ? nb1 : nb2) * 32 + 64 + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB;
+    if (item == 10) return coef + 256;
+    if (item == 11) return coef + 320;
+    return -1;
+}
+
+static int dgl_global_backward_impl(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved, const float* dg,
+                                    float* work, const StepDglParams* grads, const StepDglShard* shard, int phase, void* stream);
 
 extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                                         const float* dg, float* work, const StepDglParams* grads, void* stream) {
@@ -642,7 +722,26 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
                                               const float* dg, float* work, const StepDglParams* grads, int phase, void* stream) {
     STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18 && phase >= 0 && phase <= 2,
                  "dgl_global_backward: bad arguments");
-    const bool do_fc = phase != 2, do_rest = phase != 1;
+    return dgl_global_backward_impl(series_nt, N, T, p, saved, dg, work, grads, nullptr, phase, stream);
+}
+
+// Time slice of a data-parallel rank (see step_dgl_global_forward_shard): dg = the gradient of g averaged over the ranks.
+//   phase 1: BatchNorm3 / fc backward up to the fc weight-slice gradient and the BatchNorm2 sums ("dots", offset item 10)
+//   phase 3: BatchNorm2 coefficients from the (rank-summed) dots, fc input gradient, conv2 weight-gradient sums ("graw", item 11)
+//   phase 4: conv2 / BatchNorm1 gradients from the (rank-summed) graw, conv2 data gradient, conv1 weight gradient (a partial sum:
+//            conv1_w / conv1_b are summed, not averaged, over the ranks)
+extern "C" int step_dgl_global_backward_shard(const float* series_slice, int N, int Ts, const StepDglParams* p, const float* saved,
+                                              const float* dg, float* work, const StepDglParams* grads, const StepDglShard* shard,
+                                              int phase, void* stream) {
+    STEP_REQUIRE(series_slice && p && saved && dg && work && grads && shard && N > 0 && Ts > 18 && (phase == 1 || phase == 3 || phase == 4),
+                 "dgl_global_backward_shard: bad arguments");
+    STEP_REQUIRE(p->gemm_bf16 && Ts - 18 >= 128, "dgl_global_backward_shard: needs the bf16 contraction mode and a slice of >= 128 conv2 columns");
+    return dgl_global_backward_impl(series_slice, N, Ts, p, saved, dg, work, grads, shard, phase, stream);
+}
+
+static int dgl_global_backward_impl(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved, const float* dg,
+                                    float* work, const StepDglParams* grads, const StepDglShard* shard, int phase, void* stream) {
+    const bool do_fc = phase == 0 || phase == 1, do_mid = phase == 0 || phase == 2 || phase == 3, do_tail = phase == 0 || phase == 2 || phase == 4;
     hipStream_t st = (hipStream_t)stream;
     const int T1 = T - 9, T2 = T - 18;
     const long K = 16L * T2;
@@ -660,7 +759,8 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
     float* graw = coef + 320;
     float* wg_scratch = coef + DGL_SMALL;
     // BatchNorm2 backward without its two passes over d_a2 / a2 (1.3 GB at PEMS04): needs a tile to span at most two channels
-    const bool fuse2 = T2 >= 128 && !dgl_legacy_bn_backward();
+    const bool fuse2 = T2 >= 128 && (shard || !dgl_legacy_bn_backward());
+    const double count1 = shard ? shard->count1 : (double)N * T1, count2 = shard ? shard->count2 : (double)N * T2;
     if (do_fc) {
         // BN3 + ReLU backward, fc bias gradient
         float* colsum = coef + 128;          // column sums of dgpre [EMB] (coef holds 3 x 16 BatchNorm coefficients at most)
@@ -682,14 +782,14 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
             }
         }
     }
-    if (!do_rest) return STEP_OK;
+    if (!do_mid && !do_tail) return STEP_OK;
     // d(BN2 output) = dgpre @ fc_w
-    {
+    if (do_mid) {
         StepGemm gm = gemm_desc(N, (int)K, EMB, dgpreT, 1, N, p->fc_w, K, 1, d_a2, K);     // A(m=n, k=o) = dgpreT[o][n]
         if (p->gemm_bf16 || fuse2) { gm.A = dgpre; gm.sam = EMB; gm.sak = 1; }             // LDS-staged path: k-contiguous rows
         gm.compute_bf16 = p->gemm_bf16;
         if (fuse2) {       // coefficients from the sums of phase 1, BatchNorm2 backward + ReLU mask in the GEMM's epilogue: writes dz2
-            bn2_fused_coef_kernel<<<1, 64, 0, st>>>(dots, st2, p->bn2_w, (double)N * T2, grads->bn2_w, grads->bn2_b, coef);
+            bn2_fused_coef_kernel<<<1, 64, 0, st>>>(dots, st2, p->bn2_w, count2, grads->bn2_w, grads->bn2_b, coef);
             STEP_LAUNCH_CHECK("bn2_fused_coef");
             GemmFused fu = {nullptr, nullptr, a2, coef, st2, 16, T2};
             STEP_TRY(step_gemm_launch_fused(gm, fu, st));
@@ -698,7 +798,7 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
         }
     }
     // BN2 backward (+ReLU mask) in place -> dz2
-    if (!fuse2) {
+    if (do_mid && !fuse2) {
         dim3 grid(cdiv(T2, 1024), 16, N);
         bn_bwd_reduce_kernel<16><<<grid, 256, 0, st>>>(d_a2, a2, st2, T2, partial);
         STEP_LAUNCH_CHECK("bn2_bwd_reduce");
@@ -710,14 +810,18 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
     // conv2 backward: weights (BN1 affine folded into the input read) and data
     // bf16 mode: BatchNorm1's backward is fused as well -- its sums come out of the conv2 weight-gradient contraction, its
     // transform rides in the epilogue of the conv2 data gradient (no pass over d_a1 / a1)
-    const bool fuse1 = p->gemm_bf16 && !dgl_legacy_bn_backward();
+    const bool fuse1 = p->gemm_bf16 && (shard || !dgl_legacy_bn_backward());
     if (fuse1) {
-        STEP_TRY(dgl_conv2_wgrad_bn1_mfma(d_a2, a1, st1, p->conv2_w, p->bn1_w, p->bn1_b, wg_scratch, graw, grads->conv2_w, grads->conv2_b,
-                                          grads->bn1_w, grads->bn1_b, coef + 64, N, T1, st));
-        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, a1, coef + 64, st1, st));
+        // mid: the raw sums G' = sum dz2 * xhat1 and db2 (summed over the ranks by a sharded caller before the tail)
+        if (do_mid) STEP_TRY(dgl_conv2_wgrad_xhat_mfma(d_a2, a1, st1, wg_scratch, graw, N, T1, st));
+        if (!do_tail) return STEP_OK;
+        STEP_TRY(dgl_conv2_wgrad_finish(graw, p->conv2_w, st1, p->bn1_w, p->bn1_b, count1, grads->conv2_w, grads->conv2_b, grads->bn1_w,
+                                        grads->bn1_b, coef + 64, st));
+        // columns >= own1 of a time slice are halo: the owner (the next rank) subtracts BatchNorm1's constant terms there
+        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, a1, coef + 64, st1, shard ? shard->own1 : T1, st));
     } else if (p->gemm_bf16) {
         STEP_TRY(dgl_conv2_wgrad_mfma(d_a2, a1, st1, st1 + 8, wg_scratch, grads->conv2_w, grads->conv2_b, N, T1, st));
-        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, nullptr, nullptr, nullptr, st));
+        STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, nullptr, nullptr, nullptr, T1, st));
     } else {
         conv_bwd_weight_kernel<8, 16><<<N, 256, 0, st>>>(d_a2, a1, st1, st1 + 8, grads->conv2_w, grads->conv2_b, T1);
         STEP_LAUNCH_CHECK("conv2_bwd_weight");

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv2_fwd_mfma_kernel(const float* __rest
 // with x = bnx (= a1, laid out like din), coef = [m1 | m2 | gamma*rstd], stat = [scale | shift | mean | rstd], C = 8.
 __global__ __launch_bounds__(256) void conv2_dgrad_mfma_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                                float* __restrict__ din, int T1, const float* __restrict__ bnx,
-                                                               const float* __restrict__ coef, const float* __restrict__ stat) {
+                                                               const float* __restrict__ coef, const float* __restrict__ stat, int own) {
     __shared__ uint4 zs[FW_TT + 16][2];           // [t - (t0 - 9)][16 co] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
     const int T2 = T1 - (KW - 1), t0 = blockIdx.x * FW_TT;
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void conv2_dgrad_mfma_kernel(const float* __re
                     const int c = 4 * q + e;
                     const long idx = ((long)n * CI + c) * T1 + t;
                     const float x = bnx[idx];
-                    const float v = coef[2 * CI + c] * (acc[e] - coef[c] - (x - stat[2 * CI + c]) * stat[3 * CI + c] * coef[CI + c]);
+                    const float cst = t < own ? coef[c] + (x - stat[2 * CI + c]) * stat[3 * CI + c] * coef[CI + c] : 0.f;
+                    const float v = coef[2 * CI + c] * (acc[e] - cst);
                     din[idx] = x > 0.f ? v : 0.f;
                 }
             } else {
@@ -422,8 +423,8 @@ int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const fl
 }
 
 int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, const float* bnx, const float* coef, const float* stat,
-                         hipStream_t st) {
-    conv2_dgrad_mfma_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>(dz, w, din, T1, bnx, coef, stat);
+                         int own, hipStream_t st) {
+    conv2_dgrad_mfma_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>(dz, w, din, T1, bnx, coef, stat, own);
     STEP_LAUNCH_CHECK("conv2_dgrad_mfma");
     return STEP_OK;
 }
@@ -444,11 +445,12 @@ int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, cons
     return STEP_OK;
 }
 
-// conv2 weight / bias gradient together with the fused BatchNorm1 backward's coefficient step (see conv2_wgrad_finish_kernel):
-// stat1 = BatchNorm1's [scale | shift | mean | rstd], graw = 1296 floats of scratch, coef1 out (24 floats)
-int dgl_conv2_wgrad_bn1_mfma(const float* dz, const float* a1, const float* stat1, const float* w, const float* gamma1, const float* beta1,
-                             float* scratch, float* graw, float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, int N, int T1,
-                             hipStream_t st) {
+// conv2 weight / bias gradient together with the fused BatchNorm1 backward's coefficient step (see conv2_wgrad_finish_kernel), in
+// two calls so that a time-sliced caller can sum graw over the ranks in between:
+//   xhat:   graw (1296 floats) = [G'[co][ci][kk] = sum dz * xhat1 | db2[co] = sum dz]   (stat1 = BatchNorm1's [scale | shift | mean | rstd])
+//   finish: dw / db / dgamma1 / dbeta1 += ..., coef1 out (24 floats); count = nodes x conv1 columns of the WHOLE series
+int dgl_conv2_wgrad_xhat_mfma(const float* dz, const float* a1, const float* stat1, float* scratch, float* graw, int N, int T1,
+                              hipStream_t st) {
     const int T2 = T1 - (KW - 1);
     dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
     if (hipMemsetAsync(graw, 0, WG_OUT * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
@@ -456,7 +458,11 @@ int dgl_conv2_wgrad_bn1_mfma(const float* dz, const float* a1, const float* stat
     STEP_LAUNCH_CHECK("conv2_wgrad_mfma(xhat)");
     conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
-    conv2_wgrad_finish_kernel<<<1, 256, 0, st>>>(graw, w, stat1, gamma1, beta1, (double)N * T1, dw, db, dgamma1, dbeta1, coef1);
+    return STEP_OK;
+}
+int dgl_conv2_wgrad_finish(const float* graw, const float* w, const float* stat1, const float* gamma1, const float* beta1, double count,
+                           float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, hipStream_t st) {
+    conv2_wgrad_finish_kernel<<<1, 256, 0, st>>>(graw, w, stat1, gamma1, beta1, count, dw, db, dgamma1, dbeta1, coef1);
     STEP_LAUNCH_CHECK("conv2_wgrad_finish");
     return STEP_OK;
 }

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
                                                         float wd, float bc1, float bc2_sqrt, float max_norm,
-                                                        const float* __restrict__ partial, int npartial, float* __restrict__ out_norm) {
+                                                        const float* __restrict__ partial, int npartial, const float* __restrict__ extra_sumsq,
+                                                        float* __restrict__ out_norm) {
     __shared__ float red[4];
     __shared__ float s_coef;
     {   // total gradient norm from the partials (every block recomputes it: 1024 floats, L2-resident)
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+            const float norm = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sumsq ? *extra_sumsq : 0.f));
             float c = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;      // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
             s_coef = c < 1.f ? c : 1.f;
             if (out_norm && blockIdx.x == 0) *out_norm = norm;
@@ -68,6 +69,15 @@ extern "C" long step_adam_work_floats(void) { return NB + 8; }
 extern "C" int step_adam_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int step, float max_norm, float* work, float* out_norm,
                               void* stream) {
+    return step_adam_clip_sharded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, nullptr, work,
+                                  out_norm, stream);
+}
+
+// extra_sumsq (device scalar, may be NULL): sum of squares of gradient elements that live on OTHER ranks (parameter shards), added
+// to this buffer's own sum before the clip coefficient is formed, so that every rank clips with the norm of the whole model
+extern "C" int step_adam_clip_sharded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
+                                      float* work, float* out_norm, void* stream) {
     STEP_REQUIRE(params && grads && exp_avg && exp_avg_sq && work && n > 0 && step >= 1, "adam_clip: bad arguments");
     STEP_REQUIRE((((uintptr_t)grads) & 15) == 0, "adam_clip: gradient buffer must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -78,7 +88,7 @@ extern "C" int step_adam_clip(float* params, const float* grads, float* exp_avg,
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     adam_clip_kernel<<<blocks, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                                             max_norm, work, NB, out_norm);
+                                             max_norm, work, NB, extra_sumsq, out_norm);
     STEP_LAUNCH_CHECK("adam_clip");
     return STEP_OK;
 }

@@ -41,10 +41,10 @@ int step_gemm_rowsum_separate(StepGemm* g, hipStream_t st);
 int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
                        int N, int T1, int* nblk, hipStream_t st);
 int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int T1, const float* bnx, const float* coef, const float* stat,
-                         hipStream_t st);
-int dgl_conv2_wgrad_bn1_mfma(const float* dz, const float* a1, const float* stat1, const float* w, const float* gamma1, const float* beta1,
-                             float* scratch, float* graw, float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, int N, int T1,
-                             hipStream_t st);
+                         int own, hipStream_t st);
+int dgl_conv2_wgrad_xhat_mfma(const float* dz, const float* a1, const float* stat1, float* scratch, float* graw, int N, int T1, hipStream_t st);
+int dgl_conv2_wgrad_finish(const float* graw, const float* w, const float* stat1, const float* gamma1, const float* beta1, double count,
+                           float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, hipStream_t st);
 long dgl_conv2_wgrad_scratch_floats(int N, int T1);
 int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
                          int T1, hipStream_t st);

@@ -37,9 +37,18 @@ class FusedAdamClip:
             raise RuntimeError("FusedAdamClip.step(): no native backward has run since zero_grad()")
         pg = self.param_groups[0]
         self.step_count += 1
-        _lib.call("step_adam_clip", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+        extra = None
+        sh = self.model.discrete_graph_learning._shard
+        if sh is not None and self.max_norm:
+            # the fc weight slices of the other ranks belong to the model's gradient norm: one scalar all-reduce
+            fo, fn, _ = self.model._grad_layout()["items"]["dgl.fc_w"]
+            own = g[fo:fo + fn].double().square().sum().reshape(1)
+            tot = own.clone()
+            self.model._sum_over_ranks(tot)
+            extra = (tot - own).float()
+        _lib.call("step_adam_clip_sharded", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                   self.flat.numel(), float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
-                  float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(self.work),
+                  float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(extra), _lib.ptr(self.work),
                   _lib.ptr(self.grad_norm), _lib.stream())
 
     def state_dict(self):

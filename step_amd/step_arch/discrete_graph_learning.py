@@ -68,13 +68,83 @@ class DiscreteGraphLearning(nn.Module):
         self.fc_cat = nn.Linear(self.embedding_dim, 2)
         self.fc_out = nn.Linear(self.embedding_dim * 2, self.embedding_dim)
 
+        self._shard = None
+
     @property
     def node_feats(self):          # [T, N], the reference attribute (:57)
         return self._series_nt.t()
 
+    # ------------------------------------------------------------------ time slices over data-parallel ranks
+    @staticmethod
+    def slice_bounds(T2, world):
+        """conv2-output columns [bounds[r], bounds[r+1]) of rank r: balanced, contiguous, covering [0, T2)."""
+        return [(T2 * r) // world for r in range(world + 1)]
+
+    def shard_time_slices(self, rank, world):
+        """Keep only this rank's time slice of the global branch (conv1 -> bn1 -> conv2 -> bn2 -> fc, :131-134): series columns
+        [a, b+18), conv2-output columns [a, b) and the matching columns of ``fc.weight`` as the new parameter ``fc_weight_slice``
+        [100, 16*(b-a)] (``fc.weight`` itself stops being trained and is refreshed by ``gather_fc_weight()``).  The native
+        forward/backward then run on the slice and exchange only the BatchNorm sums, the [N,100] partial fc product and 1328
+        backward sums (step_dgl_global_*_shard in include/step_hip.h)."""
+        assert self._shard is None, "already sharded"
+        T2 = self.train_length - 18
+        bounds = self.slice_bounds(T2, world)
+        a, b = bounds[rank], bounds[rank + 1]
+        if min(bounds[r + 1] - bounds[r] for r in range(world)) < 128:
+            raise ValueError(f"time slices of {T2} conv2 columns over {world} ranks are shorter than 128 columns")
+        self._shard = {"rank": rank, "world": world, "a": a, "b": b, "Ts": b - a + 18, "bounds": bounds,
+                       "own1": (b - a) + (9 if rank == world - 1 else 0),
+                       "count1": float(self.num_nodes) * (self.train_length - 9), "count2": float(self.num_nodes) * T2}
+        self.register_buffer("_series_slice", self._series_nt[:, a:b + 18].contiguous(), persistent=False)
+        w = self.fc.weight.detach().view(self.embedding_dim, 16, T2)[:, :, a:b].contiguous().view(self.embedding_dim, -1)
+        self.fc_weight_slice = nn.Parameter(w.clone())
+        self.fc.weight.requires_grad_(False)
+        return self._shard
+
+    def shard_struct(self):
+        sh = self._shard
+        s = _lib.StepDglShard()
+        s.own1, s.count1, s.count2 = sh["own1"], sh["count1"], sh["count2"]
+        return s
+
+    def gather_fc_weight(self, process_group=None):
+        """Collective: write every rank's trained slice back into ``fc.weight`` (call on all ranks before ``state_dict()`` /
+        checkpointing; the reference's state_dict layout is then complete again)."""
+        import torch.distributed as dist
+        sh = self._shard
+        if sh is None:
+            return
+        T2 = self.train_length - 18
+        full = self.fc.weight.data.view(self.embedding_dim, 16, T2)
+        for r in range(sh["world"]):
+            a, b = sh["bounds"][r], sh["bounds"][r + 1]
+            buf = self.fc_weight_slice.data.view(self.embedding_dim, 16, b - a).clone() if r == sh["rank"] else \
+                torch.empty(self.embedding_dim, 16, b - a, device=full.device, dtype=full.dtype)
+            dist.broadcast(buf, dist.get_global_rank(process_group, r) if process_group is not None else r, group=process_group)
+            full[:, :, a:b].copy_(buf)
+
+    def refresh_fc_weight_slice(self):
+        """after loading a (full) state_dict into a sharded module: re-cut this rank's slice from ``fc.weight``"""
+        sh = self._shard
+        if sh is not None:
+            T2 = self.train_length - 18
+            with torch.no_grad():
+                self.fc_weight_slice.copy_(self.fc.weight.view(self.embedding_dim, 16, T2)[:, :, sh["a"]:sh["b"]].reshape(self.embedding_dim, -1))
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+        sd.pop(prefix + "fc_weight_slice", None)          # the reference's keys only (fc.weight carries the gathered matrix)
+        return sd
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if prefix + "fc_weight_slice" in missing_keys:
+            missing_keys.remove(prefix + "fc_weight_slice")
+
     def native_tensors(self):
         return {"conv1_w": self.conv1.weight, "conv1_b": self.conv1.bias, "conv2_w": self.conv2.weight,
-                "conv2_b": self.conv2.bias, "fc_w": self.fc.weight, "fc_b": self.fc.bias,
+                "conv2_b": self.conv2.bias, "fc_w": self.fc.weight if self._shard is None else self.fc_weight_slice, "fc_b": self.fc.bias,
                 "bn1_w": self.bn1.weight, "bn1_b": self.bn1.bias, "bn1_rm": self.bn1.running_mean, "bn1_rv": self.bn1.running_var,
                 "bn2_w": self.bn2.weight, "bn2_b": self.bn2.bias, "bn2_rm": self.bn2.running_mean, "bn2_rv": self.bn2.running_var,
                 "bn3_w": self.bn3.weight, "bn3_b": self.bn3.bias, "bn3_rm": self.bn3.running_mean, "bn3_rv": self.bn3.running_var,

@@ -91,7 +91,9 @@ class _StepFunction(torch.autograd.Function):
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
         dstruct = fill_dgl_struct(dt, bf)
         bstruct = fill_gwnet_struct(be.native_tensors(), bf)
-        Ttr = dgl.train_length
+        sh = dgl._shard                      # time slice of the global branch on this data-parallel rank (or None)
+        Ttr = dgl.train_length if sh is None else sh["Ts"]
+        series_nt = dgl._series_nt if sh is None else dgl._series_slice
         drop = be.dropout if training else 0.0
         sim = _f32(B * N * N, dev).view(B, N, N)
         adj_knn = _f32(B * N * N, dev).view(B, N, N)
@@ -113,8 +115,20 @@ class _StepFunction(torch.autograd.Function):
             ready.record(main)              # inputs, weights (the previous optimizer step) and the noise are ordered before this point
 
         def graph_and_layers(sst):
-            L.call("step_dgl_global_forward", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
-                   L.ptr(gsaved), L.ptr(gwork), L.ptr(g), sst)
+            if sh is None:
+                L.call("step_dgl_global_forward", L.ptr(series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
+                       L.ptr(gsaved), L.ptr(gwork), L.ptr(g), sst)
+            else:
+                # the slices meet in three small sums over the ranks: BatchNorm1 sums, BatchNorm2 sums, the [N,100] partial fc product
+                sstruct = dgl.shard_struct()
+                sums = torch.zeros(48, dtype=torch.float64, device=dev)
+                go = L.lib().step_dgl_global_offset(N, Ttr, 2)
+                exchange = {1: sums[:16], 2: sums[16:], 3: gsaved[go:go + N * 100]}
+                for phase in (1, 2, 3, 4):
+                    L.call("step_dgl_global_forward_shard", L.ptr(series_nt), N, Ttr, ctypes.byref(dstruct), int(training), BN_MOMENTUM,
+                           L.ptr(gsaved), L.ptr(gwork), L.ptr(sums), L.ptr(g), ctypes.byref(sstruct), phase, sst)
+                    if phase in exchange:
+                        model._sum_over_ranks(exchange[phase])
             L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
                    TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), sst)
             L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct), int(training),
@@ -179,14 +193,35 @@ class _StepFunction(torch.autograd.Function):
                L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), st)
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
         fo, fn, _ = layout["items"]["dgl.fc_w"]
-        L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-               L.ptr(gwork), ctypes.byref(dg_grads), 1, st)
-        pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
-        L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-               L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
         assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
-        pending += model._reduce_begin(flat[:fo])
-        model._reduce_finish(flat, pending)
+        sh = dgl._shard
+        if sh is None:
+            L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                   L.ptr(gwork), ctypes.byref(dg_grads), 1, st)
+            pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
+            L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                   L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
+            pending += model._reduce_begin(flat[:fo])
+            model._reduce_finish(flat, pending, flat)
+        else:
+            # time slices: the gradient of g is averaged over the ranks first, every rank then back-propagates its slice; the slices
+            # meet in two small sums (BatchNorm2's 32 "dots", the 1296 raw conv2 weight-gradient sums).  The fc weight slice's
+            # gradient stays on its rank -- 98 % of the gradient bytes never enter a collective.
+            world = sh["world"]
+            model._sum_over_ranks(dgv)
+            dgv.mul_(1.0 / world)
+            sstruct = dgl.shard_struct()
+            o_dots, o_graw = L.lib().step_dgl_global_offset(N, Ttr, 10), L.lib().step_dgl_global_offset(N, Ttr, 11)
+            exchange = {1: gwork[o_dots:o_dots + 32], 3: gwork[o_graw:o_graw + 1296]}
+            for phase in (1, 3, 4):
+                L.call("step_dgl_global_backward_shard", L.ptr(dgl._series_slice), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                       L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase, st)
+                if phase in exchange:
+                    model._sum_over_ranks(exchange[phase])
+            # conv1's gradients are per-slice partial sums: summed, not averaged, by the mean all-reduce below
+            views["dgl.conv1_w"].mul_(float(world))
+            views["dgl.conv1_b"].mul_(float(world))
+            model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
         model._flat_grad = flat
         ctx.held = None
         # fresh views with no other owner: autograd's AccumulateGrad then adopts them as .grad (aliases of the flat buffer)
@@ -275,7 +310,7 @@ class STEP(nn.Module):
         self._flat_param = flat
         return flat
 
-    def enable_native_data_parallel(self, process_group=None, sync_module_states=True):
+    def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False):
         """Average the flat gradient buffer over ranks inside backward (RCCL all-reduce of the flat buffer, in two asynchronous
         chunks; replaces DDP's bucketed reducer -- do not also wrap the module in DistributedDataParallel).  Like DDP's
         constructor, it first broadcasts rank 0's parameters and buffers (``sync_module_states``)."""
@@ -293,6 +328,13 @@ class STEP(nn.Module):
                         c = d.contiguous()
                         dist.broadcast(c, src, group=self._process_group)
                         d.copy_(c)
+        if shard_graph_learner and dist.get_world_size(self._process_group) > 1:
+            # every rank keeps one time slice of the graph learner's global branch and of fc.weight
+            if self.matmul_precision != "bf16":
+                raise ValueError("shard_graph_learner needs matmul_precision = 'bf16' (the sliced backward uses the fused BatchNorm backward)")
+            self.discrete_graph_learning.shard_time_slices(dist.get_rank(self._process_group), dist.get_world_size(self._process_group))
+            self._layout = None
+            self._flat_param = None
 
     def _reduce_begin(self, chunk):
         """Start the sum of one contiguous chunk of the flat gradient buffer over the data-parallel group (RCCL all-reduce on
@@ -304,7 +346,13 @@ class STEP(nn.Module):
             return []
         return [dist.all_reduce(chunk, group=self._process_group, async_op=True)]
 
-    def _reduce_finish(self, flat, pending):
+    def _sum_over_ranks(self, t):
+        """in-place sum of a small device tensor over the data-parallel group, ordered on the current stream"""
+        import torch.distributed as dist
+        if self._process_group is not None and dist.get_world_size(self._process_group) > 1:
+            dist.all_reduce(t, group=self._process_group)
+
+    def _reduce_finish(self, flat, pending, reduced=None):
         """Wait for the chunks and turn the sums into means.  With ``_reduce_wait_ms`` set to a list (bench.py), the time the
         compute stream spends waiting for the collectives is recorded with events (read after a synchronize)."""
         if not pending:
@@ -319,7 +367,7 @@ class STEP(nn.Module):
         if timed:
             e1.record()
             self._reduce_events.append((e0, e1))
-        flat.mul_(1.0 / dist.get_world_size(self._process_group))
+        (flat if reduced is None else reduced).mul_(1.0 / dist.get_world_size(self._process_group))
 
     def collect_reduce_waits(self):
         """ms the compute stream waited for the gradient all-reduce in each backward since the last call (needs a synchronize)."""
@@ -330,7 +378,7 @@ class STEP(nn.Module):
         return out
 
     def _reduce_flat_grads(self, flat):
-        self._reduce_finish(flat, self._reduce_begin(flat))
+        self._reduce_finish(flat, self._reduce_begin(flat), flat)
 
     # ------------------------------------------------------------------ forward
     def forward(self, history_data, long_history_data, future_data, batch_seen, epoch, **kwargs):

@@ -129,6 +129,36 @@ ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)),
 ps[0].grad = torch.full((3, 5), float(rank + 1)); ps[1].grad = torch.arange(7.0) * (rank + 1)      # ps[2] has no gradient
 bench.average_grads(ps, world)
 assert torch.equal(ps[0].grad, torch.full((3, 5), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.0) * 1.5) and ps[2].grad is None
+# time slices of the graph learner (SURVEY.md 8(f) row 2), host side: bounds, the slice parameter, state_dict keys, the gather
+from step_amd.step_arch.discrete_graph_learning import DiscreteGraphLearning as DGL
+try:
+    model.matmul_precision = "bf16"
+    model.enable_native_data_parallel(shard_graph_learner=True)          # step_tiny: 102 conv2 columns -> slices too short
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "shorter than 128" in str(e)
+torch.manual_seed(7)
+dgl = DGL("X", 3, 12, 12, data=np.random.default_rng(3).standard_normal((700, 6, 3)).astype(np.float32), train_length=600)
+keys = set(dgl.state_dict())
+full0 = dgl.fc.weight.detach().clone()
+T2 = 600 - 18
+assert DGL.slice_bounds(T2, world) == [0, 291, 582] and DGL.slice_bounds(13581, 8)[-1] == 13581
+sh = dgl.shard_time_slices(rank, world)
+assert (sh["a"], sh["b"], sh["Ts"], sh["own1"]) == ((0, 291, 309, 291) if rank == 0 else (291, 582, 309, 300))
+assert sh["count1"] == 6 * 591 and sh["count2"] == 6 * 582 and tuple(dgl._series_slice.shape) == (6, 309)
+assert torch.equal(dgl._series_slice, dgl._series_nt[:, sh["a"]:sh["b"] + 18])
+assert set(dgl.state_dict()) == keys and not dgl.fc.weight.requires_grad and dgl.fc_weight_slice.requires_grad
+assert dgl.native_tensors()["fc_w"] is dgl.fc_weight_slice and tuple(dgl.fc_weight_slice.shape) == (100, 16 * 291)
+assert torch.equal(dgl.fc_weight_slice.view(100, 16, 291), full0.view(100, 16, T2)[:, :, sh["a"]:sh["b"]])
+with torch.no_grad():
+    dgl.fc_weight_slice.add_(rank + 1.0)                                  # "training": every rank moves its slice
+    dgl.fc.weight.zero_()
+dgl.gather_fc_weight()
+want = full0.view(100, 16, T2).clone()
+want[:, :, :291] += 1.0; want[:, :, 291:] += 2.0
+assert torch.equal(dgl.fc.weight.view(100, 16, T2), want)
+dgl.load_state_dict(dgl.state_dict()); dgl.refresh_fc_weight_slice()       # reference-layout checkpoints load into a sharded module
+assert torch.equal(dgl.fc_weight_slice.view(100, 16, 291), want[:, :, sh["a"]:sh["b"]])
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """

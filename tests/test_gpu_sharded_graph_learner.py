@@ -1,0 +1,28 @@
+"""SURVEY.md 8(f) row 2 on the device: two data-parallel ranks (gloo group, both on cuda:0) with the graph learner in time slices
+against the same two ranks with the whole graph learner, and against one process evaluating both batches (tests/shard_worker.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.test_abi_and_host import _free_port
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_time_sliced_graph_learner_matches_unsharded_data_parallel():
+    script = os.path.join(ROOT, "tests", "shard_worker.py")
+    for attempt in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, script, ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(2)]
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        if all(p.returncode == 0 for p in procs):
+            break
+        if attempt == 0 and not any("AssertionError" in o or "Error" in o for o in outs):
+            continue
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-4000:]
+    print("\n".join(o[-1500:] for o in outs))
