@@ -571,7 +571,7 @@ int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out,
 
 // Small scratch block of the backward (floats): [0,128) BatchNorm coefficients, [128,256) column sums of dgpre, [256,288) the two
 // per-channel sums of the fused BatchNorm2 backward, [288,288+1296) this step's raw conv2 weight-gradient sums (fused BatchNorm1)
-constexpr int DGL_SMALL = 256 + 64 + 1344;
+constexpr int DGL_SMALL = 256 + 64 + 1344 + 100 * 32;       // ... + per-output-row BatchNorm2 sums of the channels-last path [EMB][32]
 
 // Fused BatchNorm backward (no pass over the activations): coefficients from per-channel sums that come out of the
 // weight-gradient contractions.  With dy = d(BatchNorm output), xhat the normalised input:
@@ -593,6 +593,84 @@ __global__ void bn2_fused_coef_kernel(const float* __restrict__ dots, const floa
     coef[2 * C + c] = gamma[c] * stat[3 * C + c];
 }
 
+// ---- channels-last bf16 storage of the conv activations (bf16 mode; kernels in dgl_conv_mfma.hip) ------------------------------
+// The fc then contracts over k' = t*16 + c instead of the reference's k = c*T2 + t (:134 flattens [N,16,T2]).  Per step:
+//   fc_prep:      wp[o][t*16+c] = bf16(fc_w[o][c][t] * sc2[c])  (BatchNorm2's scale folded in),  shiftdot[o] += sum fc_w[o][c][t] * sh2[c]
+//   fc_unpermute: G = dgpre^T a2 (raw, [o][t*16+c]) ->  d fc_w[o][c][t] += sc2[c] G + sh2[c] colsum(dgpre)[o],  and the BatchNorm2
+//                 backward sums per output row, dots_o[o][2c] += fc_w G, dots_o[o][2c+1] += fc_w colsum[o]  (see bn2_fused_coef_kernel)
+// One thread owns one time step of one output row (16 channels in registers): every access is coalesced along t on the [c][t]
+// side and along the row on the [t][c] side, no LDS.
+__global__ __launch_bounds__(256) void fc_prep_kernel(const float* __restrict__ fc_w, const float* __restrict__ st2, uint4* __restrict__ wp,
+                                                      float* __restrict__ shiftdot, int T2) {
+    // one thread = one time step of one output row: 16 coalesced loads along t (one per channel), one 32-byte row out
+    __shared__ float red[4];
+    const int o = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    if (t < T2) {
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = fc_w[((long)o * 16 + c) * T2 + t];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { acc += v[c] * st2[16 + c]; v[c] *= st2[c]; }
+        uint4* dst = wp + ((long)o * T2 + t) * 2;
+        dst[0] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        dst[1] = make_uint4(pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15]));
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) atomicAdd(&shiftdot[o], red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void gpre_init_kernel(float* __restrict__ gpre, const float* __restrict__ shiftdot, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gpre[i] = shiftdot[i % EMB];
+}
+__global__ __launch_bounds__(256) void fc_unpermute_kernel(const float* __restrict__ graw, const float* __restrict__ fc_w,
+                                                           const float* __restrict__ st2, const float* __restrict__ colsum,
+                                                           float* __restrict__ dfc_w, float* __restrict__ dots_o, int T2) {
+    // one thread = one time step of one output row: its 64-byte row of G, 16 coalesced loads of fc_w and of the gradient
+    __shared__ float red[4][32];
+    const int o = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
+    const float cso = colsum[o];
+    float d[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) d[i] = 0.f;
+    if (t < T2) {
+        const float4* src = (const float4*)(graw + ((long)o * T2 + t) * 16);
+        const float4 g0 = src[0], g1 = src[1], g2 = src[2], g3 = src[3];
+        const float g[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+        float w[16], old[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { const long idx = ((long)o * 16 + c) * T2 + t; w[c] = fc_w[idx]; old[c] = dfc_w[idx]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            dfc_w[((long)o * 16 + c) * T2 + t] = old[c] + st2[c] * g[c] + st2[16 + c] * cso;
+            d[2 * c] = w[c] * g[c]; d[2 * c + 1] = w[c] * cso;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float v = wave_sum(d[i]);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 32) atomicAdd(&dots_o[o * 32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+__global__ void dots_reduce_kernel(const float* __restrict__ dots_o, float* __restrict__ dots) {
+    const int i = threadIdx.x;
+    if (i >= 32) return;
+    double a = 0.0;
+    for (int o = 0; o < EMB; ++o) a += dots_o[o * 32 + i];
+    dots[i] = (float)a;
+}
+
+// bf16 mode keeps the conv activations and their gradients as channels-last bf16 rows; STEP_DGL_F32_STORAGE=1 keeps the round-1
+// [N][C][T] f32 layout (A/B measurements).  Read on every call, forward and backward of a step must see the same value.
+static bool dgl_channels_last(const StepDglParams* p) {
+    const char* e = getenv("STEP_DGL_F32_STORAGE");
+    return p->gemm_bf16 && !(e && e[0] == '1');
+}
+
 // STEP_DGL_LEGACY_BN=1 in the environment keeps the three-pass BatchNorm backward (A/B measurements, debugging)
 static bool dgl_legacy_bn_backward() {
     const char* e = getenv("STEP_DGL_LEGACY_BN");
@@ -602,7 +680,8 @@ static bool dgl_legacy_bn_backward() {
 // =========================================================================================== C ABI
 extern "C" long step_dgl_global_saved_floats(int N, int T) {
     long T1 = T - 9, T2 = T - 18;
-    return (long)N * 8 * T1 + (long)N * 16 * T2 + (long)N * EMB + 4 * 8 + 4 * 16 + 4 * EMB;
+    // ... + the BatchNorm2-scaled, (t, c)-ordered f32 copy of fc.weight and its shift term (channels-last bf16 storage, bf16 mode)
+    return (long)N * 8 * T1 + (long)N * 16 * T2 + (long)N * EMB + 4 * 8 + 4 * 16 + 4 * EMB + (long)EMB * 16 * T2 + 128;
 }
 extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long T1 = T - 9, T2 = T - 18;
@@ -612,6 +691,10 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + DGL_SMALL + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
+static float* saved_wp(float* saved, int N, int T) {        // [EMB][16 (T-18)] scaled fc weight copy, then shiftdot [128]
+    long T1 = T - 9, T2 = T - 18;
+    return saved + (long)N * 8 * T1 + (long)N * 16 * T2 + (long)N * EMB + 4 * 8 + 4 * 16 + 4 * EMB;
+}
 static void carve_saved(float* saved, int N, int T, float** a1, float** a2, float** gpre, float** st1, float** st2, float** st3) {
     long T1 = T - 9, T2 = T - 18;
     *a1 = saved; saved += (long)N * 8 * T1;
@@ -635,20 +718,30 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
     float* partial = work;
     const bool all = phase == 0;
     const double count1 = shard ? shard->count1 : (double)N * T1, count2 = shard ? shard->count2 : (double)N * T2;
+    const bool cl = dgl_channels_last(p);
+    float* wp = saved_wp(saved, N, T);
+    float* shiftdot = wp + (long)EMB * 16 * T2;
     if (all || phase == 1) {
-        dim3 grid(cdiv(T1, 256 * 4), N);
-        conv_relu_fwd_kernel<1, 8, 4><<<grid, 256, 0, st>>>(series_nt, p->conv1_w, p->conv1_b, nullptr, nullptr, a1, partial, T,
-                                                            shard ? shard->own1 : T1);
-        STEP_LAUNCH_CHECK("conv1");
-        if (shard) bn_sums_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, sums);
-        else bn_finalize_kernel<<<8, 256, 0, st>>>(partial, grid.x * grid.y, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training,
-                                                   momentum, st1);
+        int nblk;
+        if (cl) {
+            STEP_TRY(dgl_conv1_fwd_cl(series_nt, p->conv1_w, p->conv1_b, a1, partial, N, T, shard ? shard->own1 : T1, &nblk, st));
+        } else {
+            dim3 grid(cdiv(T1, 256 * 4), N);
+            conv_relu_fwd_kernel<1, 8, 4><<<grid, 256, 0, st>>>(series_nt, p->conv1_w, p->conv1_b, nullptr, nullptr, a1, partial, T,
+                                                                shard ? shard->own1 : T1);
+            STEP_LAUNCH_CHECK("conv1");
+            nblk = grid.x * grid.y;
+        }
+        if (shard) bn_sums_kernel<<<8, 256, 0, st>>>(partial, nblk, 8, sums);
+        else bn_finalize_kernel<<<8, 256, 0, st>>>(partial, nblk, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1);
         STEP_LAUNCH_CHECK("bn1");
     }
     if (all || phase == 2) {
         if (shard) bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1);
         int nblk;
-        if (p->gemm_bf16) {
+        if (cl) {
+            STEP_TRY(dgl_conv2_fwd_cl(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
+        } else if (p->gemm_bf16) {
             STEP_TRY(dgl_conv2_fwd_mfma(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
         } else {
             dim3 grid(cdiv(T2, 256 * 4), N);
@@ -664,9 +757,19 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
     if (all || phase == 3) {
         if (shard) bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums + 16, 16, count2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, training, momentum, st2);
         const long K = 16L * T2;
-        if (hipMemsetAsync(gpre, 0, (size_t)N * EMB * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
         StepGemm gm = gemm_desc(N, EMB, (int)K, a2, K, 1, p->fc_w, 1, K, gpre, EMB);
-        gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
+        if (cl) {
+            // bf16 rows of a2 against the BatchNorm2-scaled (t, c)-ordered weight copy; the shift term starts the accumulator
+            if (hipMemsetAsync(shiftdot, 0, 128 * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+            fc_prep_kernel<<<dim3(cdiv(T2, 256), EMB), 256, 0, st>>>(p->fc_w, st2, (uint4*)wp, shiftdot, T2);
+            gpre_init_kernel<<<cdiv((long)N * EMB, 256), 256, 0, st>>>(gpre, shiftdot, (long)N * EMB);
+            STEP_LAUNCH_CHECK("fc_prep");
+            gm.a_bf16 = 1;
+            gm.B = wp; gm.b_bf16 = 1;
+        } else {
+            if (hipMemsetAsync(gpre, 0, (size_t)N * EMB * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+            gm.a_kscale = st2; gm.a_kshift = st2 + 16; gm.a_kperiod = T2;
+        }
         gm.accumulate = 2;
         gm.splitk = -1;
         gm.compute_bf16 = p->gemm_bf16;
@@ -761,6 +864,44 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
     // BatchNorm2 backward without its two passes over d_a2 / a2 (1.3 GB at PEMS04): needs a tile to span at most two channels
     const bool fuse2 = T2 >= 128 && (shard || !dgl_legacy_bn_backward());
     const double count1 = shard ? shard->count1 : (double)N * T1, count2 = shard ? shard->count2 : (double)N * T2;
+    if (dgl_channels_last(p)) {
+        // channels-last bf16 storage: a1 / a2 / d_a2 / d_a1 hold bf16 rows [t][channels]; wp = scaled (t, c)-ordered fc weight of the forward
+        const float* wp = saved_wp((float*)saved, N, T);
+        float* dots_o = coef + 256 + 64 + 1344;
+        float* colsum = coef + 128;
+        if (do_fc) {
+            bn3_relu_bwd_kernel<<<EMB, 256, 0, st>>>(dg, gpre, N, p->bn3_w, st3, grads->bn3_w, grads->bn3_b, grads->fc_b, dgpre, dgpreT, colsum);
+            STEP_LAUNCH_CHECK("bn3_bwd");
+            // G = dgpre^T a2 on the raw bf16 rows (n-contiguous bf16 B operand), then back to fc.weight's [c][t] order with BatchNorm2's
+            // affine and the BatchNorm2 backward sums
+            StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, wraw, K);
+            gm.b_bf16 = 1;
+            gm.compute_bf16 = 1;
+            STEP_TRY(step_gemm_launch(gm, st));
+            if (hipMemsetAsync(dots_o, 0, EMB * 32 * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+            fc_unpermute_kernel<<<dim3(cdiv(T2, 256), EMB), 256, 0, st>>>(wraw, p->fc_w, st2, colsum, grads->fc_w, dots_o, T2);
+            dots_reduce_kernel<<<1, 64, 0, st>>>(dots_o, dots);
+            STEP_LAUNCH_CHECK("fc_unpermute");
+        }
+        if (do_mid) {
+            bn2_fused_coef_kernel<<<1, 64, 0, st>>>(dots, st2, p->bn2_w, count2, grads->bn2_w, grads->bn2_b, coef);
+            STEP_LAUNCH_CHECK("bn2_fused_coef");
+            // dz2 = BatchNorm2 backward of dgpre @ fc_w, masked by conv2's ReLU: the scale rides in wp, the rest in the epilogue; bf16 rows out
+            StepGemm gm = gemm_desc(N, (int)K, EMB, dgpre, EMB, 1, wp, K, 1, d_a2, K);
+            gm.b_bf16 = 1;
+            gm.compute_bf16 = 1;
+            GemmFused fu = {nullptr, nullptr, a2, coef, st2, 16, T2, GEMM_FUSED_INTERLEAVED};
+            STEP_TRY(step_gemm_launch_fused(gm, fu, st));
+            STEP_TRY(dgl_conv2_wgrad_cl(d_a2, a1, wg_scratch, graw, N, T1, st));
+        }
+        if (do_tail) {
+            STEP_TRY(dgl_conv2_wgrad_finish(graw, p->conv2_w, st1, p->bn1_w, p->bn1_b, count1, grads->conv2_w, grads->conv2_b, grads->bn1_w,
+                                            grads->bn1_b, coef + 64, 1, st));
+            STEP_TRY(dgl_conv2_dgrad_cl(d_a2, p->conv2_w, st1, d_a1, N, T1, a1, coef + 64, st1, shard ? shard->own1 : T1, st));
+            STEP_TRY(dgl_conv1_wgrad_cl(d_a1, series_nt, wg_scratch, grads->conv1_w, grads->conv1_b, N, T, st));
+        }
+        return STEP_OK;
+    }
     if (do_fc) {
         // BN3 + ReLU backward, fc bias gradient
         float* colsum = coef + 128;          // column sums of dgpre [EMB] (coef holds 3 x 16 BatchNorm coefficients at most)
@@ -816,7 +957,7 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
         if (do_mid) STEP_TRY(dgl_conv2_wgrad_xhat_mfma(d_a2, a1, st1, wg_scratch, graw, N, T1, st));
         if (!do_tail) return STEP_OK;
         STEP_TRY(dgl_conv2_wgrad_finish(graw, p->conv2_w, st1, p->bn1_w, p->bn1_b, count1, grads->conv2_w, grads->conv2_b, grads->bn1_w,
-                                        grads->bn1_b, coef + 64, st));
+                                        grads->bn1_b, coef + 64, 0, st));
         // columns >= own1 of a time slice are halo: the owner (the next rank) subtracts BatchNorm1's constant terms there
         STEP_TRY(dgl_conv2_dgrad_mfma(d_a2, p->conv2_w, d_a1, N, T1, a1, coef + 64, st1, shard ? shard->own1 : T1, st));
     } else if (p->gemm_bf16) {

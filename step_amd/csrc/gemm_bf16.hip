@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_bf16mfma_kernel(StepGemm g) {
 // LDS rows are k-contiguous with a 136-byte pitch: fragment reads (two ds_read_b64 per 32x16 operand) are
 // conflict-free.  Rows / columns past M / N are loaded as whatever the padded pitch holds (they only feed
 // outputs that are never stored); k past the end is zeroed in both operands.
-enum { KC_F32 = 0, KC_BF16 = 1, MC_F32 = 2 };
+enum { KC_F32 = 0, KC_BF16 = 1, MC_F32 = 2, MC_BF16 = 3 };       // MC_BF16: B operand only (8(n) x 4(k) register blocks)
 constexpr int FBK = 64;
 constexpr int FPITCH = FBK * 2 + 8;          // bf16 rows: 64 x 2 B + 8
 constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64 x 4 B + 16
@@ -258,8 +258,8 @@ __device__ __forceinline__ long remap(int i, int lg, long stride) {
 
 template <int MODE, int BR>
 struct Stage {
-    static constexpr int NV = MODE == KC_F32 ? BR * FBK / 4 / 256 : (MODE == KC_BF16 ? BR * FBK / 8 / 256 : BR * FBK / 16 / 256);
-    static constexpr int NR = MODE == MC_F32 ? NV * 4 : NV;
+    static constexpr int NV = MODE == KC_F32 ? BR * FBK / 4 / 256 : (MODE == KC_BF16 ? BR * FBK / 8 / 256 : (MODE == MC_F32 ? BR * FBK / 16 / 256 : (BR * FBK / 32 + 255) / 256));
+    static constexpr int NR = (MODE == MC_F32 || MODE == MC_BF16) ? NV * 4 : NV;
     float f[NR][4];                    // plain scalars: every index below is a compile-time constant after unrolling
 };
 
@@ -289,6 +289,19 @@ __device__ __forceinline__ void stage_load(Stage<MODE, BR>& s, const char* base,
             const long off = ok ? remap(row, rlog, rstride) * srow + remap(k, klog, kstride) : 0;
             const float4 t = *(const float4*)((const uint16_t*)base + off);
             s.f[r][0] = t.x; s.f[r][1] = t.y; s.f[r][2] = t.z; s.f[r][3] = t.w;
+        }
+    } else if constexpr (MODE == MC_BF16) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;                                                  // (64-wide tiles: threads 128.. have no block)
+            const int row = row0 + (e % (BR / 8)) * 8, kb = k0 + (e / (BR / 8)) * 4;      // 8 rows (one 16-byte load) x 4 k
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = row < rows && kb + j < kend && e < BR * FBK / 32;
+                const long off = ok ? (long)row * srow + remap(kb + j, klog, kstride) * sk : 0;
+                const float4 t = *(const float4*)((const uint16_t*)base + off);
+                s.f[r * 4 + j][0] = t.x; s.f[r * 4 + j][1] = t.y; s.f[r * 4 + j][2] = t.z; s.f[r * 4 + j][3] = t.w;
+            }
         }
     } else {
 #pragma unroll
@@ -340,6 +353,18 @@ __device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows
                 s.f[r][j] = __uint_as_float(__float_as_uint(s.f[r][j]) & m);
             }
         }
+    } else if constexpr (MODE == MC_BF16) {
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            const int row = row0 + (e % (BR / 8)) * 8, kb = k0 + (e / (BR / 8)) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = row < rows && kb + j < kend && e < BR * FBK / 32;          // rows come in whole groups of 8 (the row extent is a multiple of 8)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.f[r * 4 + j][i] = ok ? s.f[r * 4 + j][i] : 0.f;
+            }
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < s.NV; ++r) {
@@ -359,7 +384,7 @@ __device__ __forceinline__ void stage_fix(Stage<MODE, BR>& s, int row0, int rows
 template <int MODE, int BR, bool F32C>
 __device__ __forceinline__ void stage_store(const Stage<MODE, BR>& s, char* lds, int tid) {
     if constexpr (F32C) {                 // exact-f32 variant: rows of 64 f32, 16-byte writes
-        static_assert(MODE != KC_BF16, "bf16 operands only feed the bf16 variant");
+        static_assert(MODE != KC_BF16 && MODE != MC_BF16, "bf16 operands only feed the bf16 variant");
         if constexpr (MODE == KC_F32) {
 #pragma unroll
             for (int r = 0; r < s.NV; ++r) {
@@ -389,6 +414,21 @@ __device__ __forceinline__ void stage_store(const Stage<MODE, BR>& s, char* lds,
             char* d = lds + (e / (FBK / 8)) * FPITCH + (e % (FBK / 8)) * 16;
             *(uint2*)d = make_uint2(__float_as_uint(s.f[r][0]), __float_as_uint(s.f[r][1]));
             *(uint2*)(d + 8) = make_uint2(__float_as_uint(s.f[r][2]), __float_as_uint(s.f[r][3]));
+        }
+    } else if constexpr (MODE == MC_BF16) {
+        // register block: dword p of load j holds rows 2p (low half) and 2p+1 (high half) at k = kb + j; LDS rows want 4 consecutive k
+#pragma unroll
+        for (int r = 0; r < s.NV; ++r) {
+            const int e = tid + r * 256;
+            if (e >= BR * FBK / 32) continue;
+            char* d = lds + ((e % (BR / 8)) * 8) * FPITCH + (e / (BR / 8)) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t d0 = __float_as_uint(s.f[r * 4][p]), d1 = __float_as_uint(s.f[r * 4 + 1][p]);
+                const uint32_t d2 = __float_as_uint(s.f[r * 4 + 2][p]), d3 = __float_as_uint(s.f[r * 4 + 3][p]);
+                *(uint2*)(d + (2 * p) * FPITCH) = make_uint2((d0 & 0xffffu) | (d1 << 16), (d2 & 0xffffu) | (d3 << 16));
+                *(uint2*)(d + (2 * p + 1) * FPITCH) = make_uint2((d0 >> 16) | (d1 & 0xffff0000u), (d2 >> 16) | (d3 & 0xffff0000u));
+            }
         }
     } else {
 #pragma unroll
@@ -422,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     const int kend = min(g.K, (zs + 1) * per * FBK);
     const int i0 = g.batch0 ? zb % g.batch0 : zb, i1 = g.batch0 ? zb / g.batch0 : 0;
     const char* Ab = (const char*)g.A + ((long)i0 * g.sab + (long)i1 * g.sab1) * (AMODE == KC_BF16 ? 2 : 4);
-    const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * (BMODE == KC_BF16 ? 2 : 4);
+    const char* Bb = (const char*)g.B + ((long)i0 * g.sbb + (long)i1 * g.sbb1) * ((BMODE == KC_BF16 || BMODE == MC_BF16) ? 2 : 4);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -433,7 +473,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int r = lane & 31, h = lane >> 5;
-    const int ones_row = (BMODE != KC_BF16 && g.a_rowsum) ? g.N : -1;      // virtual all-ones column of B -> row sums of A
+    const int ones_row = (BMODE != KC_BF16 && BMODE != MC_BF16 && g.a_rowsum) ? g.N : -1;      // virtual all-ones column of B -> row sums of A
     if (kbeg < kend) {
         Stage<AMODE, BM> sa;
         Stage<BMODE, BN> sb;
@@ -527,6 +567,51 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             }
         __syncthreads();
         const GemmFused& fu = fa.fu;
+        constexpr int PIECES = BM * BN / 4, NPC = PIECES / 256, NB = NPC < 8 ? NPC : 8;
+        static_assert(PIECES % 256 == 0 && NPC % NB == 0, "piece loop shape");
+        if (fu.flags & GEMM_FUSED_INTERLEAVED) {
+            // channels-last bf16 activations (dgl_conv_mfma.hip): column n belongs to channel n % C, the result and the BatchNorm input
+            // are bf16.  Stored: x > 0 ? v - kc (m1 + (x - mean) rstd m2) : 0 with v = alpha A.B (the BatchNorm scale kc is already in B).
+            // A thread's 4 columns (and channels) are the same for all of its pieces: the coefficients live in registers.
+            const int C = fu.channels, cb = (n0 + (tid % (BN / 4)) * 4) % C;
+            float km1[4], km2[4], mu4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cb + i;
+                km1[i] = fu.bncoef[2 * C + c] * fu.bncoef[c];
+                km2[i] = fu.bncoef[2 * C + c] * fu.bncoef[C + c] * fu.bnstat[3 * C + c];
+                mu4[i] = fu.bnstat[2 * C + c];
+            }
+            uint16_t* Ch = (uint16_t*)Cb;
+            const uint16_t* xh = (const uint16_t*)fu.bnx;
+            for (int pb = 0; pb < NPC; pb += NB) {
+                uint2 x2[NB];
+                long off[NB];
+                bool ok[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pc = tid + (pb + u) * 256;
+                    const int gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
+                    ok[u] = gm < g.M && gn < g.N;
+                    off[u] = ok[u] ? (long)gm * g.ldc + gn : 0;
+                    x2[u] = *(const uint2*)(xh + off[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (!ok[u]) continue;
+                    const int pc = tid + (pb + u) * 256;
+                    const float4 t4 = *(const float4*)(tile + (pc / (BN / 4)) * TP + (pc % (BN / 4)) * 4);
+                    const float v[4] = {t4.x, t4.y, t4.z, t4.w};
+                    const float x[4] = {__uint_as_float(x2[u].x << 16), __uint_as_float(x2[u].x & 0xffff0000u),
+                                        __uint_as_float(x2[u].y << 16), __uint_as_float(x2[u].y & 0xffff0000u)};
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = x[i] > 0.f ? v[i] - km1[i] - (x[i] - mu4[i]) * km2[i] : 0.f;
+                    *(uint2*)(Ch + off[u]) = pack4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            return;
+        }
         const int c_lo = n0 / fu.period, nb = (c_lo + 1) * fu.period, C = fu.channels;
         float cs[2] = {1.f, 1.f}, csh[2] = {0.f, 0.f}, kk[2], m1[2], m2r[2], mu[2];
 #pragma unroll
@@ -536,39 +621,53 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             if (fu.bnx) { m1[j] = fu.bncoef[c]; m2r[j] = fu.bncoef[C + c] * fu.bnstat[3 * C + c]; kk[j] = fu.bncoef[2 * C + c]; mu[j] = fu.bnstat[2 * C + c]; }
         }
         float dw[2] = {0.f, 0.f}, dm[2] = {0.f, 0.f};
-        constexpr int PIECES = BM * BN / 4;
-#pragma unroll 2
-        for (int pc = tid; pc < PIECES; pc += 256) {
-            const int rm = pc / (BN / 4), c4 = (pc % (BN / 4)) * 4;
-            const int gm = m0 + rm, gn = n0 + c4;
-            if (gm >= g.M || gn >= g.N) continue;
-            const float4 t4 = *(const float4*)(tile + rm * TP + c4);
-            float v[4] = {t4.x, t4.y, t4.z, t4.w};
-            const long off = (long)gm * g.ldc + gn;
-            const float mv = g.c_mvec ? g.c_mvec[gm] : 0.f;
-            if (fu.dotw) {
-                const float4 w4 = *(const float4*)(fu.dotw + off);
-                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+        // batches of NB pieces per thread: all global reads of a batch (W / x / old C) are issued before the first store, so the
+        // epilogue -- which is most of the d_a2 GEMM (K = 100) -- streams instead of paying one memory latency per piece
+        for (int pb = 0; pb < NPC; pb += NB) {
+            float4 w4[NB], x4[NB], o4[NB];
+            long off[NB];
+            bool ok[NB];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; dw[j] += w[i] * v[i]; dm[j] += w[i] * mv; }
+            for (int u = 0; u < NB; ++u) {
+                const int pc = tid + (pb + u) * 256;
+                const int rm = pc / (BN / 4), c4 = (pc % (BN / 4)) * 4;
+                const int gm = m0 + rm, gn = n0 + c4;
+                ok[u] = gm < g.M && gn < g.N;
+                off[u] = ok[u] ? (long)gm * g.ldc + gn : 0;
+                if (fu.dotw) w4[u] = *(const float4*)(fu.dotw + off[u]);
+                if (fu.bnx) x4[u] = *(const float4*)(fu.bnx + off[u]);
+                if (g.accumulate == 1) o4[u] = *(const float4*)(Cb + off[u]);
             }
-            if (g.c_nscale) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; v[i] = v[i] * cs[j] + csh[j] * mv; }
-            }
-            if (fu.bnx) {
-                const float4 x4 = *(const float4*)(fu.bnx + off);
-                const float x[4] = {x4.x, x4.y, x4.z, x4.w};
+            for (int u = 0; u < NB; ++u) {
+                if (!ok[u]) continue;
+                const int pc = tid + (pb + u) * 256;
+                const int rm = pc / (BN / 4), c4 = (pc % (BN / 4)) * 4;
+                const int gm = m0 + rm, gn = n0 + c4;
+                const float4 t4 = *(const float4*)(tile + rm * TP + c4);
+                float v[4] = {t4.x, t4.y, t4.z, t4.w};
+                const float mv = g.c_mvec ? g.c_mvec[gm] : 0.f;
+                if (fu.dotw) {
+                    const float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = gn + i >= nb;
-                    v[i] = x[i] > 0.f ? kk[j] * (v[i] - m1[j] - (x[i] - mu[j]) * m2r[j]) : 0.f;
+                    for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; dw[j] += w[i] * v[i]; dm[j] += w[i] * mv; }
                 }
+                if (g.c_nscale) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int j = gn + i >= nb; v[i] = v[i] * cs[j] + csh[j] * mv; }
+                }
+                if (fu.bnx) {
+                    const float x[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = gn + i >= nb;
+                        v[i] = x[i] > 0.f ? kk[j] * (v[i] - m1[j] - (x[i] - mu[j]) * m2r[j]) : 0.f;
+                    }
+                }
+                float4 r4 = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.accumulate == 1) { r4.x += o4[u].x; r4.y += o4[u].y; r4.z += o4[u].z; r4.w += o4[u].w; }
+                *(float4*)(Cb + off[u]) = r4;
             }
-            float4* dst = (float4*)(Cb + off);
-            float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
-            if (g.accumulate == 1) { const float4 o = *dst; o4.x += o.x; o4.y += o.y; o4.z += o.z; o4.w += o.w; }
-            *dst = o4;
         }
         if (fu.dotw) {
             float q4[4] = {dw[0], dm[0], dw[1], dm[1]};
@@ -652,6 +751,10 @@ static int fast_mode(const void* base, int is_bf16, long srow, long sk, long sb0
         if (rblk) { *rlog = ilog2_exact(rblk); if (*rlog < 0) return -1; }
         return is_bf16 ? KC_BF16 : KC_F32;
     }
+    if (srow == 1 && is_bf16) {                      // n contiguous bf16 (B operand of the 128-wide tiles only, no remaps)
+        if (sk % 8 || kblk || rblk) return -1;
+        return MC_BF16;
+    }
     if (srow == 1 && !is_bf16) {                     // m / n contiguous
         if (sk % 4) return -1;
         if (kblk) { *klog = ilog2_exact(kblk); if (*klog < 0) return -1; }
@@ -665,7 +768,11 @@ template <int BM, int BN, int AMODE>
 int launch_fast_b(const StepGemm& g, const FastArgs& fa, int bmode, dim3 grid, hipStream_t st) {
     if (bmode == KC_F32) gemm_fast_kernel<BM, BN, AMODE, KC_F32, false><<<grid, 256, 0, st>>>(g, fa);
     else if (bmode == KC_BF16) gemm_fast_kernel<BM, BN, AMODE, KC_BF16, false><<<grid, 256, 0, st>>>(g, fa);
-    else gemm_fast_kernel<BM, BN, AMODE, MC_F32, false><<<grid, 256, 0, st>>>(g, fa);
+    else if (bmode == MC_F32) gemm_fast_kernel<BM, BN, AMODE, MC_F32, false><<<grid, 256, 0, st>>>(g, fa);
+    else {
+        if constexpr (AMODE != KC_BF16) gemm_fast_kernel<BM, BN, AMODE, MC_BF16, false><<<grid, 256, 0, st>>>(g, fa);
+        else { step_set_error("step_gemm: an n-contiguous bf16 B operand needs an f32 A operand"); return STEP_ERR_ARG; }
+    }
     STEP_LAUNCH_CHECK("step_gemm(bf16 fast)");
     return STEP_OK;
 }
@@ -707,10 +814,11 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, g.b_bf16, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog,
                                 &fa.b_nlog);
-    const bool fast = amode >= 0 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
-                !(g.a_rowsum && bmode == KC_BF16);
+    const bool fast = amode >= 0 && amode != MC_BF16 && bmode >= 0 && !(g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK)) &&
+                !(g.a_rowsum && (bmode == KC_BF16 || bmode == MC_BF16)) && !(bmode == MC_BF16 && g.N % 8);
     fa.wide_store = wide_store_ok(g, fused != nullptr);
-    if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 && fused->period >= 128,
+    if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 &&
+                            ((fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
                             "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
@@ -741,7 +849,7 @@ int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused
     int dummy;
     const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
     const int bmode = fast_mode(g.B, 0, g.sbn, g.sbk, g.sbb, g.sbb1, g.b_kblk, g.b_kstride, g.b_nblk, g.b_nstride, &fa.b_klog, &fa.b_nlog);
-    if (amode < 0 || bmode < 0 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
+    if (amode < 0 || bmode < 0 || amode == MC_BF16 || bmode == MC_BF16 || (g.a_kscale && (amode != KC_F32 || g.a_kperiod < FBK))) return -1;
     fa.wide_store = wide_store_ok(g, fused != nullptr);
     if (fused && !(fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 && fused->period >= 128)) return -1;
     if (g.splitk < 0) {

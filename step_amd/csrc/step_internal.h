@@ -11,10 +11,14 @@
 //   bnx ...:     the stored value becomes the BatchNorm-backward of the result, masked by the ReLU in front of the BatchNorm:
 //                C = x > 0 ? coef[2C+c] * (v - coef[c] - (x - stat[2C+c]) * stat[3C+c] * coef[C+c]) : 0,  x = bnx[m][n] (laid out like C)
 //                coef = [m1 | m2 | gamma*rstd], stat = [scale | shift | mean | rstd], C = channels.
+// flags: GEMM_FUSED_INTERLEAVED -- channels-last bf16 activations (bf16 mode): column n belongs to channel n % channels, C and bnx are bf16
+//        (ldc in bf16 elements), B already carries the BatchNorm scale:  C = x > 0 ? v - kc (m1 + (x - mean) rstd m2) : 0,  kc = coef[2C+c].
+enum { GEMM_FUSED_INTERLEAVED = 1 };
 struct GemmFused {
     const float* dotw; float* dots;
     const float* bnx; const float* bncoef; const float* bnstat;
     int channels, period;
+    int flags;
 };
 
 int step_gemm_launch(StepGemm g, hipStream_t st);
@@ -44,7 +48,16 @@ int dgl_conv2_dgrad_mfma(const float* dz, const float* w, float* din, int N, int
                          int own, hipStream_t st);
 int dgl_conv2_wgrad_xhat_mfma(const float* dz, const float* a1, const float* stat1, float* scratch, float* graw, int N, int T1, hipStream_t st);
 int dgl_conv2_wgrad_finish(const float* graw, const float* w, const float* stat1, const float* gamma1, const float* beta1, double count,
-                           float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, hipStream_t st);
+                           float* dw, float* db, float* dgamma1, float* dbeta1, float* coef1, int raw, hipStream_t st);
+// channels-last bf16 storage of the conv activations (bf16 contraction mode), dgl_conv_mfma.hip
+int dgl_conv1_fwd_cl(const float* x, const float* w, const float* b, void* a1h, float* partial, int N, int T, int stat_limit, int* nblk,
+                     hipStream_t st);
+int dgl_conv2_fwd_cl(const void* a1h, const float* w, const float* b, const float* sc, const float* sh, void* a2h, float* partial, int N,
+                     int T1, int* nblk, hipStream_t st);
+int dgl_conv2_dgrad_cl(const void* dz2h, const float* w, const float* sc, void* dz1h, int N, int T1, const void* a1h, const float* coef,
+                       const float* stat, int own, hipStream_t st);
+int dgl_conv2_wgrad_cl(const void* dz2h, const void* a1h, float* scratch, float* graw, int N, int T1, hipStream_t st);
+int dgl_conv1_wgrad_cl(const void* dz1h, const float* x, float* scratch, float* dw, float* db, int N, int T, hipStream_t st);
 long dgl_conv2_wgrad_scratch_floats(int N, int T1);
 int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, const float* sh, float* scratch, float* dw, float* db, int N,
                          int T1, hipStream_t st);

@@ -86,7 +86,9 @@ def test_dgl_fused_batchnorm_backward_matches_three_pass(N, T, bf16, monkeypatch
     """The BatchNorm backward passes are fused away (dgl.hip: the two per-channel sums come out of the weight-gradient
     contractions -- exactly, see conv2_wgrad_finish_kernel / bn2_fused_coef_kernel --, the transform rides in the epilogue of the
     kernel that produces the incoming gradient).  STEP_DGL_LEGACY_BN=1 keeps the three-pass form (reduce, finalize, apply):
-    same gradients up to summation order in exact-f32 mode, up to the bf16 rounding of the two sums in bf16 mode."""
+    same gradients up to summation order in exact-f32 mode.  In bf16 mode the default additionally stores the conv activations and
+    their gradients as channels-last bf16 rows (dgl_conv_mfma.hip, STEP_DGL_F32_STORAGE=1 keeps f32): one more bf16 rounding of values
+    that the matrix cores round anyway."""
     from step_amd import _lib as L
     from step_amd.step_arch.discrete_graph_learning import fill_dgl_struct
     gen = torch.Generator().manual_seed(N + T)
@@ -106,14 +108,18 @@ def test_dgl_fused_batchnorm_backward_matches_three_pass(N, T, bf16, monkeypatch
     trainable = {k: v for k, v in t.items() if not (k.endswith("_rm") or k.endswith("_rv"))}
     dg = torch.randn(N, 100, generator=gen).cuda()
     monkeypatch.setenv("STEP_DGL_LEGACY_BN", "1")
+    monkeypatch.setenv("STEP_DGL_F32_STORAGE", "1")       # bf16 mode: the reference run also keeps the [N][C][T] f32 activations
     _, legacy = _run(L, series, t, trainable, dg, bf16, fill_dgl_struct)
     monkeypatch.setenv("STEP_DGL_LEGACY_BN", "0")
+    monkeypatch.setenv("STEP_DGL_F32_STORAGE", "0")       # ... against the default: channels-last bf16 rows, everything fused
     _, fused = _run(L, series, t, trainable, dg, bf16, fill_dgl_struct)
     errs = {k: rel_l2(fused[k].cpu(), legacy[k].cpu()) for k in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "bn1_w", "bn1_b", "bn2_w", "bn2_b", "fc_w")}
     print(f"N={N} T={T} bf16={bf16}: fused vs three-pass BatchNorm backward, gradient rel-L2:", {k: f"{v:.1e}" for k, v in errs.items()})
     if not bf16:
         assert max(errs.values()) < 5e-4, errs
     else:
+        # two bf16 realisations of gradients that are small differences of large sums (each is 5-10 % from the exact-f32 mode,
+        # test_dgl_global_bf16_mode_vs_f32_mode); at full size the whole gradient of the step agrees to 7e-3 (test_gpu_full_size.py)
         for k in ("conv1_w", "conv2_w", "fc_w", "bn1_w", "bn2_w"):
-            assert errs[k] < 5e-2, errs
-        assert max(errs.values()) < 0.3, errs
+            assert errs[k] < 0.25, errs
+        assert max(errs.values()) < 0.4, errs
