@@ -240,6 +240,8 @@ constexpr int FPITCH = FBK * 2 + 8;          // bf16 rows: 64 x 2 B + 8
 constexpr int FPITCH32 = FBK * 4 + 16;       // f32 rows (exact-f32 variant): 64 x 4 B + 16
 
 struct FastArgs {
+    const GemmKSeg* ktab;              // segmented contraction (KTAB kernels): one entry per 32-wide k block and outer batch index
+    int ktab_per;                      // entries per outer batch index i1
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
     int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
     GemmFused fu;                      // fused epilogues of the DGL fc backward (step_internal.h); all-null = off
@@ -317,6 +319,24 @@ __device__ __forceinline__ void stage_load(Stage<MODE, BR>& s, const char* base,
                 s.f[r * 4 + j][0] = t.x; s.f[r * 4 + j][1] = t.y; s.f[r * 4 + j][2] = t.z; s.f[r * 4 + j][3] = t.w;
             }
         }
+    }
+}
+
+// Segmented contraction: k block kb = k >> 5 of operand `which` lives at base + seg[kb].off + row * seg[kb].rs + i0 * seg[kb].bs (+ k & 31):
+// blocks of 32 contiguous k values scattered over several buffers (the per-layer gcn buffers of the GraphWaveNet, gwnet.hip).
+template <int BR>
+__device__ __forceinline__ void stage_load_seg(Stage<KC_F32, BR>& s, const float* base, int row0, int rows, int k0, int kend,
+                                               const GemmKSeg* seg, int which, long i0, int tid) {
+#pragma unroll
+    for (int r = 0; r < s.NV; ++r) {
+        const int e = tid + r * 256;
+        const int k = k0 + (e % (FBK / 4)) * 4, row = row0 + e / (FBK / 4);
+        const bool ok = row < rows && k < kend;
+        const GemmKSeg sg = seg[(ok ? k : k0) >> 5];
+        const long off = ok ? (which ? sg.b_off + (long)row * sg.b_rs + i0 * sg.b_bs : sg.a_off + (long)row * sg.a_rs + i0 * sg.a_bs) + (k & 31)
+                            : (which ? sg.b_off : sg.a_off);
+        const float4 t = *(const float4*)(base + off);
+        s.f[r][0] = t.x; s.f[r][1] = t.y; s.f[r][2] = t.z; s.f[r][3] = t.w;
     }
 }
 
@@ -445,8 +465,9 @@ __device__ __forceinline__ void stage_store(const Stage<MODE, BR>& s, char* lds,
 // F32C = true: same staging, but LDS keeps f32 and the products run on v_mfma_f32_32x32x2_f32 (exact f32).  A lane of that
 // instruction supplies one k per operand (k = lane >> 5); it reads 16-byte chunk 2*ks + (lane >> 5) of its row and feeds the
 // four values to four successive MFMAs -- both operands permute k identically, so the contraction is unchanged.
-template <int BM, int BN, int AMODE, int BMODE, bool F32C>
+template <int BM, int BN, int AMODE, int BMODE, bool F32C, bool KTAB = false>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa) {
+    static_assert(!KTAB || (AMODE == KC_F32 && BMODE == KC_F32), "segmented contraction: k-contiguous f32 blocks on both sides");
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PITCH_ = F32C ? FPITCH32 : FPITCH;
     constexpr int BUF = (BM + BN) * PITCH_;
@@ -477,9 +498,20 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     if (kbeg < kend) {
         Stage<AMODE, BM> sa;
         Stage<BMODE, BN> sb;
+        __shared__ GemmKSeg segs[KTAB ? GEMM_KSEG_MAX : 1];
+        if constexpr (KTAB) {
+            const int nseg = (g.K + 31) >> 5;
+            for (int i = tid; i < nseg; i += 256) segs[i] = fa.ktab[(long)i1 * fa.ktab_per + i];
+            __syncthreads();
+        }
         auto fetch = [&](int k0) {
-            stage_load<AMODE, BM>(sa, Ab, m0, g.M, g.sam, g.sak, k0, kend, fa.a_klog, g.a_kstride, 30, 0, tid);
-            stage_load<BMODE, BN>(sb, Bb, n0, g.N, g.sbn, g.sbk, k0, kend, fa.b_klog, g.b_kstride, fa.b_nlog, g.b_nstride, tid);
+            if constexpr (KTAB) {
+                stage_load_seg<BM>(sa, (const float*)g.A, m0, g.M, k0, kend, segs, 0, i0, tid);
+                stage_load_seg<BN>(sb, (const float*)g.B, n0, g.N, k0, kend, segs, 1, i0, tid);
+            } else {
+                stage_load<AMODE, BM>(sa, Ab, m0, g.M, g.sam, g.sak, k0, kend, fa.a_klog, g.a_kstride, 30, 0, tid);
+                stage_load<BMODE, BN>(sb, Bb, n0, g.N, g.sbn, g.sbk, k0, kend, fa.b_klog, g.b_kstride, fa.b_nlog, g.b_nstride, tid);
+            }
         };
         auto commit = [&](int k0, char* buf) {          // masks / affine, bf16 rounding, LDS writes
             stage_fix<AMODE, BM>(sa, m0, g.M, k0, kend, g.a_kscale, g.a_kshift, g.a_kperiod, -1, tid);
@@ -808,7 +840,7 @@ int launch_bf16(const StepGemm& g, hipStream_t st) {
 
 int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     FastArgs fa;
-    memset(&fa.fu, 0, sizeof(fa.fu));
+    memset(&fa, 0, sizeof(fa));
     if (fused) fa.fu = *fused;
     int dummy;
     const int amode = fast_mode(g.A, g.a_bf16, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);
@@ -841,10 +873,39 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
 
 // Exact-f32 GEMM through the same staged pipeline (64 x 64 tiles).  Returns -1 when the operands do not qualify
 // (alignment / layout), in which case the caller falls back to the general kernels of gemm.hip.
+// C[i1][i0] (M x N, row-major ldc, batch strides scb1 / scb) = sum over the K = 32 * nseg segmented k values (see stage_load_seg);
+// g.A / g.B are the base pointers the table offsets refer to, g.batch0 = number of inner batch indices i0, g.batch = total.
+int step_gemm_segmented_launch(StepGemm g, const GemmKSeg* ktab, int ktab_per, hipStream_t st) {
+    STEP_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0 && g.K / 32 <= GEMM_KSEG_MAX && ktab && g.A && g.B && g.C && g.batch >= 1,
+                 "step_gemm(segmented): bad descriptor");
+    STEP_REQUIRE(g.accumulate != 2 && !g.bias && !g.relu && !g.a_rowsum && !g.a_kscale && g.scn <= 1 && !g.c_nblk,
+                 "step_gemm(segmented): plain store / += only");
+    STEP_REQUIRE((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0, "step_gemm(segmented): 16-byte aligned bases");
+    g.scn = 1; g.splitk = 1;
+    if (g.batch0 == 0) g.batch0 = g.batch;
+    FastArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.ktab = ktab; fa.ktab_per = ktab_per;
+    fa.a_klog = fa.b_klog = fa.b_nlog = 30;
+    fa.wide_store = 0;
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch;
+    if (g.M > 64 && g.N > 64 && tiles128 >= 256) {
+        dim3 grid(cdiv(g.N, 128), cdiv(g.M, 128), g.batch);
+        if (g.compute_bf16) gemm_fast_kernel<128, 128, KC_F32, KC_F32, false, true><<<grid, 256, 0, st>>>(g, fa);
+        else { dim3 g64(cdiv(g.N, 64), cdiv(g.M, 64), g.batch); gemm_fast_kernel<64, 64, KC_F32, KC_F32, true, true><<<g64, 256, 0, st>>>(g, fa); }
+    } else {
+        dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), g.batch);
+        if (g.compute_bf16) gemm_fast_kernel<64, 64, KC_F32, KC_F32, false, true><<<grid, 256, 0, st>>>(g, fa);
+        else gemm_fast_kernel<64, 64, KC_F32, KC_F32, true, true><<<grid, 256, 0, st>>>(g, fa);
+    }
+    STEP_LAUNCH_CHECK("step_gemm(segmented)");
+    return STEP_OK;
+}
+
 int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     if (g.a_bf16 || g.b_bf16) return -1;
     FastArgs fa;
-    memset(&fa.fu, 0, sizeof(fa.fu));
+    memset(&fa, 0, sizeof(fa));
     if (fused) fa.fu = *fused;
     int dummy;
     const int amode = fast_mode(g.A, 0, g.sam, g.sak, g.sab, g.sab1, g.a_kblk, g.a_kstride, 0, 0, &fa.a_klog, &dummy);

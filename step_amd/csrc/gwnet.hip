@@ -698,6 +698,27 @@ __global__ __launch_bounds__(256) void rowsum_mod_kernel(const float* __restrict
     if (threadIdx.x == 0) atomicAdd(&out[row % mod], red[0] + red[1] + red[2] + red[3]);
 }
 
+// Adjacency gradients of all 7 gcn layers as ONE segmented contraction per support (instead of 14 read-modify-write passes over
+// the [3][B][N][N] gradient stack):  dP_s[b][v][w] = sum_layers sum_t sum_c ( x1_s[v][t][c] d_x2_s[w][t][c] + z[v][t][c] d_x1_s[w][t][c] ).
+// k block (layer i, t, pair) -> 32 channels of one slot of cat_i (A side, offsets from `saved`) and of dcat_i (B side, offsets from
+// the per-layer gradient buffers); table [3 supports][ADJ_NSEG].
+constexpr int ADJ_NSEG = 2 * (12 + 10 + 9 + 7 + 6 + 4 + 3);
+struct AdjOffsets { long cat[NL - 1], dcat[NL - 1]; };
+__global__ void adj_ktab_kernel(AdjOffsets o, int N, GemmKSeg* __restrict__ tab) {
+    const int j = threadIdx.x, s = blockIdx.x;
+    if (j >= ADJ_NSEG) return;
+    constexpr int tout[NL - 1] = {12, 10, 9, 7, 6, 4, 3};
+    int i = 0, rem = j >> 1;
+    while (rem >= tout[i]) { rem -= tout[i]; ++i; }
+    const int t = rem, pair = j & 1, T = tout[i];
+    GemmKSeg g;
+    g.a_off = o.cat[i] + (long)t * CAT + (pair == 0 ? (1 + 2 * s) * C : 0);
+    g.b_off = o.dcat[i] + (long)t * CAT + (pair == 0 ? (2 + 2 * s) * C : (1 + 2 * s) * C);
+    g.a_rs = g.b_rs = T * CAT;
+    g.a_bs = g.b_bs = (long)N * T * CAT;
+    tab[s * ADJ_NSEG + j] = g;
+}
+
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // ---------------------------------------------------------------------------- buffer carving
@@ -755,7 +776,8 @@ struct Work {
     float *wcat, *wcatT, *bcat, *wskip, *wmixT, *dwcat, *dbcat, *dwskip;       // [8][64][64] x2, [8][64], [256][256], [7][224][32]; d* and acc64 contiguous (one memset)
     double* acc64;             // [7 BatchNorms][NCOPY][64] f64 accumulators of the in-kernel BatchNorm sums
     float *xcat, *bsum;
-    float *dcat, *dpre, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
+    float *dcat[NL - 1], *dpre, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;     // dcat: one gcn-buffer gradient per layer (all needed at the end)
+    GemmKSeg* ktab;
     float *d_e1, *d_xh, *d_h2, *d_h1;
     long total;
 };
@@ -775,7 +797,8 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.xcat = backward ? cv.take(BN * 12 * 64) : nullptr;
     w.bsum = cv.take(CS);
     if (backward) {
-        w.dcat = cv.take(BN * 12 * CAT);
+        for (int i = 0; i < NL - 1; ++i) w.dcat[i] = cv.take(BN * TOUT[i] * CAT);
+        w.ktab = (GemmKSeg*)cv.take(3L * ADJ_NSEG * sizeof(GemmKSeg) / sizeof(float));
         w.dpre = cv.take(BN * 12 * 64);
         w.dh = cv.take(BN * 12 * C);
         w.dres = cv.take(BN * 12 * C);
@@ -996,21 +1019,20 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             // BatchNorm_i backward (sums left by the previous iteration's tcn_bwd) + dropout + mix data gradient
             const BnBwd bn = {p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
             mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh,
-                                                                            W.dcat);
+                                                                            W.dcat[i]);
             STEP_LAUNCH_CHECK("mix_bwd");
             StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = -1;
             gw.a_rowsum = grads->gconv_b[i];
             gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, st));
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
-            STEP_TRY(nconv_bwd_adj3(cat, 1, 2, W.dcat, 2, W.dPstk, B, N, Tout, BF16, st));      // dP += x1 (x) d_x2
-            STEP_TRY(nconv_bwd_adj3(cat, 0, 0, W.dcat, 1, W.dPstk, B, N, Tout, BF16, st));      // dP += z  (x) d_x1
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat, 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
+            // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
-        tcn_bwd_kernel<BF16><<<(unsigned)cdiv(BN, TB_ROWS / Tout), 256, 0, st>>>(i < NL - 1 ? W.dcat : nullptr, W.dskip, i, S.tf[i], S.sg[i],
+        tcn_bwd_kernel<BF16><<<(unsigned)cdiv(BN, TB_ROWS / Tout), 256, 0, st>>>(i < NL - 1 ? W.dcat[i] : nullptr, W.dskip, i, S.tf[i], S.sg[i],
                                                                                 W.wcatT + i * 4096, i < NL - 1 ? W.dres : nullptr, BN, Tin, Tout, dil,
                                                                                 W.dpre, dx, i > 0 ? S.y[i - 1] : nullptr,
                                                                                 i > 0 ? S.bnstat[i - 1] : nullptr,
@@ -1026,6 +1048,17 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         dx_next = dx;
     }
     *dx0 = dx_next;
+    {   // dP_s = sum over layers, time steps and channels of x1_s (x) d_x2_s + z (x) d_x1_s: one segmented contraction, K = 3264
+        AdjOffsets o;
+        for (int i = 0; i < NL - 1; ++i) { o.cat[i] = S.cat[i] - S.cat[0]; o.dcat[i] = W.dcat[i] - W.dcat[0]; }
+        adj_ktab_kernel<<<3, 128, 0, st>>>(o, N, W.ktab);
+        STEP_LAUNCH_CHECK("adj_ktab");
+        StepGemm g = gemm_desc(N, N, 32 * ADJ_NSEG, S.cat[0], 0, 1, W.dcat[0], 1, 0, W.dPstk, N);
+        g.batch = 3 * B; g.batch0 = B;
+        g.scb = (long)N * N; g.scb1 = (long)B * N * N;
+        g.compute_bf16 = BF16;
+        STEP_TRY(step_gemm_segmented_launch(g, W.ktab, ADJ_NSEG, st));
+    }
     return STEP_OK;
 }
 
@@ -1044,7 +1077,6 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     STEP_TRY(pack_weights(p, W, st));
     STEP_TRY(zero(W.dwcat, (long)((float*)W.acc64 - W.dwcat) + 2L * 7 * NCOPY * 64, st));       // dwcat, dbcat, dwskip, acc64
     const long NN = (long)N * N;
-    STEP_TRY(zero(W.dPstk, 3L * B * NN, st));
 
     // ---------------------------------------------------------------- head (model.py:215-220)
     {

@@ -21,6 +21,11 @@ struct GemmFused {
     int flags;
 };
 
+// one 32-wide block of a segmented contraction (step_gemm_segmented_launch): element offsets from the A / B base pointers
+struct GemmKSeg { long a_off, b_off, a_bs, b_bs; int a_rs, b_rs; };
+constexpr int GEMM_KSEG_MAX = 128;
+int step_gemm_segmented_launch(StepGemm g, const GemmKSeg* ktab, int ktab_per, hipStream_t st);
+
 int step_gemm_launch(StepGemm g, hipStream_t st);
 int step_gemm_launch_fused(StepGemm g, const GemmFused& fused, hipStream_t st);      // STEP_ERR_ARG (message set) when the operands do not qualify
 int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused = nullptr);
