@@ -351,7 +351,7 @@ static void attn_attrs() {
 }
 extern "C" int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                                      void* stream) {
-    STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 512, "pt_attention_fwd: bad arguments (T=%d)", T);
+    STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336, "pt_attention_fwd: bad arguments (T=%d; at most 336 tokens, the limit of the backward)", T);
     attn_attrs();
     size_t lds = (size_t)(3 * T * DH) * sizeof(float);
     attn_kernel<false><<<(unsigned)(S * H), 256, lds, (hipStream_t)stream>>>(qkv, S, T, p, SEED_LO(seed), SEED_HI(seed), site, out, stats,

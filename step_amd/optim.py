@@ -15,26 +15,37 @@ import torch
 from . import _lib
 
 
-class FusedAdamClip:
+class FusedAdamClip(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler.MultiStepLR`` -- the reference's ``CFG.TRAIN.LR_SCHEDULER``,
+    step/STEP_PEMS04.py:98-102 -- drives ``param_groups[0]["lr"]`` as usual) whose single parameter is the model's flat buffer."""
+
     def __init__(self, model, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None):
         self.model = model
         self.flat = model._flat_param if model._flat_param is not None else model.flatten_parameters()
+        super().__init__([self.flat], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]   # lr schedulers edit this
         self.max_norm = max_norm
         self.step_count = 0
         self.work = torch.empty(int(_lib.lib().step_adam_work_floats()), device=self.flat.device)
         self.grad_norm = torch.zeros(1, device=self.flat.device)
+        model._backward_count = 0
 
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad(set_to_none=set_to_none)
         self.model._flat_grad = None
+        self.model._backward_count = 0
 
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError("FusedAdamClip.step() takes no closure")
         g = self.model._flat_grad
         if g is None:
             raise RuntimeError("FusedAdamClip.step(): no native backward has run since zero_grad()")
+        if self.model._backward_count != 1:
+            raise RuntimeError(f"FusedAdamClip.step(): {self.model._backward_count} native backwards since zero_grad() -- the flat gradient buffer "
+                               "holds the last one only; accumulate with torch.optim.Adam on model.parameters() instead")
         pg = self.param_groups[0]
         self.step_count += 1
         extra = None
@@ -52,10 +63,12 @@ class FusedAdamClip:
                   _lib.ptr(self.grad_norm), _lib.stream())
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": groups}
 
     def load_state_dict(self, sd):
         self.step_count = sd["step"]
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups = sd["param_groups"]
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in src.items() if k != "params"})

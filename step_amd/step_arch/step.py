@@ -223,6 +223,7 @@ class _StepFunction(torch.autograd.Function):
             views["dgl.conv1_b"].mul_(float(world))
             model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
         model._flat_grad = flat
+        model._backward_count = getattr(model, "_backward_count", 0) + 1
         ctx.held = None
         # fresh views with no other owner: autograd's AccumulateGrad then adopts them as .grad (aliases of the flat buffer)
         # instead of cloning every gradient (the clone of the fc weight gradient alone is an 87 MB copy)
@@ -253,6 +254,7 @@ class STEP(nn.Module):
         self._last = {}
         self._flat_param = None
         self._flat_grad = None
+        self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
         self._side = {}
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills

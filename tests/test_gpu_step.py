@@ -254,6 +254,24 @@ def test_fused_adam_clip_matches_torch():
             assert max_abs(p.detach().cpu(), sp.detach().cpu()) < 2e-6 + 2e-5 * float(sp.abs().max()), (it, n)
     print("losses", losses)
     assert losses[-1] < losses[0]               # the flattened parameters are the ones the native forward reads
+    # a torch Optimizer: the reference's scheduler (CFG.TRAIN.LR_SCHEDULER = MultiStepLR, STEP_PEMS04.py:98-102) drives its learning rate
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1, 2], gamma=0.5)
+    sched.step(); sched.step()
+    assert opt.param_groups[0]["lr"] == pytest.approx(2e-3 * 0.25)
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == pytest.approx(2e-3 * 0.25) and opt.step_count == 4
+    # one backward per step(): the flat gradient buffer holds the last backward only (gradient accumulation must use torch's Adam)
+    opt.zero_grad(set_to_none=True)
+    for _ in range(2):
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=9, epoch=1)
+        O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef).backward()
+    with pytest.raises(RuntimeError, match="2 native backwards"):
+        opt.step()
+    opt.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="no native backward"):
+        opt.step()
 
 
 def test_native_step_loss_matches_reference_loss():
