@@ -465,7 +465,9 @@ __device__ __forceinline__ void stage_store(const Stage<MODE, BR>& s, char* lds,
 // F32C = true: same staging, but LDS keeps f32 and the products run on v_mfma_f32_32x32x2_f32 (exact f32).  A lane of that
 // instruction supplies one k per operand (k = lane >> 5); it reads 16-byte chunk 2*ks + (lane >> 5) of its row and feeds the
 // four values to four successive MFMAs -- both operands permute k identically, so the contraction is unchanged.
-template <int BM, int BN, int AMODE, int BMODE, bool F32C, bool KTAB = false>
+// FUSED: the DGL fc-backward epilogues (GemmFused).  A separate instantiation: their batched loads would otherwise set the register
+// allocation (and with it the occupancy) of every staged GEMM of the step.
+template <int BM, int BN, int AMODE, int BMODE, bool F32C, bool KTAB = false, bool FUSED = false>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa) {
     static_assert(!KTAB || (AMODE == KC_F32 && BMODE == KC_F32), "segmented contraction: k-contiguous f32 blocks on both sides");
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
     }
 
     float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
-    if (fa.wide_store && (fa.fu.dotw || fa.fu.bnx)) {
+    if constexpr (FUSED) {
         // Wide-store epilogue with the fused pieces of the DGL BatchNorm2 backward (GemmFused, step_internal.h).  The RAW
         // alpha * A.B tile is staged; the column-block affine, the per-channel reductions against W and the BatchNorm-backward
         // transform run in the piece loop, where a thread holds 4 consecutive columns of one row.  A tile spans at most two
@@ -815,6 +817,25 @@ int launch_fast(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hip
     if (amode == KC_BF16) return launch_fast_b<BM, BN, KC_BF16>(g, fa, bmode, grid, st);
     return launch_fast_b<BM, BN, MC_F32>(g, fa, bmode, grid, st);
 }
+// the fused DGL epilogues: only the operand combinations dgl.hip uses
+template <int BM, int BN>
+int launch_fast_fused(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
+    if (amode == KC_F32 && bmode == MC_BF16) gemm_fast_kernel<BM, BN, KC_F32, MC_BF16, false, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (amode == KC_F32 && bmode == MC_F32) gemm_fast_kernel<BM, BN, KC_F32, MC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (amode == MC_F32 && bmode == MC_F32) gemm_fast_kernel<BM, BN, MC_F32, MC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else { step_set_error("step_gemm(fused): operand layout not instantiated"); return STEP_ERR_ARG; }
+    STEP_LAUNCH_CHECK("step_gemm(bf16 fused)");
+    return STEP_OK;
+}
+int launch_fast_f32_fused(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+    dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), 1);
+    if (amode == KC_F32 && bmode == MC_F32) gemm_fast_kernel<64, 64, KC_F32, MC_F32, true, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (amode == MC_F32 && bmode == MC_F32) gemm_fast_kernel<64, 64, MC_F32, MC_F32, true, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else { step_set_error("step_gemm(fused): operand layout not instantiated"); return STEP_ERR_ARG; }
+    STEP_LAUNCH_CHECK("step_gemm(f32 fused)");
+    return STEP_OK;
+}
 int launch_fast_f32(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
     dim3 grid(cdiv(g.N + (g.a_rowsum ? 1 : 0), 64), cdiv(g.M, 64), g.batch * g.splitk);
     if (amode == KC_F32 && bmode == KC_F32) gemm_fast_kernel<64, 64, KC_F32, KC_F32, true><<<grid, 256, 0, st>>>(g, fa);
@@ -865,6 +886,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
     const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
+    if (fast && fused) return big ? launch_fast_fused<128, 128>(g, fa, amode, bmode, st) : launch_fast_fused<64, 64>(g, fa, amode, bmode, st);
     if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
     STEP_TRY(step_gemm_rowsum_separate(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
@@ -923,5 +945,6 @@ int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused
     if (g.splitk < 1) g.splitk = 1;
     if (g.splitk > 1) STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2");
     STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
+    if (fused) return launch_fast_f32_fused(g, fa, amode, bmode, st);
     return launch_fast_f32(g, fa, amode, bmode, st);
 }
