@@ -262,6 +262,251 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     }
 }
 
+// ------------------------------------------------------------------------------------ self-attention on the matrix cores (bf16 mode)
+// Same operation as attn_kernel with bf16 operands and f32 accumulation on v_mfma_f32_32x32x16_bf16, one workgroup per (sequence,
+// head), one wave per 32-token tile.  Everything is computed TRANSPOSED, S^T = K Q^T: an accumulator then holds 16 keys of ONE query
+// per lane (row statistics are per-lane scalars) and becomes the B operand of the next product by a plain pack -- a 16-deep k step
+// takes accumulator registers [8s, 8s+8), i.e. keys {16s+4h+0..3, 16s+8+4h+0..3} of lane half h, and the A operand (rows of a
+// transposed LDS copy) reads exactly those keys (any pairing of k is a valid contraction order).
+// Dropout of the attention probabilities: the same Philox stream and element index as attn_kernel (one call covers 4 keys).
+constexpr int MA_DP = 32;                 // head dim padded to two k steps
+constexpr int MA_RP = 40;                 // row pitch of the row-major LDS arrays (bf16 elements): 80 B, conflict-free 16-byte reads
+__device__ __forceinline__ int ma_tpitch(int Tp) { return Tp + 8; }      // pitch of the transposed arrays
+__device__ __forceinline__ bf16x8 ma_row8(const uint16_t* row) { return __builtin_bit_cast(bf16x8, *(const uint4*)row); }
+__device__ __forceinline__ bf16x8 ma_tr8(const uint16_t* trow, int k0, int h) {      // keys k0 + {4h..4h+3, 8+4h..8+4h+3} of one d row
+    const uint2 a = *(const uint2*)(trow + k0 + 4 * h), b = *(const uint2*)(trow + k0 + 8 + 4 * h);
+    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+__device__ __forceinline__ bf16x8 ma_pack(const float* v) { return pack8(v); }
+// keep decisions (as multipliers 1/(1-p) or 0) of elements elem0 .. elem0+3 of the attention-dropout stream
+__device__ __forceinline__ void ma_keep4(uint32_t lo, uint32_t hi, uint32_t site, long elem0, float p, float ks, float* m) {
+    uint32_t r[8];
+    const long blk = elem0 >> 2;
+    const int off = (int)(elem0 & 3);
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), site, 0xD20Fu, lo, hi, r);
+    if (off) philox4x32((uint32_t)(blk + 1), (uint32_t)((blk + 1) >> 32), site, 0xD20Fu, lo, hi, r + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t v = r[j];
+        if (off == 1) v = r[j + 1]; else if (off == 2) v = r[j + 2]; else if (off == 3) v = r[j + 3];
+        m[j] = u32_to_unit(v) >= p ? ks : 0.f;
+    }
+}
+__device__ __forceinline__ int ma_key(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }     // accumulator register -> row of the tile
+
+// forward: out [S][T][96], stats [S][H][T][2] = (row max, row sum) like attn_kernel
+__global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
+                                                            uint32_t site, float* __restrict__ out, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
+    const int TPt = ma_tpitch(Tp);
+    uint16_t* Qs = ml;                       // [Tp][MA_RP]  q * scale
+    uint16_t* Ks = Qs + Tp * MA_RP;          // [Tp][MA_RP]
+    uint16_t* VT = Ks + Tp * MA_RP;          // [32][TPt]
+    const long s = blockIdx.x / H;
+    const int hd = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const float scale = 0.20412414523193154f;
+    const float* base = qkv + s * (long)T * 288;
+    for (int e = tid; e < Tp * MA_DP; e += blockDim.x) {
+        const int t = e >> 5, d = e & 31;
+        const bool ok = t < T && d < DH;
+        const float q = ok ? base[(long)t * 288 + hd * DH + d] * scale : 0.f, k = ok ? base[(long)t * 288 + 96 + hd * DH + d] : 0.f;
+        const float v = ok ? base[(long)t * 288 + 192 + hd * DH + d] : 0.f;
+        Qs[t * MA_RP + d] = (uint16_t)f32_to_bf16_bits(q);
+        Ks[t * MA_RP + d] = (uint16_t)f32_to_bf16_bits(k);
+        VT[d * TPt + t] = (uint16_t)f32_to_bf16_bits(v);
+    }
+    __syncthreads();
+    const int q = wave * 32 + col, nkt = Tp / 32;
+    const long srow = (s * H + hd) * (long)T;
+    bf16x8 bq[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) bq[st] = ma_row8(Qs + q * MA_RP + 16 * st + 8 * h);
+    auto scores = [&](int kt, f32x16& acc) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Ks + (kt * 32 + col) * MA_RP + 16 * st + 8 * h), bq[st], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (kt * 32 + ma_key(e, h) >= T) acc[e] = -1e30f;
+    };
+    float mx = -1e30f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 acc;
+        scores(kt, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float l = 0.f;
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 acc;
+        scores(kt, acc);
+        float pv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { pv[e] = __expf(acc[e] - mx); l += pv[e]; }
+        if (p > 0.f && q < T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m4[4];
+                ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[4 * g + j] *= m4[j];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(VT + col * TPt, kt * 32 + 16 * st, h), ma_pack(pv + 8 * st), o, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (q < T) {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int d = ma_key(e, h);
+            if (d < DH) out[(s * T + q) * D + hd * DH + d] = o[e] * inv;
+        }
+        if (h == 0) { stats[(srow + q) * 2] = mx; stats[(srow + q) * 2 + 1] = l; }
+    }
+}
+
+// backward: phase A (wave = query tile) -> dQ and the keep bits, phase B (wave = key tile) -> dK, dV
+__global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                            const float* __restrict__ dout, const float* __restrict__ stats, int T, int Tp,
+                                                            float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
+    const int TPt = ma_tpitch(Tp), nt = Tp / 32;
+    uint16_t* Qs = ml;                        // row-major [Tp][MA_RP]: q*scale, k, v, dO
+    uint16_t* Ks = Qs + Tp * MA_RP;
+    uint16_t* Vs = Ks + Tp * MA_RP;
+    uint16_t* Os = Vs + Tp * MA_RP;
+    uint16_t* QT = Os + Tp * MA_RP;           // transposed [32][TPt]: q*scale, k, dO
+    uint16_t* KT = QT + 32 * TPt;
+    uint16_t* OT = KT + 32 * TPt;
+    float* smx = (float*)(OT + 32 * TPt);     // [Tp] row max, 1 / row sum, delta
+    float* sinv = smx + Tp;
+    float* sdl = sinv + Tp;
+    uint32_t* bits = (uint32_t*)(sdl + Tp);   // [Tp][nt] keep bits of (query, key tile)
+    const long s = blockIdx.x / H;
+    const int hd = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const float scale = 0.20412414523193154f;
+    const float* base = qkv + s * (long)T * 288;
+    const long srow = (s * H + hd) * (long)T;
+    for (int e = tid; e < Tp * MA_DP; e += blockDim.x) {
+        const int t = e >> 5, d = e & 31;
+        const bool ok = t < T && d < DH;
+        const uint16_t q = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + hd * DH + d] * scale : 0.f);
+        const uint16_t k = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 96 + hd * DH + d] : 0.f);
+        const uint16_t v = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 192 + hd * DH + d] : 0.f);
+        const uint16_t g = (uint16_t)f32_to_bf16_bits(ok ? dout[(s * T + t) * D + hd * DH + d] : 0.f);
+        Qs[t * MA_RP + d] = q; Ks[t * MA_RP + d] = k; Vs[t * MA_RP + d] = v; Os[t * MA_RP + d] = g;
+        QT[d * TPt + t] = q; KT[d * TPt + t] = k; OT[d * TPt + t] = g;
+    }
+    for (int i = tid; i < Tp; i += blockDim.x) {
+        float dl = 0.f, m = 0.f, iv = 0.f;
+        if (i < T) {
+#pragma unroll
+            for (int d = 0; d < DH; ++d) dl += dout[(s * T + i) * D + hd * DH + d] * out[(s * T + i) * D + hd * DH + d];
+            m = stats[(srow + i) * 2];
+            iv = 1.f / stats[(srow + i) * 2 + 1];
+        }
+        sdl[i] = dl; smx[i] = m; sinv[i] = iv;
+    }
+    __syncthreads();
+    const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    float* db = dqkv + s * (long)T * 288;
+    {   // ---- phase A: this wave's 32 queries against every key tile (keys in registers, query = lane)
+        const int q = wave * 32 + col;
+        const float mq = smx[q], iq = sinv[q], dq_ = sdl[q];
+        bf16x8 bq[2], bo[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { bq[st] = ma_row8(Qs + q * MA_RP + 16 * st + 8 * h); bo[st] = ma_row8(Os + q * MA_RP + 16 * st + 8 * h); }
+        f32x16 dqa;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqa[e] = 0.f;
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Ks + (kt * 32 + col) * MA_RP + 16 * st + 8 * h), bq[st], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Vs + (kt * 32 + col) * MA_RP + 16 * st + 8 * h), bo[st], dp, 0, 0, 0);
+            }
+            float mk[16];
+            uint32_t word = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p > 0.f && q < T) ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mk[4 * g + j] = m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
+            }
+            word |= __shfl_xor(word, 32, 64);
+            if (h == 0) bits[q * nt + kt] = word;
+            float ds[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool kok = kt * 32 + ma_key(e, h) < T;
+                const float pij = kok ? __expf(sc[e] - mq) * iq : 0.f;
+                ds[e] = pij * (dp[e] * mk[e] - dq_);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(KT + col * TPt, kt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dqa, 0, 0, 0);
+        }
+        if (q < T) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const int d = ma_key(e, h); if (d < DH) db[(long)q * 288 + hd * DH + d] = dqa[e] * scale; }
+        }
+    }
+    __syncthreads();
+    {   // ---- phase B: this wave's 32 keys against every query tile (queries in registers, key = lane)
+        const int kj = wave * 32 + col;
+        bf16x8 bk[2], bv[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) { bk[st] = ma_row8(Ks + kj * MA_RP + 16 * st + 8 * h); bv[st] = ma_row8(Vs + kj * MA_RP + 16 * st + 8 * h); }
+        f32x16 dka, dva;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dka[e] = 0.f; dva[e] = 0.f; }
+        for (int qt = 0; qt < nt; ++qt) {
+            f32x16 sc, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Qs + (qt * 32 + col) * MA_RP + 16 * st + 8 * h), bk[st], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Os + (qt * 32 + col) * MA_RP + 16 * st + 8 * h), bv[st], dp, 0, 0, 0);
+            }
+            float pm[16], ds[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = qt * 32 + ma_key(e, h);
+                const float mkv = (bits[qi * nt + wave] >> col) & 1u ? ks : 0.f;
+                const float pij = kj < T ? __expf(sc[e] - smx[qi]) * sinv[qi] : 0.f;      // rows qi >= T: sinv = 0
+                pm[e] = pij * mkv;
+                ds[e] = pij * (dp[e] * mkv - sdl[qi]);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                dva = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(OT + col * TPt, qt * 32 + 16 * st, h), ma_pack(pm + 8 * st), dva, 0, 0, 0);
+                dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(QT + col * TPt, qt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dka, 0, 0, 0);
+            }
+        }
+        if (kj < T) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int d = ma_key(e, h);
+                if (d < DH) { db[(long)kj * 288 + 96 + hd * DH + d] = dka[e]; db[(long)kj * 288 + 192 + hd * DH + d] = dva[e]; }
+            }
+        }
+    }
+}
+
 __global__ void relu_mask_kernel(float* __restrict__ d, const float* __restrict__ y, long n) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n && !(y[i] > 0.f)) d[i] = 0.f;
@@ -367,6 +612,38 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
     attn_kernel<true><<<(unsigned)(S * H), 256, lds, (hipStream_t)stream>>>(qkv, S, T, p, SEED_LO(seed), SEED_HI(seed), site,
                                                                            const_cast<float*>(out), const_cast<float*>(stats), dout, dqkv);
     STEP_LAUNCH_CHECK("pt_attention_bwd");
+    return STEP_OK;
+}
+// the same attention on the matrix cores (bf16 operands, f32 accumulation) -- what TSFormer(mode="pre-train") uses with matmul_precision = "bf16"
+static size_t ma_fwd_lds(int Tp) { return (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2; }
+static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MA_RP + 3 * 32 * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
+extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
+                                          void* stream) {
+    STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f, "pt_attention_fwd_bf16: bad arguments (T=%d)", T);
+    const int Tp = (T + 31) & ~31;
+    if (hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        step_set_error("pt_attention_fwd_bf16: cannot raise the dynamic LDS limit");
+        return STEP_ERR_HIP;
+    }
+    attn_mfma_fwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_fwd_lds(Tp), (hipStream_t)stream>>>(qkv, T, Tp, p, SEED_LO(seed), SEED_HI(seed),
+                                                                                                    site, out, stats);
+    STEP_LAUNCH_CHECK("pt_attention_fwd_bf16");
+    return STEP_OK;
+}
+extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
+                                          uint64_t seed, uint32_t site, float* dqkv, void* stream) {
+    STEP_REQUIRE(qkv && out && dout && stats && dqkv && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f,
+                 "pt_attention_bwd_bf16: bad arguments (T=%d)", T);
+    const int Tp = (T + 31) & ~31;
+    if (ma_bwd_lds(Tp) > 160 * 1024)        // (T > 256: seven operand copies + keep bits no longer fit the LDS -- the f32 kernel takes over)
+        return step_pt_attention_bwd(qkv, out, dout, stats, S, T, p, seed, site, dqkv, stream);
+    if (hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        step_set_error("pt_attention_bwd_bf16: cannot raise the dynamic LDS limit");
+        return STEP_ERR_HIP;
+    }
+    attn_mfma_bwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_bwd_lds(Tp), (hipStream_t)stream>>>(qkv, out, dout, stats, T, Tp, p, SEED_LO(seed),
+                                                                                                    SEED_HI(seed), site, dqkv);
+    STEP_LAUNCH_CHECK("pt_attention_bwd_bf16");
     return STEP_OK;
 }
 extern "C" int step_pt_relu_mask(float* d, const float* y, long n, void* stream) {

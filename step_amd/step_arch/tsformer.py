@@ -177,7 +177,7 @@ class _PretrainFunction(torch.autograd.Function):
         qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
         a = _empty(R, 96, like=x)
         stats = _empty(S * 4 * T, 2, like=x)
-        L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
+        L.call("step_pt_attention_fwd_bf16" if _BF16 else "step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
         o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
         h1pre = _empty(R, 96, like=x)
         L.call("step_pt_add_dropout", L.ptr(x), L.ptr(o), L.ptr(h1pre), R * 96, p, seed, site + 1, st)
@@ -230,7 +230,7 @@ class _PretrainFunction(torch.autograd.Function):
         _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
                     G[pre + "self_attn.out_proj.bias"], da)
         dqkv = _empty(R, 288, like=dh2)
-        L.call("step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
+        L.call("step_pt_attention_bwd_bf16" if _BF16 else "step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
         dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
         _linear_bwd(dqkv, sv["x"], P_[pre + "self_attn.in_proj_weight"], G[pre + "self_attn.in_proj_weight"],
                     G[pre + "self_attn.in_proj_bias"], dx, accumulate_dx=True)

@@ -103,3 +103,35 @@ def test_pretrain_bf16_mode_close_to_f32_mode():
     assert e < 2e-2
     assert res["bf16"][1] == pytest.approx(res["f32"][1], rel=5e-3)
     assert (num / den) ** 0.5 < 0.15         # masked-MAE gradients flip sign where reconstruction ~ label (8 % measured)
+
+
+@pytest.mark.parametrize("T,p", [(42, 0.1), (168, 0.1), (40, 0.0), (77, 0.25), (336, 0.1)])
+def test_matrix_core_attention_matches_f32_attention(T, p):
+    """step_pt_attention_{fwd,bwd}_bf16 (bf16 operands on the matrix cores, what the pre-training module uses in bf16 mode) against
+    the exact-f32 kernels: same row statistics, same dropout stream (identical keep masks for identical seed / site), outputs and
+    gradients within bf16 operand rounding.  T = 336 exercises the backward's fall-back (LDS), T = 77 an unaligned mask stream."""
+    from step_amd import _lib as L
+    S = 6
+    gen = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).cuda()
+    dout = torch.randn(S, T, 96, generator=gen).cuda()
+    seed, site = 0x1234_5678_9ABC, 7
+    st = L.stream()
+    res = {}
+    for tag in ("", "_bf16"):
+        out = torch.empty(S, T, 96, device="cuda")
+        stats = torch.empty(S * 4 * T, 2, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda")
+        L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
+        L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
+        torch.cuda.synchronize()
+        res[tag] = (out.cpu(), stats.cpu(), dqkv.cpu())
+    (o0, s0, g0), (o1, s1, g1) = res[""], res["_bf16"]
+    e_out, e_g = rel_l2(o1, o0), rel_l2(g1, g0)
+    e_m = float((s1[:, 0] - s0[:, 0]).abs().max())
+    e_l = float(((s1[:, 1] - s0[:, 1]).abs() / s0[:, 1]).max())
+    parts = {k: rel_l2(g1[..., a:a + 96], g0[..., a:a + 96]) for k, a in (("dq", 0), ("dk", 96), ("dv", 192))}
+    print(f"T={T} p={p}: out rel-L2 {e_out:.2e}, dqkv {e_g:.2e} {parts}, row max abs {e_m:.2e}, row sum rel {e_l:.2e}")
+    assert e_out < 1.5e-2 and e_g < 2.5e-2 and max(parts.values()) < 3e-2
+    assert e_m < 0.1 and e_l < 3e-2
+    assert torch.isfinite(g1).all() and torch.isfinite(o1).all()
