@@ -246,6 +246,8 @@ int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* h
  * rows = sequence-major tokens.  Dropout masks are a pure function of (seed, site, element index), so a
  * backward call with the same arguments replays the forward mask. */
 int step_pt_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* d = dropout(d) * [relu_of > 0] in one pass: the backward of relu -> dropout (same mask stream as step_pt_dropout at `site`) */
+int step_pt_dropout_relu_mask(float* d, const float* relu_of, long n, float p, uint64_t seed, uint32_t site, void* stream);
 int step_pt_add_dropout(const float* a, const float* b, float* out, long n, float p, uint64_t seed, uint32_t site, void* stream);
 /* x[s][p][:] += vec[idx ? idx[p] : p][:]   (positional embedding, positional_encoding.py:28-31) */
 int step_pt_add_rows(float* x, long S, int P, const float* vec, const int* idx, void* stream);

@@ -19,17 +19,50 @@ __device__ __forceinline__ float keep_scale(uint32_t lo, uint32_t hi, uint32_t s
     return u32_to_unit(r[elem & 3]) >= p ? 1.f / (1.f - p) : 0.f;
 }
 
-// y = x * mask (in place or out of place); the same call with the same (seed, site) replays the mask (backward)
+// keep multipliers of the 4 consecutive elements 4*blk .. 4*blk+3 (one Philox call)
+__device__ __forceinline__ void keep_scale4(uint32_t lo, uint32_t hi, uint32_t site, long blk, float p, float* m) {
+    uint32_t r[4];
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), site, 0xD20Fu, lo, hi, r);
+    const float ks = 1.f / (1.f - p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = u32_to_unit(r[j]) >= p ? ks : 0.f;
+}
+// y = x * mask (in place or out of place); the same call with the same (seed, site) replays the mask (backward).
+// One thread = 4 consecutive elements = one Philox call (n is a multiple of 4 on this path: rows of 96 / 384; the tail is scalar).
+// relu_of != nullptr: additionally y = 0 where relu_of <= 0 (the ReLU mask of the feed-forward backward in the same pass).
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, uint32_t lo, uint32_t hi,
-                               uint32_t site) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = x[i] * keep_scale(lo, hi, site, i, p);
+                               uint32_t site, const float* __restrict__ relu_of) {
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b * 4 + 3 < n) {
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) keep_scale4(lo, hi, site, b, p, m);
+        const float4 v = ((const float4*)x)[b];
+        float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+        if (relu_of) {
+            const float4 r = ((const float4*)relu_of)[b];
+            o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f; o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+        }
+        ((float4*)y)[b] = o;
+    } else {
+        for (long i = b * 4; i < n; ++i) {
+            float v = x[i] * (p > 0.f ? keep_scale(lo, hi, site, i, p) : 1.f);
+            if (relu_of && !(relu_of[i] > 0.f)) v = 0.f;
+            y[i] = v;
+        }
+    }
 }
 // out = a + dropout(b)
 __global__ void add_dropout_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n, float p,
                                    uint32_t lo, uint32_t hi, uint32_t site) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = a[i] + (p > 0.f ? b[i] * keep_scale(lo, hi, site, i, p) : b[i]);
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k * 4 + 3 < n) {
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) keep_scale4(lo, hi, site, k, p, m);
+        const float4 va = ((const float4*)a)[k], vb = ((const float4*)b)[k];
+        ((float4*)out)[k] = make_float4(va.x + vb.x * m[0], va.y + vb.y * m[1], va.z + vb.z * m[2], va.w + vb.w * m[3]);
+    } else {
+        for (long i = k * 4; i < n; ++i) out[i] = a[i] + (p > 0.f ? b[i] * keep_scale(lo, hi, site, i, p) : b[i]);
+    }
 }
 // x[s][p][:] += vec[idx ? idx[p] : p][:]
 __global__ void add_rows_kernel(float* __restrict__ x, long S, int P, const float* __restrict__ vec, const int* __restrict__ idx) {
@@ -521,13 +554,23 @@ inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 extern "C" int step_pt_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream) {
     STEP_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "pt_dropout: bad arguments");
-    dropout_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(x, y, n, p, SEED_LO(seed), SEED_HI(seed), site);
+    STEP_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "pt_dropout: 16-byte aligned buffers");
+    dropout_kernel<<<g1((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, y, n, p, SEED_LO(seed), SEED_HI(seed), site, nullptr);
     STEP_LAUNCH_CHECK("pt_dropout");
+    return STEP_OK;
+}
+// d = dropout(d) masked by relu_of > 0 in one pass (backward of relu -> dropout: the same mask stream as step_pt_dropout at `site`)
+extern "C" int step_pt_dropout_relu_mask(float* d, const float* relu_of, long n, float p, uint64_t seed, uint32_t site, void* stream) {
+    STEP_REQUIRE(d && relu_of && n > 0 && p >= 0.f && p < 1.f, "pt_dropout_relu_mask: bad arguments");
+    STEP_REQUIRE((((uintptr_t)d | (uintptr_t)relu_of) & 15) == 0, "pt_dropout_relu_mask: 16-byte aligned buffers");
+    dropout_kernel<<<g1((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(d, d, n, p, SEED_LO(seed), SEED_HI(seed), site, relu_of);
+    STEP_LAUNCH_CHECK("pt_dropout_relu_mask");
     return STEP_OK;
 }
 extern "C" int step_pt_add_dropout(const float* a, const float* b, float* out, long n, float p, uint64_t seed, uint32_t site, void* stream) {
     STEP_REQUIRE(a && b && out && n > 0 && p >= 0.f && p < 1.f, "pt_add_dropout: bad arguments");
-    add_dropout_kernel<<<g1(n), 256, 0, (hipStream_t)stream>>>(a, b, out, n, p, SEED_LO(seed), SEED_HI(seed), site);
+    STEP_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "pt_add_dropout: 16-byte aligned buffers");
+    add_dropout_kernel<<<g1((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(a, b, out, n, p, SEED_LO(seed), SEED_HI(seed), site);
     STEP_LAUNCH_CHECK("pt_add_dropout");
     return STEP_OK;
 }

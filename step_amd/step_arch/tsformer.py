@@ -214,9 +214,7 @@ class _PretrainFunction(torch.autograd.Function):
             L.call("step_pt_dropout", L.ptr(dh2pre), L.ptr(df2), R * 96, p, seed, site + 3, st)
         df1d = _empty(R, 384, like=dh2)
         _linear_bwd(df2, sv["f1d"], P_[pre + "linear2.weight"], G[pre + "linear2.weight"], G[pre + "linear2.bias"], df1d)
-        if p > 0:
-            L.call("step_pt_dropout", L.ptr(df1d), L.ptr(df1d), R * 384, p, seed, site + 2, st)
-        L.call("step_pt_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, st)
+        L.call("step_pt_dropout_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, p, seed, site + 2, st)      # dropout and ReLU backward in one pass
         dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
         _linear_bwd(df1d, sv["h1"], P_[pre + "linear1.weight"], G[pre + "linear1.weight"], G[pre + "linear1.bias"], dh1, accumulate_dx=True)
         dh1pre = _empty(R, 96, like=dh2)
