@@ -243,6 +243,7 @@ struct FastArgs {
     const GemmKSeg* ktab;              // segmented contraction (KTAB kernels): one entry per 32-wide k block and outer batch index
     int ktab_per;                      // entries per outer batch index i1
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
+    int xcd_swizzle;                   // remap block ids so that the n tiles of an m tile share an XCD (see gemm_fast_kernel)
     int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
     GemmFused fu;                      // fused epilogues of the DGL fc backward (step_internal.h); all-null = off
 };
@@ -477,8 +478,17 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int zb = blockIdx.z / g.splitk, zs = blockIdx.z % g.splitk;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order (fa.xcd_swizzle, host-checked: gridDim.y * gridDim.z % 8 == 0): flattened block b is observed to run on XCD
+    // b % 8, so the n tiles of one (m tile, batch) group are given ids 8 apart -- they share that group's A rows in ONE XCD's L2 instead
+    // of fetching them into up to 8.  Bijective; a pure placement choice.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (fa.xcd_swizzle) {
+        const unsigned gx = gridDim.x, lin = bx + gx * (by + gridDim.y * bz);
+        const unsigned q = lin >> 3, j = q / gx, grp = (lin & 7u) + 8u * j;
+        bx = q - j * gx; by = grp % gridDim.y; bz = grp / gridDim.y;
+    }
+    const int zb = bz / g.splitk, zs = bz % g.splitk;
+    const int m0 = by * BM, n0 = bx * BN;
     const int ksteps = (g.K + FBK - 1) / FBK;
     const int per = (ksteps + g.splitk - 1) / g.splitk;
     const int kbeg = zs * per * FBK;
@@ -811,8 +821,11 @@ int launch_fast_b(const StepGemm& g, const FastArgs& fa, int bmode, dim3 grid, h
     return STEP_OK;
 }
 template <int BM, int BN>
-int launch_fast(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+int launch_fast(const StepGemm& g, const FastArgs& fa_in, int amode, int bmode, hipStream_t st) {
     dim3 grid(cdiv(g.N + (g.a_rowsum ? 1 : 0), BN), cdiv(g.M, BM), g.batch * g.splitk);
+    FastArgs fa = fa_in;
+    // worth it when A is re-read by several n tiles and is too big for one L2 (the adjacency of a large graph, the Gram operand)
+    fa.xcd_swizzle = grid.x >= 2 && (grid.y * grid.z) % 8 == 0 && (long)g.M * g.K * g.batch >= (8L << 20);
     if (amode == KC_F32) return launch_fast_b<BM, BN, KC_F32>(g, fa, bmode, grid, st);
     if (amode == KC_BF16) return launch_fast_b<BM, BN, KC_BF16>(g, fa, bmode, grid, st);
     return launch_fast_b<BM, BN, MC_F32>(g, fa, bmode, grid, st);
@@ -887,6 +900,12 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
     const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
     if (fast && fused) return big ? launch_fast_fused<128, 128>(g, fa, amode, bmode, st) : launch_fast_fused<64, 64>(g, fa, amode, bmode, st);
+    if (fast && !big && bmode != MC_BF16 && g.M >= 1024 && g.N > 64) {
+        // tall products with a short n axis (the diffusion hops of large graphs: 4096 x 32 T x 4096): 128 x 64 tiles -- three workgroups per
+        // compute unit and half the A-operand LDS traffic of 64 x 64 -- when they still fill the chip
+        const long t = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * g.batch * g.splitk;
+        if (t >= 256) return launch_fast<128, 64>(g, fa, amode, bmode, st);
+    }
     if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
     STEP_TRY(step_gemm_rowsum_separate(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
