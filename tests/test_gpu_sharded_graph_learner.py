@@ -1,4 +1,4 @@
-"""SURVEY.md 8(f) row 2 on the device: two data-parallel ranks (gloo group, both on cuda:0) with the graph learner in time slices
+"""SURVEY.md 8(f) row 2 on the device: two / four data-parallel ranks (gloo group, all on cuda:0) with the graph learner in time slices
 against the same two ranks with the whole graph learner, and against one process evaluating both batches (tests/shard_worker.py)."""
 import os
 import subprocess
@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_time_sliced_graph_learner_matches_unsharded_data_parallel():
+@pytest.mark.parametrize("world", [2, 4])
+def test_time_sliced_graph_learner_matches_unsharded_data_parallel(world):
     script = os.path.join(ROOT, "tests", "shard_worker.py")
     for attempt in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs = [subprocess.Popen([sys.executable, script, ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-                 for r in range(2)]
+                 for r in range(world)]
         outs = [p.communicate(timeout=600)[0].decode() for p in procs]
         if all(p.returncode == 0 for p in procs):
             break
