@@ -80,7 +80,7 @@ def encoder_flops(cfg, B):
 def cpu_baseline(cfg, data, seed=0):
     """The CPU oracle (restatement of the reference algorithm, kind "port") timed on this host's cores on a bounded sample of
     the same workload: full training steps (forward + step_loss + backward + clip_grad_norm_ + Adam) of ONE window each --
-    one warm-up and three timed steps on all cores (median reported), then one step with two threads, the thread count the
+    two warm-up and five timed steps on all cores (median reported), then one step with two threads, the thread count the
     reference ships with (step/run.py:10 torch.set_num_threads(2)).  The reference itself cannot run on the GPU box
     (no /root/reference there); its own CPU timing, taken in the build container, is profiles/r02_cpu_reference_baseline.json."""
     from oracle import step_oracle as O
@@ -109,14 +109,15 @@ def cpu_baseline(cfg, data, seed=0):
         return time.perf_counter() - t0
     cores = min(os.cpu_count() or 1, 32)          # torch CPU ops stop scaling (and oversubscribe) beyond a few tens of threads
     torch.set_num_threads(cores)
-    one_step(0)
-    ts = sorted(one_step(1 + i) for i in range(3))
+    one_step(0); one_step(1)
+    ts = sorted(one_step(2 + i) for i in range(5))
     torch.set_num_threads(2)
-    t2 = one_step(4)
+    t2 = one_step(7)
     torch.set_num_threads(cores)
-    return {"value": 1.0 / ts[1], "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"full training steps (fwd+loss+bwd+clip+Adam) of 1 window of the same workload, torch CPU fp32 oracle: 1 warm-up + 3 timed "
-                      f"on {cores} threads ({ts[0]:.1f} / {ts[1]:.1f} / {ts[2]:.1f} s, median reported), 1 step on 2 threads ({t2:.1f} s)",
+    med = ts[len(ts) // 2]
+    return {"value": 1.0 / med, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"full training steps (fwd+loss+bwd+clip+Adam) of 1 window of the same workload, torch CPU fp32 oracle: 2 warm-up + 5 timed "
+                      f"on {cores} threads ({ts[0]:.1f} .. {med:.1f} .. {ts[-1]:.1f} s, median reported), 1 step on 2 threads ({t2:.1f} s)",
             "two_threads": {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}}
 
 
