@@ -687,7 +687,7 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long T1 = T - 9, T2 = T - 18;
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
-    if (!backward) return part;
+    if (!backward) return part + dgl_conv2_pack_floats();
     return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + DGL_SMALL + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
@@ -740,7 +740,8 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
         if (shard) bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1);
         int nblk;
         if (cl) {
-            STEP_TRY(dgl_conv2_fwd_cl(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
+            STEP_TRY(dgl_conv2_fwd_cl(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk,
+                                      work + ((long)N * cdiv(T1, 1024) > (long)N * cdiv(T2, 1024) ? (long)N * cdiv(T1, 1024) : (long)N * cdiv(T2, 1024)) * 32 + 64, st));
         } else if (p->gemm_bf16) {
             STEP_TRY(dgl_conv2_fwd_mfma(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
         } else {
@@ -897,7 +898,7 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
         if (do_tail) {
             STEP_TRY(dgl_conv2_wgrad_finish(graw, p->conv2_w, st1, p->bn1_w, p->bn1_b, count1, grads->conv2_w, grads->conv2_b, grads->bn1_w,
                                             grads->bn1_b, coef + 64, 1, st));
-            STEP_TRY(dgl_conv2_dgrad_cl(d_a2, p->conv2_w, st1, d_a1, N, T1, a1, coef + 64, st1, shard ? shard->own1 : T1, st));
+            STEP_TRY(dgl_conv2_dgrad_cl(d_a2, p->conv2_w, st1, d_a1, N, T1, a1, coef + 64, st1, shard ? shard->own1 : T1, wraw, st));      // (wraw is free again: weight fragments)
             STEP_TRY(dgl_conv1_wgrad_cl(d_a1, series_nt, wg_scratch, grads->conv1_w, grads->conv1_b, N, T, st));
         }
         return STEP_OK;

@@ -495,15 +495,40 @@ __global__ __launch_bounds__(256) void conv1_fwd_cl_kernel(const float* __restri
         partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * (2 * C1_) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// conv2's weights with BatchNorm1's scale folded in, as the MFMA operand fragments of the forward (3 x 64 lanes) and of the data
+// gradient (5 x 64 lanes), plus the folded bias [16]: built once per launch instead of by every workgroup (a workgroup streams
+// only 48 KB, ~100 scalar weight loads per lane were a visible part of its life).  pack: uint4[8 * 64] then float[16].
+__global__ void conv2_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ sc,
+                                  const float* __restrict__ sh, uint4* __restrict__ pack) {
+    const int lane = threadIdx.x & 63, s = threadIdx.x >> 6, ln = lane & 15, q = lane >> 4;      // 8 waves: s = 0..2 forward, 3..7 dgrad
+    float v[8];
+    if (s < 3) {
+        const int kk = 4 * s + q;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) v[ci] = kk < KW ? w[(ln * CI + ci) * KW + kk] * sc[ci] : 0.f;
+    } else {
+        const int kk = 2 * (s - 3) + (q >> 1), c0 = 8 * (q & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ln < CI ? w[((c0 + j) * CI + ln) * KW + kk] * sc[ln] : 0.f;
+    }
+    pack[s * 64 + lane] = make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7]));
+    if (threadIdx.x < CO) {
+        float a = b[threadIdx.x];
+        for (int ci = 0; ci < CI; ++ci) {
+            float ws = 0.f;
+            for (int kk = 0; kk < KW; ++kk) ws += w[(threadIdx.x * CI + ci) * KW + kk];
+            a += ws * sh[ci];
+        }
+        ((float*)(pack + 8 * 64))[threadIdx.x] = a;
+    }
+}
+
 // conv2 forward: a2h[n][t][co] = relu(b'[co] + sum_{ci,kk} w'[co][ci][kk] a1h[n][t+kk][ci]) with w' = w * sc1[ci] and
 // b' = b + sum w * sh1[ci] (BatchNorm1 folded: the conv is valid, every output meets all taps); BatchNorm2 partial sums.
-__global__ __launch_bounds__(256) void conv2_fwd_cl_kernel(const uint4* __restrict__ a1h, const float* __restrict__ w,
-                                                           const float* __restrict__ b, const float* __restrict__ sc,
-                                                           const float* __restrict__ sh, uint2* __restrict__ a2h,
-                                                           float* __restrict__ partial, int T1) {
+__global__ __launch_bounds__(256) void conv2_fwd_cl_kernel(const uint4* __restrict__ a1h, const uint4* __restrict__ pack,
+                                                           uint2* __restrict__ a2h, float* __restrict__ partial, int T1) {
     __shared__ uint4 xs[FW_TT + 16];
     __shared__ float red[4][2 * CO];
-    __shared__ float bfold[CO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.y;
     const int T2 = T1 - (KW - 1), t0 = blockIdx.x * FW_TT;
     const int ln = lane & 15, q = lane >> 4;
@@ -511,28 +536,13 @@ __global__ __launch_bounds__(256) void conv2_fwd_cl_kernel(const uint4* __restri
         const int t = t0 + tt;
         xs[tt] = t < T1 ? a1h[(long)n * T1 + t] : make_uint4(0u, 0u, 0u, 0u);
     }
-    if (tid < CO) {
-        float a = b[tid];
-        for (int ci = 0; ci < CI; ++ci) {
-            float ws = 0.f;
-            for (int kk = 0; kk < KW; ++kk) ws += w[(tid * CI + ci) * KW + kk];
-            a += ws * sh[ci];
-        }
-        bfold[tid] = a;
-    }
     bf16x8 wf[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int kk = 4 * s + q;
-        float v[CI];
-#pragma unroll
-        for (int ci = 0; ci < CI; ++ci) v[ci] = kk < KW ? w[(ln * CI + ci) * KW + kk] * sc[ci] : 0.f;
-        wf[s] = as_frag(make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7])));
-    }
-    __syncthreads();
+    for (int s = 0; s < 3; ++s) wf[s] = as_frag(pack[s * 64 + lane]);
     float bias[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias[e] = bfold[4 * q + e];
+    for (int e = 0; e < 4; ++e) bias[e] = ((const float*)(pack + 8 * 64))[4 * q + e];
+    __syncthreads();
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tile = wave; tile < FW_TT / 16; tile += 4) {
         const int tb = tile * 16;
@@ -561,8 +571,8 @@ __global__ __launch_bounds__(256) void conv2_fwd_cl_kernel(const uint4* __restri
 
 // conv2 data gradient + fused BatchNorm1 backward: dz1h = [x > 0] kc (d_a1 - [t < own] (m1 + (x - mean) rstd m2)),  x = a1h;
 // d_a1 = full correlation of dz2h with w' = w * sc1 -- the BatchNorm1 scale kc = gamma rstd = sc1 is already in the weights.
-__global__ __launch_bounds__(256) void conv2_dgrad_cl_kernel(const uint4* __restrict__ dz2h, const float* __restrict__ w,
-                                                             const float* __restrict__ sc, uint2* __restrict__ dz1h, int T1,
+__global__ __launch_bounds__(256) void conv2_dgrad_cl_kernel(const uint4* __restrict__ dz2h, const uint4* __restrict__ pack,
+                                                             uint2* __restrict__ dz1h, int T1,
                                                              const uint2* __restrict__ a1h, const float* __restrict__ coef,
                                                              const float* __restrict__ stat, int own) {
     __shared__ uint4 zs[FW_TT + 16][2];
@@ -586,13 +596,7 @@ __global__ __launch_bounds__(256) void conv2_dgrad_cl_kernel(const uint4* __rest
     }
     bf16x8 wf[5];
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        const int kk = 2 * s + (q >> 1), c0 = 8 * (q & 1);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ln < CI ? w[((c0 + j) * CI + ln) * KW + kk] * sc[ln] : 0.f;
-        wf[s] = as_frag(make_uint4(cvt2(v[0], v[1]), cvt2(v[2], v[3]), cvt2(v[4], v[5]), cvt2(v[6], v[7])));
-    }
+    for (int s = 0; s < 5; ++s) wf[s] = as_frag(pack[(3 + s) * 64 + lane]);
     float km1[4] = {0.f, 0.f, 0.f, 0.f}, km2[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f};
     if (q < 2) {
 #pragma unroll
@@ -877,18 +881,22 @@ int dgl_conv1_fwd_cl(const float* x, const float* w, const float* b, void* a1h, 
     *nblk = grid.x * grid.y;
     return STEP_OK;
 }
+// pack: 8 * 64 * 16 + 64 bytes of scratch (dgl_conv2_pack_floats())
+long dgl_conv2_pack_floats() { return 8 * 64 * 4 + 16; }
 int dgl_conv2_fwd_cl(const void* a1h, const float* w, const float* b, const float* sc, const float* sh, void* a2h, float* partial, int N,
-                     int T1, int* nblk, hipStream_t st) {
+                     int T1, int* nblk, float* pack, hipStream_t st) {
     const int T2 = T1 - (KW - 1);
     dim3 grid(cdiv(T2, FW_TT), N);
-    conv2_fwd_cl_kernel<<<grid, 256, 0, st>>>((const uint4*)a1h, w, b, sc, sh, (uint2*)a2h, partial, T1);
+    conv2_pack_kernel<<<1, 512, 0, st>>>(w, b, sc, sh, (uint4*)pack);
+    conv2_fwd_cl_kernel<<<grid, 256, 0, st>>>((const uint4*)a1h, (const uint4*)pack, (uint2*)a2h, partial, T1);
     STEP_LAUNCH_CHECK("conv2_fwd_cl");
     *nblk = grid.x * grid.y;
     return STEP_OK;
 }
 int dgl_conv2_dgrad_cl(const void* dz2h, const float* w, const float* sc, void* dz1h, int N, int T1, const void* a1h, const float* coef,
-                       const float* stat, int own, hipStream_t st) {
-    conv2_dgrad_cl_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>((const uint4*)dz2h, w, sc, (uint2*)dz1h, T1, (const uint2*)a1h, coef, stat, own);
+                       const float* stat, int own, float* pack, hipStream_t st) {
+    conv2_pack_kernel<<<1, 512, 0, st>>>(w, w, sc, sc, (uint4*)pack);       // (the bias part is not used by the data gradient)
+    conv2_dgrad_cl_kernel<<<dim3(cdiv(T1, FW_TT), N), 256, 0, st>>>((const uint4*)dz2h, (const uint4*)pack, (uint2*)dz1h, T1, (const uint2*)a1h, coef, stat, own);
     STEP_LAUNCH_CHECK("conv2_dgrad_cl");
     return STEP_OK;
 }

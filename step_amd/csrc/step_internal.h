@@ -57,10 +57,11 @@ int dgl_conv2_wgrad_finish(const float* graw, const float* w, const float* stat1
 // channels-last bf16 storage of the conv activations (bf16 contraction mode), dgl_conv_mfma.hip
 int dgl_conv1_fwd_cl(const float* x, const float* w, const float* b, void* a1h, float* partial, int N, int T, int stat_limit, int* nblk,
                      hipStream_t st);
+long dgl_conv2_pack_floats();
 int dgl_conv2_fwd_cl(const void* a1h, const float* w, const float* b, const float* sc, const float* sh, void* a2h, float* partial, int N,
-                     int T1, int* nblk, hipStream_t st);
+                     int T1, int* nblk, float* pack, hipStream_t st);
 int dgl_conv2_dgrad_cl(const void* dz2h, const float* w, const float* sc, void* dz1h, int N, int T1, const void* a1h, const float* coef,
-                       const float* stat, int own, hipStream_t st);
+                       const float* stat, int own, float* pack, hipStream_t st);
 int dgl_conv2_wgrad_cl(const void* dz2h, const void* a1h, float* scratch, float* graw, int N, int T1, hipStream_t st);
 int dgl_conv1_wgrad_cl(const void* dz1h, const float* x, float* scratch, float* dw, float* db, int N, int T, hipStream_t st);
 long dgl_conv2_wgrad_scratch_floats(int N, int T1);
