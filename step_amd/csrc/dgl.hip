@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const float* __res
 // sndT is [EMB][N] (coalesced along j), rcv is [N][EMB] and already contains fc_out.bias.
 __global__ __launch_bounds__(256) void edge_logit_kernel(const float* __restrict__ sndT, const float* __restrict__ rcv,
                                                          const float* __restrict__ wcat, const float* __restrict__ bcat, int N,
-                                                         float* __restrict__ z) {
+                                                         float* __restrict__ z, int vec4) {
     __shared__ float sr[EMB], sw[EMB];
     const int i = blockIdx.y;
     if (threadIdx.x < EMB) {
@@ -430,9 +430,23 @@ __global__ __launch_bounds__(256) void edge_logit_kernel(const float* __restrict
         sw[threadIdx.x] = wcat[threadIdx.x] - wcat[EMB + threadIdx.x];
     }
     __syncthreads();
+    const float b0 = bcat[0] - bcat[1];
+    if (vec4) {        // four senders per thread: 16-byte loads of the feature rows (N % 4 == 0, aligned buffers: checked by the host)
+        const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (j >= N) return;
+        float a0 = b0, a1 = b0, a2 = b0, a3 = b0;
+#pragma unroll 4
+        for (int f = 0; f < EMB; ++f) {
+            const float4 s4 = *(const float4*)(sndT + (long)f * N + j);
+            const float r = sr[f], w = sw[f];
+            a0 += w * fmaxf(r + s4.x, 0.f); a1 += w * fmaxf(r + s4.y, 0.f); a2 += w * fmaxf(r + s4.z, 0.f); a3 += w * fmaxf(r + s4.w, 0.f);
+        }
+        *(float4*)(z + (long)i * N + j) = make_float4(a0, a1, a2, a3);
+        return;
+    }
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
-    float acc = bcat[0] - bcat[1];
+    float acc = b0;
 #pragma unroll 4
     for (int f = 0; f < EMB; ++f) acc += sw[f] * fmaxf(sr[f] + sndT[(long)f * N + j], 0.f);
     z[(long)i * N + j] = acc;
@@ -505,10 +519,19 @@ __global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restri
         const float* srow = sndT + (long)f * N;
         const float rf = sr[f];
         float a = 0.f, h = 0.f;
-        for (int j = lane; j < N; j += 64) {
-            const float d = sdz[j];
+        // four senders per lane and iteration (16-byte loads of the feature row and of the staged dz row), selects instead of branches
+        const int n4 = ((uintptr_t)srow & 15) == 0 ? N & ~3 : 0;
+        for (int j = 4 * lane; j < n4; j += 256) {
+            const float4 s4 = *(const float4*)(srow + j), d4 = *(const float4*)(sdz + j);
+            const float h0 = rf + s4.x, h1 = rf + s4.y, h2 = rf + s4.z, h3 = rf + s4.w;
+            const float m0 = h0 > 0.f ? d4.x : 0.f, m1 = h1 > 0.f ? d4.y : 0.f, m2 = h2 > 0.f ? d4.z : 0.f, m3 = h3 > 0.f ? d4.w : 0.f;
+            a += (m0 + m1) + (m2 + m3);
+            h += (m0 * h0 + m1 * h1) + (m2 * h2 + m3 * h3);
+        }
+        for (int j = n4 + lane; j < N; j += 64) {
             const float hid = rf + srow[j];
-            if (hid > 0.f) { a += d; h += d * hid; }
+            const float m = hid > 0.f ? sdz[j] : 0.f;
+            a += m; h += m * hid;
         }
         a = wave_sum(a); h = wave_sum(h);
         if (lane == 0) { ra[f] = a; rh[f] = h; }
@@ -525,24 +548,39 @@ __global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restri
         atomicAdd(&dbcat[1], -s);
     }
 }
+// VJ consecutive senders per lane (VJ = 4: one 16-byte load of dz per receiver and lane)
+template <int VJ>
 __global__ __launch_bounds__(256) void edge_bwd_col_kernel(const float* __restrict__ dz, const float* __restrict__ sndT,
                                                            const float* __restrict__ rcv, const float* __restrict__ wcat, int N,
                                                            float* __restrict__ dsndT) {
-    // block: 64 sender columns j (lanes) x 4 features (one per wave); grid (N/64, EMB/4)
+    // block: 64 * VJ sender columns j (lanes) x 4 features (one per wave); grid (N / (64 VJ), EMB/4)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
+    const int j = (blockIdx.x * 64 + lane) * VJ;
     const int f = blockIdx.y * 4 + wave;
     if (j >= N || f >= EMB) return;
-    const float s = sndT[(long)f * N + j];
     const float wd = wcat[f] - wcat[EMB + f];
-    float a = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < N; ++i) {
-        float hid = rcv[(long)i * EMB + f] + s;
-        float d = dz[(long)i * N + j];
-        a += hid > 0.f ? d : 0.f;
+    if constexpr (VJ == 4) {
+        const float4 s4 = *(const float4*)(sndT + (long)f * N + j);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < N; ++i) {
+            const float r = rcv[(long)i * EMB + f];
+            const float4 d = *(const float4*)(dz + (long)i * N + j);
+            a0 += r + s4.x > 0.f ? d.x : 0.f; a1 += r + s4.y > 0.f ? d.y : 0.f;
+            a2 += r + s4.z > 0.f ? d.z : 0.f; a3 += r + s4.w > 0.f ? d.w : 0.f;
+        }
+        *(float4*)(dsndT + (long)f * N + j) = make_float4(a0 * wd, a1 * wd, a2 * wd, a3 * wd);
+    } else {
+        const float s = sndT[(long)f * N + j];
+        float a = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < N; ++i) {
+            float hid = rcv[(long)i * EMB + f] + s;
+            float d = dz[(long)i * N + j];
+            a += hid > 0.f ? d : 0.f;
+        }
+        dsndT[(long)f * N + j] = a * wd;
     }
-    dsndT[(long)f * N + j] = a * wd;
 }
 
 __global__ void colsum_kernel(const float* __restrict__ x, long rows, int cols, long ld, float* __restrict__ out) {
@@ -1009,7 +1047,10 @@ extern "C" int step_dgl_edges_forward(const float* g, int N, int B, const StepDg
     StepGemm gr = gemm_desc(N, EMB, EMB, g, EMB, 1, p->fc_out_w + EMB, 1, 2 * EMB, rcv, EMB);
     gr.bias = p->fc_out_b;
     STEP_TRY(step_gemm_launch(gr, st));
-    edge_logit_kernel<<<dim3(cdiv(N, 256), N), 256, 0, st>>>(sndT, rcv, p->fc_cat_w, p->fc_cat_b, N, z);
+    {
+        const int vec4 = N % 4 == 0 && N >= 1024 && (((uintptr_t)sndT | (uintptr_t)z) & 15) == 0;
+        edge_logit_kernel<<<dim3(cdiv(N, vec4 ? 1024 : 256), N), 256, 0, st>>>(sndT, rcv, p->fc_cat_w, p->fc_cat_b, N, z, vec4);
+    }
     STEP_LAUNCH_CHECK("edge_logit");
     int gx = cdiv((long)N * N, 256);
     if (gx > 4096) gx = 4096;
@@ -1045,7 +1086,10 @@ extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepD
     STEP_LAUNCH_CHECK("edge_dz");
     edge_bwd_row_kernel<<<N, 256, (size_t)N * sizeof(float), st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
     STEP_LAUNCH_CHECK("edge_bwd_row");
-    edge_bwd_col_kernel<<<dim3(cdiv(N, 64), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
+    if (N % 4 == 0 && N >= 1024 && (((uintptr_t)dz | (uintptr_t)sndT | (uintptr_t)dsndT) & 15) == 0)
+        edge_bwd_col_kernel<4><<<dim3(cdiv(N, 256), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
+    else
+        edge_bwd_col_kernel<1><<<dim3(cdiv(N, 64), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
     STEP_LAUNCH_CHECK("edge_bwd_col");
     // dg = drcv @ W[:, 100:] + dsnd @ W[:, :100]
     StepGemm g1 = gemm_desc(N, EMB, EMB, drcv, EMB, 1, p->fc_out_w + EMB, 2 * EMB, 1, dg, EMB);
