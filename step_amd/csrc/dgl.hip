@@ -139,6 +139,22 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const float* __restrict__ 
     }
     if (tid == 0) { sums[c] = r1[0]; sums[C + c] = r2[0]; }
 }
+// the same sums with the partial rows split over grid.y blocks per channel (f64 atomics into zeroed sums): at N = 4096 one block per
+// channel walked 70 000 partial rows
+__global__ __launch_bounds__(256) void bn_sums_sliced_kernel(const float* __restrict__ partial, int nblk, int C, double* __restrict__ sums) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, beg = blockIdx.y * per, end = min(nblk, beg + per);
+    double a = 0.0, q = 0.0;
+    for (int i = beg + tid; i < end; i += 256) { a += partial[(long)i * 2 * C + c]; q += partial[(long)i * 2 * C + C + c]; }
+    r1[tid] = a; r2[tid] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) { unsafeAtomicAdd(sums + c, r1[0]); unsafeAtomicAdd(sums + C + c, r2[0]); }
+}
 __global__ void bn_finalize_sums_kernel(const double* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                         int training, float momentum, float* __restrict__ stat) {
@@ -725,7 +741,7 @@ extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long T1 = T - 9, T2 = T - 18;
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
-    if (!backward) return part + dgl_conv2_pack_floats();
+    if (!backward) return part + dgl_conv2_pack_floats() + 64;
     return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + DGL_SMALL + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
@@ -743,6 +759,20 @@ static void carve_saved(float* saved, int N, int T, float** a1, float** a2, floa
     *st3 = saved;
 }
 
+// BatchNorm statistics from the per-block partial rows: one block per channel for few rows, sliced f64-atomic sums for many
+static int dgl_bn_stats(const float* partial, int nblk, int C, double count, const float* gamma, const float* beta, float* rm, float* rv,
+                        int training, float momentum, float* stat, double* sums, hipStream_t st) {
+    if (nblk < 8192) {
+        bn_finalize_kernel<<<C, 256, 0, st>>>(partial, nblk, C, count, gamma, beta, rm, rv, training, momentum, stat);
+    } else {
+        if (hipMemsetAsync(sums, 0, 2 * C * sizeof(double), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
+        bn_sums_sliced_kernel<<<dim3(C, 32), 256, 0, st>>>(partial, nblk, C, sums);
+        bn_finalize_sums_kernel<<<1, 64, 0, st>>>(sums, C, count, gamma, beta, rm, rv, training, momentum, stat);
+    }
+    STEP_LAUNCH_CHECK("bn_stats");
+    return STEP_OK;
+}
+
 // Forward in up to four phases.  shard == nullptr: the whole series on this device (phase must be 0).  With a shard the caller
 // sums `sums` (after phases 1 and 2) and gpre (after phase 3) over the ranks between the calls:
 //   1: conv1 + its BatchNorm sums -> sums[0..16)            2: BatchNorm1 statistics, conv2 + sums -> sums[16..48)
@@ -757,6 +787,8 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
     const bool all = phase == 0;
     const double count1 = shard ? shard->count1 : (double)N * T1, count2 = shard ? shard->count2 : (double)N * T2;
     const bool cl = dgl_channels_last(p);
+    const long part_floats = ((long)N * cdiv(T1, 1024) > (long)N * cdiv(T2, 1024) ? (long)N * cdiv(T1, 1024) : (long)N * cdiv(T2, 1024)) * 32 + 64;
+    double* own_sums = (double*)(work + part_floats + dgl_conv2_pack_floats());       // 32 f64 (unsharded statistics of many partial rows)
     float* wp = saved_wp(saved, N, T);
     float* shiftdot = wp + (long)EMB * 16 * T2;
     if (all || phase == 1) {
@@ -771,7 +803,7 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
             nblk = grid.x * grid.y;
         }
         if (shard) bn_sums_kernel<<<8, 256, 0, st>>>(partial, nblk, 8, sums);
-        else bn_finalize_kernel<<<8, 256, 0, st>>>(partial, nblk, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1);
+        else STEP_TRY(dgl_bn_stats(partial, nblk, 8, count1, p->bn1_w, p->bn1_b, p->bn1_rm, p->bn1_rv, training, momentum, st1, own_sums, st));
         STEP_LAUNCH_CHECK("bn1");
     }
     if (all || phase == 2) {
@@ -779,7 +811,7 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
         int nblk;
         if (cl) {
             STEP_TRY(dgl_conv2_fwd_cl(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk,
-                                      work + ((long)N * cdiv(T1, 1024) > (long)N * cdiv(T2, 1024) ? (long)N * cdiv(T1, 1024) : (long)N * cdiv(T2, 1024)) * 32 + 64, st));
+                                      work + part_floats, st));
         } else if (p->gemm_bf16) {
             STEP_TRY(dgl_conv2_fwd_mfma(a1, p->conv2_w, p->conv2_b, st1, st1 + 8, a2, partial, N, T1, &nblk, st));
         } else {
@@ -789,8 +821,7 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
             nblk = grid.x * grid.y;
         }
         if (shard) bn_sums_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, sums + 16);
-        else bn_finalize_kernel<<<16, 256, 0, st>>>(partial, nblk, 16, count2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, training, momentum,
-                                                    st2);
+        else STEP_TRY(dgl_bn_stats(partial, nblk, 16, count2, p->bn2_w, p->bn2_b, p->bn2_rm, p->bn2_rv, training, momentum, st2, own_sums, st));
         STEP_LAUNCH_CHECK("bn2");
     }
     if (all || phase == 3) {

@@ -805,6 +805,12 @@ __global__ __launch_bounds__(256) void conv1_wgrad_cl_kernel(const uint4* __rest
 
 }  // namespace
 
+// row slices of the partial-row reduction: ~64 rows per thread at least, at most 128 slices (one atomic per slice and output)
+static int wgrad_slices(long nrows) {
+    long s = nrows / 256;
+    return (int)(s < 16 ? 16 : (s > 128 ? 128 : s));
+}
+
 int dgl_conv2_fwd_mfma(const float* a1, const float* w, const float* b, const float* sc, const float* sh, float* a2, float* partial,
                        int N, int T1, int* nblk, hipStream_t st) {
     const int T2 = T1 - (KW - 1);
@@ -833,7 +839,7 @@ int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, cons
     dim3 grid(cdiv(T2, WG_SC * WG_PASSES), N);
     conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, sc, sh, scratch, T1, 0);
     STEP_LAUNCH_CHECK("conv2_wgrad_mfma");
-    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, dw, db);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), wgrad_slices(grid.x * grid.y)), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, dw, db);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
     return STEP_OK;
 }
@@ -849,7 +855,7 @@ int dgl_conv2_wgrad_xhat_mfma(const float* dz, const float* a1, const float* sta
     if (hipMemsetAsync(graw, 0, WG_OUT * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
     conv2_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, a1, stat1, nullptr, scratch, T1, 1);
     STEP_LAUNCH_CHECK("conv2_wgrad_mfma(xhat)");
-    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), wgrad_slices(grid.x * grid.y)), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
     return STEP_OK;
 }
@@ -866,7 +872,7 @@ int dgl_conv1_wgrad_mfma(const float* dz, const float* x, float* scratch, float*
     dim3 grid(cdiv(T1, WG_SC * WG_PASSES), N);
     conv1_wgrad_mfma_kernel<<<grid, 256, 0, st>>>(dz, x, scratch, T);
     STEP_LAUNCH_CHECK("conv1_wgrad_mfma");
-    conv_wgrad_reduce_kernel<<<dim3(cdiv(W1_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, W1_OUT, C1 * KW, dw, db);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(W1_OUT, 64), wgrad_slices(grid.x * grid.y)), 256, 0, st>>>(scratch, grid.x * grid.y, W1_OUT, C1 * KW, dw, db);
     STEP_LAUNCH_CHECK("conv1_wgrad_reduce");
     return STEP_OK;
 }
@@ -906,7 +912,7 @@ int dgl_conv2_wgrad_cl(const void* dz2h, const void* a1h, float* scratch, float*
     if (hipMemsetAsync(graw, 0, WG_OUT * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
     conv2_wgrad_cl_kernel<<<grid, 256, 0, st>>>((const uint4*)dz2h, (const uint4*)a1h, scratch, T1);
     STEP_LAUNCH_CHECK("conv2_wgrad_cl");
-    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(WG_OUT, 64), wgrad_slices(grid.x * grid.y)), 256, 0, st>>>(scratch, grid.x * grid.y, WG_OUT, CO * CI * KW, graw, graw + CO * CI * KW);
     STEP_LAUNCH_CHECK("conv2_wgrad_reduce");
     return STEP_OK;
 }
@@ -915,7 +921,7 @@ int dgl_conv1_wgrad_cl(const void* dz1h, const float* x, float* scratch, float* 
     dim3 grid(cdiv(T1, WG_SC * WG_PASSES), N);
     conv1_wgrad_cl_kernel<<<grid, 256, 0, st>>>((const uint4*)dz1h, x, scratch, T);
     STEP_LAUNCH_CHECK("conv1_wgrad_cl");
-    conv_wgrad_reduce_kernel<<<dim3(cdiv(W1_OUT, 64), 16), 256, 0, st>>>(scratch, grid.x * grid.y, W1_OUT, C1 * KW, dw, db);
+    conv_wgrad_reduce_kernel<<<dim3(cdiv(W1_OUT, 64), wgrad_slices(grid.x * grid.y)), 256, 0, st>>>(scratch, grid.x * grid.y, W1_OUT, C1 * KW, dw, db);
     STEP_LAUNCH_CHECK("conv1_wgrad_reduce");
     return STEP_OK;
 }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void start_conv_bwd_kernel(const float* __rest
 }
 
 // degree vectors: rs[b][i] = 1 + sum_j A[b][i][j] ; cs[b][j] = 1 + sum_i A[b][i][j]
-__global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__ A, int N, float* __restrict__ rs) {
+__global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__ A, int N, float* __restrict__ rs, float* __restrict__ cs_init) {
     __shared__ float red[4];
     const long row = blockIdx.x;                            // b*N + i
     float s = 0.f;
@@ -79,18 +79,21 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const float* __restrict__
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) rs[row] = 1.f + red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) { rs[row] = 1.f + red[0] + red[1] + red[2] + red[3]; cs_init[row] = 1.f; }      // cs starts at 1 (the + I), see col_sums_kernel
 }
+// column sums on top of cs = 1 (written by row_sums_kernel, same element count): grid (columns / 64, row slices, B), one atomic per
+// slice and column -- a single slice per column read 4096 rows sequentially at N = 4096
 __global__ __launch_bounds__(256) void col_sums_kernel(const float* __restrict__ A, int N, float* __restrict__ cs) {
     __shared__ float red[4][64];
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int per = (N + gridDim.y - 1) / gridDim.y, ibeg = blockIdx.y * per, iend = min(N, ibeg + per);
     float s = 0.f;
     if (j < N)
-        for (int i = w; i < N; i += 4) s += A[((long)b * N + i) * N + j];
+        for (int i = ibeg + w; i < iend; i += 4) s += A[((long)b * N + i) * N + j];
     red[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && j < N) cs[(long)b * N + j] = 1.f + red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (w == 0 && j < N) atomicAdd(&cs[(long)b * N + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // P_f = D^-1 (A + I),  P_b = Dc^-1 (A^T + I)       (model.py:121-130,160); 32x32 tiles, grid (N/32, N/32, B)
 // Writes both supports and their transposes (the adjoint hops read the transposed stack so that the
@@ -952,8 +955,13 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
     start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
     STEP_LAUNCH_CHECK("start_conv");
     // supports (model.py:160-166)
-    row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs);
-    col_sums_kernel<<<dim3(cdiv(N, 64), B), 256, 0, st>>>(adj, N, S.cs);
+    row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs, S.cs);
+    {
+        int slices = cdiv(512, cdiv(N, 64) * B);          // ~2 blocks per compute unit
+        if (slices > cdiv(N, 64)) slices = cdiv(N, 64);
+        if (slices < 1) slices = 1;
+        col_sums_kernel<<<dim3(cdiv(N, 64), slices, B), 256, 0, st>>>(adj, N, S.cs);
+    }
     const long NN = (long)N * N;
     rw_build_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(adj, N, S.rs, S.cs, S.Pstk, S.Pstk + B * NN, S.PTstk,
                                                                        S.PTstk + B * NN);
