@@ -535,18 +535,25 @@ __global__ __launch_bounds__(256) void edge_bwd_row_kernel(const float* __restri
         const float* srow = sndT + (long)f * N;
         const float rf = sr[f];
         float a = 0.f, h = 0.f;
-        // four senders per lane and iteration (16-byte loads of the feature row and of the staged dz row), selects instead of branches
-        const int n4 = ((uintptr_t)srow & 15) == 0 ? N & ~3 : 0;
-        for (int j = 4 * lane; j < n4; j += 256) {
-            const float4 s4 = *(const float4*)(srow + j), d4 = *(const float4*)(sdz + j);
+        // four senders per lane and iteration: one 16-byte load of the feature row (the first j0 elements of a row that does not start
+        // on a 16-byte boundary are peeled off), selects instead of branches
+        const int j0 = (int)((4 - (((uintptr_t)srow >> 2) & 3)) & 3);
+        const int n4 = j0 + ((N - j0) & ~3);
+        const bool lds4 = j0 == 0;                               // the staged dz row is 16-byte aligned only without a peel
+        for (int j = j0 + 4 * lane; j < n4; j += 256) {
+            const float4 s4 = *(const float4*)(srow + j);
+            float4 d4;
+            if (lds4) d4 = *(const float4*)(sdz + j);
+            else d4 = make_float4(sdz[j], sdz[j + 1], sdz[j + 2], sdz[j + 3]);
             const float h0 = rf + s4.x, h1 = rf + s4.y, h2 = rf + s4.z, h3 = rf + s4.w;
             const float m0 = h0 > 0.f ? d4.x : 0.f, m1 = h1 > 0.f ? d4.y : 0.f, m2 = h2 > 0.f ? d4.z : 0.f, m3 = h3 > 0.f ? d4.w : 0.f;
             a += (m0 + m1) + (m2 + m3);
             h += (m0 * h0 + m1 * h1) + (m2 * h2 + m3 * h3);
         }
-        for (int j = n4 + lane; j < N; j += 64) {
-            const float hid = rf + srow[j];
-            const float m = hid > 0.f ? sdz[j] : 0.f;
+        for (int j = lane; j < j0 + (N - n4); j += 64) {         // the peeled head and the tail
+            const int jj = j < j0 ? j : n4 + (j - j0);
+            const float hid = rf + srow[jj];
+            const float m = hid > 0.f ? sdz[jj] : 0.f;
             a += m; h += m * hid;
         }
         a = wave_sum(a); h = wave_sum(h);
