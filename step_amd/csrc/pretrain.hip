@@ -77,8 +77,10 @@ __global__ __launch_bounds__(384) void sum_over_seq_kernel(const float* __restri
     __shared__ float red[4][D];
     const int pj = blockIdx.x;                 // 0..p_cnt
     const int f = threadIdx.x % D, part = threadIdx.x / D;      // 4 partial sums per feature
+    // grid.y slices of the sequences (already an atomic accumulation): one block per token walked all 5200 sequences of C3 alone
+    const long per = (S + gridDim.y - 1) / gridDim.y, qbeg = blockIdx.y * per, qend = qbeg + per < S ? qbeg + per : S;
     float s = 0.f;
-    for (long q = part; q < S; q += 4) s += dx[(q * ldp + p_off + pj) * D + f];
+    for (long q = qbeg + part; q < qend; q += 4) s += dx[(q * ldp + p_off + pj) * D + f];
     red[part][f] = s;
     __syncthreads();
     if (part == 0) atomicAdd(&dvec[(long)(idx ? idx[pj] : pj) * D + f], red[0][f] + red[1][f] + red[2][f] + red[3][f]);
@@ -582,7 +584,10 @@ extern "C" int step_pt_add_rows(float* x, long S, int P, const float* vec, const
 }
 extern "C" int step_pt_sum_over_seq(const float* dx, long S, int ldp, int p_off, int p_cnt, const int* idx, float* dvec, void* stream) {
     STEP_REQUIRE(dx && dvec && S > 0 && p_cnt > 0, "pt_sum_over_seq: bad arguments");
-    sum_over_seq_kernel<<<p_cnt, 384, 0, (hipStream_t)stream>>>(dx, S, 0, p_off, p_cnt, ldp, idx, dvec);
+    int slices = (int)(2048 / p_cnt);
+    if (slices > S / 16) slices = (int)(S / 16);
+    if (slices < 1) slices = 1;
+    sum_over_seq_kernel<<<dim3(p_cnt, slices), 384, 0, (hipStream_t)stream>>>(dx, S, 0, p_off, p_cnt, ldp, idx, dvec);
     STEP_LAUNCH_CHECK("pt_sum_over_seq");
     return STEP_OK;
 }
