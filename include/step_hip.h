@@ -271,11 +271,13 @@ int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t see
 int step_pt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
                           uint64_t seed, uint32_t site, float* dqkv, void* stream);
 /* The same attention with bf16 operands on the matrix cores (f32 accumulation, same statistics layout, same dropout stream); what the
- * pre-training module uses when matmul_precision == "bf16".  T <= 336; the backward needs 0.44 T + 0.03 T^2/32 KB of LDS. */
+ * pre-training module uses when matmul_precision == "bf16".  T <= 336; the backward needs 0.44 T + 0.03 T^2/32 KB of LDS (T > 256 falls
+ * back to the f32 kernel).  keepbits (nullable): [S][4][T][ceil(T/32)] words -- the forward stores the keep decisions of every (query,
+ * key tile), a backward given the same buffer reads them instead of regenerating the Philox stream. */
 int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
-                               void* stream);
+                               uint32_t* keepbits, void* stream);
 int step_pt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
-                               uint64_t seed, uint32_t site, float* dqkv, void* stream);
+                               uint64_t seed, uint32_t site, float* dqkv, const uint32_t* keepbits, void* stream);
 int step_pt_relu_mask(float* d, const float* y, long n, void* stream);      /* d *= (y > 0) */
 int step_colsum(const float* x, long rows, int cols, long ld, float* out, void* stream);   /* out[c] += sum_r x[r*ld + c] */
 

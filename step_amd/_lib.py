@@ -98,8 +98,8 @@ _SIGS = {
     "step_pt_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_attention_fwd": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
     "step_pt_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
-    "step_pt_attention_fwd_bf16": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
-    "step_pt_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_attention_fwd_bf16": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "step_pt_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
     "step_pt_relu_mask": (_i, [_vp, _vp, _l, _vp]),
     "step_colsum": (_i, [_vp, _l, _i, _l, _vp, _vp]),
     "step_loss_fwd_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),

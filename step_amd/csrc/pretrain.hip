@@ -331,7 +331,8 @@ __device__ __forceinline__ int ma_key(int i, int h) { return (i & 3) + 8 * (i >>
 
 // forward: out [S][T][96], stats [S][H][T][2] = (row max, row sum) like attn_kernel
 __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
-                                                            uint32_t site, float* __restrict__ out, float* __restrict__ stats) {
+                                                            uint32_t site, float* __restrict__ out, float* __restrict__ stats,
+                                                            uint32_t* __restrict__ keepbits) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp);
     uint16_t* Qs = ml;                       // [Tp][MA_RP]  q * scale
@@ -384,14 +385,20 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
         float pv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { pv[e] = __expf(acc[e] - mx); l += pv[e]; }
-        if (p > 0.f && q < T) {
+        if (p > 0.f) {
+            uint32_t word = 0u;
+            if (q < T) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float m4[4];
-                ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+                for (int g = 0; g < 4; ++g) {
+                    float m4[4];
+                    ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[4 * g + j] *= m4[j];
+                    for (int j = 0; j < 4; ++j) { pv[4 * g + j] *= m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
+                }
             }
+            // the keep decisions of (query, key tile) as one word: the backward reads them instead of re-running Philox
+            word |= __shfl_xor(word, 32, 64);
+            if (keepbits && h == 0 && q < T) keepbits[(srow + q) * nkt + kt] = word;
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -412,7 +419,8 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
 // backward: phase A (wave = query tile) -> dQ and the keep bits, phase B (wave = key tile) -> dK, dV
 __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                             const float* __restrict__ dout, const float* __restrict__ stats, int T, int Tp,
-                                                            float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ dqkv) {
+                                                            float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ dqkv,
+                                                            const uint32_t* __restrict__ keepbits) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp), nt = Tp / 32;
     uint16_t* Qs = ml;                        // row-major [Tp][MA_RP]: q*scale, k, v, dO
@@ -474,14 +482,22 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             }
             float mk[16];
             uint32_t word = 0u;
+            if (keepbits && p > 0.f) {               // the forward's keep decisions
+                word = q < T ? keepbits[(srow + q) * nt + kt] : 0u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float m4[4] = {1.f, 1.f, 1.f, 1.f};
-                if (p > 0.f && q < T) ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { mk[4 * g + j] = m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
+                    for (int j = 0; j < 4; ++j) mk[4 * g + j] = (word >> (8 * g + 4 * h + j)) & 1u ? ks : 0.f;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p > 0.f && q < T) ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { mk[4 * g + j] = m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
+                }
+                word |= __shfl_xor(word, 32, 64);
             }
-            word |= __shfl_xor(word, 32, 64);
             if (h == 0) bits[q * nt + kt] = word;
             float ds[16];
 #pragma unroll
@@ -666,7 +682,7 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
 static size_t ma_fwd_lds(int Tp) { return (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2; }
 static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MA_RP + 3 * 32 * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
 extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
-                                          void* stream) {
+                                          uint32_t* keepbits, void* stream) {
     STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f, "pt_attention_fwd_bf16: bad arguments (T=%d)", T);
     const int Tp = (T + 31) & ~31;
     if (hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -674,12 +690,12 @@ extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float
         return STEP_ERR_HIP;
     }
     attn_mfma_fwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_fwd_lds(Tp), (hipStream_t)stream>>>(qkv, T, Tp, p, SEED_LO(seed), SEED_HI(seed),
-                                                                                                    site, out, stats);
+                                                                                                    site, out, stats, keepbits);
     STEP_LAUNCH_CHECK("pt_attention_fwd_bf16");
     return STEP_OK;
 }
 extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
-                                          uint64_t seed, uint32_t site, float* dqkv, void* stream) {
+                                          uint64_t seed, uint32_t site, float* dqkv, const uint32_t* keepbits, void* stream) {
     STEP_REQUIRE(qkv && out && dout && stats && dqkv && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f,
                  "pt_attention_bwd_bf16: bad arguments (T=%d)", T);
     const int Tp = (T + 31) & ~31;
@@ -690,7 +706,7 @@ extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, co
         return STEP_ERR_HIP;
     }
     attn_mfma_bwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_bwd_lds(Tp), (hipStream_t)stream>>>(qkv, out, dout, stats, T, Tp, p, SEED_LO(seed),
-                                                                                                    SEED_HI(seed), site, dqkv);
+                                                                                                    SEED_HI(seed), site, dqkv, keepbits);
     STEP_LAUNCH_CHECK("pt_attention_bwd_bf16");
     return STEP_OK;
 }

@@ -177,7 +177,12 @@ class _PretrainFunction(torch.autograd.Function):
         qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
         a = _empty(R, 96, like=x)
         stats = _empty(S * 4 * T, 2, like=x)
-        L.call("step_pt_attention_fwd_bf16" if _BF16 else "step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
+        kb = None
+        if _BF16:       # matrix-core attention; the keep decisions of the probability dropout are handed to the backward as bit masks
+            kb = torch.empty(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device=x.device) if p > 0 else None
+            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), L.ptr(kb), st)
+        else:
+            L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
         o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
         h1pre = _empty(R, 96, like=x)
         L.call("step_pt_add_dropout", L.ptr(x), L.ptr(o), L.ptr(h1pre), R * 96, p, seed, site + 1, st)
@@ -195,7 +200,7 @@ class _PretrainFunction(torch.autograd.Function):
         h2 = _empty(R, 96, like=x)
         st2 = _empty(R, 2, like=x)
         L.call("step_pt_layernorm_fwd", L.ptr(h2pre), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]), L.ptr(h2), L.ptr(st2), st)
-        return h2, dict(x=x, qkv=qkv, a=a, stats=stats, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
+        return h2, dict(x=x, qkv=qkv, a=a, stats=stats, keepbits=kb, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
                         site=site, T=T)
 
     @staticmethod
@@ -228,7 +233,11 @@ class _PretrainFunction(torch.autograd.Function):
         _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
                     G[pre + "self_attn.out_proj.bias"], da)
         dqkv = _empty(R, 288, like=dh2)
-        L.call("step_pt_attention_bwd_bf16" if _BF16 else "step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
+        if _BF16:
+            L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
+                   L.ptr(sv["keepbits"]), st)
+        else:
+            L.call("step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
         dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
         _linear_bwd(dqkv, sv["x"], P_[pre + "self_attn.in_proj_weight"], G[pre + "self_attn.in_proj_weight"],
                     G[pre + "self_attn.in_proj_bias"], dx, accumulate_dx=True)

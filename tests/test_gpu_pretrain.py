@@ -122,8 +122,13 @@ def test_matrix_core_attention_matches_f32_attention(T, p):
         out = torch.empty(S, T, 96, device="cuda")
         stats = torch.empty(S * 4 * T, 2, device="cuda")
         dqkv = torch.zeros(S, T, 288, device="cuda")
-        L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
-        L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
+        if tag:
+            kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda") if T != 77 else None      # (T = 77: the backward regenerates the masks)
+            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
+        else:
+            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
+            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
         torch.cuda.synchronize()
         res[tag] = (out.cpu(), stats.cpu(), dqkv.cpu())
     (o0, s0, g0), (o1, s1, g1) = res[""], res["_bf16"]
