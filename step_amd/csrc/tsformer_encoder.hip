@@ -598,10 +598,12 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
     if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);
     if (a.nkt <= 8) return dr ? launch_enc<8, true, true>(a, st) : launch_enc<8, false, true>(a, st);
-    {   // STEP_ENC_NO_PARK=1: keep the operand copy in registers even where LDS could hold it (66 KB of LDS per compute unit stay free
-        // for kernels of other streams; A/B measurements)
-        const char* e = getenv("STEP_ENC_NO_PARK");
-        if (e && e[0] == '1' && a.nkt > 8 && a.nkt <= 11) return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
+    if (a.nkt > 8 && a.nkt <= 11) {
+        // 9..11 token tiles (P = 336): the operand copy stays in registers -- same kernel time as parking it in LDS (2.54 vs 2.55 ms at
+        // C2), but 66 KB of LDS per compute unit stay free for the second stream's kernels (step 5.39 -> 5.37 ms).  STEP_ENC_PARK=1
+        // selects the parked variant (A/B measurements).
+        const char* e = getenv("STEP_ENC_PARK");
+        if (!(e && e[0] == '1')) return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
     }
     if (a.nkt <= 11) return dr ? launch_enc<12, true, true>(a, st) : launch_enc<12, false, true>(a, st);
     if (a.nkt <= 12) return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
