@@ -25,6 +25,13 @@
 // first key tile always takes it (that sets the initial shift).  With the reference's sqrt(96) input scaling and default
 // initialisation the scores are in the hundreds, so this path does run (about once per head); tests force it on every
 // tile (flags bit 1) and on adversarial inputs.
+// Fast schedule (TSF_FAST_ATTN, the default): the per-tile maximum / compare / branch of that loop costs more than its ten
+// instructions (it splits the loop body and serialises on a vector compare), and after the first tile it practically never
+// fires.  So a head is first run with the shift FIXED at what the first key tile sets -- a branch-free loop of exp2, packs and
+// MFMAs -- and checked once at the end: every probability is positive, so a denominator below 2^TSF_LIMIT_LOG2 proves that no
+// score went above the shift by more than that and nothing overflowed.  Otherwise (any query of the wave) the head is redone
+// from its K / V fragments with the re-shifting loop above, and the remaining heads of that layer skip the attempt.  When no
+// later tile would have re-shifted, both schedules execute the same arithmetic in the same order.
 //
 // Dropout (training-mode TSFormer inside STEP, positional_encoding.py:32 and the four sites of each encoder layer): keep-masks
 // are lane masks fetched with scalar loads from the per-step pool (tsformer_device.h), one v_cndmask_b32 per element; all
@@ -42,9 +49,22 @@ namespace {
 #define TSF_ABLATE 0        // timing experiments only (WRONG results): 1 no exp2, 2 no attention keep-masks, 4 no re-shift check, 16 no denominator adds,
                             // 32 no key-tile loop at all, 64 one FFN stage instead of six, 128 no LayerNorm arithmetic
 #endif
+#ifndef TSF_FAST_ATTN
+#define TSF_FAST_ATTN 1     // 0: always the re-shifting loop (A/B builds)
+#endif
+#define TSF_LIMIT 1.2980742e33f   // 2^110: largest softmax denominator the fast schedule accepts
 #ifndef TSF_MASK_EARLY
 #define TSF_MASK_EARLY 1    // fetch a tile's keep-mask words at the top of its step instead of next to their use
 #endif
+
+#ifndef TSF_RING12
+#define TSF_RING12 4        // ring slots of the 9..12 tile variant without the parked operand copy (2: one barrier per block, A/B builds)
+#endif
+template <int MAXW, bool PARK>
+constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
+
+struct Yes { static constexpr bool value = true; };
+struct No { static constexpr bool value = false; };
 
 template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE>
 __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
@@ -71,23 +91,31 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     char* kbuf = smem;
     char* vbuf = smem + nkt * 2 * TSF_FRAG;
     char* ring = smem + nkt * 4 * TSF_FRAG;
+    // Ring of NSLOT stage blocks.  With four slots (where the LDS budget allows: the 9..12 tile variant without the parked
+    // operand copy) the six feed-forward blocks are consumed in PAIRS -- one barrier per two blocks, fills issued two blocks ahead.
+    constexpr int NSLOT = ring_slots<MAXW, PARK>();
+    constexpr bool PAIR = NSLOT == 4;
     // PARK: the 16-bit operand copy of the residual stream (6 fragments per wave) lives in a wave-private LDS
     // area while the attention loops run, which frees 24 VGPRs for the software-pipelined score tiles
-    char* xpark = ring + 2 * TSF_BLOCK + wave * 6 * TSF_FRAG;
+    char* xpark = ring + NSLOT * TSF_BLOCK + wave * 6 * TSF_FRAG;
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(ring));
     const int nstage = A.depth * TSF_STAGES;
 
-    auto issue_fill = [&](int g) {            // stage block g -> ring slot g & 1, pieces spread over the waves
+    auto slot_of = [&](int g) -> const char* { return ring + (g & (NSLOT - 1)) * TSF_BLOCK; };
+    auto issue_fill = [&](int g) {            // stage block g -> ring slot g mod NSLOT, pieces spread over the waves
         const char* src = W + TSF_LAYER0 + (long)g * TSF_BLOCK + lane * 16;
-        const uint32_t dst = ring_addr + (uint32_t)(g & 1) * TSF_BLOCK;
+        const uint32_t dst = ring_addr + (uint32_t)(g & (NSLOT - 1)) * TSF_BLOCK;
         for (int pc = wave; pc < 25; pc += nkt) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
     };
-    // Stage boundary: my DMA pieces of block g have landed (vmcnt), everybody's have (barrier), and
-    // everybody is done reading the other slot, which is then refilled with block g+1.
-    auto stage_begin = [&](int g) -> const char* {
+    // Stage boundary: my DMA pieces of every block requested so far have landed (vmcnt), everybody's have (barrier), and
+    // everybody is done with the blocks before g -- whose slots are then refilled, up to `ahead` blocks beyond g (block b lands
+    // in the slot of block b - NSLOT, and ahead < NSLOT).
+    int issued = 1;                           // next block to request (wave-uniform)
+    auto stage_begin = [&](int g, int ahead) -> const char* {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (g + 1 < nstage) issue_fill(g + 1);
-        return ring + (g & 1) * TSF_BLOCK;
+        const int upto = g + ahead < nstage ? g + ahead : nstage - 1;
+        for (; issued <= upto; ++issued) issue_fill(issued);
+        return slot_of(g);
     };
 
     issue_fill(0);
@@ -140,7 +168,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 
         // the first head's stage is opened outside the loop so that the f32 residual stream xT is
         // dead (folded into acc / xb) while the head loop runs
-        const char* blk = stage_begin(g);
+        const char* blk = stage_begin(g, 1);
         const float* tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
@@ -155,10 +183,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = (drop ? 0.f : xT[t][i]) + bo[t * 16 + i];
         }
+        bool skip_fast = false;                 // wave-uniform: a head of this layer overflowed the fixed-shift schedule
 #pragma unroll 1
         for (int hd = 0; hd < TSF_HEADS; ++hd, ++g) {
             if (hd > 0) {
-                blk = stage_begin(g);
+                blk = stage_begin(g, PAIR && hd == TSF_HEADS - 1 ? 2 : 1);      // the last head also requests the second ffn block
                 tail = (const float*)(blk + TSF_TAIL);
             }
             if constexpr (PARK) {
@@ -313,7 +342,89 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     finish_tile(cur, kt, tm);
                 }
             };
-            if (TSF_ABLATE & 32) {
+            // fast schedule: one tile with the shift already fixed -- no maximum, no branch.  LDS and scalar loads share one
+            // wait counter and scalar loads return out of order, so a wait for ANY LDS read also waits for every scalar load in
+            // flight.  Hence the order: all four operand fragments of the step are requested at its top and waited for once
+            // (behind the exponentials); the keep-mask words are loop carried, the next tile's being fetched into the same
+            // scalar registers right after this tile's selects have consumed them -- nothing waits on that counter again
+            // before the next step's exponentials are done.
+            auto fast_step = [&](f32x16& cur, f32x16& nxt, int kt, TileMask& tm, auto has_next) {
+                constexpr bool NEXT = decltype(has_next)::value;
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                op8 k0, k1;
+                if constexpr (NEXT) {
+                    k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane);
+                    k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                exp_tile(cur, cur);
+                if constexpr (drop) {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        lsum2 += f32x2{cur[i], cur[i + 1]};
+                        lsum2b += f32x2{cur[i + 2], cur[i + 3]};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NEXT) {
+                    nxt = mfma16<F16>(k0, qb[0], zero);
+                    nxt = mfma16<F16>(k1, qb[1], nxt);
+                }
+                if constexpr (drop) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
+                    if constexpr (NEXT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        tm = load_mask(kt + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const bf16x8 p0 = pack_half<false>(cur, 0), p1 = pack_half<false>(cur, 1);
+                o = mfma16<false>(v0, p0, o);
+                o = mfma16<false>(v1, p1, o);
+            };
+            auto denominator = [&]() -> float {
+                if constexpr (drop) {
+                    float lo, hi;
+                    both_halves((lsum2[0] + lsum2[1]) + (lsum2b[0] + lsum2b[1]), lo, hi);
+                    return (lo + hi) * keep;
+                } else {
+                    return __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
+                }
+            };
+            float den = 1.0f;
+            bool redo = true;                        // wave-uniform
+            if (TSF_FAST_ATTN && !(TSF_ABLATE & 32) && !A.always_rescale && !skip_fast) {
+                f32x16 sa = score_tile(0), sb;
+                TileMask tm;
+                if constexpr (drop) tm = load_mask(0);
+                reshift(sa, tile_max(sa), true);
+                int kt = 0;
+#pragma unroll 1
+                for (; kt + 2 < nkt; kt += 2) {             // both tiles of the pair have a successor
+                    fast_step(sa, sb, kt, tm, Yes{});
+                    fast_step(sb, sa, kt + 1, tm, Yes{});
+                }
+                if (kt + 1 < nkt) {
+                    fast_step(sa, sb, kt, tm, Yes{});
+                    fast_step(sb, sa, kt + 1, tm, No{});
+                } else {
+                    fast_step(sa, sb, kt, tm, No{});
+                }
+                den = denominator();
+                redo = __builtin_amdgcn_ballot_w64(!(den < TSF_LIMIT)) != 0;
+                if (redo) {
+                    skip_fast = true;                // the other heads of this layer see the same tokens: straight to the re-shifting loop
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                    lsum2 = f32x2{0.f, 0.f};
+                    lsum2b = f32x2{0.f, 0.f};
+                    shift = 0.f;
+                    if (h == 0) qb[1][5] = (ope)0.0f;
+                }
+            }
+            if (!redo) {
+            } else if (TSF_ABLATE & 32) {
             } else if constexpr (PIPE == 2) {
                 // software pipeline over two alternating score tiles (no register copies)
                 f32x16 sa = score_tile(0), sb;
@@ -339,14 +450,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     tile_step(sa, sa, kt);
                 }
             }
-            float den;
-            if constexpr (drop) {
-                float lo, hi;
-                both_halves((lsum2[0] + lsum2[1]) + (lsum2b[0] + lsum2b[1]), lo, hi);
-                den = (lo + hi) * keep;
-            } else {
-                den = __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
-            }
+            if (redo) den = denominator();
             const float inv = 1.0f / den;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] *= inv;
@@ -373,7 +477,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
-        blk = stage_begin(g);
+        blk = stage_begin(g, PAIR ? 3 : 1);
         tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
@@ -389,7 +493,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll 1
         for (int j = 0; j < ((TSF_ABLATE & 64) ? 1 : 6); ++j, g += ((TSF_ABLATE & 64) ? 6 : 1)) {
             if (j > 0) {
-                blk = stage_begin(g);
+                blk = (PAIR && (j & 1)) ? slot_of(g) : stage_begin(g, PAIR ? 3 : 1);      // PAIR: odd blocks arrived with their predecessor
                 tail = (const float*)(blk + TSF_TAIL);
             }
             TSF_PRIO_CHAIN(1);
@@ -511,7 +615,7 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
 
 template <int MAXW, bool DROP, bool PARK, bool F16>
 int launch_enc_t(const EncArgs& a, hipStream_t st) {
-    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + 2 * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
+    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
     // per launch, not once per process: the attribute is per device and setting it is cheap
     hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -16,7 +16,8 @@ from step_amd import tsformer_pack as TP
 from tests import enc_dropout_host as DH
 
 THR, BIAS = 100.0, 60.0          # TSF_THR / TSF_BIAS of csrc/tsformer_encoder.hip
-STATS = {"reshifts": 0, "tiles": 0}
+LIMIT = 2.0 ** 110               # TSF_LIMIT: largest softmax denominator the fast schedule accepts
+STATS = {"reshifts": 0, "tiles": 0, "redone": 0}
 
 LANES = np.arange(64)
 H = LANES // 32
@@ -147,6 +148,7 @@ def encode_sequence(series, packed, P, depth, round_bf16=True, drop=None, always
         bo = tailf(hblk(0), 64, 96).reshape(2, 48)
         acc = [(xT[w] if drop is None else 0.0) + bo[H].reshape(64, 3, 16).transpose(1, 0, 2) for w in range(nkt)]
         xop = lambda frs: np.stack([np.concatenate([frs[2 * t], frs[2 * t + 1]], axis=1) for t in range(3)])   # operand copy -> [3,64,16]
+        skip_fast = [False] * nkt
         for hd in range(4):
             kf, vf, qb = {}, {}, []
             bq = tailf(hblk(hd), 0, 32).reshape(2, 16)
@@ -170,30 +172,44 @@ def encode_sequence(series, packed, P, depth, round_bf16=True, drop=None, always
                     key = kt * 32 + ROW[H]                                # [64,16]
                     return np.where(key >= P, s_ - 30000.0, s_)          # slot 26: (is_padding | -30000)
                 # one pass, online softmax: `shift` rides through the score MFMA (slot 25), see the kernel header
-                shift = np.zeros(64)
-                ov = np.zeros((64, 16))
-                lsum = np.zeros(64)
-                for kt in range(nkt):
-                    sc = scores(kt) - shift[:, None]
-                    tmax = sc.max(axis=1)
-                    STATS["tiles"] += 1
-                    if kt == 0 or bool((tmax > thr).any()):
-                        STATS["reshifts"] += kt > 0
-                        t = np.maximum(tmax, tmax[LANES ^ 32])
-                        upd = (t > thr) | (kt == 0)
-                        ns = round_to_operand(shift + t + BIAS) if rnd else shift + t + BIAS
-                        d = np.where(upd, ns - shift, 0.0)
-                        shift = np.where(upd, ns, shift)
-                        a = np.ones(64) if kt == 0 else np.exp2(-d)
-                        ov = ov * a[:, None]
-                        lsum = lsum * a
-                        sc = sc - d[:, None]
-                    p = np.exp2(sc)
-                    if drop is not None:
-                        lsum = lsum + p.sum(axis=1)
-                        p = p * lane_bits(pool, cbase(layer) + ((hd * nkt + w) * nkt + kt) * 16)
-                    ov = mfma_fast(vf[(kt, 0)], pack_half(p, 0, rnd, BF), ov)
-                    ov = mfma_fast(vf[(kt, 1)], pack_half(p, 1, rnd, BF), ov)
+                def key_loop(fast):
+                    """fast: the shift stays where the first key tile puts it (no per-tile maximum); else the re-shifting loop."""
+                    shift = np.zeros(64)
+                    ov = np.zeros((64, 16))
+                    lsum = np.zeros(64)
+                    for kt in range(nkt):
+                        sc = scores(kt) - shift[:, None]
+                        tmax = sc.max(axis=1)
+                        STATS["tiles"] += 1
+                        if kt == 0 or (not fast and bool((tmax > thr).any())):
+                            STATS["reshifts"] += kt > 0
+                            t = np.maximum(tmax, tmax[LANES ^ 32])
+                            upd = (t > thr) | (kt == 0)
+                            ns = round_to_operand(shift + t + BIAS) if rnd else shift + t + BIAS
+                            d = np.where(upd, ns - shift, 0.0)
+                            shift = np.where(upd, ns, shift)
+                            a = np.ones(64) if kt == 0 else np.exp2(-d)
+                            ov = ov * a[:, None]
+                            lsum = lsum * a
+                            sc = sc - d[:, None]
+                        with np.errstate(over="ignore", invalid="ignore"):
+                            p = np.exp2(sc)
+                            p = np.where(p > 3.4028234e38, np.inf, p)                  # f32 range: overflows where the kernel does
+                            if drop is not None:
+                                lsum = lsum + p.sum(axis=1)
+                                p = p * lane_bits(pool, cbase(layer) + ((hd * nkt + w) * nkt + kt) * 16)
+                            ov = mfma_fast(vf[(kt, 0)], pack_half(p, 0, rnd, BF), ov)
+                            ov = mfma_fast(vf[(kt, 1)], pack_half(p, 1, rnd, BF), ov)
+                    return ov, lsum
+                denom = lambda ov, lsum: ov[C, 12] if drop is None else (lsum + lsum[LANES ^ 32]) * keep
+                redo = True
+                if not always_reshift and not skip_fast[w]:
+                    ov, lsum = key_loop(True)
+                    redo = not bool((denom(ov, lsum) < LIMIT).all())        # NaN and inf fail the comparison, as in the kernel
+                    STATS["redone"] += redo
+                    skip_fast[w] = redo                                     # per wave, sticky for the rest of the layer
+                if redo:
+                    ov, lsum = key_loop(False)
                 den = ov[C, 12] if drop is None else (lsum + lsum[LANES ^ 32]) * keep
                 ov = ov / den[:, None]
                 ob = [pack_half(ov, 0, rnd), pack_half(ov, 1, rnd)]

@@ -58,6 +58,8 @@ def main():
     m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=P, mask_ratio=0.75,
                  encoder_depth=4, decoder_depth=1, mode="forecasting")
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # the untouched initialisation (what bench.py's random-init model holds): timing only, see enc_ab.cpp
+    TP.pack_tsformer(sd, P, operand="f16").numpy().tofile(os.path.join(OUT, "pack_f16_plain.bin"))
     g = torch.Generator().manual_seed(1)
     for k, v in sd.items():                       # sharper attention than the 0.02-std initialisation, no exactly-zero biases
         if v.ndim >= 2 and "position" not in k and "mask_token" not in k:

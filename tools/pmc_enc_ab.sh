@@ -42,13 +42,13 @@ for name in ("mem1", "mem2"):
         for kn, pn, v in cur.execute("""select s.kernel_name, p.name, sum(e.value) / count(distinct d.id) from rocpd_pmc_event e
                join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id
                join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-               where s.kernel_name like '%tsformer_encoder_kernelILi12ELb1ELb1ELb1E%' and d.grid_size_x > 1000000 group by s.kernel_name, p.name""").fetchall():
+               where s.kernel_name like '%tsformer_encoder_kernelILi12ELb1ELb0ELb1E%' and d.grid_size_x > 1000000 group by s.kernel_name, p.name""").fetchall():
             vals[pn] = v
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     # per-dispatch sums over the XCDs are what rocprofv3 stores per event row; avg over dispatches.  FETCH_SIZE x2 on gfx950 (guide, HBM section)
     rec = {"STEP_PEMS04:B8": {"read_bytes": int(vals["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(vals["WRITE_SIZE"] * 1024), "raw": vals,
                               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/enc_ab.cpp, tools/pmc_enc_ab.sh default mem, "
-                                        "encoder v2, S=2456 P=336, dropout on, float16 operands"}}
+                                        "encoder (fixed-shift softmax schedule, 4-slot weight ring), S=2456 P=336, dropout on, float16 operands"}}
     json.dump(rec, open("gpurun_out/encoder_pmc.json", "w"), indent=1)
     print(rec)
 PY
