@@ -142,20 +142,53 @@ __device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
 #ifndef TSF_ABLATE
 #define TSF_ABLATE 0
 #endif
+#ifndef TSF_LN_PACKED
+#define TSF_LN_PACKED 1      // 0: the scalar reduction chains of the first version (A/B builds)
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
     if (TSF_ABLATE & 128) return;
-    float s = 0.f;
+    float s, q;
+    if (TSF_LN_PACKED) {
+        // both reductions as two chains of packed adds / fmas (v_pk_add_f32, v_pk_fma_f32): half the instructions of a
+        // scalar chain and a quarter of its dependency depth
+        f32x2_t s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += a[t][i];
+            for (int i = 0; i < 16; i += 4) {
+                s0 += f32x2_t{a[t][i], a[t][i + 1]};
+                s1 += f32x2_t{a[t][i + 2], a[t][i + 3]};
+            }
+        s = (s0[0] + s0[1]) + (s1[0] + s1[1]);
+    } else {
+        s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += a[t][i];
+    }
     s += __shfl_xor(s, 32, 64);
     const float mean = s * (1.0f / 96.0f);
-    float q = 0.f;
+    if (TSF_LN_PACKED) {
+        const f32x2_t m2 = {mean, mean};
+        f32x2_t q0 = {0.f, 0.f}, q1 = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
+            for (int i = 0; i < 16; i += 4) {
+                const f32x2_t d0 = f32x2_t{a[t][i], a[t][i + 1]} - m2, d1 = f32x2_t{a[t][i + 2], a[t][i + 3]} - m2;
+                q0 += d0 * d0;
+                q1 += d1 * d1;
+            }
+        q = (q0[0] + q0[1]) + (q1[0] + q1[1]);
+    } else {
+        q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
+    }
     q += __shfl_xor(q, 32, 64);
     const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
 #pragma unroll

@@ -63,6 +63,16 @@ namespace {
 template <int MAXW, bool PARK>
 constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
 
+#ifndef TSF_RELU_PACKED
+#define TSF_RELU_PACKED 1   // 0: f32 clamp before the pack (A/B builds)
+#endif
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <bool F16>
+__device__ __forceinline__ typename Opnd<F16>::v8 relu_packed(typename Opnd<F16>::v8 v) {
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(typename Opnd<F16>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
+
 struct Yes { static constexpr bool value = true; };
 struct No { static constexpr bool value = false; };
 
@@ -130,21 +140,26 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             float4 t4 = tok_ok ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
             xin[4 * v] = t4.x; xin[4 * v + 1] = t4.y; xin[4 * v + 2] = t4.z; xin[4 * v + 3] = t4.w;
         }
-        const float4* wpe = (const float4*)(W + TSF_G_WPE) + h * 48 * 3;
-        const float* bpe = (const float*)(W + TSF_G_BPE) + h * 48;
-        const float* pos = (const float*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc * 2 + h) * 48;
+        // x W_pe^T on the matrix cores in full f32 (v_mfma_f32_32x32x2_f32, K = 12 in six steps): A = W_pe rows (features) of
+        // block t, stored per lane by the packer ([3][6][64] floats, one coalesced dword load each), B = this token's inputs
+        // 2s + h; the accumulators start from pos + b_pe (pre-added by the packer) and come out in the layout of every other tile
+        const float4* pos = (const float4*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc * 2 + h) * 12;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int qd = t * 16 + i;
-                float4 w0 = wpe[qd * 3], w1 = wpe[qd * 3 + 1], w2 = wpe[qd * 3 + 2];
-                float acc = bpe[qd];
-                acc += w0.x * xin[0] + w0.y * xin[1] + w0.z * xin[2] + w0.w * xin[3];
-                acc += w1.x * xin[4] + w1.y * xin[5] + w1.z * xin[6] + w1.w * xin[7];
-                acc += w2.x * xin[8] + w2.y * xin[9] + w2.z * xin[10] + w2.w * xin[11];
-                xT[t][i] = acc + pos[qd];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 p4 = pos[t * 4 + q4];
+                xT[t][4 * q4] = p4.x; xT[t][4 * q4 + 1] = p4.y; xT[t][4 * q4 + 2] = p4.z; xT[t][4 * q4 + 3] = p4.w;
             }
+        const float* wpe = (const float*)(W + TSF_G_WPE) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            // (a plain `h ? odd : even` is turned into a dynamically indexed private array, i.e. scratch memory)
+            const uint32_t hm = 0u - (uint32_t)h;
+            const float xb = __uint_as_float((__float_as_uint(xin[2 * ks]) & ~hm) | (__float_as_uint(xin[2 * ks + 1]) & hm));
+#pragma unroll
+            for (int t = 0; t < 3; ++t) xT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpe[(t * 6 + ks) * 64], xb, xT[t], 0, 0, 0);
+        }
         float sc = 9.797958971132712f;   // sqrt(96), transformer_layers.py:15
         if constexpr (drop) {            // positional_encoding.py:32; the survivor scale rides on sqrt(d)
             const uint32_t chunk = drop_chunk_base(A.seed, (uint32_t)seq, (uint32_t)A.depth, pmask);
@@ -505,10 +520,20 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 for (int i = 0; i < 16; ++i) hh[i] = b1[i];
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) hh = mfma16<F16>(lfrag<F16>(blk, cc * 12 + ks, lane), xb[ks], hh);
+                op8 hb0, hb1;
+                if (TSF_RELU_PACKED) {
+                    // ReLU after the pack, on 16-bit pairs: a negative float16 / bfloat16 is a negative int16, so one
+                    // v_pk_max_i16 against zero per two hidden units replaces two f32 clamps (rounding commutes with the clamp)
+                    if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
+                    hb0 = relu_packed<F16>(pack_half<F16>(hh, 0));
+                    hb1 = relu_packed<F16>(pack_half<F16>(hh, 1));
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
-                if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
-                op8 hb0 = pack_half<F16>(hh, 0), hb1 = pack_half<F16>(hh, 1);
+                    for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
+                    if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
+                    hb0 = pack_half<F16>(hh, 0);
+                    hb1 = pack_half<F16>(hh, 1);
+                }
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 6 + t * 2, lane), hb0, acc[t]);

@@ -30,13 +30,13 @@
 #define TSF_PATCH 12
 #define TSF_FRAG 1024
 
-#define TSF_MAGIC 0x54534632 /* "TSF2" */
+#define TSF_MAGIC 0x54534633 /* "TSF3": W_pe as f32 MFMA operands, b_pe folded into the positional table */
 
 // header: int32 magic, P (tokens), depth, reserved
 #define TSF_HDR_BYTES 64
 // --- global section (f32) ---
-#define TSF_G_WPE (TSF_HDR_BYTES)                       /* [2][48][12] */
-#define TSF_G_BPE (TSF_G_WPE + 2 * 48 * 12 * 4)         /* [2][48] */
+#define TSF_G_WPE (TSF_HDR_BYTES)                       /* [3][6][64]: A operands of v_mfma_f32_32x32x2_f32, value (t, s, lane) = W_pe[32 t + lane % 32][2 s + lane / 32] */
+#define TSF_G_BPE (TSF_G_WPE + 2 * 48 * 12 * 4)         /* [2][48] b_pe (informative: the kernel reads it pre-added to the positional table) */
 #define TSF_G_NORM_G (TSF_G_BPE + 2 * 48 * 4)           /* encoder_norm weight [2][48] */
 #define TSF_G_NORM_B (TSF_G_NORM_G + 2 * 48 * 4)
 #define TSF_LAYER0 ((TSF_G_NORM_B + 2 * 48 * 4 + 1023) / 1024 * 1024)   /* 1 KB aligned */
@@ -45,6 +45,6 @@
 #define TSF_STAGES 10
 #define TSF_LAYER_BYTES (TSF_STAGES * TSF_BLOCK)
 #define TSF_TAIL (24 * TSF_FRAG)
-// --- positional table follows the last layer: f32 [P][2][48] ---
+// --- positional table + b_pe follows the last layer: f32 [P][2][48] ---
 #define TSF_POS_OFF(depth) (TSF_LAYER0 + (long)(depth) * TSF_LAYER_BYTES)
 #define TSF_TOTAL_BYTES(depth, P) (TSF_POS_OFF(depth) + (long)(P) * 2 * 48 * 4)

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 D, HEADS, HDIM, FFN, PATCH, FRAG = 96, 4, 24, 384, 12, 1024
-MAGIC = 0x54534632
+MAGIC = 0x54534633
 HDR = 64
 
 _h = np.arange(64) // 32
@@ -85,7 +85,8 @@ def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder", operand="bf16"):
     hdr[0], hdr[1], hdr[2], hdr[3] = MAGIC, P, depth, int(operand == "f16")
     out.extend(hdr.tobytes())
     wpe = g("patch_embedding.input_embedding.weight")[:, 0, :, 0]        # [96, 12]
-    out.extend(f32_bytes(np.stack([wpe[_lane_vec96(np.arange(96))[h]] for h in (0, 1)])))   # [2,48,12]
+    lane = np.arange(64)
+    out.extend(f32_bytes(np.stack([[wpe[32 * t + lane % 32, 2 * s + lane // 32] for s in range(6)] for t in range(3)])))   # [3,6,64]
     out.extend(f32_bytes(_lane_vec96(g("patch_embedding.input_embedding.bias"))))
     out.extend(f32_bytes(_lane_vec96(g(enc + "_norm.weight"))))
     out.extend(f32_bytes(_lane_vec96(g(enc + "_norm.bias"))))
@@ -151,7 +152,7 @@ def pack_tsformer(sd, P, depth=4, prefix="", enc="encoder", operand="bf16"):
             blk.extend(tail.tobytes())
             assert len(blk) == BLOCK
             out.extend(blk)
-    pos = g("positional_encoding.position_embedding")[:P]              # [P, 96]
+    pos = g("positional_encoding.position_embedding")[:P] + g("patch_embedding.input_embedding.bias")[None, :]     # [P, 96], b_pe folded in
     out.extend(f32_bytes(np.stack([_lane_vec96(pos[p]) for p in range(P)])))         # [P,2,48]
     assert len(out) == total_bytes(depth, P), (len(out), total_bytes(depth, P))
     return torch.from_numpy(np.frombuffer(bytes(out), dtype=np.uint8).copy())

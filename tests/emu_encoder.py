@@ -123,7 +123,9 @@ def encode_sequence(series, packed, P, depth, round_bf16=True, drop=None, always
     G_NB = G_NG + 2 * 48 * 4
     L0 = TP.LAYER0
     POS = L0 + depth * LB
-    wpe = B.f32(G_WPE, 2 * 48 * 12).reshape(2, 48, 12)
+    wsec = B.f32(G_WPE, 3 * 6 * 64).reshape(3, 6, 2, 32)                         # A operands of the f32 MFMA: (t, s, k = lane / 32, row = lane % 32)
+    wfull = wsec.transpose(0, 3, 1, 2).reshape(96, 12)                           # W_pe [feature 32 t + row][input 2 s + k]
+    wpe = np.stack([wfull[(32 * np.arange(3)[:, None] + ROW[h][None, :]).reshape(-1)] for h in (0, 1)])     # [2, 48 (accumulator order), 12]
     bpe = B.f32(G_BPE, 96).reshape(2, 48)
     xT = []
     for w in range(nkt):
@@ -132,7 +134,7 @@ def encode_sequence(series, packed, P, depth, round_bf16=True, drop=None, always
         tokc = np.where(ok, tok, 0)
         xin = np.where(ok[:, None], series[tokc[:, None] * 12 + np.arange(12)[None, :]], 0.0)     # [64,12]
         pos = np.stack([B.f32(POS + (int(tokc[l]) * 2 + int(H[l])) * 48 * 4, 48) for l in range(64)])
-        e = (np.einsum("lqj,lj->lq", wpe[H], xin) + bpe[H] + pos).reshape(64, 3, 16).transpose(1, 0, 2).copy()   # [3,64,16]
+        e = (np.einsum("lqj,lj->lq", wpe[H], xin) + pos).reshape(64, 3, 16).transpose(1, 0, 2).copy()   # [3,64,16]; b_pe rides in the table
         sc = np.sqrt(96.0)
         if drop is not None:
             for t in range(3):
