@@ -63,6 +63,9 @@ namespace {
 template <int MAXW, bool PARK>
 constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
 
+#ifndef TSF_BATCH_FRAGS
+#define TSF_BATCH_FRAGS 0   // 1: scheduling fences around the batched weight-fragment reads (measured: forces the operand copy into scratch, 1.93 -> 2.22 ms)
+#endif
 #ifndef TSF_RELU_PACKED
 #define TSF_RELU_PACKED 1   // 0: f32 clamp before the pack (A/B builds)
 #endif
@@ -209,41 +212,65 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
 #pragma unroll
                 for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
             }
-            // ---- Q^T (kept in registers as the B operand of S^T = K Q^T)
+            // ---- Q^T (kept in registers as the B operand of S^T = K Q^T), K^T, V.  Left to itself the compiler cycles a single
+            // 4-register buffer through read -> wait -> MFMA, one exposed LDS latency per MFMA.
             TSF_PRIO_CHAIN(1);
             op8 qb[2];
             {
+                // the 18 weight fragments are written as two rolling 3-fragment buffers (reads of the batch after the next issued
+                // behind each batch's MFMAs); the order is a hint -- pinning it with scheduling fences (TSF_BATCH_FRAGS=1) costs
+                // registers the attention loop needs (the operand copy lands in scratch), so the final schedule is the compiler's
+                op8 wa[3], wb[3];
+                auto load3 = [&](op8 (&w)[3], int f0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) w[k] = lfrag<F16>(blk, f0 + k, lane);
+                };
+                auto fence = [&]() { if (TSF_BATCH_FRAGS) __builtin_amdgcn_sched_barrier(0); };
+                load3(wa, 0);
+                load3(wb, 3);
                 f32x16 q;
                 const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
+                const float bv = tail[32 + c];
+                fence();
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) q = mfma16<F16>(lfrag<F16>(blk, ks, lane), xb[ks], q);
+                for (int k = 0; k < 3; ++k) q = mfma16<F16>(wa[k], xb[k], q);
+                load3(wa, 6);
+                fence();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q = mfma16<F16>(wb[k], xb[3 + k], q);
+                load3(wb, 9);
+                fence();
+                // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
+                f32x16 kk;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kk[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) kk = mfma16<F16>(wa[k], xb[k], kk);
+                load3(wa, 12);
                 qb[0] = pack_half<F16>(q, 0);
                 qb[1] = pack_half<F16>(q, 1);
                 // head-dim slots 25 / 26 (the head dim is 24 of 32) carry the softmax shift and the key-padding mask
                 // through the contraction: the key side holds (1, is_padding), the query side (-shift, -30000)
                 if (h == 0) { qb[1][5] = (ope)0.0f; qb[1][6] = (ope)(-30000.0f); }
-            }
-            // ---- K^T -> this tile's A-operand fragments (bias dropped: it cancels in softmax)
-            {
-                f32x16 kk;
+                fence();
 #pragma unroll
-                for (int i = 0; i < 16; ++i) kk[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) kk = mfma16<F16>(lfrag<F16>(blk, 6 + ks, lane), xb[ks], kk);
-                if (h == 0) { kk[13] = 1.0f; kk[14] = tok_ok ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
-                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
-                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
-            }
-            // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T; always bfloat16 (like P): see the header
-            {
+                for (int k = 0; k < 3; ++k) kk = mfma16<F16>(wb[k], xb[3 + k], kk);
+                load3(wb, 15);
+                fence();
+                // ---- V (tokens as rows) -> this tile's A-operand fragments of V^T; always bfloat16 (like P): see the header
                 f32x16 vv;
-                const float bv = tail[32 + c];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) vv = mfma16<F16>(xb[ks], lfrag<F16>(blk, 12 + ks, lane), vv);
+                for (int k = 0; k < 3; ++k) vv = mfma16<F16>(xb[k], wa[k], vv);
+                if (h == 0) { kk[13] = 1.0f; kk[14] = tok_ok ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                fence();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vv = mfma16<F16>(xb[3 + k], wb[k], vv);
                 *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
                 *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
@@ -472,10 +499,16 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             op8 ob0 = pack_half<F16>(o, 0), ob1 = pack_half<F16>(o, 1);
             // ---- out-projection of this head accumulates onto the residual
             TSF_PRIO_CHAIN(1);
+            {
+                op8 wo[6];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                acc[t] = mfma16<F16>(lfrag<F16>(blk, 18 + t * 2, lane), ob0, acc[t]);
-                acc[t] = mfma16<F16>(lfrag<F16>(blk, 19 + t * 2, lane), ob1, acc[t]);
+                for (int f = 0; f < 6; ++f) wo[f] = lfrag<F16>(blk, 18 + f, lane);
+                if (TSF_BATCH_FRAGS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = mfma16<F16>(wo[t * 2], ob0, acc[t]);
+                    acc[t] = mfma16<F16>(wo[t * 2 + 1], ob1, acc[t]);
+                }
             }
             TSF_PRIO_CHAIN(0);
         }  // heads
@@ -514,30 +547,49 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             TSF_PRIO_CHAIN(1);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
+                // both weight fragment sets of the chunk and its keep-mask words are requested up front
+                op8 wu[6], wd[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wu[ks] = lfrag<F16>(blk, cc * 12 + ks, lane);
                 f32x16 hh;
                 const float* b1 = tail + (cc * 2 + h) * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[i] = b1[i];
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) hh = mfma16<F16>(lfrag<F16>(blk, cc * 12 + ks, lane), xb[ks], hh);
+                for (int f = 0; f < 6; ++f) wd[f] = lfrag<F16>(blk, cc * 12 + 6 + f, lane);
+                unsigned long long mw[16];
+                if constexpr (drop) {
+                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mw[i] = mp[i];
+                }
+                if (TSF_BATCH_FRAGS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) hh = mfma16<F16>(wu[ks], xb[ks], hh);
                 op8 hb0, hb1;
                 if (TSF_RELU_PACKED) {
                     // ReLU after the pack, on 16-bit pairs: a negative float16 / bfloat16 is a negative int16, so one
                     // v_pk_max_i16 against zero per two hidden units replaces two f32 clamps (rounding commutes with the clamp)
-                    if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[i]) ? hh[i] : 0.f;
+                    }
                     hb0 = relu_packed<F16>(pack_half<F16>(hh, 0));
                     hb1 = relu_packed<F16>(pack_half<F16>(hh, 1));
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_fmed3f(hh[i], 0.f, 3.0e38f);      // relu, one VALU op
-                    if constexpr (drop) keep16(hh, mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u));
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[i]) ? hh[i] : 0.f;
+                    }
                     hb0 = pack_half<F16>(hh, 0);
                     hb1 = pack_half<F16>(hh, 1);
                 }
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 6 + t * 2, lane), hb0, acc[t]);
-                    acc[t] = mfma16<F16>(lfrag<F16>(blk, cc * 12 + 7 + t * 2, lane), hb1, acc[t]);
+                    acc[t] = mfma16<F16>(wd[t * 2], hb0, acc[t]);
+                    acc[t] = mfma16<F16>(wd[t * 2 + 1], hb1, acc[t]);
                 }
             }
             TSF_PRIO_CHAIN(0);
