@@ -244,10 +244,11 @@ def test_encoder_dropout_device_pool_statistics(L):
 
 
 def test_encoder_softmax_reshift_path(L):
-    """Single-pass softmax with a running shift (cdna_hip_programming.md 5.4 rule 26: force the rare branch, full-tensor
-    reference).  Doubling the q/k projections makes the scores reach the thousands and jump by more than the head room between
-    key tiles, so the re-shift branch runs on later tiles as well (counted by the lane-level emulation, which shares the kernel's
-    constants); the test flag re-shifts on every new running maximum instead.  Such a razor-sharp softmax is ill-conditioned --
+    """Single-pass softmax: fixed-shift schedule with the re-shifting loop as its fallback (cdna_hip_programming.md 5.4 rule 26:
+    force the rare branch, full-tensor reference).  Doubling the q/k projections makes the scores reach the thousands and jump by
+    more than the head room between key tiles, so some heads overflow the fixed shift, are redone, and re-shift on later tiles as
+    well (counted by the lane-level emulation, which shares the kernel's constants and control flow); the test flag skips the
+    fixed-shift attempt and re-shifts on every new running maximum instead.  Such a razor-sharp softmax is ill-conditioned --
     the ORACLE moves by several per cent when its weights are rounded to float16 -- so the kernel is held (a) to the emulation
     of its own arithmetic, (b) to agreement between the two schedules, (c) to the oracle within that sensitivity; with the
     plain weights both schedules must meet the usual tolerance."""
@@ -272,12 +273,14 @@ def test_encoder_softmax_reshift_path(L):
     normal, _, _, _ = _encode(L, series, packed, f16=1)
     forced, _, _, _ = _encode(L, series, packed, f16=1, flags=L.ENC_ALWAYS_RESHIFT)
     E.OPERAND = torch.float16
-    E.STATS.update(reshifts=0, tiles=0)
+    E.STATS.update(reshifts=0, tiles=0, redone=0)
     try:
         emu = torch.from_numpy(E.encode_sequence(x[0, :, 0].double().numpy(), packed, P, 4, round_bf16=True))
     finally:
         E.OPERAND = torch.bfloat16
-    assert E.STATS["reshifts"] > 20, E.STATS
+    # the fixed-shift schedule overflows on some heads (those are redone with the re-shifting loop, which then re-shifts on later
+    # tiles too) and holds on others: both paths of the kernel run on this input
+    assert E.STATS["reshifts"] > 20 and 0 < E.STATS["redone"] < 4 * 4 * ((P + 31) // 32), E.STATS
     e0, e1, e01 = rel_l2(normal.cpu(), want), rel_l2(forced.cpu(), want), rel_l2(normal.cpu(), forced.cpu())
     ee = rel_l2(normal.cpu()[0], emu)
     print(f"re-shift ({E.STATS['reshifts']} of {E.STATS['tiles']} tiles of sequence 0): vs emulation {ee:.3e}; vs oracle {e0:.3e} (head-room schedule), "
