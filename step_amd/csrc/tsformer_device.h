@@ -15,6 +15,8 @@ struct EncArgs {
     float* last_f32;
     float* sqn;
     float keep;                              // 1 - dropout probability (1 when dropout is off)
+    float inv_keep, inv_keep2;               // 1 / keep and its square, computed on the host: as kernel arguments they are scalar operands
+                                             // of the packed fmas, not loop-invariant vector register pairs that end up in scratch
     uint32_t seed;
     const unsigned long long* pool;          // Bernoulli(keep) lane-mask words (step_dropout_pool_fill); NULL when dropout is off
     uint32_t pool_mask;                      // number of pool words - 1 (a power of two, multiple of 16)
@@ -137,6 +139,25 @@ __device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
     hi = __uint_as_float(r[1]);
 }
 
+// the lane id, recomputed (two VALU ops) instead of kept alive: `volatile` keeps the compiler from merging it with earlier copies
+__device__ __forceinline__ int fresh_lane_id() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// sum over the 64 lanes: xor butterflies inside each half on the LDS crossbar (ds_swizzle, bit mode), then the two halves
+__device__ __forceinline__ float wave_sum_swz(float v) {
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x041F));      // and 0x1f, xor 1
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x081F));      // xor 2
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));      // xor 4
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x201F));      // xor 8
+    v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // xor 16
+    float lo, hi;
+    both_halves(v, lo, hi);
+    return lo + hi;
+}
+
 // LayerNorm over the 96 features of token (lane&31): each lane holds 48, its partner lane^32 the rest.
 // g / b point at this lane-half's 48 values (accumulator-register order).
 #ifndef TSF_ABLATE
@@ -168,7 +189,11 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) s += a[t][i];
     }
-    s += __shfl_xor(s, 32, 64);
+    {   // the partner half's sum by v_permlane32_swap: no lane-address register to keep alive (a ds_bpermute needs one)
+        float lo, hi;
+        both_halves(s, lo, hi);
+        s = lo + hi;
+    }
     const float mean = s * (1.0f / 96.0f);
     if (TSF_LN_PACKED) {
         const f32x2_t m2 = {mean, mean};
@@ -189,7 +214,11 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) { float d = a[t][i] - mean; q += d * d; }
     }
-    q += __shfl_xor(q, 32, 64);
+    {
+        float lo, hi;
+        both_halves(q, lo, hi);
+        q = lo + hi;
+    }
     const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
 #pragma unroll
     for (int t = 0; t < 3; ++t)

@@ -62,6 +62,13 @@ namespace {
 #endif
 template <int MAXW, bool PARK>
 constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
+#ifndef TSF_PARK1
+#define TSF_PARK1 1         // 0: leave the allocation to the compiler (it spills one operand fragment to scratch memory; A/B builds)
+#endif
+// number of operand-copy fragments (of 6) parked in LDS while the attention loops run: all of them (PARK), or just the one the
+// register allocator would otherwise put into scratch memory in the 9..12 tile variant
+template <int MAXW, bool PARK>
+constexpr int parked_frags() { return PARK ? 6 : (MAXW == 12 && TSF_PARK1) ? 1 : 0; }
 
 #ifndef TSF_BATCH_FRAGS
 #define TSF_BATCH_FRAGS 0   // 1: scheduling fences around the batched weight-fragment reads (measured: forces the operand copy into scratch, 1.93 -> 2.22 ms)
@@ -97,8 +104,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     const mask_ptr pool = (mask_ptr)(uintptr_t)A.pool;
     const uint32_t pmask = A.pool_mask;
     const DropLayout dl(nkt);
-    const float keep = A.keep, inv_keep = 1.0f / A.keep;
+    const float keep = A.keep, inv_keep = A.inv_keep;
     auto mask_words = [&](uint32_t chunk, uint32_t off) -> mask_ptr { return pool + ((chunk + off) & pmask); };
+    // 48 h, re-derived from a fresh lane id at every use: as a hoisted loop invariant it (or h) is the value the register allocator
+    // sends to scratch memory
+    auto h48 = [&]() -> int { return (fresh_lane_id() >> 5) * 48; };
 
     // LDS: [K frags nkt*2 KB][V frags nkt*2 KB][weight ring: 2 stage blocks of 25 KB]
     char* kbuf = smem;
@@ -110,7 +120,8 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     constexpr bool PAIR = NSLOT == 4;
     // PARK: the 16-bit operand copy of the residual stream (6 fragments per wave) lives in a wave-private LDS
     // area while the attention loops run, which frees 24 VGPRs for the software-pipelined score tiles
-    char* xpark = ring + NSLOT * TSF_BLOCK + wave * 6 * TSF_FRAG;
+    constexpr int NPARK = parked_frags<MAXW, PARK>();      // fragments 6 - NPARK .. 5 of the operand copy
+    char* xpark = ring + NSLOT * TSF_BLOCK + wave * NPARK * TSF_FRAG;
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(ring));
     const int nstage = A.depth * TSF_STAGES;
 
@@ -191,11 +202,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         {
 #pragma unroll
             for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half<F16>(xT[t], 0); xb[2 * t + 1] = pack_half<F16>(xT[t], 1); }
-            if constexpr (PARK) {
+            if constexpr (NPARK > 0) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) *(op8*)(xpark + f * TSF_FRAG + lane * 16) = xb[f];
+                for (int f = 6 - NPARK; f < 6; ++f) *(op8*)(xpark + (f - (6 - NPARK)) * TSF_FRAG + lane * 16) = xb[f];
             }
-            const float* bo = tail + 64 + h * 48;
+            const float* bo = tail + 64 + h48();
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -208,9 +219,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 blk = stage_begin(g, PAIR && hd == TSF_HEADS - 1 ? 2 : 1);      // the last head also requests the second ffn block
                 tail = (const float*)(blk + TSF_TAIL);
             }
-            if constexpr (PARK) {
+            if constexpr (NPARK > 0) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
+                for (int f = 6 - NPARK; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f - (6 - NPARK), lane);
             }
             // ---- Q^T (kept in registers as the B operand of S^T = K Q^T), K^T, V.  Left to itself the compiler cycles a single
             // 4-register buffer through read -> wait -> MFMA, one exposed LDS latency per MFMA.
@@ -431,7 +442,9 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     both_halves((lsum2[0] + lsum2[1]) + (lsum2b[0] + lsum2b[1]), lo, hi);
                     return (lo + hi) * keep;
                 } else {
-                    return __shfl(o[12], c, 64);      // V^T row 24 == ones: lane-half 0, register 12
+                    float lo, hi;
+                    both_halves(o[12], lo, hi);      // V^T row 24 == ones: lane-half 0, register 12
+                    return lo;
                 }
             };
             float den = 1.0f;
@@ -514,15 +527,15 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         }  // heads
         if constexpr (drop) {
             // dropout1 on (attention output + b_o); residual re-read from its 16-bit operand copy
-            if constexpr (PARK) {
+            if constexpr (NPARK > 0) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f, lane);
+                for (int f = 6 - NPARK; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f - (6 - NPARK), lane);
             }
             const mask_ptr w1[3] = {mask_words(chunk, dl.d1 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 1) * 16u),
                                     mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w1, inv_keep);
         }
-        layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN1 params ride in head 3's block
+        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
         blk = stage_begin(g, PAIR ? 3 : 1);
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         {
 #pragma unroll
             for (int t = 0; t < 3; ++t) { xb[2 * t] = pack_half<F16>(acc[t], 0); xb[2 * t + 1] = pack_half<F16>(acc[t], 1); }
-            const float* b2 = tail + 64 + h * 48;
+            const float* b2 = tail + 64 + h48();
             // training: the hidden-unit survivor scale is NOT applied per element; b2 is pre-multiplied by keep instead and the
             // whole sub-layer output gets 1/keep^2 in the residual fma (one scale for the FFN dropout, one for dropout2)
 #pragma unroll
@@ -597,39 +610,44 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         if constexpr (drop) {
             const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 1) * 16u),
                                     mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 2) * 16u)};
-            add_residual_op<F16>(acc, xb, w2, inv_keep * inv_keep);
+            add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
         }
-        layer_norm96(acc, tail + 64 + h * 48, tail + 160 + h * 48);      // LN2 params ride in the last ffn block
+        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
 #pragma unroll
         for (int t = 0; t < 3; ++t) xT[t] = acc[t];
     }  // layers
 
     // ------------------------------------------------------------------ encoder_norm + outputs
-    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G) + h * 48, (const float*)(W + TSF_G_NORM_B) + h * 48);
+    // Lane-derived indices are re-derived here from a fresh lane id: kept alive from the kernel's start they sit in scratch memory
+    // for its whole duration (64 bytes per lane and wave of HBM write-back for nothing).
+    const int lane_e = fresh_lane_id();
+    const int h_e = lane_e >> 5;
+    const int tok_e = wave * 32 + (lane_e & 31);
+    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G) + h_e * 48, (const float*)(W + TSF_G_NORM_B) + h_e * 48);
     float sq = 0.f;
-    if (tok_ok) {
-        const long row = ((long)seq * P + tok) * TSF_D;
+    if (tok_e < P) {
+        const long row = ((long)seq * P + tok_e) * TSF_D;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int f0 = t * 32 + 8 * g4 + 4 * h;
+                const int f0 = t * 32 + 8 * g4 + 4 * h_e;
                 float v0 = xT[t][4 * g4], v1 = xT[t][4 * g4 + 1], v2 = xT[t][4 * g4 + 2], v3 = xT[t][4 * g4 + 3];
                 u32x2 pk;
                 pk[0] = pack_bf16x2(v0, v1);
                 pk[1] = pack_bf16x2(v2, v3);
                 if (A.hid_bf16) *(u32x2*)(A.hid_bf16 + row + f0) = pk;
                 if (A.hid_f32) *(float4*)(A.hid_f32 + row + f0) = make_float4(v0, v1, v2, v3);
-                if (A.last_f32 && tok == P - 1) *(float4*)(A.last_f32 + (long)seq * TSF_D + f0) = make_float4(v0, v1, v2, v3);
+                if (A.last_f32 && tok_e == P - 1) *(float4*)(A.last_f32 + (long)seq * TSF_D + f0) = make_float4(v0, v1, v2, v3);
                 float r0 = bf16_bits_to_f32(pk[0] & 0xffffu), r1 = bf16_bits_to_f32(pk[0] >> 16);
                 float r2 = bf16_bits_to_f32(pk[1] & 0xffffu), r3 = bf16_bits_to_f32(pk[1] >> 16);
                 sq += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
             }
     }
     if (A.sqn) {
-        sq = wave_sum(sq);
-        if (lane == 0) A.sqn[(long)seq * 16 + wave] = sq;
-        if (wave == 0 && lane >= nkt && lane < 16) A.sqn[(long)seq * 16 + lane] = 0.f;
+        sq = wave_sum_swz(sq);
+        if (lane_e == 0) A.sqn[(long)seq * 16 + wave] = sq;
+        if (wave == 0 && lane_e >= nkt && lane_e < 16) A.sqn[(long)seq * 16 + lane_e] = 0.f;
     }
 }
 
@@ -692,7 +710,7 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
 
 template <int MAXW, bool DROP, bool PARK, bool F16>
 int launch_enc_t(const EncArgs& a, hipStream_t st) {
-    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (PARK ? (size_t)a.nkt * 6 * TSF_FRAG : 0);
+    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (size_t)a.nkt * parked_frags<MAXW, PARK>() * TSF_FRAG;
     // per launch, not once per process: the attribute is per device and setting it is cheap
     hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -770,7 +788,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
                      pool_words, (long)DropLayout(a.nkt).words);
     }
     a.wpack = (const char*)wpack; a.hid_bf16 = hidden_bf16; a.hid_f32 = hidden_f32; a.last_f32 = last_f32;
-    a.sqn = sqnorm_part; a.keep = 1.0f - dropout_p; a.seed = (uint32_t)(seed ^ (seed >> 32));
+    a.sqn = sqnorm_part; a.keep = 1.0f - dropout_p; a.inv_keep = 1.0f / a.keep; a.inv_keep2 = a.inv_keep * a.inv_keep; a.seed = (uint32_t)(seed ^ (seed >> 32));
     a.pool = dr ? (const unsigned long long*)drop_pool : nullptr;
     a.pool_mask = dr ? (uint32_t)(pool_words - 1) : 0u;
     a.f16 = (flags & STEP_ENC_F16) != 0;
