@@ -117,7 +117,11 @@ assert e["dp_vs_sequential"] < 1e-4 and e["grad_norm"] < 1e-4, e
 Bm.discrete_graph_learning.gather_fc_weight()
 sa, sb = A.state_dict(), Bm.state_dict()
 assert set(sa) == set(sb)
-worst = max((rel_l2(sb[k].float().cpu(), sa[k].float().cpu()), k) for k in sa if sa[k].is_floating_point() and sa[k].numel() > 1)
+# (the graph-convolution biases are left out of the per-tensor figure: their exact gradient is zero -- see compare() -- so Adam's first
+#  step moves each of their elements by +-lr on the sign of round-off noise, independently in the two models; dmax below still bounds them)
+noise_driven = lambda k: k.startswith("backend.gconv.") and k.endswith(".mlp.mlp.bias")
+worst = max((rel_l2(sb[k].float().cpu(), sa[k].float().cpu()), k) for k in sa
+            if sa[k].is_floating_point() and sa[k].numel() > 1 and not noise_driven(k))
 dmax = max(float((sb[k].float() - sa[k].float()).abs().max()) for k in sa if sa[k].is_floating_point() and not k.endswith("running_var"))
 print(f"rank {rank}: parameters after the step, worst rel-L2 sharded vs unsharded {worst}, largest element difference {dmax:.2e} (lr 2e-3)", flush=True)
 assert worst[0] < 2e-2 and dmax <= 2.05 * 2e-3, (worst, dmax)
