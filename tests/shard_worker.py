@@ -94,7 +94,7 @@ print(f"rank {rank} same batch on all ranks: {e}", flush=True)
 assert e["flips"] == 0 and e["g"] < 1e-4 and e["pred"] < 1e-4 and e["theta"] < 1e-4 and e["loss"] < 1e-5, e
 # worst tensor: the conv1 / conv2 bias and weight gradients are sums over bf16-stored rows (2^-9 per element) with heavy cancellation,
 # and the slices round them at different points than the unsharded pass; measured 7e-4 .. 2.2e-3 over builds and world sizes
-assert e["grad_rest"] < 2e-4 and e["grad_fc_slice"] < 3e-4 and e["worst_tensor"][0] < 6e-3, e
+assert e["grad_rest"] < 2e-4 and e["grad_fc_slice"] < 5e-4 and e["worst_tensor"][0] < 6e-3, e          # fc slice: measured 0.5 .. 1.9e-4
 
 # II. per-rank batches: A rounds each rank's d(fc output) to bf16 and averages the products, B averages first and rounds once --
 #     two equally valid bf16 roundings (2^-9 per element), amplified a little by the cancellations of the BatchNorm backward
