@@ -6,10 +6,12 @@
 // lane & 31), weights are the MFMA A operand, and thanks to the k-slot map in
 // tsformer_layout.h every accumulator tile becomes the next MFMA's B operand by a plain
 // f32->16-bit pack.  Inter-wave traffic: the per-head K and V operand fragments (2 KB per key tile
-// each) through LDS, and the weights, which every workgroup streams ONCE from L2 into a 2-slot
-// LDS ring (global_load_lds DMA, 25 KB stage blocks, prefetched one stage ahead) shared by all waves.
+// each) through LDS, and the weights, which every workgroup streams ONCE from L2 into an LDS ring of 25 KB stage blocks
+// (global_load_lds DMA, prefetched ahead; 2 slots, or 4 with the feed-forward blocks consumed in pairs) shared by all waves.
+// No scratch memory in the variants for P <= 384: values derived from the lane id are re-derived where they are used
+// rather than kept alive (fresh_lane_id()), and what does not fit the 168 registers is parked in LDS explicitly.
 //
-//   patch embed + pos-emb (f32 VALU)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> per key tile: S^T = K Q^T
+//   patch embed + pos-emb (exact f32 on v_mfma_f32_32x32x2_f32)  ->  4 x { per head: Q,K,V (MFMA, K=96) -> per key tile: S^T = K Q^T
 //   -> P = exp2(S - shift) -> O^T += V^T P^T  (ONE pass over the keys: online softmax, see below)
 //   -> out-proj accumulates onto (x + b_o) ; LN1 ; FFN in 12 chunks of 32 hidden units, never leaving
 //   registers ; LN2 }  ->  encoder_norm  ->  hidden (bf16 and/or f32), last-patch state, squared norms.
@@ -28,7 +30,7 @@
 // Fast schedule (TSF_FAST_ATTN, the default): the per-tile maximum / compare / branch of that loop costs more than its ten
 // instructions (it splits the loop body and serialises on a vector compare), and after the first tile it practically never
 // fires.  So a head is first run with the shift FIXED at what the first key tile sets -- a branch-free loop of exp2, packs and
-// MFMAs -- and checked once at the end: every probability is positive, so a denominator below 2^TSF_LIMIT_LOG2 proves that no
+// MFMAs -- and checked once at the end: every probability is positive, so a denominator below TSF_LIMIT = 2^110 proves that no
 // score went above the shift by more than that and nothing overflowed.  Otherwise (any query of the wave) the head is redone
 // from its K / V fragments with the re-shifting loop above, and the remaining heads of that layer skip the attempt.  When no
 // later tile would have re-shifted, both schedules execute the same arithmetic in the same order.

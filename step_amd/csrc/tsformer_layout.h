@@ -9,7 +9,7 @@
 // 32*block + F(s, h, j).  One fragment = 64 lanes * 8 bf16 = 1024 bytes, lane-major.
 //
 // Each encoder layer is 10 "stage blocks" of 25 KB (24 operand fragments + 1 KB of f32 vectors):
-// the kernel streams them through a 2-slot LDS ring with global_load_lds, one block per stage,
+// the kernel streams them through an LDS ring (2 or 4 slots) with global_load_lds, one block per stage,
 // so every workgroup reads each weight byte from L2 exactly once.
 //   head block hd (stage hd):   frags  0..5  Wq(hd) k-steps (A operand, pre-scaled by log2(e)/sqrt(24))
 //                                      6..11 Wk(hd) k-steps (A operand)
