@@ -79,8 +79,8 @@ int step_gemm(const StepGemm* g, void* stream);
  *              operand fragments + f32 vectors), built once per checkpoint
  *  flags       STEP_ENC_F16: the fragments of wpack are float16 (v_mfma_f32_32x32x16_f16; same rate as bfloat16, 3 more
  *              mantissa bits; P and V of the attention stay bfloat16 for their exponent range) -- must match how wpack was
- *              packed; 0: bfloat16 fragments.  STEP_ENC_ALWAYS_RESHIFT (tests): re-shift the online softmax on every new
- *              running maximum instead of only when its head room is used up.
+ *              packed; 0: bfloat16 fragments.  STEP_ENC_ALWAYS_RESHIFT (tests): skip the fixed-shift softmax schedule and run
+ *              the re-shifting loop, re-shifting on every new running maximum instead of only when its head room is used up.
  *  hidden_bf16 bf16 [S, P, 96] or NULL
  *  hidden_f32  f32  [S, P, 96] or NULL   (parity tests)
  *  last_f32    f32  [S, 96]    or NULL   (state of the last patch = step.py:64)
