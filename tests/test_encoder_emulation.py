@@ -142,3 +142,26 @@ def test_emulated_online_softmax_reshift_paths():
     assert counts[True] > counts[False]
     assert rel_l2(torch.from_numpy(got[False]), torch.from_numpy(got[True])) < 1e-9
     assert rel_l2(torch.from_numpy(got[False]), want) < 16 * TOL["f16"][0]
+
+
+def test_packed_patch_embedding_section_is_the_f32_mfma_operand_layout():
+    """csrc/tsformer_layout.h TSF_G_WPE: value (t, s, lane) = W_pe[32 t + lane % 32][2 s + lane / 32] -- what lane `lane` hands
+    v_mfma_f32_32x32x2_f32 as its A operand in k-step s of feature block t; and the positional table carries b_pe."""
+    g = load_golden("step_tiny")
+    p = params_of(g, requires_grad=False)
+    sd = {k[len("tsformer."):]: v for k, v in p.items() if k.startswith("tsformer.")}
+    P = 40
+    raw = TP.pack_tsformer(sd, P, operand="f16").numpy().tobytes()
+    sec = np.frombuffer(raw, dtype=np.float32, count=3 * 6 * 64, offset=TP.HDR).reshape(3, 6, 64)
+    w = sd["patch_embedding.input_embedding.weight"][:, 0, :, 0].numpy()          # [96, 12]
+    for t in range(3):
+        for s in range(6):
+            for lane in (0, 1, 31, 32, 45, 63):
+                assert sec[t, s, lane] == w[32 * t + lane % 32, 2 * s + lane // 32]
+    pos = np.frombuffer(raw, dtype=np.float32, count=P * 96, offset=TP.LAYER0 + 4 * TP.layer_bytes()).reshape(P, 2, 48)
+    want = (sd["positional_encoding.position_embedding"][:P] + sd["patch_embedding.input_embedding.bias"][None, :]).numpy()
+    rows = E.ROW                                                                    # [2, 16]: accumulator register -> row of a 32-row tile
+    for tok in (0, 7, P - 1):
+        for h in (0, 1):
+            feat = np.concatenate([32 * t + rows[h] for t in range(3)])
+            assert np.array_equal(pos[tok, h], want[tok, feat])
