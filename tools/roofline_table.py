@@ -64,6 +64,17 @@ def main():
         tf = flop / us / 1e6 if flop else None
         print(f"| {label} | {calls / steps:.0f} | {us:.1f} | {nbytes / MB:.0f} | {gbs:.0f} | {100 * gbs / HBM:.0f} % | "
               f"{'' if tf is None else f'{tf:.1f}'} | {bound} |")
+    # measured HBM traffic of the dominant kernel (PMC passes of tools/pmc_enc_ab.sh), next to its algorithmic bytes
+    import json
+    import os
+    pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "encoder_pmc.json")
+    if os.path.exists(pmc):
+        ent = json.load(open(pmc)).get("STEP_PEMS04:B8")
+        if ent:
+            print()
+            print(f"Encoder, measured HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, `profiles/encoder_pmc.json`): "
+                  f"{ent['read_bytes'] / MB:.0f} MB read + {ent['write_bytes'] / MB:.0f} MB written, against 40 MB of input and 158 MB of "
+                  f"bf16 hidden states that have to move.")
 
 
 if __name__ == "__main__":
