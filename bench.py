@@ -1,15 +1,29 @@
 """bench.py -- STEP training windows/s on MI355X (BASELINE.json metric, config C2 = STEP_PEMS04).
 
 One "step" = one full training step of the native STEP model on one synthetic minibatch that is already
-resident in HBM: TSFormer encoder forward (frozen) + kNN prior + DiscreteGraphLearning forward/backward +
+resident in HBM: TSFormer encoder forward (frozen, pre-trained weights) + kNN prior + DiscreteGraphLearning forward/backward +
 GraphWaveNet forward/backward + step_loss + gradient all-reduce (N>1) + clip_grad_norm_(3.0) + Adam.
 Prints ONE JSON line (rank 0).  Launch:  python bench.py [--gpus N --steps K --warmup W]
 (for N>1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...).
+
+"pre-trained TSFormer_PEMS04.pt loaded" (BASELINE config 2, step/step_arch/step.py:27-35): the checkpoint is produced before the
+timed region by tools/pretrain_checkpoint.py -- `--pretrain-steps` native masked-pre-training steps (the repository's own config-C3
+path) on the same synthetic series -- saved in the reference's format and loaded through `pre_trained_tsformer_path`.  The encoder's
+softmax schedule is data dependent (units whose scores outrun the fixed shift are redone by the re-shifting loop); the line reports
+how many did (`roofline.fallback_units_per_launch`) and a second figure with random-init weights (`random_init`).
+
+The frozen branch (TSFormer + kNN prior) of batch i+1 is queued on its own stream before the backward pass of batch i
+(`STEP.prefetch`, step_amd/step_arch/step.py): it reads nothing the optimizer updates, so its outputs are bit-identical
+(tests/test_gpu_step.py::test_prefetched_frozen_branch_is_bit_identical); every timed step still contains exactly one encoder
+launch.  `no_prefetch` is the same loop with the branch computed inside forward().
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,6 +41,7 @@ CONFIGS = {
     # BASELINE config 3: masked pre-training of TSFormer (reference step/TSFormer_PEMS-BAY.py: B=16... batch per GPU)
     "TSFormer_PEMS-BAY": dict(N=325, L=288 * 7, T_train=36482, T_all=52116, B=16, k=0, pretrain=True),
 }
+PEAK_TFLOPS = 2500.0            # dense bf16 / f16 MFMA peak, MI355X_MICROARCH.md
 
 
 def synth_series(T, N, seed=0):
@@ -40,34 +55,33 @@ def synth_series(T, N, seed=0):
     return np.stack([ch0, ch1, ch2], -1).astype(np.float32)
 
 
-def pmc_traffic(config, B):
-    """HBM bytes per encoder launch from the committed rocprofv3 PMC passes (profiles/encoder_pmc.json, produced by
-    tools/pmc_enc_ab.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md "HBM").  A counter run cannot be nested inside this process, so the number is NOT a measurement of
-    this run: it is looked up for the same kernel / config / batch and labelled "static": true; None when no matching
-    measurement is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "encoder_pmc.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        ent = rec.get(f"{config}:B{B}")
-        return None if ent is None else {"hbm_bytes_per_launch": ent["read_bytes"] + ent["write_bytes"], "read_bytes": ent["read_bytes"],
-                                          "write_bytes": ent["write_bytes"], "static": True, "source": ent["source"]}
-    except (OSError, ValueError, KeyError):
-        return None
+def tsformer_args(L, mode):
+    return dict(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=L / 12,
+                mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode=mode)
 
 
-def make_model(cfg, data):
+def make_model(cfg, data, ckpt=None):
     from step_amd import STEP
     N, L = cfg["N"], cfg["L"]
-    targs = dict(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=L / 12,
-                 mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode="forecasting")
     bargs = dict(num_nodes=N, support_len=2, dropout=0.3, gcn_bool=True, addaptadj=True, aptinit=None, in_dim=2, out_dim=12,
                  residual_channels=32, dilation_channels=32, skip_channels=256, end_channels=512, kernel_size=2, blocks=4, layers=2)
     dargs = dict(dataset_name="SYNTH", k=cfg["k"], input_seq_len=12, output_seq_len=12, data=data, train_length=cfg["T_train"],
                  tsformer_tokens=L // 12)
     torch.manual_seed(0)
-    return STEP("SYNTH", None, targs, bargs, dargs)
+    return STEP("SYNTH", ckpt, tsformer_args(L, "forecasting"), bargs, dargs)
+
+
+def native_checkpoint(name, cfg, data, steps, dev, workdir):
+    """tsformer_ckpt/TSFormer_<name>.pt made by `steps` native pre-training steps (tools/pretrain_checkpoint.py); returns
+    (path, info).  Outside every timed region."""
+    from tools.pretrain_checkpoint import pretrain
+    t0 = time.perf_counter()
+    sd, losses = pretrain(data, cfg["L"], steps=steps, batch=6, device=dev, matmul="bf16", seed=0)
+    path = os.path.join(workdir, "tsformer_ckpt", f"TSFormer_{name}.pt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"model_state_dict": sd}, path)
+    torch.cuda.synchronize()
+    return path, {"steps": steps, "batch": 6, "first_loss": losses[0], "last_loss": losses[-1], "seconds": time.perf_counter() - t0, "sd": sd}
 
 
 def encoder_flops(cfg, B):
@@ -75,6 +89,86 @@ def encoder_flops(cfg, B):
     N*P*(4*(221184 + 384*P) + 2304)."""
     P = cfg["L"] // 12
     return B * cfg["N"] * P * (4 * (221184 + 384 * P) + 2304)
+
+
+def step_flops(cfg, B):
+    """Algorithmic FLOPs of one whole training step: B * W_window + W_step."""
+    N, P, T = cfg["N"], cfg["L"] // 12, cfg["T_train"]
+    w_window = N * P * (4 * (221184 + 384 * P) + 2304) + 2 * N * N * P * 96 + 3 * (19968 * N * N + 2.66e6 * N)
+    w_step = 3 * (2 * N * (80 * (T - 9) + 1280 * (T - 18) + 1600 * (T - 18)) + N * N * 500 + 40000 * N)
+    return B * w_window + w_step
+
+
+def static_pmc_traffic(config, B):
+    """HBM bytes per encoder launch from the committed rocprofv3 PMC passes (profiles/encoder_pmc.json, tools/pmc_enc_ab.sh):
+    the fallback when no counter run can be made from inside this process (no rocprofv3 on the box)."""
+    path = os.path.join(ROOT, "profiles", "encoder_pmc.json")
+    try:
+        with open(path) as f:
+            ent = json.load(f).get(f"{config}:B{B}")
+        return None if ent is None else {"hbm_bytes_per_launch": ent["read_bytes"] + ent["write_bytes"], "read_bytes": ent["read_bytes"],
+                                          "write_bytes": ent["write_bytes"], "static": True, "source": ent["source"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def live_pmc_traffic(config, B, ckpt, timeout=240):
+    """HBM bytes of the encoder launch measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE -- they do
+    not fit one pass; --kernel-trace only, no other trace domain) over a child process that loads the same checkpoint and launches
+    the training-mode encoder at this config's size (bench.py --pmc-child).  Units and the gfx950 correction as
+    MI355X_MICROARCH.md "HBM" prescribes: both counters in KiB, FETCH_SIZE doubled.  None if rocprofv3 is unavailable or fails."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    import glob
+    import sqlite3
+    vals = {}
+    work = tempfile.mkdtemp(prefix="step_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = os.path.join(work, ctr)
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", ckpt or "-",
+               "--config", config, "--batch", str(B)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
+                cur = sqlite3.connect(db).cursor()
+                rows = cur.execute("""select p.name, sum(e.value), count(distinct d.id) from rocpd_pmc_event e
+                    join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id
+                    join rocpd_info_kernel_symbol s on d.kernel_id = s.id where s.kernel_name like '%tsformer_encoder_kernel%'
+                    group by p.name""").fetchall()
+                for name, total, n in rows:
+                    vals[name] = total / max(n, 1)
+        except Exception:          # noqa: BLE001 -- any failure of the optional counter run falls back to the committed measurement
+            pass
+    shutil.rmtree(work, ignore_errors=True)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    rd, wr = int(vals["FETCH_SIZE"] * 1024 * 2), int(vals["WRITE_SIZE"] * 1024)
+    return {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "static": False,
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) around `bench.py --pmc-child` in this run: "
+                      "same checkpoint, same launch size, dropout on; KiB counters, FETCH_SIZE x2 (gfx950)"}
+
+
+def pmc_child(args):
+    """Child of live_pmc_traffic: three training-mode encoder launches at the config's size, nothing else."""
+    from step_amd import TSFormer
+    cfg = dict(CONFIGS[args.config])
+    B = args.batch or cfg["B"]
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = TSFormer(**tsformer_args(cfg["L"], "forecasting")).to(dev)
+    if args.pmc_child != "-":
+        m.load_state_dict(torch.load(args.pmc_child, map_location="cpu")["model_state_dict"])
+    m.train()
+    S = B * cfg["N"]
+    rng = np.random.default_rng(0)
+    t = np.arange(cfg["L"], dtype=np.float32)[None]
+    x = np.sin(2 * np.pi * t / 288.0 + rng.uniform(0, 6.28, (S, 1)).astype(np.float32)) + 0.5 * rng.standard_normal((S, cfg["L"]), dtype=np.float32)
+    series = torch.from_numpy(x.astype(np.float32)).to(dev)
+    for _ in range(3):
+        m.encode_series(series)
+    torch.cuda.synchronize()
 
 
 def cpu_baseline(cfg, data, seed=0):
@@ -121,23 +215,57 @@ def cpu_baseline(cfg, data, seed=0):
             "two_threads": {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}}
 
 
-def average_grads(params, world):
-    """Data-parallel exchange step of the pre-training bench: one all-reduce (mean) over the flattened gradients
-    (2.67 MB at C3), the job DistributedDataParallel does for easytorch in the reference."""
+def average_grads(model, params, world):
+    """Data-parallel exchange step of the pre-training bench (the job DistributedDataParallel does for easytorch in the reference):
+    the native backward leaves every gradient in ONE flat buffer (TSFormer._flat_grad) that autograd adopts as the parameters'
+    .grad, so the exchange is one all-reduce (mean) of 2.67 MB with no flatten / scatter-back copies.  If autograd cloned instead
+    of adopting (checked by address), fall back to the flatten + scatter form."""
     if world <= 1:
         return
     import torch.distributed as dist
+    flat = model._flat_grad
+    lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
     grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
-    flat.mul_(1.0 / world)
+    if all(lo <= g.data_ptr() < hi for g in grads):
+        dist.all_reduce(flat)
+        flat.mul_(1.0 / world)
+        return
+    buf = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(buf)
+    buf.mul_(1.0 / world)
     off = 0
     for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
+        g.copy_(buf[off:off + g.numel()].view_as(g))
         off += g.numel()
 
 
-def pretrain_main(args, cfg, world, rank, dev):
+def timed_loop(step, warmup, steps, barrier, start=0):
+    """`warmup` untimed steps, then exactly `steps` timed ones between two barriers (+ device synchronize): seconds, per-step ms."""
+    for i in range(warmup):
+        step(start + i)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    marks[0].record()
+    out = None
+    for i in range(steps):
+        out = step(start + warmup + i)
+        marks[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)])
+    return dt, per_step, out
+
+
+def max_over_ranks(dt, world, dev):
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t)
+    return dt
+
+
+def pretrain_run(args, cfg, world, rank, dev, warmup, steps):
     """Config C3: one step = TSFormer masked pre-training forward + masked_mae + backward + clip(5.0) + Adam
     (reference step/TSFormer_PEMS-BAY.py:52-72), windows/s = sequences of L steps x N nodes per second."""
     import random
@@ -147,7 +275,7 @@ def pretrain_main(args, cfg, world, rank, dev):
     data = synth_series(cfg["T_all"], N)
     torch.manual_seed(0)
     random.seed(0)
-    model = TSFormer(12, 1, 96, 4, 4, 0.1, Lh / 12, 0.75, 4, 1, mode="pre-train").to(dev)
+    model = TSFormer(**tsformer_args(Lh, "pre-train")).to(dev)
     model.train()
     model.matmul_precision = args.matmul
     params = [p for p in model.parameters() if p.requires_grad]
@@ -164,39 +292,213 @@ def pretrain_main(args, cfg, world, rank, dev):
         recon, label = model(history_data=batches[i % len(batches)], future_data=None, batch_seen=i, epoch=1)
         loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
         loss.backward()
-        average_grads(params, world)
+        average_grads(model, params, world)
         torch.nn.utils.clip_grad_norm_(params, max_norm=5.0)
         opt.step()
         return loss
 
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tdt)
-    if rank == 0:
-        print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": B * world * args.steps / dt,
-                          "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": args.matmul, "data": "synthetic",
-                          "config": {"workload": f"TSFormer_PEMS-BAY pre-train: N={N}, L={Lh} (P={Lh // 12}, 42 unmasked), batch {B}/GPU, "
-                                                 "fwd+bwd" + ("+grad all-reduce" if world > 1 else "") + "+clip+Adam, unfused path, "
-                                                 + ("bf16 operands / f32 accumulate GEMMs" if args.matmul == "bf16" else "exact-f32 GEMMs"),
-                                     "global_batch": B * world, "parallelism": f"dp{world}",
-                                     "final_loss": float(loss.detach())}}), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    dt, per_step, loss = timed_loop(step, warmup, steps, barrier)
+    dt = max_over_ranks(dt, world, dev)
+    flops = B * 87.2e9
+    return {"value": B * world * steps / dt, "unit": "windows/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "whole_step_tflops": flops / (dt / steps) / 1e12, "whole_step_frac_of_mfma_peak": flops / (dt / steps) / 1e12 / PEAK_TFLOPS,
+            "workload": f"TSFormer_PEMS-BAY pre-train: N={N}, L={Lh} (P={Lh // 12}, 42 unmasked), batch {B}/GPU, fwd+bwd"
+                        + ("+grad all-reduce" if world > 1 else "") + "+clip+Adam, "
+                        + ("bf16 operands / f32 accumulate GEMMs" if args.matmul == "bf16" else "exact-f32 GEMMs"),
+            "final_loss": float(loss.detach())}
+
+
+class StepBench:
+    """One STEP config on this rank: model, resident batches, optimizer, step functions."""
+
+    def __init__(self, name, cfg, args, world, rank, dev, ckpt):
+        from step_amd.step_loss import step_loss_native
+        self.name, self.cfg, self.args, self.world, self.rank, self.dev = name, cfg, args, world, rank, dev
+        self.step_loss = step_loss_native
+        N, Lh, B = cfg["N"], cfg["L"], cfg["B"]
+        self.data = synth_series(cfg["T_all"], N)
+        self.model = make_model(cfg, self.data, ckpt).to(dev)
+        self.model.train()
+        self.model.matmul_precision = args.matmul
+        if args.eval_dropout_off:
+            self.model.backend.dropout = 0.0
+            self.model.tsformer.dropout_p = 0.0
+        if world > 1:
+            # SURVEY.md 8(f) row 2: each rank keeps one time slice of the graph learner's global branch and of fc.weight (bf16 mode)
+            self.model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim)
+        self.sharded = self.model.discrete_graph_learning._shard is not None
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        if args.torch_optim:
+            self.opt = torch.optim.Adam(self.params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)    # step/STEP_PEMS04.py:90-96
+        else:
+            from step_amd.optim import FusedAdamClip
+            self.opt = FusedAdamClip(self.model, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8, max_norm=3.0)   # same rule, one fused pass
+        self.dser = torch.from_numpy(self.data).to(dev)
+        rng = np.random.default_rng(1234 + rank)
+        self.batches = []
+        for _ in range(8):                               # resident input batches, cycled (119 MB each at C2)
+            ts = rng.integers(Lh, cfg["T_all"] - 12, size=B)
+            hist = torch.stack([self.dser[t - 12:t] for t in ts])
+            fut = torch.stack([self.dser[t:t + 12] for t in ts])
+            longh = torch.stack([self.dser[t - Lh:t] for t in ts])
+            self.batches.append((hist, longh, fut))
+        self.mean, self.std = 200.0, 150.0
+        self.prefetch = not args.no_prefetch
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def eval_step(self, i):
+        from step_amd.step_loss import masked_mae
+        hist, longh, fut = self.batches[i % len(self.batches)]
+        with torch.no_grad():
+            pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=None)
+            return masked_mae(pred[..., :1] * self.std + self.mean, fut[..., :1] * self.std + self.mean, 0.0)       # base_tsf_runner.py:257-318
+
+    def train_step(self, i, epoch=1):
+        hist, longh, fut = self.batches[i % len(self.batches)]
+        self.opt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
+        if self.prefetch:                 # the next batch's frozen branch (TSFormer + kNN prior) runs next to this batch's backward + Adam
+            self.model.prefetch(self.batches[(i + 1) % len(self.batches)][1])
+        # target-feature selection + inverse scaling, as the runner does (step_runner.py:86-92); slices, not index kernels
+        loss = self.step_loss(pred[..., :1] * self.std + self.mean, fut[..., :1] * self.std + self.mean, theta, knn, coef, null_val=0.0)
+        loss.backward()
+        if self.args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(self.params, max_norm=3.0)                    # STEP_PEMS04.py:103-105
+        self.opt.step()
+        return loss
+
+    def step(self, i):
+        return self.eval_step(i) if self.args.forward_only else self.train_step(i)
+
+    def run(self, warmup, steps, start=0):
+        """-> dict(value, ms_per_step, p10/p50/p90, encoder ms in-step, fallback units per launch, final loss)"""
+        m = self.model
+        if self.args.forward_only:
+            m.eval()
+        for i in range(warmup):
+            self.step(start + i)
+        m.tsformer._events = []
+        m.tsformer.fallback_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if self.world > 1:
+            m._reduce_wait_ms = []
+        dt, per_step, loss = timed_loop(self.step, 0, steps, self.barrier, start + warmup)
+        if self.world > 1:
+            m.collect_reduce_waits()
+        dt = max_over_ranks(dt, self.world, self.dev)
+        ev = m.tsformer._events
+        enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        launches = max(len(ev), 1)
+        slow = int(m.tsformer.fallback_counter.item())
+        m.tsformer._events, m.tsformer.fallback_counter = None, None
+        B = self.cfg["B"]
+        return {"value": B * self.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                "p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)), "p90": float(np.percentile(per_step, 90)),
+                "enc_ms": enc_ms, "enc_launches": len(ev), "fallback_units_per_launch": slow / launches, "final_loss": float(loss.detach())}
+
+    def softmax_units(self):
+        P = self.cfg["L"] // 12
+        return self.cfg["B"] * self.cfg["N"] * 4 * 4 * ((P + 31) // 32)
+
+    def encoder_alone_ms(self, start):
+        """the kernel's own duration: a few untimed steps with neither the second stream nor the prefetch next to it"""
+        m = self.model
+        keep = (m.overlap_streams, self.prefetch)
+        m.overlap_streams, self.prefetch = False, False
+        m._prefetched = None
+        m.tsformer._events = []
+        for i in range(6):
+            self.step(start + i)
+        torch.cuda.synchronize()
+        ev = m.tsformer._events[1:]
+        m.tsformer._events = None
+        m.overlap_streams, self.prefetch = keep
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+
+    def loader_figure(self, steps):
+        """the same step fed by the index-only loader over the device-resident series, forecast origins drawn over the
+        WHOLE training split -- including the windows that start before a full long history exists (all-zero history,
+        forecasting_dataset.py:66-67: 39 % of PEMS04's training windows) -- gather launches inside the timed region"""
+        from step_amd.step_arch.step import DeviceWindowLoader
+        cfg, B, Lh = self.cfg, self.cfg["B"], self.cfg["L"]
+        loader = DeviceWindowLoader(self.dser, Lh)
+        n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
+        lrng = np.random.default_rng(4321 + self.rank)
+        origins = [torch.from_numpy(lrng.integers(12, 12 + n_train, size=B)).to(self.dev) for _ in range(steps + 5)]
+        zero_frac = float(np.mean([float((o < Lh).float().mean()) for o in origins[3:]]))
+        state = {"next": loader.batch(origins[0])}
+
+        def loader_step(i):
+            hist, ref, fut = state["next"]
+            self.opt.zero_grad(set_to_none=True)
+            pred, theta, knn, coef = self.model(history_data=hist, long_history_data=ref, future_data=None, batch_seen=i, epoch=1)
+            state["next"] = loader.batch(origins[i + 1])          # the loader is one batch ahead, like a DataLoader's prefetch
+            if self.prefetch:
+                self.model.prefetch(state["next"][1])
+            loss = self.step_loss(pred[..., :1] * self.std + self.mean, fut[..., :1] * self.std + self.mean, theta, knn, coef, null_val=0.0)
+            loss.backward()
+            if self.args.torch_optim:
+                torch.nn.utils.clip_grad_norm_(self.params, max_norm=3.0)
+            self.opt.step()
+            return loss
+        self.model._prefetched = None
+        dtl, _, _ = timed_loop(loader_step, 3, steps, self.barrier)
+        dtl = max_over_ranks(dtl, self.world, self.dev)
+        self.model._prefetched = None
+        return {"value": B * self.world * steps / dtl, "unit": "windows/s", "ms_per_step": dtl / steps * 1e3, "steps": steps,
+                "zero_history_fraction": zero_frac,
+                "what": "same training step, windows gathered on the device from the resident series by forecast origin "
+                        "(step_gather_windows, LongHistoryRef), origins uniform over the training split, loader one batch ahead"}
+
+    def comm_figure(self):
+        """data-parallel exchange: the flat-gradient all-reduce alone (isolated) and the part of it the step does not hide"""
+        import torch.distributed as dist
+        model, dev, world = self.model, self.dev, self.world
+        lay = model._grad_layout()
+        fo, fn, _ = lay["items"]["dgl.fc_w"]
+        buf = torch.zeros(lay["total"], device=dev)
+        reps = 5
+        for _ in range(2):
+            dist.all_reduce(buf[:fo])          # (with time slices the fc chunk has a different length on every rank and is never reduced)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            if not self.sharded:
+                dist.all_reduce(buf[fo:fo + fn])
+            dist.all_reduce(buf[:fo])
+        e1.record()
+        torch.cuda.synchronize()
+        iso = e0.elapsed_time(e1) / reps
+        exposed = float(np.mean(model._reduce_wait_ms)) if model._reduce_wait_ms else float("nan")
+        small = model.collect_small_collectives() if hasattr(model, "collect_small_collectives") else None
+        t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t_ex) for _ in range(world)]
+        dist.all_gather(gathered, t_ex)
+        return {"allreduce_bytes": int((fo if self.sharded else lay["total"]) * 4),
+                "chunks": [int(fo * 4)] if self.sharded else [int(fn * 4), int(fo * 4)],
+                "graph_learner_time_slices": bool(self.sharded),
+                "per_rank_allreduce_ms_isolated": [float(g[0]) for g in gathered],
+                "per_rank_exposed_wait_ms": [float(g[1]) for g in gathered],
+                "overlap_fraction": [float(1.0 - g[1] / g[0]) if float(g[0]) > 0 else None for g in gathered],
+                "small_collectives": small,
+                "what": "isolated = the chunked all-reduces of the flat gradient alone; exposed = time the compute stream waits "
+                        "for them at the end of backward (events around the waits), averaged over the timed steps; small_collectives = "
+                        "count and exposed ms per step of the time-sliced graph learner's blocking sums"}
+
+    def close(self):
+        self.model._prefetched = None
+        del self.model, self.opt, self.batches, self.dser, self.params
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -208,6 +510,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loader-figure", action="store_true", help="skip the second timed loop through the device-resident window loader")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no random-init / no-prefetch / other-config figures, no counter run")
+    ap.add_argument("--other-configs", default=None, help="comma list of further configs measured after the headline (default: the three "
+                    "north-star configs at N=1, none at N>1; '-' = none)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic falls back to the committed record)")
+    ap.add_argument("--pretrain-steps", type=int, default=300, help="native TSFormer pre-training steps behind the loaded checkpoint (0: random init)")
+    ap.add_argument("--no-prefetch", action="store_true", help="compute the frozen branch inside forward() instead of a step ahead")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -215,7 +523,10 @@ def main():
                     help="validation / test path (SURVEY 8f-4): eval-mode forward + metric under no_grad, no backward / optimizer")
     ap.add_argument("--no-shard", action="store_true", help="--gpus > 1: keep the whole graph learner (and fc.weight) on every rank")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child is not None:
+        return pmc_child(args)
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
@@ -232,211 +543,150 @@ def main():
             dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
         else:
             dist.init_process_group(args.backend)                  # e.g. gloo: exercises the data-parallel path on one device
-    from step_amd.step_loss import step_loss_native as step_loss
     import step_amd._lib as L
     L.lib()
-
+    workdir = tempfile.mkdtemp(prefix=f"step_bench_r{rank}_")
     N, Lh, B = cfg["N"], cfg["L"], cfg["B"]
+
     if cfg.get("pretrain"):
-        return pretrain_main(args, cfg, world, rank, dev)
-    data = synth_series(cfg["T_all"], N)
-    model = make_model(cfg, data).to(dev)
-    model.train()
-    model.matmul_precision = args.matmul
-    if args.eval_dropout_off:
-        model.backend.dropout = 0.0
-        model.tsformer.dropout_p = 0.0
-    if world > 1:
-        # each rank keeps one time slice of the graph learner's global branch and of fc.weight (bf16 mode)
-        model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim)
-    sharded = model.discrete_graph_learning._shard is not None
-    params = [p for p in model.parameters() if p.requires_grad]
-    if args.torch_optim:
-        opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)    # step/STEP_PEMS04.py:90-96
-    else:
-        from step_amd.optim import FusedAdamClip
-        opt = FusedAdamClip(model, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8, max_norm=3.0)   # same rule, one fused pass
-    dser = torch.from_numpy(data).to(dev)
-    rng = np.random.default_rng(1234 + rank)
-    nb = args.steps + args.warmup
-    batches = []
-    for _ in range(min(nb, 8)):                       # resident input batches, cycled (119 MB each at C2)
-        ts = rng.integers(Lh, cfg["T_all"] - 12, size=B)
-        hist = torch.stack([dser[t - 12:t] for t in ts])
-        fut = torch.stack([dser[t:t + 12] for t in ts])
-        longh = torch.stack([dser[t - Lh:t] for t in ts])
-        batches.append((hist, longh, fut))
-    mean, std = 200.0, 150.0
-
-    def eval_step(i):
-        hist, longh, fut = batches[i % len(batches)]
-        with torch.no_grad():
-            pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=None)
-            from step_amd.step_loss import masked_mae
-            return masked_mae(pred[..., :1] * std + mean, fut[..., :1] * std + mean, 0.0)       # base_tsf_runner.py:257-318
-
-    def step(i, epoch=1):
-        if args.forward_only:
-            return eval_step(i)
-        hist, longh, fut = batches[i % len(batches)]
-        opt.zero_grad(set_to_none=True)
-        pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
-        # target-feature selection + inverse scaling, as the runner does (step_runner.py:86-92); slices, not index kernels
-        loss = step_loss(pred[..., :1] * std + mean, fut[..., :1] * std + mean, theta, knn, coef, null_val=0.0)
-        loss.backward()
-        if args.torch_optim:
-            torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)                    # STEP_PEMS04.py:103-105
-        opt.step()
-        return loss
-
-    def barrier():
+        r = pretrain_run(args, cfg, world, rank, dev, args.warmup, args.steps)
+        if rank == 0:
+            print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": r["value"], "unit": "windows/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "bf16 operands, f32 accumulate" if args.matmul == "bf16" else "f32", "data": "synthetic",
+                              "config": {"workload": r["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
+                                         "final_loss": r["final_loss"]},
+                              "whole_step": {"tflops": r["whole_step_tflops"], "frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"]}}), flush=True)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            torch.distributed.destroy_process_group()
+        return
 
-    if args.forward_only:
-        model.eval()
-    for i in range(args.warmup):
-        step(i)
-    model.tsformer._events = []
-    if world > 1:
-        model._reduce_wait_ms = []
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    barrier()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-        marks[i + 1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        model.collect_reduce_waits()
-    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
-    if world > 1:
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt)
-    ev = model.tsformer._events
-    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-    model.tsformer._events = None
-    # In the timed steps the graph learner and the WaveNet layers run on a second stream next to the encoder (step.py), so the
-    # encoder's launch-to-completion time above includes the compute units it lends them.  A few extra (untimed) steps with the
-    # overlap off give the kernel's own duration.
-    enc_alone_ms = None
-    if getattr(model, "overlap_streams", False) and not args.forward_only:
-        model.overlap_streams = False
-        model.tsformer._events = []
-        for i in range(6):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        ev2 = model.tsformer._events[1:]
-        enc_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in ev2])) if ev2 else None
-        model.tsformer._events = None
-        model.overlap_streams = True
-    # ---- second figure: the same step fed by the index-only loader over the device-resident series, forecast
-    # origins drawn over the WHOLE training split -- including the windows that start before a full long history exists
-    # (all-zero history, forecasting_dataset.py:66-67: 39 % of PEMS04's training windows) -- gather launches inside the timed region
-    loader_fig = None
-    if not args.forward_only and not args.no_loader_figure:
-        from step_amd.step_arch.step import DeviceWindowLoader
-        loader = DeviceWindowLoader(dser, Lh)
-        n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
-        lrng = np.random.default_rng(4321 + rank)
-        nl = max(args.steps // 2, 10)
-        origins = [torch.from_numpy(lrng.integers(12, 12 + n_train, size=B)).to(dev) for _ in range(nl + 3)]
-        zero_frac = float(np.mean([float((o < Lh).float().mean()) for o in origins[3:]]))
-
-        def loader_step(i):
-            hist, ref, fut = loader.batch(origins[i])
-            opt.zero_grad(set_to_none=True)
-            pred, theta, knn, coef = model(history_data=hist, long_history_data=ref, future_data=None, batch_seen=i, epoch=1)
-            loss = step_loss(pred[..., :1] * std + mean, fut[..., :1] * std + mean, theta, knn, coef, null_val=0.0)
-            loss.backward()
-            if args.torch_optim:
-                torch.nn.utils.clip_grad_norm_(params, max_norm=3.0)
-            opt.step()
-        for i in range(3):
-            loader_step(i)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(nl):
-            loader_step(3 + i)
-        barrier()
-        dtl = time.perf_counter() - t1
-        if world > 1:
-            tdl = torch.tensor([dtl], device=dev, dtype=torch.float64)
-            dist.all_reduce(tdl, op=dist.ReduceOp.MAX)
-            dtl = float(tdl)
-        loader_fig = {"value": B * world * nl / dtl, "unit": "windows/s", "ms_per_step": dtl / nl * 1e3, "steps": nl,
-                      "zero_history_fraction": zero_frac,
-                      "what": "same training step, windows gathered on the device from the resident series by forecast origin "
-                              "(step_gather_windows, LongHistoryRef), origins uniform over the training split"}
-    # ---- data-parallel exchange: the flat-gradient all-reduce alone (isolated) and the part of it the step does not hide
-    comm = None
-    if world > 1 and not args.forward_only:
-        lay = model._grad_layout()
-        fo, fn, _ = lay["items"]["dgl.fc_w"]
-        buf = torch.zeros(lay["total"], device=dev)
-        reps = 5
-        for _ in range(2):
-            dist.all_reduce(buf[:fo])          # (with time slices the fc chunk has a different length on every rank and is never reduced)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            if not sharded:
-                dist.all_reduce(buf[fo:fo + fn])
-            dist.all_reduce(buf[:fo])
-        e1.record()
-        torch.cuda.synchronize()
-        iso = e0.elapsed_time(e1) / reps
-        exposed = float(np.mean(model._reduce_wait_ms)) if model._reduce_wait_ms else float("nan")
-        t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
-        gathered = [torch.zeros_like(t_ex) for _ in range(world)]
-        dist.all_gather(gathered, t_ex)
-        comm = {"allreduce_bytes": int((fo if sharded else lay["total"]) * 4), "chunks": [int(fo * 4)] if sharded else [int(fn * 4), int(fo * 4)],
-                "graph_learner_time_slices": bool(sharded),
-                "per_rank_allreduce_ms_isolated": [float(g[0]) for g in gathered],
-                "per_rank_exposed_wait_ms": [float(g[1]) for g in gathered],
-                "overlap_fraction": [float(1.0 - g[1] / g[0]) if float(g[0]) > 0 else None for g in gathered],
-                "what": "isolated = the two chunked all-reduces of the flat gradient alone; exposed = time the compute stream waits "
-                        "for them at the end of backward (events around the waits), averaged over the timed steps"}
+    # ---- the checkpoint the model loads: native pre-training, before any timed region
+    ckpt, ckpt_info = None, None
+    if args.pretrain_steps > 0:
+        ckpt, ckpt_info = native_checkpoint(args.config.replace("STEP_", ""), cfg, synth_series(cfg["T_all"], N), args.pretrain_steps, dev, workdir)
+    bench = StepBench(args.config, cfg, args, world, rank, dev, ckpt)
+    res = bench.run(args.warmup, args.steps)
+    nxt = args.warmup + args.steps
+    extras = not args.no_extras
+    enc_alone_ms = bench.encoder_alone_ms(nxt) if (not args.forward_only and extras) else None
+    loader_fig = bench.loader_figure(max(args.steps // 2, 10)) if (not args.forward_only and not args.no_loader_figure and extras) else None
+    comm = bench.comm_figure() if (world > 1 and not args.forward_only) else None
+    # ---- secondary figures of the same config: frozen branch inside forward(); random-init TSFormer
+    no_prefetch, random_init = None, None
+    short = max(min(args.steps // 3, 40), 5)
+    if extras and not args.forward_only:
+        if bench.prefetch:
+            bench.prefetch = False
+            bench.model._prefetched = None
+            r2 = bench.run(3, short, nxt + 16)
+            no_prefetch = {"value": r2["value"], "unit": "windows/s", "ms_per_step": r2["ms_per_step"], "steps": short,
+                           "encoder_ms_per_launch": r2["enc_ms"],
+                           "what": "same step with the frozen branch (encoder + kNN prior) launched inside forward(), next to the second stream only"}
+            bench.prefetch = True
+        if ckpt is not None:
+            from step_amd import TSFormer
+            torch.manual_seed(0)
+            fresh = TSFormer(**tsformer_args(Lh, "forecasting")).state_dict()
+            bench.model.tsformer.load_state_dict(fresh)
+            r3 = bench.run(3, short, nxt + 64)
+            random_init = {"value": r3["value"], "unit": "windows/s", "ms_per_step": r3["ms_per_step"], "steps": short,
+                           "encoder_ms_per_launch": r3["enc_ms"], "fallback_units_per_launch": r3["fallback_units_per_launch"],
+                           "what": "same step with the TSFormer at its random initialisation (no checkpoint): the encoder's softmax schedule is data dependent"}
+            bench.model.tsformer.load_state_dict(ckpt_info["sd"])
+    sharded = bench.sharded
+    units = bench.softmax_units()
+    data = bench.data
+    bench.close()
+    # ---- the other north-star configs (short loops, after and outside the headline's timed region)
+    others = None
+    names = args.other_configs
+    if names is None:
+        names = "STEP_PEMS07,SYNTH_4096,TSFormer_PEMS-BAY" if (world == 1 and extras and not args.forward_only and args.config == "STEP_PEMS04") else "-"
+    if names != "-":
+        others = {}
+        for name in [n for n in names.split(",") if n]:
+            try:
+                c2 = dict(CONFIGS[name])
+                if c2.get("pretrain"):
+                    r = pretrain_run(args, c2, world, rank, dev, 5, 15)
+                    others[name] = {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": 15,
+                                    "whole_step_frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"], "workload": r["workload"]}
+                else:
+                    ck2 = None
+                    if args.pretrain_steps > 0:
+                        ck2, _ = native_checkpoint(name.replace("STEP_", ""), c2, synth_series(c2["T_all"], min(c2["N"], 512)), min(args.pretrain_steps, 100), dev, workdir)
+                    b2 = StepBench(name, c2, args, world, rank, dev, ck2)
+                    r = b2.run(8, 20)
+                    fl = step_flops(c2, c2["B"])
+                    others[name] = {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": 20,
+                                    "encoder_ms_per_launch": r["enc_ms"], "fallback_units_per_launch": r["fallback_units_per_launch"],
+                                    "whole_step_tflops": fl / (r["ms_per_step"] * 1e-3) / 1e12,
+                                    "whole_step_frac_of_mfma_peak": fl / (r["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS,
+                                    "workload": f"{name}: N={c2['N']}, L={c2['L']}, batch {c2['B']}/GPU, full train step, natively pre-trained TSFormer"}
+                    b2.close()
+            except Exception as ex:          # noqa: BLE001 -- a failing extra must not take the headline line with it
+                others[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0:
         flops = encoder_flops(cfg, B)
+        enc_ms = res["enc_ms"]
         ach = flops / (enc_ms * 1e-3) / 1e12
+        traffic = None
+        if extras and not args.no_pmc and world == 1:
+            traffic = live_pmc_traffic(args.config, B, ckpt)
+        if traffic is None:
+            traffic = static_pmc_traffic(args.config, B)
+        wl = (f"{args.config}: N={N} nodes, long history L={Lh} (P={Lh // 12} patches), 12->12, train series T={cfg['T_train']}, batch {B}/GPU, "
+              + (f"pre-trained TSFormer (native C3 path, {ckpt_info['steps']} steps, masked MAE {ckpt_info['first_loss']:.1f} -> {ckpt_info['last_loss']:.1f}) "
+                 f"loaded from tsformer_ckpt/, " if ckpt_info else "random-init weights, ")
+              + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)")
+              + (", frozen branch of the next batch prefetched on its own stream" if (bench.prefetch and not args.forward_only) else ""))
+        sfl = step_flops(cfg, B)
         out = {
             "metric": ("validation windows/sec (eval-mode forward + masked MAE)" if args.forward_only else
                        "training windows/sec on PEMS04, horizon-12 MAE parity, 1/2/4/8 MI355X"),
-            "value": B * world * args.steps / dt, "unit": "windows/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.matmul == "bf16" else "bf16 (TSFormer) + f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: N={N} nodes, long history L={Lh} (P={Lh // 12} patches), 12->12, "
-                                   f"train series T={cfg['T_train']}, batch {B}/GPU, random-init weights, "
-                                   + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)"),
-                       "global_batch": B * world,
+            "value": res["value"], "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": ("f16 (TSFormer Q/K/weights) + bf16 (P, V, GraphWaveNet / graph-learner GEMMs) operands, f32 accumulate" if args.matmul == "bf16"
+                      else "f16/bf16 operands (TSFormer) + f32 (everything else), f32 accumulate"),
+            "data": "synthetic",
+            "config": {"workload": wl, "global_batch": B * world,
                        "parallelism": f"dp{world}" + (" + graph-learner time slices (fc.weight sharded)" if sharded else ""),
-                       "final_loss": float(loss.detach())},
-            "step_ms": {"p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)),
-                        "p90": float(np.percentile(per_step, 90))},
-            "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": 2500.0,
-                         "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": pmc_traffic(args.config, B), "ms_per_launch": enc_ms,
+                       "final_loss": res["final_loss"]},
+            "step_ms": {"p10": res["p10"], "p50": res["p50"], "p90": res["p90"]},
+            "whole_step": {"algorithmic_flop": sfl, "tflops": sfl / (res["ms_per_step"] * 1e-3) / 1e12,
+                           "frac_of_mfma_peak": sfl / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS},
+            "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": traffic, "ms_per_launch": enc_ms,
+                         "launches_in_timed_region": res["enc_launches"],
                          "algorithmic_flop_per_launch": flops,
                          "ms_per_launch_alone": enc_alone_ms,
                          "achieved_alone": (flops / (enc_alone_ms * 1e-3) / 1e12) if enc_alone_ms else None,
-                         "note": "achieved / ms_per_launch: events around the kernel inside the timed steps, where it shares the GPU with the "
-                                 "second stream's kernels (graph learner + WaveNet layers); *_alone: the same kernel in 5 extra steps with "
-                                 "the overlap off"},
+                         "frac_alone": (flops / (enc_alone_ms * 1e-3) / 1e12 / PEAK_TFLOPS) if enc_alone_ms else None,
+                         "fallback_units_per_launch": res["fallback_units_per_launch"], "softmax_units_per_launch": units,
+                         "note": "achieved / ms_per_launch: events around the kernel on its launch stream inside the timed steps, where it shares "
+                                 "the GPU with the backward pass of the previous batch (prefetch stream) or the second stream's kernels; *_alone: "
+                                 "the same kernel in 5 extra steps with nothing next to it; fallback_units: (32-token tile, head, layer, "
+                                 "sequence) units whose softmax left the fixed-shift schedule (device counter)"},
         }
+        if no_prefetch is not None:
+            out["no_prefetch"] = no_prefetch
+        if random_init is not None:
+            out["random_init"] = random_init
         if loader_fig is not None:
             out["device_loader"] = loader_fig
         if comm is not None:
             out["data_parallel"] = comm
+        if others is not None:
+            out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, data)
         print(json.dumps(out), flush=True)
+    shutil.rmtree(workdir, ignore_errors=True)
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -90,19 +90,24 @@ int step_gemm(const StepGemm* g, void* stream);
  *              from drop_pool: pool_words (a power of two, >= 2 * step_tsformer_dropout_words(L, depth)) 64-bit words of
  *              Bernoulli(1 - dropout_p) bits written by step_dropout_pool_fill(dropout_p) -- bit l of a word is lane l's
  *              keep flag for one accumulator register.  Sequence s, layer l reads the step_tsformer_dropout_words() words
- *              that start at word ((mix32(seed32 + s*0x9E3779B1 + (l+1)*0x632BE5AB) << 4) mod pool_words) (wrapping); the
+ *              that start at word (mix32(seed32 + s*0x9E3779B1 + (l+1)*0x632BE5AB) mod pool_words) (wrapping; the buffer holds
+ *              pool_words + 16 words, the last 16 a copy of the first 16, which step_dropout_pool_fill writes); the
  *              layout inside that window is documented in csrc/tsformer_device.h and mirrored by tests/enc_dropout_host.py.
  *              The pool is only read.  Refill it (new seed) before every training step.
+ *  fallback_count  optional device counter (NULL: off): += number of (32-token tile, head, layer, sequence) units whose softmax
+ *              left the fixed-shift fast schedule and ran the re-shifting loop (the kernel's data-dependent slow path); of
+ *              S * depth * 4 * ceil(P / 32) units per launch.
  */
 #define STEP_ENC_F16 1
 #define STEP_ENC_ALWAYS_RESHIFT 2
 int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
                          int depth, int flags, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
                          float* sqnorm_part, float dropout_p, const uint64_t* drop_pool, long pool_words, uint64_t seed,
-                         void* stream);
+                         unsigned int* fallback_count, void* stream);
 /* Keep-mask pool for the encoder's dropout: word w, bit l = (Philox4x32-10(counter = (w, w >> 32, l / 4, 0x5EEDD80F),
- * key = (seed, seed >> 32))[l % 4] >= dropout_p * 2^32).  `words` must be a power of two >= 16.  Replaces the device
- * generator draws of torch.nn.functional.dropout at the sites listed above. */
+ * key = (seed, seed >> 32))[l % 4] >= dropout_p * 2^32).  `words` must be a power of two >= 16 and the buffer must hold
+ * words + 16 words: the first 16 are repeated behind the pool.  Replaces the device generator draws of
+ * torch.nn.functional.dropout at the sites listed above. */
 int step_dropout_pool_fill(uint64_t* pool, long words, float dropout_p, uint64_t seed, void* stream);
 long step_tsformer_dropout_words(int L, int depth);       /* mask words one (sequence, layer) reads; 0 on bad arguments */
 

@@ -58,7 +58,7 @@ _SIGS = {
     "step_last_error": (ctypes.c_char_p, []),
     "step_abi_version": (_i, []),
     "step_gemm": (_i, [ctypes.POINTER(StepGemm), _vp]),
-    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _l, _u64, _vp]),
+    "step_tsformer_encode": (_i, [_vp, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _l, _u64, _vp, _vp]),
     "step_dropout_pool_fill": (_i, [_vp, _l, _f, _u64, _vp]),
     "step_tsformer_dropout_words": (_l, [_i, _i]),
     "step_gather_windows": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -111,7 +111,7 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
 
 

@@ -19,7 +19,8 @@ struct EncArgs {
                                              // of the packed fmas, not loop-invariant vector register pairs that end up in scratch
     uint32_t seed;
     const unsigned long long* pool;          // Bernoulli(keep) lane-mask words (step_dropout_pool_fill); NULL when dropout is off
-    uint32_t pool_mask;                      // number of pool words - 1 (a power of two, multiple of 16)
+    uint32_t pool_mask;                      // number of pool words - 1 (a power of two); 16 more words (a copy of the first 16) follow
+    unsigned int* fallback;                  // optional counter: (wave, head) pairs that ran the re-shifting softmax loop; NULL = not counted
     bool f16;          // operand fragments of wpack are float16 (else bfloat16)
     bool always_rescale;                     // test hook: take the softmax re-shift path on every key tile
 };
@@ -60,8 +61,11 @@ __device__ __forceinline__ typename Opnd<F16>::v8 pack_half(const f32x16& v, int
 // are not generated in this kernel: they are read with scalar loads (s_load_dwordx8/x16, no vector-ALU work at all) from a pool
 // of Bernoulli(keep) bits that step_dropout_pool_fill() regenerates from the step's seed (Philox4x32-10) before every launch,
 // and applied with ONE v_cndmask_b32 per element (the mask is the instruction's SGPR-pair operand).  Every (sequence, layer)
-// owns a contiguous window of the pool ("chunk") at a hashed, 16-word aligned offset; inside the chunk every site has its own
-// words, so no two elements of one (sequence, layer) ever share a bit (tests/enc_dropout_host.py mirrors this layout):
+// owns a contiguous window of the pool ("chunk") at a hashed offset of WORD granularity (scalar loads only need dword alignment),
+// so two chunks that overlap are shifted against each other by a whole number of registers unless their bases coincide exactly
+// (probability 1 / pool words per pair; tests/test_encoder_dropout_pool.py counts them).  The pool is followed by a copy of its
+// first 16 words, so a 16-word group that starts in the last 15 words reads on without wrapping.  Inside the chunk every site
+// has its own words, so no two elements of one (sequence, layer) ever share a bit (tests/enc_dropout_host.py mirrors this layout):
 //     attention probabilities  (head hd, query tile = wave, key tile kt)   ATT + ((hd*nkt + wave)*nkt + kt)*16 + reg
 //     FFN hidden units         (wave, chunk ch of 32 units)                FFN + (wave*12 + ch)*16 + reg
 //     dropout1 / dropout2      (wave, 32-feature block t)                  D1 / D2 + (wave*3 + t)*16 + reg
@@ -80,7 +84,7 @@ struct DropLayout {
     }
 };
 __device__ __forceinline__ uint32_t drop_chunk_base(uint32_t seed, uint32_t seq, uint32_t layer, uint32_t pool_mask) {
-    return (mix32(seed + seq * 0x9E3779B1u + (layer + 1u) * 0x632BE5ABu) << 4) & pool_mask;
+    return mix32(seed + seq * 0x9E3779B1u + (layer + 1u) * 0x632BE5ABu) & pool_mask;
 }
 // The pool is read through the constant address space: that is what lets hipcc use scalar loads for it (a plain global
 // pointer inside the by-value argument struct is not provably unclobbered, and would be fetched with vector loads +
@@ -126,6 +130,41 @@ __device__ __forceinline__ void add_residual_op(f32x16 (&acc)[3], const typename
     }
 }
 
+// the lane id, recomputed (two VALU ops) instead of kept alive: `volatile` keeps the compiler from merging it with earlier copies
+__device__ __forceinline__ int fresh_lane_id() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// The same tail with the residual on the matrix cores: acc = keep-mask(acc) + c * x, i.e. c times what add_residual_op computes
+// with scale 1 / c (the LayerNorm that follows is invariant to the common factor once its eps is scaled by c^2).  x is the 16-bit
+// operand copy, already in B-operand layout; the A operand is c times the identity in the chain k-slot order of tsformer_layout.h:
+// row r of k-step s sits in slot j of lane-half h where r = 16 s + 8 (j >> 2) + 4 h + (j & 3).
+template <bool F16>
+__device__ __forceinline__ void add_residual_mfma(f32x16 (&acc)[3], const typename Opnd<F16>::v8 (&xb)[6], const mask_ptr (&w)[3], float c) {
+    typedef typename Opnd<F16>::v8 op8;
+    typedef typename Opnd<F16>::elem ope;
+    const int lane = fresh_lane_id();
+    const int r = lane & 31, h = lane >> 5;
+    op8 id[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int d = r - 16 * s - 4 * h;
+        const bool ok = d >= 0 && d < 16 && !(d & 4);
+        const int j = ((d >> 3) << 2) | (d & 3);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) id[s][jj] = (ok && j == jj) ? (ope)c : (ope)0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_amdgcn_inverse_ballot_w64(w[t][i]) ? acc[t][i] : 0.f;
+        acc[t] = mfma16<F16>(id[0], xb[2 * t], acc[t]);
+        acc[t] = mfma16<F16>(id[1], xb[2 * t + 1], acc[t]);
+    }
+}
+
 // value of the 16-bit operand type nearest to x (what the MFMA will see when x is stored into an operand slot)
 template <bool F16>
 __device__ __forceinline__ float round_to_operand(float x) {
@@ -137,13 +176,6 @@ __device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
-}
-
-// the lane id, recomputed (two VALU ops) instead of kept alive: `volatile` keeps the compiler from merging it with earlier copies
-__device__ __forceinline__ int fresh_lane_id() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
 }
 
 // sum over the 64 lanes: xor butterflies inside each half on the LDS crossbar (ds_swizzle, bit mode), then the two halves
@@ -167,7 +199,7 @@ __device__ __forceinline__ float wave_sum_swz(float v) {
 #define TSF_LN_PACKED 1      // 0: the scalar reduction chains of the first version (A/B builds)
 #endif
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
+__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb, float eps = 1e-5f) {
     if (TSF_ABLATE & 128) return;
     float s, q;
     if (TSF_LN_PACKED) {
@@ -219,7 +251,7 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
         both_halves(q, lo, hi);
         q = lo + hi;
     }
-    const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
+    const float rstd = rsqrtf(q * (1.0f / 96.0f) + eps);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll

@@ -72,6 +72,15 @@ constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
 template <int MAXW, bool PARK>
 constexpr int parked_frags() { return PARK ? 6 : (MAXW == 12 && TSF_PARK1) ? 1 : 0; }
 
+#ifndef TSF_SUM_SCALAR
+#define TSF_SUM_SCALAR 0    // 1: softmax row sums as four chains of plain v_add_f32 instead of two chains of v_pk_add_f32 (A/B builds)
+#endif
+#ifndef TSF_RES_MFMA
+#define TSF_RES_MFMA 0      // 1 (training mode): the residual re-enters through the matrix cores (identity operand x 16-bit operand copy) instead of
+#endif                      // 48 conversions + 48 fmas on the vector ALU per site; the survivor scale moves to the identity (LayerNorm is scale invariant)
+#ifndef TSF_STATIC_PRIO
+#define TSF_STATIC_PRIO 0   // 1: the later-dispatched half of the workgroup's waves runs at s_setprio 1 for the whole kernel (A/B builds)
+#endif
 #ifndef TSF_BATCH_FRAGS
 #define TSF_BATCH_FRAGS 0   // 1: scheduling fences around the batched weight-fragment reads (measured: forces the operand copy into scratch, 1.93 -> 2.22 ms)
 #endif
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     };
 
     issue_fill(0);
+    if (TSF_STATIC_PRIO && wave * 2 >= nkt) __builtin_amdgcn_s_setprio(1);
 
     // ------------------------------------------------------------------ patch embedding + pos
     f32x16 xT[3];
@@ -307,6 +317,27 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             for (int i = 0; i < 16; ++i) o[i] = 0.f;
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             f32x2 lsum2 = {0.f, 0.f}, lsum2b = {0.f, 0.f};
+            auto row_sums = [&](const f32x16& pr) {
+                if (TSF_SUM_SCALAR) {
+                    // plain adds, kept unpacked (the optimiser would re-fuse adjacent f32 adds into v_pk_add_f32)
+                    float a0 = lsum2[0], a1 = lsum2[1], a2 = lsum2b[0], a3 = lsum2b[1];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        asm("v_add_f32 %0, %1, %2" : "=v"(a0) : "v"(a0), "v"(pr[i]));
+                        asm("v_add_f32 %0, %1, %2" : "=v"(a1) : "v"(a1), "v"(pr[i + 1]));
+                        asm("v_add_f32 %0, %1, %2" : "=v"(a2) : "v"(a2), "v"(pr[i + 2]));
+                        asm("v_add_f32 %0, %1, %2" : "=v"(a3) : "v"(a3), "v"(pr[i + 3]));
+                    }
+                    lsum2 = f32x2{a0, a1};
+                    lsum2b = f32x2{a2, a3};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {                          // v_pk_add_f32, two independent chains
+                        lsum2 += f32x2{pr[i], pr[i + 1]};
+                        lsum2b += f32x2{pr[i + 2], pr[i + 3]};
+                    }
+                }
+            };
             float shift = 0.f;                       // what slot 25 currently subtracts (a value of the operand type)
             // test hook: re-shift whenever a tile holds a new running maximum (classic online softmax) instead of only
             // when the head room is used up
@@ -386,13 +417,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     if constexpr (drop && !TSF_MASK_EARLY) tm = load_mask(kt);
                     exp_tile(cur, cur);
                     if constexpr (drop) {
-                        if (!(TSF_ABLATE & 16)) {
-#pragma unroll
-                            for (int i = 0; i < 16; i += 4) {                          // v_pk_add_f32, two independent chains
-                                lsum2 += f32x2{cur[i], cur[i + 1]};
-                                lsum2b += f32x2{cur[i + 2], cur[i + 3]};
-                            }
-                        }
+                        if (!(TSF_ABLATE & 16)) row_sums(cur);
                     }
                     finish_tile(cur, kt, tm);
                 }
@@ -413,13 +438,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 exp_tile(cur, cur);
-                if constexpr (drop) {
-#pragma unroll
-                    for (int i = 0; i < 16; i += 4) {
-                        lsum2 += f32x2{cur[i], cur[i + 1]};
-                        lsum2b += f32x2{cur[i + 2], cur[i + 3]};
-                    }
-                }
+                if constexpr (drop) row_sums(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NEXT) {
                     nxt = mfma16<F16>(k0, qb[0], zero);
@@ -480,6 +499,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     if (h == 0) qb[1][5] = (ope)0.0f;
                 }
             }
+            if (redo && A.fallback != nullptr && fresh_lane_id() == 0) atomicAdd(A.fallback, 1u);
             if (!redo) {
             } else if (TSF_ABLATE & 32) {
             } else if constexpr (PIPE == 2) {
@@ -535,9 +555,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             }
             const mask_ptr w1[3] = {mask_words(chunk, dl.d1 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 1) * 16u),
                                     mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 2) * 16u)};
-            add_residual_op<F16>(acc, xb, w1, inv_keep);
+            if (TSF_RES_MFMA) add_residual_mfma<F16>(acc, xb, w1, keep);
+            else add_residual_op<F16>(acc, xb, w1, inv_keep);
         }
-        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
+        // (TSF_RES_MFMA: the sum above is keep x the reference's; LayerNorm undoes the scale exactly when eps is scaled with it)
+        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48(), (drop && TSF_RES_MFMA) ? 1e-5f * keep * keep : 1e-5f);      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
         blk = stage_begin(g, PAIR ? 3 : 1);
@@ -612,9 +634,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         if constexpr (drop) {
             const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 1) * 16u),
                                     mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 2) * 16u)};
-            add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
+            if (TSF_RES_MFMA) add_residual_mfma<F16>(acc, xb, w2, keep * keep);
+            else add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
         }
-        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
+        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48(), (drop && TSF_RES_MFMA) ? 1e-5f * (keep * keep) * (keep * keep) : 1e-5f);      // LN2 params ride in the last ffn block
 #pragma unroll
         for (int t = 0; t < 3; ++t) xT[t] = acc[t];
     }  // layers
@@ -744,7 +767,11 @@ __global__ __launch_bounds__(256) void dropout_pool_kernel(unsigned long long* _
     uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) { lo |= __shfl_xor(lo, o, 64); hi |= __shfl_xor(hi, o, 64); }
-    if (q == 0 && w < words) pool[w] = ((unsigned long long)hi << 32) | lo;
+    if (q == 0 && w < words) {
+        const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+        pool[w] = v;
+        if (w < 16) pool[words + w] = v;          // the wrap-around copy behind the pool (see tsformer_device.h)
+    }
 }
 
 }  // namespace
@@ -769,7 +796,7 @@ extern "C" long step_tsformer_dropout_words(int L, int depth) {
 extern "C" int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
                                     int depth, int flags, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
                                     float* sqnorm_part, float dropout_p, const uint64_t* drop_pool, long pool_words, uint64_t seed,
-                                    void* stream) {
+                                    unsigned int* fallback_count, void* stream) {
     STEP_REQUIRE(series && wpack, "tsformer_encode: null input");
     STEP_REQUIRE(S > 0 && L > 0 && L % TSF_PATCH == 0, "tsformer_encode: L=%d must be a positive multiple of %d", L, TSF_PATCH);
     const int P = L / TSF_PATCH;
@@ -793,6 +820,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.sqn = sqnorm_part; a.keep = 1.0f - dropout_p; a.inv_keep = 1.0f / a.keep; a.inv_keep2 = a.inv_keep * a.inv_keep; a.seed = (uint32_t)(seed ^ (seed >> 32));
     a.pool = dr ? (const unsigned long long*)drop_pool : nullptr;
     a.pool_mask = dr ? (uint32_t)(pool_words - 1) : 0u;
+    a.fallback = fallback_count;
     a.f16 = (flags & STEP_ENC_F16) != 0;
     a.always_rescale = (flags & STEP_ENC_ALWAYS_RESHIFT) != 0;
     hipStream_t st = (hipStream_t)stream;

@@ -72,20 +72,11 @@ class _StepFunction(torch.autograd.Function):
         training = model.training
         st = L.stream()
         hist = hist.contiguous().float()
-        # ---- TSFormer (frozen): [B,L,N,C] -> hidden bf16 [B*N, P, 96]
-        series = _f32(B * N * Lh, dev).view(B * N, Lh)
-        if isinstance(long_hist, LongHistoryRef):          # index-only loader: gather straight from the resident series
-            d = long_hist.data
-            L.call("step_gather_windows", L.ptr(d), d.shape[0], d.shape[1], d.shape[2], 0, L.ptr(long_hist.t0), B, Lh, 12,
-                   L.ptr(series), None, None, st)
-        else:
-            long_hist = long_hist.contiguous().float()
-            L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
+        frozen = model._take_prefetched(long_hist)      # the frozen branch of this batch, if STEP.prefetch() already queued it
         # Everything up to the GraphWaveNet head is independent of the (frozen) TSFormer: the DGL's global feature, the edge
         # logits, the Gumbel sample and the 8 WaveNet layers only need the train series, the short history and the weights.
         # They are queued on a second stream next to the encoder: its workgroups keep the compute units busy while that chain of
         # small, latency-bound kernels advances.  Buffers are allocated on the main stream and outlive the join below.
-        P = Lh // 12
         dgl, be = model.discrete_graph_learning, model.backend
         dt = dgl.native_tensors()
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
@@ -95,9 +86,6 @@ class _StepFunction(torch.autograd.Function):
         Ttr = dgl.train_length if sh is None else sh["Ts"]
         series_nt = dgl._series_nt if sh is None else dgl._series_slice
         drop = be.dropout if training else 0.0
-        sim = _f32(B * N * N, dev).view(B, N, N)
-        adj_knn = _f32(B * N * N, dev).view(B, N, N)
-        kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
         gsaved = _f32(L.lib().step_dgl_global_saved_floats(N, Ttr), dev)
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 0), dev)
         g = _f32(N * 100, dev).view(N, 100)
@@ -113,6 +101,7 @@ class _StepFunction(torch.autograd.Function):
         if side is not None:
             ready = torch.cuda.Event()
             ready.record(main)              # inputs, weights (the previous optimizer step) and the noise are ordered before this point
+        P = Lh // 12
 
         def graph_and_layers(sst):
             if sh is None:
@@ -134,20 +123,26 @@ class _StepFunction(torch.autograd.Function):
             L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct), int(training),
                    float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, sst)
 
-        # ---- TSFormer (frozen) and the kNN prior graph (no grad) on the main stream
-        enc = model.tsformer.encode_series(series)
+        # ---- TSFormer (frozen) and the kNN prior graph (no grad): on the main stream, or already in flight on the prefetch stream
+        if frozen is None:
+            frozen = model._frozen_branch(long_hist, B, N)
         if side is not None:
             side.wait_event(ready)
-            with torch.cuda.stream(side):
-                graph_and_layers(L.stream())
-                joined = torch.cuda.Event()
-                joined.record(side)
-        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, dgl.k * N, L.ptr(sim),
-               L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
-        if side is not None:
-            main.wait_event(joined)
+            try:
+                with torch.cuda.stream(side):
+                    hist.record_stream(side)
+                    if u is not None:
+                        u.record_stream(side)
+                    graph_and_layers(L.stream())
+            finally:
+                # the join is queued even when a launch above raised: buffers handed back to the allocator must not be
+                # re-used by main-stream work while side-stream kernels may still write them
+                main.wait_stream(side)
         else:
             graph_and_layers(st)
+        if frozen["done"] is not None:
+            main.wait_event(frozen["done"])
+        enc, sim, adj_knn = frozen["enc"], frozen["sim"], frozen["adj_knn"]
         # ---- GraphWaveNet head: the only consumer of the TSFormer's last hidden state
         L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), None, ctypes.byref(bstruct), int(training),
                float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), 2, st)
@@ -257,6 +252,8 @@ class STEP(nn.Module):
         self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
         self._side = {}
+        self._prefetched = None             # record of the frozen branch queued by prefetch() for the next batch
+        self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
         self._reduce_events = []
 
@@ -271,6 +268,87 @@ class STEP(nn.Module):
     # ------------------------------------------------------------------ helpers
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
+    # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
+    def _frozen_branch(self, long_hist, B, N):
+        """[B,L,N,C] long history (or a LongHistoryRef) -> TSFormer hidden states -> cosine kNN prior graph, queued on the CURRENT
+        stream.  Depends only on the input and the frozen TSFormer (step.py:34-35, discrete_graph_learning.py:139,164-166):
+        no parameter the optimizer touches is read, which is what lets prefetch() run it a step ahead."""
+        L = _lib
+        st = L.stream()
+        dev = self.backend.nodevec1.device
+        Lh = long_hist.shape[1]
+        series = _f32(B * N * Lh, dev).view(B * N, Lh)
+        if isinstance(long_hist, LongHistoryRef):          # index-only loader: gather straight from the resident series
+            d = long_hist.data
+            L.call("step_gather_windows", L.ptr(d), d.shape[0], d.shape[1], d.shape[2], 0, L.ptr(long_hist.t0), B, Lh, 12,
+                   L.ptr(series), None, None, st)
+        else:
+            long_hist = long_hist.contiguous().float()
+            L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
+        P = Lh // 12
+        enc = self.tsformer.encode_series(series)
+        sim = _f32(B * N * N, dev).view(B, N, N)
+        adj_knn = _f32(B * N * N, dev).view(B, N, N)
+        kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
+        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, self.discrete_graph_learning.k * N,
+               L.ptr(sim), L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
+        return {"enc": enc, "sim": sim, "adj_knn": adj_knn, "held": (series, kwork, long_hist), "done": None}
+
+    @staticmethod
+    def _batch_key(long_hist):
+        t = long_hist.t0 if isinstance(long_hist, LongHistoryRef) else long_hist
+        return (t.data_ptr(), tuple(t.shape), t._version, bool(isinstance(long_hist, LongHistoryRef)))
+
+    def prefetch(self, long_history_data):
+        """Queue the frozen branch (TSFormer encoder + kNN prior) of an UPCOMING batch on its own stream, so that it runs next to
+        the backward pass and optimizer step of the current one.  Legal because the TSFormer is frozen in this stage
+        (step.py:34-35): nothing the optimizer updates is read, and the branch's outputs are bit-identical to computing them inside
+        forward() -- dropout seeds are drawn per encoder launch in the same order either way.  forward() recognises the batch by
+        the identity of ``long_history_data`` (storage, shape, version) and falls back to the inline path for any other input.
+        Training-loop use:  ``out = model(batch_i); model.prefetch(long_history_of_batch_i+1); loss.backward(); opt.step()``."""
+        if not self.prefetch_enabled:
+            return
+        if isinstance(long_history_data, LongHistoryRef):
+            dev = long_history_data.data.device
+        else:
+            if not long_history_data.is_cuda:
+                raise RuntimeError("step_amd.STEP runs only on an AMD GPU: libstep_hip has no CPU fallback")
+            dev = long_history_data.device
+        B, _, N, _ = long_history_data.shape
+        main = torch.cuda.current_stream()
+        ps = self._prefetch_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)                  # the batch (a gather on the main stream) and any inline encoder launch come first
+        ps.wait_event(ready)
+        mode = self.training
+        with torch.cuda.stream(ps):
+            rec = self._frozen_branch(long_history_data, B, N)
+            rec["done"] = torch.cuda.Event()
+            rec["done"].record(ps)
+        # everything the branch allocated is consumed on the main stream after the `done` event
+        for t in (rec["enc"]["hidden_bf16"], rec["enc"]["last"], rec["enc"]["sqnorm"], rec["sim"], rec["adj_knn"]):
+            if t is not None:
+                t.record_stream(main)
+        rec["key"], rec["training"] = self._batch_key(long_history_data), mode
+        self._prefetched = rec
+
+    def _take_prefetched(self, long_hist):
+        rec, self._prefetched = self._prefetched, None
+        if rec is None:
+            return None
+        main = torch.cuda.current_stream()
+        if rec["key"] != self._batch_key(long_hist) or rec["training"] != self.training:
+            # not the batch that was announced: order the streams (the keep-mask pool is shared) and compute inline
+            main.wait_event(rec["done"])
+            return None
+        return rec
+
+    def _prefetch_stream(self, dev):
+        key = ("prefetch", dev.type, dev.index)
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]

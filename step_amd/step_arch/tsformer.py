@@ -334,12 +334,15 @@ class TSFormer(nn.Module):
         self.encoder_operand = "f16"
         self._seed_counter = 0
         # training-mode dropout: pool of Bernoulli(1 - p) keep bits the encoder kernel reads its lane masks from, refilled from
-        # the step's seed before every launch (step_dropout_pool_fill); 2^18 words = 2 MB stay resident in every XCD's L2
-        self.dropout_pool_words = 1 << 18
+        # the step's seed before every launch (step_dropout_pool_fill).  2^20 words = 8 MB; every (sequence, layer) reads its
+        # 10 912 words (PEMS04) at a hashed word offset, so two of the 12 280 chunks of a launch coincide with probability 2^-20
+        # per pair (tests/test_encoder_dropout_pool.py)
+        self.dropout_pool_words = 1 << 20
         self._drop_pool = None
         self._pool_override = None          # tests: int64 cuda tensor of keep-mask words used instead of the Philox fill
         self.encoder_debug_flags = 0        # tests: _lib.ENC_ALWAYS_RESHIFT
         self._events = None          # bench.py: list collecting (start, end) events around the encoder launch
+        self.fallback_counter = None # bench.py / tests: uint32 cuda tensor [1] the kernel adds its slow-path softmax units to
 
     # ------------------------------------------------------------------ packed operand cache
     def _pack_key(self, P):
@@ -358,13 +361,18 @@ class TSFormer(nn.Module):
         (tests) supplies the bits instead of the Philox fill, so a test can reproduce every mask on the host."""
         if self._pool_override is not None:
             pool = self._pool_override
-            return pool, pool.numel()
+            words = pool.numel()
+            if words & (words - 1) == 0:            # bare pool: append the wrap-around copy of its first 16 words
+                pool = torch.cat([pool, pool[:16]])
+            else:
+                words -= 16
+            return pool, words
         need = 2 * _lib.lib().step_tsformer_dropout_words(int(L), self.encoder_depth)
         words = self.dropout_pool_words
         while words < need:
             words *= 2
-        if self._drop_pool is None or self._drop_pool.numel() != words or self._drop_pool.device != device:
-            self._drop_pool = torch.empty(words, dtype=torch.int64, device=device)
+        if self._drop_pool is None or self._drop_pool.numel() != words + 16 or self._drop_pool.device != device:
+            self._drop_pool = torch.empty(words + 16, dtype=torch.int64, device=device)      # + the wrap-around copy of the first 16
         _lib.call("step_dropout_pool_fill", _lib.ptr(self._drop_pool), words, float(drop), int(seed), _lib.stream())
         return self._drop_pool, words
 
@@ -395,7 +403,8 @@ class TSFormer(nn.Module):
         flags = (_lib.ENC_F16 if self.encoder_operand == "f16" else 0) | self.encoder_debug_flags
         _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
                   flags, _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
-                  _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.stream())
+                  _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.ptr(self.fallback_counter),
+                  _lib.stream())
         if self._events is not None:
             ev[1].record()
             self._events.append(ev)

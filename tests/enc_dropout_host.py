@@ -38,7 +38,7 @@ class DropLayout:
 
 
 def chunk_base(s32, seq, layer, pool_words):
-    return (mix32(s32 + seq * 0x9E3779B1 + (layer + 1) * 0x632BE5AB) << 4) & (pool_words - 1)
+    return mix32(s32 + seq * 0x9E3779B1 + (layer + 1) * 0x632BE5AB) & (pool_words - 1)
 
 
 _I = np.arange(16)

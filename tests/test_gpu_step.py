@@ -437,3 +437,84 @@ def test_step_training_parity_with_gcn_dropout_masks(name):
     assert e_pred < 2e-3 and moved > 20 * e_pred
     assert float(loss) == pytest.approx(float(o_loss), rel=2e-3)
     assert worst < 1e-2
+
+
+def test_prefetched_frozen_branch_is_bit_identical():
+    """STEP.prefetch(): the frozen branch (TSFormer encoder with dropout on + kNN prior) of the NEXT batch queued on its own stream
+    before the current batch's backward.  (a) The branch itself: same launch counter -> the prefetched hidden states and last-patch
+    states are BIT-identical to the inline ones, the kNN graph identical (its cosine Gram may use split-K atomics: compared to
+    1e-6 / threshold ties).  (b) Three training steps on three different batches, inline vs one step ahead, identically seeded:
+    every prediction, graph, loss and parameter agrees to accumulation-order round-off (the backward uses atomics, so two INLINE
+    runs differ by as much).  (c) A prefetch for a batch that is then NOT the one passed to forward() is ignored."""
+    g = load_golden("step_tiny")
+    N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    hist, long_hist, fut = inputs_of(g)
+    gen = torch.Generator().manual_seed(3)
+    batches = [(hist, long_hist, fut)]
+    for _ in range(3):
+        lh = long_hist.clone()
+        lh[..., 0] = lh[..., 0] + 0.3 * torch.randn(lh[..., 0].shape, generator=gen).cuda()
+        batches.append((hist + 0.1 * torch.randn(hist.shape, generator=gen).cuda(), lh, fut))
+    # ---- (a)
+    torch.manual_seed(99)
+    model = build_native(g)
+    model.train()
+    model.tsformer._seed_counter = 41
+    inline = model._frozen_branch(batches[1][1], B, N)
+    torch.cuda.synchronize()
+    model.tsformer._seed_counter = 41
+    model.prefetch(batches[1][1])
+    rec = model._take_prefetched(batches[1][1])
+    assert rec is not None and model._prefetched is None
+    torch.cuda.current_stream().wait_event(rec["done"])
+    torch.cuda.synchronize()
+    assert torch.equal(rec["enc"]["hidden_bf16"], inline["enc"]["hidden_bf16"]) and torch.equal(rec["enc"]["last"], inline["enc"]["last"])
+    assert rel_l2(rec["sim"].cpu(), inline["sim"].cpu()) < 1e-6 and int((rec["adj_knn"] != inline["adj_knn"]).sum()) <= 2
+    model.prefetch(batches[2][1])
+    assert model._take_prefetched(batches[1][1]) is None and model._prefetched is None        # another batch: not used
+    torch.cuda.synchronize()
+
+    # ---- (b), (c)
+    def run(prefetch, wrong_announcement=False, dropout=True):
+        torch.manual_seed(1234)
+        model = build_native(g)
+        model.train()                                  # dropout on in both the encoder and the gcn layers: seeds matter
+        if not dropout:
+            model.backend.dropout, model.tsformer.dropout_p = 0.0, 0.0
+        model.gumbel_noise = "device"
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=2e-3)
+        outs = []
+        for i in range(3):
+            h, lh, f = batches[i]
+            opt.zero_grad(set_to_none=True)
+            pred, theta, knn, coef = model(history_data=h, long_history_data=lh, future_data=None, batch_seen=i, epoch=1)
+            if prefetch:
+                model.prefetch(batches[i + 1][1] if not wrong_announcement else batches[(i + 2) % 4][1])
+            loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(f[..., [0]], mean, std), theta, knn, coef)
+            loss.backward()
+            opt.step()
+            outs.append((pred.detach().clone(), theta.detach().clone(), knn.clone(), loss.detach().clone()))
+        torch.cuda.synchronize()
+        return outs, [p.detach().clone() for p in params], model
+
+    def close(x, y, px, py, what):
+        worst = 0.0
+        for (p0, t0, k0, l0), (p1, t1, k1, l1) in zip(x, y):
+            worst = max(worst, rel_l2(p1.cpu(), p0.cpu()), rel_l2(t1.cpu(), t0.cpu()), abs(float(l1 - l0)) / abs(float(l0)))
+            assert int((k0 != k1).sum()) <= 4
+        wp = max(rel_l2(b_.cpu(), a_.cpu()) for a_, b_ in zip(px, py))
+        print(f"{what}: worst prediction / theta / loss difference over 3 steps {worst:.2e}, worst parameter {wp:.2e}")
+        return max(worst, wp)
+    a, pa, _ = run(False)
+    a2, pa2, _ = run(False)
+    b, pb, mb = run(True)
+    assert mb._prefetched is not None                  # the last announcement is still pending
+    noise = close(a, a2, pa, pa2, "inline vs inline (atomics)")
+    assert close(a, b, pa, pb, "inline vs prefetched") <= max(10 * noise, 1e-5)
+    # announced batches that never match: forward() must ignore them and take the inline path.  The extra encoder launches consume
+    # dropout seeds, so the comparison is made with dropout off
+    d0, pd0, _ = run(False, dropout=False)
+    d1, pd1, _ = run(True, wrong_announcement=True, dropout=False)
+    assert close(d0, d1, pd0, pd1, "inline vs mismatching announcements (dropout off)") <= max(10 * noise, 1e-5)

@@ -221,3 +221,63 @@ def test_h12_mae_parity(mode):
     assert tail == pytest.approx(o_tail, rel=2e-2)
     assert h12 == pytest.approx(o_h12, rel=2e-2)
     assert mae == pytest.approx(o_mae, rel=1e-2)
+
+
+# ------------------------------------------------------------------- horizon-12 MAE after 200 steps, dropout ON (as benchmarked)
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_h12_mae_parity_dropout_on(mode):
+    """N1 in the configuration bench.py times: the frozen TSFormer in train mode (dropout 0.1 at its 17 sites, keep-masks from
+    the device pool, a fresh seed per launch) and F.dropout(0.3) after every gcn (device Philox).  The oracle side
+    (tools/make_n1_dropout_golden.py -> tests/golden/n1_oracle_dropout.npz) ran the same 200 steps four times with INDEPENDENT
+    Bernoulli masks (torch.bernoulli), the i.i.d. dropout of the reference (positional_encoding.py:32,
+    transformer_layers.py:10, graphwavenet/model.py:47).  Different realisations cannot be matched step by step; what must
+    agree is the distribution: the MEAN held-out horizon-12 MAE of three native runs (different seeds) within 2 % of the
+    oracle's mean (or 3 standard errors of the two means, whichever is larger), all horizons within 1.5 %."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "n1_oracle_dropout.npz"))
+    N, L, T_train, steps, B, k = [int(x) for x in z["cfg"]]
+    runs = z["runs"]
+    o_h12, o_mae, o_tail = runs[:, 1].mean(), runs[:, 2].mean(), runs[:, 3].mean()
+    prob = TPb.Problem(N, L, T_train)
+    schedule, noises = prob.schedule(steps, B), prob.noises(steps, B)
+    res = []
+    for run in range(3):
+        model = TPb.build_native(N, L, T_train, prob.series, k=k).cuda()
+        torch.manual_seed(7000 + run)                   # the native dropout seeds derive from torch.initial_seed()
+        model.train()
+        model.matmul_precision = mode
+        assert model.backend.dropout == pytest.approx(float(z["keep"][1]) * -1 + 1) and model.tsformer.dropout_p == pytest.approx(1 - float(z["keep"][0]))
+        params = [q for q in model.parameters() if q.requires_grad]
+        opt = torch.optim.Adam(params, lr=TPb.LR0, weight_decay=1e-5, eps=1e-8)
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=list(TPb.LR_MILESTONES), gamma=TPb.LR_GAMMA)
+        losses = []
+        for it, ts in enumerate(schedule):
+            hist, longh, fut = [x.cuda() for x in prob.batch(ts)]
+            model._noise_override = noises[it]
+            opt.zero_grad(set_to_none=True)
+            pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=it, epoch=1)
+            loss = O.step_loss(O.rescale(pred[..., [0]], prob.mean, prob.std), O.rescale(fut[..., [0]], prob.mean, prob.std), theta, knn, coef)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 3.0)
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+        model.eval()
+        model._noise_override = torch.rand(len(prob.eval_t), N * N, 2, generator=torch.Generator().manual_seed(999))
+        hist, longh, fut = [x.cuda() for x in prob.batch(prob.eval_t)]
+        with torch.no_grad():
+            pred, _, _, _ = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=0, epoch=None)
+        pr, fu = O.rescale(pred[..., [0]].cpu(), prob.mean, prob.std), O.rescale(fut[..., [0]].cpu(), prob.mean, prob.std)
+        res.append((float(O.masked_mae(pr[:, 11], fu[:, 11], 0.0)), float(O.masked_mae(pr, fu, 0.0)), float(np.mean(losses[-20:])), losses[0]))
+    r = np.array(res)
+    h12, mae, tail = r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean()
+    se = lambda a, b: float(np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b)))
+    se_h12, se_mae = se(r[:, 0], runs[:, 1]) / o_h12, se(r[:, 1], runs[:, 2]) / o_mae
+    print(f"N1 dropout ON [{mode}] {steps} steps x 3 native seeds vs {len(runs)} oracle runs with i.i.d. masks: training loss tail {tail:.3f} "
+          f"(oracle {o_tail:.3f}); held-out horizon-12 MAE native {h12:.4f} (runs {np.round(r[:, 0], 3).tolist()}) vs oracle {o_h12:.4f} "
+          f"(runs {np.round(runs[:, 1], 3).tolist()}): {(h12 / o_h12 - 1) * 100:+.2f} % (standard error of the difference {100 * se_h12:.2f} %); "
+          f"all horizons {mae:.4f} vs {o_mae:.4f}: {(mae / o_mae - 1) * 100:+.2f} % (s.e. {100 * se_mae:.2f} %)")
+    assert tail < 0.7 * r[:, 3].mean()                              # it trains
+    assert tail == pytest.approx(o_tail, rel=3e-2)
+    assert abs(h12 / o_h12 - 1) < max(2e-2, 3 * se_h12)
+    assert abs(mae / o_mae - 1) < max(1.5e-2, 3 * se_mae)

@@ -19,6 +19,8 @@
 
 typedef int (*enc4_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, const uint64_t*, long,
                        uint64_t, void*);
+typedef int (*enc5_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, const uint64_t*, long,
+                       uint64_t, unsigned int*, void*);
 typedef int (*enc3_fn)(const float*, int, int, const void*, long, int, int, uint16_t*, float*, float*, float*, float, uint64_t, void*);
 typedef int (*fill_fn)(uint64_t*, long, float, uint64_t, void*);
 typedef const char* (*err_fn)(void);
@@ -39,10 +41,12 @@ static std::vector<char> slurp(const char* path) {
 struct Lib {
     std::string tag;
     int abi;
-    enc4_fn e4; enc3_fn e3; fill_fn fill; err_fn err;
+    enc4_fn e4; enc3_fn e3; enc5_fn e5; fill_fn fill; err_fn err;
+    unsigned int* counter = nullptr;         // ABI 5: device counter of softmax units on the re-shifting (slow) path
     // unified call: flags bit0 f16, bit1 always-reshift (ABI 4 only)
     int run(const float* x, int S, int L, const void* pk, long pkb, int flags, uint16_t* h16, float* h32, float* last, float* sqn, float p,
             const uint64_t* pool, long words, uint64_t seed, hipStream_t st) const {
+        if (abi >= 5) return e5(x, S, L, pk, pkb, 4, flags, h16, h32, last, sqn, p, pool, words, seed, counter, st);
         if (abi >= 4) return e4(x, S, L, pk, pkb, 4, flags, h16, h32, last, sqn, p, pool, words, seed, st);
         return e3(x, S, L, pk, pkb, 4, flags & 1, h16, h32, last, sqn, p, seed, st);
     }
@@ -70,7 +74,7 @@ int main(int argc, char** argv) {
         l.err = (err_fn)dlsym(h, "step_last_error");
         if (!abi || !l.err) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
         l.abi = abi();
-        l.e4 = (enc4_fn)dlsym(h, "step_tsformer_encode"); l.e3 = (enc3_fn)l.e4;
+        l.e4 = (enc4_fn)dlsym(h, "step_tsformer_encode"); l.e3 = (enc3_fn)l.e4; l.e5 = (enc5_fn)l.e4;
         l.fill = (fill_fn)dlsym(h, "step_dropout_pool_fill");
         if (!l.e4 || (l.abi >= 4 && !l.fill)) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
         printf("[%s] abi %d\n", l.tag.c_str(), l.abi);
@@ -94,10 +98,15 @@ int main(int argc, char** argv) {
     void* d_pack[3];
     HIPCK(hipMalloc(&d_series, series.size()));
     HIPCK(hipMemcpy(d_series, series.data(), series.size(), hipMemcpyHostToDevice));
-    HIPCK(hipMalloc(&d_pool, poolf.size()));
+    HIPCK(hipMalloc(&d_pool, poolf.size() + 128));          // + the wrap-around copy of the first 16 words (ABI 5 kernels read on into it)
     HIPCK(hipMemcpy(d_pool, poolf.data(), poolf.size(), hipMemcpyHostToDevice));
-    const long words2 = 1L << 18;
-    HIPCK(hipMalloc(&d_pool2, words2 * 8));
+    HIPCK(hipMemcpy((char*)d_pool + poolf.size(), poolf.data(), 128, hipMemcpyHostToDevice));
+    const long words2 = getenv("ENC_AB_POOL_LOG2") ? 1L << atoi(getenv("ENC_AB_POOL_LOG2")) : 1L << 20;
+    HIPCK(hipMalloc(&d_pool2, (words2 + 16) * 8));
+    unsigned int* d_counter;
+    HIPCK(hipMalloc(&d_counter, 4));
+    for (Lib& l : libs) l.counter = d_counter;
+    printf("timing pool: 2^%d words\n", (int)log2((double)words2));
     for (int k = 0; k < 3; ++k) {
         HIPCK(hipMalloc(&d_pack[k], pack[k].size()));
         HIPCK(hipMemcpy(d_pack[k], pack[k].data(), pack[k].size(), hipMemcpyHostToDevice));
@@ -166,11 +175,13 @@ int main(int argc, char** argv) {
         const float p = (mode == 0 || mode == 3) ? 0.f : 0.1f;
         const float* src = mode >= 3 ? d_like : d_big;
         std::vector<std::vector<float>> t(libs.size());
+        std::vector<unsigned int> slow(libs.size(), 0u);
         for (int r = -1; r < rounds; ++r)             // round -1 = warm-up
             for (size_t li = 0; li < libs.size(); ++li) {
                 const Lib& l = libs[li];
                 if (p > 0 && l.abi >= 4) { int rc = l.fill(d_pool2, words2, p, 77 + r, st); if (rc) { printf("fill failed: %s\n", l.err()); return 1; } }
                 for (int rep = 0; rep < 3; ++rep) {
+                    if (r == rounds - 1 && rep == 2) HIPCK(hipMemsetAsync(d_counter, 0, 4, st));
                     HIPCK(hipEventRecord(e0, st));
                     int rc = l.run(src, S, L, d_pack[k], (long)pack[k].size(), fl, d_hid16, nullptr, d_last, d_sqn, p, d_pool2, words2, 100 + r * 3 + rep, st);
                     HIPCK(hipEventRecord(e1, st));
@@ -178,6 +189,7 @@ int main(int argc, char** argv) {
                     if (rc) { printf("[%s] encode failed: %s\n", l.tag.c_str(), l.err()); return 1; }
                     float ms; HIPCK(hipEventElapsedTime(&ms, e0, e1));
                     if (r >= 0) t[li].push_back(ms);
+                    if (r == rounds - 1 && rep == 2) HIPCK(hipMemcpy(&slow[li], d_counter, 4, hipMemcpyDeviceToHost));
                 }
             }
         for (size_t li = 0; li < libs.size(); ++li) {
@@ -186,8 +198,9 @@ int main(int argc, char** argv) {
             const float med = v[v.size() / 2];
             std::vector<uint16_t> hb((size_t)64 * P * 96);
             HIPCK(hipMemcpy(hb.data(), d_hid16, hb.size() * 2, hipMemcpyDeviceToHost));
-            printf("[%s] %s%s dropout %.1f: median %.3f ms, min %.3f, max %.3f (%zu launches, S=%d P=%d) = %.1f TFLOP/s algorithmic, %.1f %% of 2.5 PF\n",
-                   libs[li].tag.c_str(), fl ? "f16 " : "bf16", mode >= 3 ? " bench-like data" : "", p, med, v.front(), v.back(), v.size(), S, P, flop / med / 1e9, flop / med / 1e9 / 25.0);
+            printf("[%s] %s%s dropout %.1f: median %.3f ms, min %.3f, max %.3f (%zu launches, S=%d P=%d) = %.1f TFLOP/s algorithmic, %.1f %% of 2.5 PF; slow-path softmax units %u of %d\n",
+                   libs[li].tag.c_str(), fl ? "f16 " : "bf16", mode >= 3 ? " bench-like data" : "", p, med, v.front(), v.back(), v.size(), S, P, flop / med / 1e9, flop / med / 1e9 / 25.0,
+                   slow[li], S * 4 * 4 * 11);
         }
     }
     // sanity of the last dropout-on output of the last library: LayerNorm output, mean square ~1 per feature
