@@ -127,7 +127,14 @@ assert gathered[0] != gathered[1]
 import bench
 ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2))]
 ps[0].grad = torch.full((3, 5), float(rank + 1)); ps[1].grad = torch.arange(7.0) * (rank + 1)      # ps[2] has no gradient
-bench.average_grads(ps, world)
+class _M:            # (a) gradients cloned by autograd: the flatten / scatter-back form
+    _flat_grad = torch.zeros(4)
+bench.average_grads(_M, ps, world)
+assert torch.equal(ps[0].grad, torch.full((3, 5), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.0) * 1.5) and ps[2].grad is None
+_M._flat_grad = torch.zeros(24)          # (b) gradients that ARE views of the flat buffer (what the native backward leaves): one all-reduce
+ps[0].grad = _M._flat_grad[:15].view(3, 5); ps[1].grad = _M._flat_grad[16:23]
+ps[0].grad.fill_(float(rank + 1)); ps[1].grad.copy_(torch.arange(7.0) * (rank + 1))
+bench.average_grads(_M, ps, world)
 assert torch.equal(ps[0].grad, torch.full((3, 5), 1.5)) and torch.equal(ps[1].grad, torch.arange(7.0) * 1.5) and ps[2].grad is None
 # time slices of the graph learner (SURVEY.md 8(f) row 2), host side: bounds, the slice parameter, state_dict keys, the gather
 from step_amd.step_arch.discrete_graph_learning import DiscreteGraphLearning as DGL
