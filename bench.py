@@ -386,7 +386,7 @@ class StepBench:
         for i in range(warmup):
             self.step(start + i)
         m.tsformer._events = []
-        m.tsformer.fallback_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        m.tsformer.fallback_counter = torch.zeros(64, dtype=torch.int32, device=self.dev)
         if self.world > 1:
             m._reduce_wait_ms = []
         dt, per_step, loss = timed_loop(self.step, 0, steps, self.barrier, start + warmup)
@@ -396,7 +396,7 @@ class StepBench:
         ev = m.tsformer._events
         enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
         launches = max(len(ev), 1)
-        slow = int(m.tsformer.fallback_counter.item())
+        slow = int(m.tsformer.fallback_counter.sum().item())
         m.tsformer._events, m.tsformer.fallback_counter = None, None
         B = self.cfg["B"]
         return {"value": B * self.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,

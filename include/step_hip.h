@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream); 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -94,9 +94,9 @@ int step_gemm(const StepGemm* g, void* stream);
  *              pool_words + 16 words, the last 16 a copy of the first 16, which step_dropout_pool_fill writes); the
  *              layout inside that window is documented in csrc/tsformer_device.h and mirrored by tests/enc_dropout_host.py.
  *              The pool is only read.  Refill it (new seed) before every training step.
- *  fallback_count  optional device counter (NULL: off): += number of (32-token tile, head, layer, sequence) units whose softmax
- *              left the fixed-shift fast schedule and ran the re-shifting loop (the kernel's data-dependent slow path); of
- *              S * depth * 4 * ceil(P / 32) units per launch.
+ *  fallback_count  optional device counters, uint32 [64] (NULL: off): their SUM grows by the number of (32-token tile, head, layer,
+ *              sequence) units whose softmax left the fixed-shift fast schedule and ran the re-shifting loop (the kernel's
+ *              data-dependent slow path); of S * depth * 4 * ceil(P / 32) units per launch.
  */
 #define STEP_ENC_F16 1
 #define STEP_ENC_ALWAYS_RESHIFT 2
@@ -238,10 +238,14 @@ int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const flo
                              const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                              float* saved, float* work, float* pred, int phase, void* stream);
 /* dpred [B,12,N] -> parameter gradients (+=) and dadj [B,N,N] (gradient w.r.t. the sampled adjacency,
- * through both random-walk normalisations, model.py:121-130,160). */
+ * through both random-walk normalisations, model.py:121-130,160).
+ * aux_stream (may be NULL or equal to stream: everything on `stream`): a second stream of the same device for the LEAVES of the
+ * backward -- the weight / bias gradients of every layer and the whole fc_his branch, which nothing else in the backward reads.
+ * They are forked after the kernels that produce their inputs (event on `stream`, wait on aux_stream) and joined before the
+ * call's last kernels, so on return all work of the call is ordered before whatever the caller queues on `stream` next. */
 int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                         const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
-                        float* dadj, int dropout, void* stream);
+                        float* dadj, int dropout, void* aux_stream, void* stream);
 
 /* ---------------------------------------------------------------- TSFormer pre-training -----
  * Building blocks (exact f32) of the masked-autoencoder stage, forward and backward; the contractions

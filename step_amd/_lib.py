@@ -84,7 +84,7 @@ _SIGS = {
     "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),
     "step_gwnet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _vp]),
     "step_gwnet_forward_phase": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _i, _vp]),
-    "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp]),
+    "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp, _vp]),
     "step_pt_dropout": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_dropout_relu_mask": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_add_dropout": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),

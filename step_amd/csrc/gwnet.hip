@@ -15,6 +15,7 @@
 // dead code (model.py:202-213 for i = 7), so gconv.7 / bn.7 / residual_convs.* get no gradient.
 #include "common.h"
 #include "step_internal.h"
+#include <vector>
 
 namespace {
 
@@ -778,8 +779,10 @@ Saved carve_saved(float* base, int B, int N, bool dropout) {
 struct Work {
     float *wcat, *wcatT, *bcat, *wskip, *wmixT, *dwcat, *dbcat, *dwskip;       // [8][64][64] x2, [8][64], [256][256], [7][224][32]; d* and acc64 contiguous (one memset)
     double* acc64;             // [7 BatchNorms][NCOPY][64] f64 accumulators of the in-kernel BatchNorm sums
-    float *xcat, *bsum;
-    float *dcat[NL - 1], *dpre, *dh, *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;     // dcat: one gcn-buffer gradient per layer (all needed at the end)
+    // xcat / dpre / dh: per-layer copies of what the weight-gradient GEMMs read -- those GEMMs are leaves of the backward and run on
+    // the auxiliary stream while the data-gradient chain goes on; dcat: one gcn-buffer gradient per layer (all needed at the end)
+    float *xcat[NL], *bsum;
+    float *dcat[NL - 1], *dpre[NL], *dh[NL - 1], *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
     GemmKSeg* ktab;
     float *d_e1, *d_xh, *d_h2, *d_h1;
     long total;
@@ -797,13 +800,13 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.dbcat = cv.take(NL * 64);
     w.dwskip = cv.take(CS * CS);
     w.acc64 = (double*)cv.take(2L * 7 * NCOPY * 64);
-    w.xcat = backward ? cv.take(BN * 12 * 64) : nullptr;
+    for (int i = 0; i < NL; ++i) w.xcat[i] = backward ? cv.take(BN * TOUT[i] * 64) : nullptr;
     w.bsum = cv.take(CS);
     if (backward) {
         for (int i = 0; i < NL - 1; ++i) w.dcat[i] = cv.take(BN * TOUT[i] * CAT);
         w.ktab = (GemmKSeg*)cv.take(3L * ADJ_NSEG * sizeof(GemmKSeg) / sizeof(float));
-        w.dpre = cv.take(BN * 12 * 64);
-        w.dh = cv.take(BN * 12 * C);
+        for (int i = 0; i < NL; ++i) w.dpre[i] = cv.take(BN * TOUT[i] * 64);
+        for (int i = 0; i < NL - 1; ++i) w.dh[i] = cv.take(BN * TOUT[i] * C);
         w.dres = cv.take(BN * 12 * C);
         w.dxa = cv.take(BN * 13 * C);
         w.dxb = cv.take(BN * 13 * C);
@@ -821,6 +824,44 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.total = cv.used;
     return w;
 }
+
+// Fork / join between the caller's stream and its auxiliary stream with re-usable events (one small pool per host thread and device:
+// a wait captures the state of its event when it is queued, so re-recording an event for a later fork is safe).
+struct AuxLane {
+    hipStream_t main, aux;
+    bool on;
+    int next = 0;
+    AuxLane(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr && a != m) {}
+    static hipEvent_t event(int k) {
+        thread_local std::vector<hipEvent_t> pool[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::vector<hipEvent_t>& v = pool[dev & 15];
+        while ((int)v.size() <= k) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            v.push_back(e);
+        }
+        return v[k];
+    }
+    // the stream leaf work goes to, ordered after everything queued on the main stream so far
+    hipStream_t fork() {
+        if (!on) return main;
+        hipEvent_t e = event(next++ & 63);
+        if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
+        return aux;
+    }
+    // the main stream waits for everything queued on the auxiliary stream so far
+    int join() {
+        if (!on) return STEP_OK;
+        hipEvent_t e = event(next++ & 63);
+        if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
+            step_set_error("gwnet_backward: stream join failed");
+            return STEP_ERR_HIP;
+        }
+        return STEP_OK;
+    }
+};
 
 int zero(float* p, long n, hipStream_t st) {
     if (hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st) != hipSuccess) {
@@ -1015,7 +1056,7 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
 
 template <bool BF16>
 static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams* grads, const Saved& S, const Work& W, int B, int N,
-                                 float** dx0, hipStream_t st) {
+                                 float** dx0, hipStream_t st, AuxLane& lane) {
     const long BN = (long)B * N;
     float* dx_next = nullptr;
     float* dxbuf[2] = {W.dxa, W.dxb};
@@ -1026,13 +1067,13 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         if (i < NL - 1) {
             // BatchNorm_i backward (sums left by the previous iteration's tcn_bwd) + dropout + mix data gradient
             const BnBwd bn = {p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
-            mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh,
+            mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh[i],
                                                                             W.dcat[i]);
             STEP_LAUNCH_CHECK("mix_bwd");
-            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh, 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
+            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh[i], 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = -1;
             gw.a_rowsum = grads->gconv_b[i];
-            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, st));
+            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, lane.fork()));          // leaf: nothing in the backward reads it
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
@@ -1042,17 +1083,18 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         float* dx = dxbuf[i & 1];
         tcn_bwd_kernel<BF16><<<(unsigned)cdiv(BN, TB_ROWS / Tout), 256, 0, st>>>(i < NL - 1 ? W.dcat[i] : nullptr, W.dskip, i, S.tf[i], S.sg[i],
                                                                                 W.wcatT + i * 4096, i < NL - 1 ? W.dres : nullptr, BN, Tin, Tout, dil,
-                                                                                W.dpre, dx, i > 0 ? S.y[i - 1] : nullptr,
+                                                                                W.dpre[i], dx, i > 0 ? S.y[i - 1] : nullptr,
                                                                                 i > 0 ? S.bnstat[i - 1] : nullptr,
                                                                                 i > 0 ? W.acc64 + (long)(i - 1) * NCOPY * 64 : nullptr);
         STEP_LAUNCH_CHECK("tcn_bwd");
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
-        im2col_kernel<<<g1(npos * 64), 256, 0, st>>>(xin, BN, Tin, Tout, dil, W.xcat);
+        hipStream_t leaf = lane.fork();           // gate / filter weight gradient of this layer: a leaf as well
+        im2col_kernel<<<g1(npos * 64), 256, 0, leaf>>>(xin, BN, Tin, Tout, dil, W.xcat[i]);
         STEP_LAUNCH_CHECK("im2col");
-        StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre, 1, 64, W.xcat, 64, 1, W.dwcat + i * 4096, 64);
+        StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre[i], 1, 64, W.xcat[i], 64, 1, W.dwcat + i * 4096, 64);
         gw.accumulate = 2; gw.splitk = -1;
         gw.a_rowsum = W.dbcat + i * 64;
-        gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, st));
+        gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, leaf));
         dx_next = dx;
     }
     *dx0 = dx_next;
@@ -1072,10 +1114,11 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
 
 extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                                    const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
-                                   float* dadj, int dropout, void* stream) {
+                                   float* dadj, int dropout, void* aux_stream, void* stream) {
     STEP_REQUIRE(hist && hidden_last && p && saved && work && dpred && grads && dadj, "gwnet_backward: null argument");
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_backward: bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    AuxLane lane(st, (hipStream_t)aux_stream);
     Saved S = carve_saved((float*)saved, B, N, dropout != 0);
     Work W = carve_work(work, B, N, true);
     const long BN = (long)B * N;
@@ -1087,62 +1130,72 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     const long NN = (long)N * N;
 
     // ---------------------------------------------------------------- head (model.py:215-220)
+    // Main stream: the data-gradient chain d_e1 -> d_xh -> d zlast (what the layers need).  Everything else here -- the weight and
+    // bias gradients and the whole fc_his branch -- is a leaf of the backward and goes to the auxiliary stream (lane.fork()).
     {
         // d_e1[b,n,:] = sum_o dpred[b][o][n] W2[o,:], masked by relu(e1)
         StepGemm g = gemm_desc(N, CE, OUT, dpred, 1, N, p->end2_w, CE, 1, W.d_e1, CE);
         g.batch = B; g.sab = (long)OUT * N; g.scb = (long)N * CE;
         STEP_TRY(step_gemm_launch(g, st));
-        // dW2[o,:] += sum_{b,n} dpred[b][o][n] e1[b,n,:]   (batches accumulate atomically)
-        StepGemm gw = gemm_desc(OUT, CE, N, dpred, N, 1, S.e1, CE, 1, grads->end2_w, CE);
-        gw.batch = B; gw.sab = (long)OUT * N; gw.sbb = (long)N * CE; gw.scb = 0; gw.accumulate = 2;
-        STEP_TRY(step_gemm_launch(gw, st));
-        rowsum_mod_kernel<<<B * OUT, 256, 0, st>>>(dpred, N, OUT, grads->end2_b);
-        STEP_LAUNCH_CHECK("end2_bias_grad");
+        {
+            hipStream_t leaf = lane.fork();
+            // dW2[o,:] += sum_{b,n} dpred[b][o][n] e1[b,n,:]   (batches accumulate atomically)
+            StepGemm gw = gemm_desc(OUT, CE, N, dpred, N, 1, S.e1, CE, 1, grads->end2_w, CE);
+            gw.batch = B; gw.sab = (long)OUT * N; gw.sbb = (long)N * CE; gw.scb = 0; gw.accumulate = 2;
+            STEP_TRY(step_gemm_launch(gw, leaf));
+            rowsum_mod_kernel<<<B * OUT, 256, 0, leaf>>>(dpred, N, OUT, grads->end2_b);
+            STEP_LAUNCH_CHECK("end2_bias_grad");
+        }
         relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_e1, S.e1, BN * CE);
-        StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
-        gw1.accumulate = 2; gw1.splitk = split_for(BN);
-        gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
-        gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, st));
+        {
+            StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
+            gw1.accumulate = 2; gw1.splitk = split_for(BN);
+            gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
+            gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, lane.fork()));
+        }
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
         gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_xh, S.xh, BN * CS);       // = d skip = d h2 (pre-mask)
-        {   // the 8 skip biases all receive colsum(d skip)
-            STEP_TRY(zero(W.bsum, CS, st));
-            STEP_TRY(step_colsum_launch(W.d_xh, BN, CS, CS, W.bsum, st));
-            MPtr8 gb;
-            for (int i = 0; i < NL; ++i) gb.p[i] = grads->skip_b[i];
-            add_to8_kernel<<<1, 256, 0, st>>>(gb, W.bsum, CS);
-        }
-        {   // the 8 skip convolutions: d zlast = d skip @ Wskip (every layer's last-step gradient), dWskip = d skip^T zlast
+        {   // the 8 skip convolutions, data side: d zlast = d skip @ Wskip (every layer's last-step gradient)
+            hipStream_t leaf = lane.fork();
             StepGemm gz = gemm_desc((int)BN, CS, CS, W.d_xh, CS, 1, W.wskip, CS, 1, W.dskip, CS);
             gz.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gz, st));
+            // ---- leaves that read d_xh
+            // the 8 skip biases all receive colsum(d skip)
+            STEP_TRY(zero(W.bsum, CS, leaf));
+            STEP_TRY(step_colsum_launch(W.d_xh, BN, CS, CS, W.bsum, leaf));
+            MPtr8 gb;
+            for (int i = 0; i < NL; ++i) gb.p[i] = grads->skip_b[i];
+            add_to8_kernel<<<1, 256, 0, leaf>>>(gb, W.bsum, CS);
+            // dWskip = d skip^T zlast
             StepGemm gws = gemm_desc(CS, CS, (int)BN, W.d_xh, 1, CS, S.zlast, CS, 1, W.dwskip, CS);
             gws.accumulate = 2; gws.splitk = split_for(BN);
-            gws.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gws, st));
+            gws.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gws, leaf));
+            // fc_his (reads the TSFormer's last hidden state; nothing upstream of it takes a gradient)
+            if (hipMemcpyAsync(W.d_h2, W.d_xh, (size_t)BN * CS * sizeof(float), hipMemcpyDeviceToDevice, leaf) != hipSuccess) {
+                step_set_error("gwnet_backward: copy failed");
+                return STEP_ERR_HIP;
+            }
+            relu_bwd_kernel<<<g1(BN * CS), 256, 0, leaf>>>(W.d_h2, S.h2, BN * CS);
+            StepGemm gw2 = gemm_desc(CS, CE, (int)BN, W.d_h2, 1, CS, S.h1, CE, 1, grads->fc_his2_w, CE);
+            gw2.accumulate = 2; gw2.splitk = split_for(BN);
+            gw2.a_rowsum = grads->fc_his2_b;
+            gw2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw2, leaf));
+            StepGemm gh1 = gemm_desc((int)BN, CE, CS, W.d_h2, CS, 1, p->fc_his2_w, CE, 1, W.d_h1, CE);
+            gh1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gh1, leaf));
+            relu_bwd_kernel<<<g1(BN * CE), 256, 0, leaf>>>(W.d_h1, S.h1, BN * CE);
+            StepGemm gw0 = gemm_desc(CE, HID, (int)BN, W.d_h1, 1, CE, hidden_last, HID, 1, grads->fc_his0_w, HID);
+            gw0.accumulate = 2; gw0.splitk = split_for(BN);
+            gw0.a_rowsum = grads->fc_his0_b;
+            gw0.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw0, leaf));
         }
-        // fc_his
-        if (hipMemcpyAsync(W.d_h2, W.d_xh, (size_t)BN * CS * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            step_set_error("gwnet_backward: copy failed");
-            return STEP_ERR_HIP;
-        }
-        relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_h2, S.h2, BN * CS);
-        StepGemm gw2 = gemm_desc(CS, CE, (int)BN, W.d_h2, 1, CS, S.h1, CE, 1, grads->fc_his2_w, CE);
-        gw2.accumulate = 2; gw2.splitk = split_for(BN);
-        gw2.a_rowsum = grads->fc_his2_b;
-        gw2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw2, st));
-        StepGemm gh1 = gemm_desc((int)BN, CE, CS, W.d_h2, CS, 1, p->fc_his2_w, CE, 1, W.d_h1, CE);
-        gh1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gh1, st));
-        relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_h1, S.h1, BN * CE);
-        StepGemm gw0 = gemm_desc(CE, HID, (int)BN, W.d_h1, 1, CE, hidden_last, HID, 1, grads->fc_his0_w, HID);
-        gw0.accumulate = 2; gw0.splitk = split_for(BN);
-        gw0.a_rowsum = grads->fc_his0_b;
-        gw0.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw0, st));
     }
 
     // ---------------------------------------------------------------- WaveNet layers, reversed
     float* dx0 = nullptr;
-    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st));
-    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st));
+    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane));
+    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane));
+    STEP_TRY(lane.join());          // every leaf is finished from here on: the packed weight gradients are complete
     {
         GatePtrs gg;
         SkipPtrs sg;

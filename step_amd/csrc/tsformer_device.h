@@ -20,7 +20,7 @@ struct EncArgs {
     uint32_t seed;
     const unsigned long long* pool;          // Bernoulli(keep) lane-mask words (step_dropout_pool_fill); NULL when dropout is off
     uint32_t pool_mask;                      // number of pool words - 1 (a power of two); 16 more words (a copy of the first 16) follow
-    unsigned int* fallback;                  // optional counter: (wave, head) pairs that ran the re-shifting softmax loop; NULL = not counted
+    unsigned int* fallback;                  // optional 64 counters (summed by the caller): (wave, head) pairs that ran the re-shifting softmax loop; NULL = not counted
     bool f16;          // operand fragments of wpack are float16 (else bfloat16)
     bool always_rescale;                     // test hook: take the softmax re-shift path on every key tile
 };
@@ -137,34 +137,6 @@ __device__ __forceinline__ int fresh_lane_id() {
     return l;
 }
 
-// The same tail with the residual on the matrix cores: acc = keep-mask(acc) + c * x, i.e. c times what add_residual_op computes
-// with scale 1 / c (the LayerNorm that follows is invariant to the common factor once its eps is scaled by c^2).  x is the 16-bit
-// operand copy, already in B-operand layout; the A operand is c times the identity in the chain k-slot order of tsformer_layout.h:
-// row r of k-step s sits in slot j of lane-half h where r = 16 s + 8 (j >> 2) + 4 h + (j & 3).
-template <bool F16>
-__device__ __forceinline__ void add_residual_mfma(f32x16 (&acc)[3], const typename Opnd<F16>::v8 (&xb)[6], const mask_ptr (&w)[3], float c) {
-    typedef typename Opnd<F16>::v8 op8;
-    typedef typename Opnd<F16>::elem ope;
-    const int lane = fresh_lane_id();
-    const int r = lane & 31, h = lane >> 5;
-    op8 id[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int d = r - 16 * s - 4 * h;
-        const bool ok = d >= 0 && d < 16 && !(d & 4);
-        const int j = ((d >> 3) << 2) | (d & 3);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) id[s][jj] = (ok && j == jj) ? (ope)c : (ope)0.0f;
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_amdgcn_inverse_ballot_w64(w[t][i]) ? acc[t][i] : 0.f;
-        acc[t] = mfma16<F16>(id[0], xb[2 * t], acc[t]);
-        acc[t] = mfma16<F16>(id[1], xb[2 * t + 1], acc[t]);
-    }
-}
-
 // value of the 16-bit operand type nearest to x (what the MFMA will see when x is stored into an operand slot)
 template <bool F16>
 __device__ __forceinline__ float round_to_operand(float x) {
@@ -199,7 +171,7 @@ __device__ __forceinline__ float wave_sum_swz(float v) {
 #define TSF_LN_PACKED 1      // 0: the scalar reduction chains of the first version (A/B builds)
 #endif
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb, float eps = 1e-5f) {
+__device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
     if (TSF_ABLATE & 128) return;
     float s, q;
     if (TSF_LN_PACKED) {
@@ -251,7 +223,7 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
         both_halves(q, lo, hi);
         q = lo + hi;
     }
-    const float rstd = rsqrtf(q * (1.0f / 96.0f) + eps);
+    const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll

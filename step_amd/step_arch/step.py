@@ -178,8 +178,10 @@ class _StepFunction(torch.autograd.Function):
         dpred = dpred.contiguous().float().view(B, 12, N) if dpred is not None else torch.zeros(B, 12, N, device=dev)
         dadj = _f32(B * N * N, dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
+        # the weight / bias gradients of the WaveNet are leaves of the backward: the library forks them onto the second stream
+        aux = ctypes.c_void_p(model._side_stream(dev).cuda_stream) if (model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1") else None
         L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
-               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), st)
+               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, st)
         del wwork
         ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
         dgv = _f32(N * 100, dev)

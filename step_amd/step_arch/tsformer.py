@@ -334,15 +334,16 @@ class TSFormer(nn.Module):
         self.encoder_operand = "f16"
         self._seed_counter = 0
         # training-mode dropout: pool of Bernoulli(1 - p) keep bits the encoder kernel reads its lane masks from, refilled from
-        # the step's seed before every launch (step_dropout_pool_fill).  2^20 words = 8 MB; every (sequence, layer) reads its
-        # 10 912 words (PEMS04) at a hashed word offset, so two of the 12 280 chunks of a launch coincide with probability 2^-20
-        # per pair (tests/test_encoder_dropout_pool.py)
-        self.dropout_pool_words = 1 << 20
+        # the step's seed before every launch (step_dropout_pool_fill).  2^18 words = 2 MB stay resident in every XCD's L2 (with
+        # 2^20 words the launch reads 0.94 GB more through L2 misses and takes 6 % longer, profiles/r03_a_*); every (sequence,
+        # layer) reads its 10 912 words (PEMS04) at a hashed WORD offset, so two of the 12 280 chunks of a launch coincide with
+        # probability 2^-18 per pair (tests/test_encoder_dropout_pool.py counts them)
+        self.dropout_pool_words = 1 << 18
         self._drop_pool = None
         self._pool_override = None          # tests: int64 cuda tensor of keep-mask words used instead of the Philox fill
         self.encoder_debug_flags = 0        # tests: _lib.ENC_ALWAYS_RESHIFT
         self._events = None          # bench.py: list collecting (start, end) events around the encoder launch
-        self.fallback_counter = None # bench.py / tests: uint32 cuda tensor [1] the kernel adds its slow-path softmax units to
+        self.fallback_counter = None # bench.py / tests: int32 cuda tensor [64] whose sum the kernel raises by its slow-path softmax units
 
     # ------------------------------------------------------------------ packed operand cache
     def _pack_key(self, P):

@@ -19,8 +19,13 @@ def _bases(seed64, S, depth, words):
 
 
 def test_pool_chunk_coincidences_at_pems04_launch_size():
-    """S = 8 x 307 sequences, 4 layers + the positional site = 12 280 chunks of 10 912 words in a 2^20-word pool."""
-    S, depth, words, B, N = 2456, 4, 1 << 20, 8, 307
+    """S = 8 x 307 sequences, 4 layers + the positional site = 12 280 chunks of 10 912 words in the default 2^18-word pool: about
+    290 of the 7.5e7 chunk pairs of a launch coincide (4600 with the 16-word aligned offsets of round 2), and of the 376 000 node
+    pairs the kNN graph compares, about 7 share the masks of ONE of their five dropout layers -- never of two."""
+    from step_amd.step_arch.tsformer import TSFormer
+    S, depth, B, N = 2456, 4, 8, 307
+    words = TSFormer(12, 1, 96, 4, 4, 0.1, 336, 0.75, 4, 1, mode="forecasting").dropout_pool_words
+    assert words == 1 << 18
     chunk = DH.DropLayout(11).words
     assert chunk == 10912 and 2 * chunk <= words
     same, same_sample, twice = [], [], 0
@@ -45,8 +50,8 @@ def test_pool_chunk_coincidences_at_pems04_launch_size():
     pairs = 12280 * 12279 / 2
     print(f"equal chunk offsets per launch (of {pairs:.3g} pairs; expectation {pairs / words:.0f}): {same}; same layer within one sample "
           f"(of {8 * 5 * 307 * 306 // 2} node pairs; expectation {8 * 5 * 307 * 306 / 2 / words:.2f}): {same_sample}")
-    assert max(same) < 130                                       # Poisson(72)
-    assert max(same_sample) <= 9                                 # Poisson(1.8) per launch
+    assert max(same) < 1.25 * pairs / words + 30                 # Poisson(288)
+    assert max(same_sample) <= 20                                # Poisson(7.2) per launch
     assert twice == 0
 
 
@@ -70,22 +75,28 @@ def test_realised_dropout_noise_is_uncorrelated_across_sequences():
     x = row[None].repeat(S, 1).contiguous().cuda()
     clean, _, _, _ = _encode(L, x, packed, f16=1)
     assert torch.equal(clean[0], clean[-1])
-    words = 1 << 20
-    pool = torch.empty(words + 16, dtype=torch.int64, device="cuda")
-    L.call("step_dropout_pool_fill", L.ptr(pool), words, 0.1, 0xABCDEF12345, L.stream())
-    hid = torch.empty(S, P, 96, device="cuda")
+    words = 1 << 18
     pk = packed.cuda()
-    L.call("step_tsformer_encode", L.ptr(x), S, P * 12, L.ptr(pk), pk.numel(), 4, L.ENC_F16, None, L.ptr(hid), None, None, 0.1,
-           L.ptr(pool), words, 0x1234567, None, L.stream())
-    torch.cuda.synchronize()
-    noise = (hid - clean).reshape(S, -1).double()
-    noise = noise - noise.mean(0, keepdim=True)                  # the shift every sequence shares
-    nn = noise / noise.norm(dim=1, keepdim=True)
-    corr = (nn @ nn.T).cpu().numpy()
-    off = corr[~np.eye(S, dtype=bool)]
-    dim = noise.shape[1]
-    print(f"cross-sequence correlation of the dropout noise ({S} identical inputs, {dim} values each): max |r| {np.abs(off).max():.4f}, "
-          f"rms {np.sqrt((off ** 2).mean()):.5f} (1/sqrt(dim) = {dim ** -0.5:.5f}; -1/(S-1) from the mean removal = {-1 / (S - 1):.5f})")
-    assert np.abs(off).max() < 0.05
-    assert np.sqrt((off ** 2).mean()) < 0.02
-    assert len({hid[i].cpu().numpy().tobytes() for i in range(S)}) == S          # no two sequences got the same masks
+
+    def noisy(seed):
+        pool = torch.empty(words + 16, dtype=torch.int64, device="cuda")
+        L.call("step_dropout_pool_fill", L.ptr(pool), words, 0.1, seed * 7919 + 13, L.stream())
+        hid = torch.empty(S, P, 96, device="cuda")
+        L.call("step_tsformer_encode", L.ptr(x), S, P * 12, L.ptr(pk), pk.numel(), 4, L.ENC_F16, None, L.ptr(hid), None, None, 0.1,
+               L.ptr(pool), words, seed, None, L.stream())
+        torch.cuda.synchronize()
+        n = (hid - clean).reshape(S, -1).double()
+        n = n - n.mean(0, keepdim=True)                          # the shift every sequence shares (bias of dropout through the non-linear layers)
+        return hid, n / n.norm(dim=1, keepdim=True)
+    hid_a, na = noisy(0x1234567)
+    _, nb = noisy(0x7654321)
+    same = (na @ na.T).cpu().numpy()[~np.eye(S, dtype=bool)]     # pairs of sequences of ONE launch (one pool)
+    null = (na @ nb.T).cpu().numpy().reshape(-1)                 # pairs from two launches: independent pools by construction
+    rms = lambda v: float(np.sqrt((v ** 2).mean()))
+    q = lambda v: float(np.quantile(np.abs(v), 0.999))
+    print(f"correlation of the dropout noise between sequences with identical input ({S} sequences, {na.shape[1]} values each): one launch rms "
+          f"{rms(same):.5f}, 99.9 % quantile {q(same):.4f}, max {np.abs(same).max():.4f}; independent pools (null) rms {rms(null):.5f}, "
+          f"99.9 % {q(null):.4f}, max {np.abs(null).max():.4f}")
+    assert rms(same) < 1.15 * rms(null) + 1e-3 and q(same) < 1.25 * q(null) + 2e-3
+    assert np.abs(same).max() < 0.5                               # a pair with identical masks would sit at 1.0
+    assert len({hid_a[i].cpu().numpy().tobytes() for i in range(S)}) == S          # no two sequences got the same masks

@@ -74,7 +74,7 @@ def test_pack_long_history(L):
 
 def _encode(L, series, packed, depth=4, f32=True, drop=0.0, seed=0, f16=0, pool=None, flags=0, fallback=None):
     """pool: int64 cuda tensor of keep-mask words, a power of two of them (None with drop > 0: filled on the device from `seed`);
-    fallback: optional int32 cuda tensor [1] counting the softmax units that left the fixed-shift schedule."""
+    fallback: optional int32 cuda tensor [64] whose sum counts the softmax units that left the fixed-shift schedule."""
     S, Lh = series.shape
     P = Lh // 12
     hid32 = torch.empty(S, P, 96, device="cuda") if f32 else None
@@ -220,16 +220,16 @@ def test_encoder_training_mode_on_sharp_weights_matches_operand_format_model(L, 
     exact0, exact1 = RM.encode(x, sd, None, None), RM.encode(x, sd, None, None, drop=masks, keep=keep)
     model0, model1 = rel_l2(RM.encode(x, sd, dt), exact0), rel_l2(RM.encode(x, sd, dt, drop=masks, keep=keep), exact1)
     series = x.cuda()
-    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
     h0, _, _, _ = _encode(L, series, packed, f16=operand == "f16", fallback=cnt)
-    slow0 = int(cnt.item())
+    slow0 = int(cnt.sum().item())
     cnt.zero_()
     h1, _, _, _ = _encode(L, series, packed, drop=1.0 - keep, seed=seed, f16=operand == "f16", pool=torch.from_numpy(pool.view(np.int64)).cuda(),
                           fallback=cnt)
     e0, e1 = rel_l2(h0.cpu().double(), exact0), rel_l2(h1.cpu().double(), exact1)
     units = S * 4 * 4 * 11
     print(f"sharp weights, {operand}: dropout off kernel {e0:.2e} / model {model0:.2e}; dropout on kernel {e1:.2e} / model {model1:.2e}; "
-          f"softmax units on the re-shifting path {slow0} / {int(cnt.item())} of {units}")
+          f"softmax units on the re-shifting path {slow0} / {int(cnt.sum().item())} of {units}")
     assert torch.isfinite(h1).all()
     assert e0 < 1.5 * model0 + 5e-4 and e1 < 1.5 * model1 + 5e-4
 

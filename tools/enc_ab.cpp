@@ -101,10 +101,10 @@ int main(int argc, char** argv) {
     HIPCK(hipMalloc(&d_pool, poolf.size() + 128));          // + the wrap-around copy of the first 16 words (ABI 5 kernels read on into it)
     HIPCK(hipMemcpy(d_pool, poolf.data(), poolf.size(), hipMemcpyHostToDevice));
     HIPCK(hipMemcpy((char*)d_pool + poolf.size(), poolf.data(), 128, hipMemcpyHostToDevice));
-    const long words2 = getenv("ENC_AB_POOL_LOG2") ? 1L << atoi(getenv("ENC_AB_POOL_LOG2")) : 1L << 20;
+    const long words2 = getenv("ENC_AB_POOL_LOG2") ? 1L << atoi(getenv("ENC_AB_POOL_LOG2")) : 1L << 18;
     HIPCK(hipMalloc(&d_pool2, (words2 + 16) * 8));
     unsigned int* d_counter;
-    HIPCK(hipMalloc(&d_counter, 4));
+    HIPCK(hipMalloc(&d_counter, 256));
     for (Lib& l : libs) l.counter = d_counter;
     printf("timing pool: 2^%d words\n", (int)log2((double)words2));
     for (int k = 0; k < 3; ++k) {
@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
                 const Lib& l = libs[li];
                 if (p > 0 && l.abi >= 4) { int rc = l.fill(d_pool2, words2, p, 77 + r, st); if (rc) { printf("fill failed: %s\n", l.err()); return 1; } }
                 for (int rep = 0; rep < 3; ++rep) {
-                    if (r == rounds - 1 && rep == 2) HIPCK(hipMemsetAsync(d_counter, 0, 4, st));
+                    if (r == rounds - 1 && rep == 2) HIPCK(hipMemsetAsync(d_counter, 0, 256, st));
                     HIPCK(hipEventRecord(e0, st));
                     int rc = l.run(src, S, L, d_pack[k], (long)pack[k].size(), fl, d_hid16, nullptr, d_last, d_sqn, p, d_pool2, words2, 100 + r * 3 + rep, st);
                     HIPCK(hipEventRecord(e1, st));
@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
                     if (rc) { printf("[%s] encode failed: %s\n", l.tag.c_str(), l.err()); return 1; }
                     float ms; HIPCK(hipEventElapsedTime(&ms, e0, e1));
                     if (r >= 0) t[li].push_back(ms);
-                    if (r == rounds - 1 && rep == 2) HIPCK(hipMemcpy(&slow[li], d_counter, 4, hipMemcpyDeviceToHost));
+                    if (r == rounds - 1 && rep == 2) { unsigned int c64[64]; HIPCK(hipMemcpy(c64, d_counter, 256, hipMemcpyDeviceToHost)); slow[li] = 0; for (int q = 0; q < 64; ++q) slow[li] += c64[q]; }
                 }
             }
         for (size_t li = 0; li < libs.size(); ++li) {
