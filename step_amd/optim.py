@@ -32,9 +32,7 @@ class FusedAdamClip(torch.optim.Optimizer):
         model._backward_count = 0
 
     def zero_grad(self, set_to_none=True):
-        self.model.zero_grad(set_to_none=set_to_none)
-        self.model._flat_grad = None
-        self.model._backward_count = 0
+        self.model.zero_grad(set_to_none=set_to_none)          # STEP.zero_grad also resets the flat-gradient bookkeeping
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,6 +44,12 @@ class FusedAdamClip(torch.optim.Optimizer):
         if self.model._backward_count != 1:
             raise RuntimeError(f"FusedAdamClip.step(): {self.model._backward_count} native backwards since zero_grad() -- the flat gradient buffer "
                                "holds the last one only; accumulate with torch.optim.Adam on model.parameters() instead")
+        if self.flat is not self.model._flat_param or g.numel() != self.flat.numel():
+            # enable_native_data_parallel(shard_graph_learner=True) / flatten_parameters() after this optimizer was built re-home the
+            # parameters: the captured buffer and moments no longer match the gradient layout
+            raise RuntimeError("FusedAdamClip: the model's flat parameter buffer changed after the optimizer was created "
+                               f"({self.flat.numel()} parameters here, {g.numel()} gradient values): build the optimizer after "
+                               "enable_native_data_parallel() / flatten_parameters()")
         pg = self.param_groups[0]
         self.step_count += 1
         extra = None

@@ -99,6 +99,7 @@ class DiscreteGraphLearning(nn.Module):
         w = self.fc.weight.detach().view(self.embedding_dim, 16, T2)[:, :, a:b].contiguous().view(self.embedding_dim, -1)
         self.fc_weight_slice = nn.Parameter(w.clone())
         self.fc.weight.requires_grad_(False)
+        self._slice_dirty = False            # set by the native backward: fc.weight no longer holds what the slices hold
         return self._shard
 
     def shard_struct(self):
@@ -122,6 +123,7 @@ class DiscreteGraphLearning(nn.Module):
                 torch.empty(self.embedding_dim, 16, b - a, device=full.device, dtype=full.dtype)
             dist.broadcast(buf, dist.get_global_rank(process_group, r) if process_group is not None else r, group=process_group)
             full[:, :, a:b].copy_(buf)
+        self._slice_dirty = False
 
     def refresh_fc_weight_slice(self):
         """after loading a (full) state_dict into a sharded module: re-cut this rank's slice from ``fc.weight``"""
@@ -132,6 +134,10 @@ class DiscreteGraphLearning(nn.Module):
                 self.fc_weight_slice.copy_(self.fc.weight.view(self.embedding_dim, 16, T2)[:, :, sh["a"]:sh["b"]].reshape(self.embedding_dim, -1))
 
     def state_dict(self, *args, **kwargs):
+        if self._shard is not None and self._slice_dirty:
+            # a checkpoint written now would silently carry the UNTRAINED fc.weight (the trained values live in the ranks' slices)
+            raise RuntimeError("DiscreteGraphLearning is sharded in time slices and has been trained since the last gather: call "
+                               "gather_fc_weight() on ALL ranks (e.g. in the runner's on_epoch_end) before state_dict() / save_model()")
         sd = super().state_dict(*args, **kwargs)
         prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
         sd.pop(prefix + "fc_weight_slice", None)          # the reference's keys only (fc.weight carries the gathered matrix)
@@ -141,10 +147,14 @@ class DiscreteGraphLearning(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
         if prefix + "fc_weight_slice" in missing_keys:
             missing_keys.remove(prefix + "fc_weight_slice")
+        if self._shard is not None:          # a (full) checkpoint was loaded into a sharded module: re-cut this rank's slice
+            self.refresh_fc_weight_slice()
+            self._slice_dirty = False
 
-    def native_tensors(self):
+    def native_tensors(self, full=False):
+        """full=True: the whole fc.weight even when sharded (the unsharded evaluation path)"""
         return {"conv1_w": self.conv1.weight, "conv1_b": self.conv1.bias, "conv2_w": self.conv2.weight,
-                "conv2_b": self.conv2.bias, "fc_w": self.fc.weight if self._shard is None else self.fc_weight_slice, "fc_b": self.fc.bias,
+                "conv2_b": self.conv2.bias, "fc_w": self.fc.weight if (self._shard is None or full) else self.fc_weight_slice, "fc_b": self.fc.bias,
                 "bn1_w": self.bn1.weight, "bn1_b": self.bn1.bias, "bn1_rm": self.bn1.running_mean, "bn1_rv": self.bn1.running_var,
                 "bn2_w": self.bn2.weight, "bn2_b": self.bn2.bias, "bn2_rm": self.bn2.running_mean, "bn2_rv": self.bn2.running_var,
                 "bn3_w": self.bn3.weight, "bn3_b": self.bn3.bias, "bn3_rm": self.bn3.running_mean, "bn3_rv": self.bn3.running_var,

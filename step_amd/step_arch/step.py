@@ -78,11 +78,22 @@ class _StepFunction(torch.autograd.Function):
         # They are queued on a second stream next to the encoder: its workgroups keep the compute units busy while that chain of
         # small, latency-bound kernels advances.  Buffers are allocated on the main stream and outlive the join below.
         dgl, be = model.discrete_graph_learning, model.backend
-        dt = dgl.native_tensors()
+        sh = dgl._shard                      # time slice of the global branch on this data-parallel rank (or None)
+        if sh is not None and not training:
+            # Evaluation of a sharded model: the reference's validate() / test() are @master_only (base_tsf_runner.py:276,320), so
+            # the other ranks are not here to answer the slices' collectives.  The whole graph learner is evaluated on this rank
+            # from the gathered fc.weight -- no collective -- and refuses to run on stale weights.
+            if dgl._slice_dirty:
+                raise RuntimeError("evaluation of a time-sliced graph learner needs the gathered fc.weight: call "
+                                   "model.discrete_graph_learning.gather_fc_weight() on ALL ranks after the training epoch "
+                                   "(the runner's on_epoch_end) before the master-only validation")
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                raise RuntimeError("a time-sliced graph learner evaluates without gradients only (wrap the call in torch.no_grad())")
+            sh = None
+        dt = dgl.native_tensors(full=sh is None)
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
         dstruct = fill_dgl_struct(dt, bf)
         bstruct = fill_gwnet_struct(be.native_tensors(), bf)
-        sh = dgl._shard                      # time slice of the global branch on this data-parallel rank (or None)
         Ttr = dgl.train_length if sh is None else sh["Ts"]
         series_nt = dgl._series_nt if sh is None else dgl._series_slice
         drop = be.dropout if training else 0.0
@@ -207,6 +218,7 @@ class _StepFunction(torch.autograd.Function):
             world = sh["world"]
             model._sum_over_ranks(dgv)
             dgv.mul_(1.0 / world)
+            dgl._slice_dirty = True          # the optimizer is about to change the slices: fc.weight / state_dict() are stale until a gather
             sstruct = dgl.shard_struct()
             o_dots, o_graw = L.lib().step_dgl_global_offset(N, Ttr, 10), L.lib().step_dgl_global_offset(N, Ttr, 11)
             exchange = {1: gwork[o_dots:o_dots + 32], 3: gwork[o_graw:o_graw + 1296]}
@@ -461,6 +473,13 @@ class STEP(nn.Module):
 
     def _reduce_flat_grads(self, flat):
         self._reduce_finish(flat, self._reduce_begin(flat), flat)
+
+    def zero_grad(self, set_to_none=True):
+        """also forgets the flat gradient buffer of the last native backward (so `model.zero_grad(); loss.backward(); opt.step()`
+        loops work with FusedAdamClip like `opt.zero_grad()` ones)"""
+        super().zero_grad(set_to_none=set_to_none)
+        self._flat_grad = None
+        self._backward_count = 0
 
     # ------------------------------------------------------------------ forward
     def forward(self, history_data, long_history_data, future_data, batch_seen, epoch, **kwargs):

@@ -160,12 +160,23 @@ assert torch.equal(dgl.fc_weight_slice.view(100, 16, 291), full0.view(100, 16, T
 with torch.no_grad():
     dgl.fc_weight_slice.add_(rank + 1.0)                                  # "training": every rank moves its slice
     dgl.fc.weight.zero_()
+dgl._slice_dirty = True                                                   # what the native backward sets
+try:
+    dgl.state_dict()
+    raise SystemExit("expected RuntimeError: stale fc.weight")
+except RuntimeError as e:
+    assert "gather_fc_weight" in str(e)
 dgl.gather_fc_weight()
+assert not dgl._slice_dirty
 want = full0.view(100, 16, T2).clone()
 want[:, :, :291] += 1.0; want[:, :, 291:] += 2.0
 assert torch.equal(dgl.fc.weight.view(100, 16, T2), want)
-dgl.load_state_dict(dgl.state_dict()); dgl.refresh_fc_weight_slice()       # reference-layout checkpoints load into a sharded module
+sd_full = dgl.state_dict()
+with torch.no_grad():
+    dgl.fc_weight_slice.zero_()
+dgl.load_state_dict(sd_full)                                              # reference-layout checkpoints load into a sharded module: the slice is re-cut
 assert torch.equal(dgl.fc_weight_slice.view(100, 16, 291), want[:, :, sh["a"]:sh["b"]])
+assert dgl.native_tensors(full=True)["fc_w"] is dgl.fc.weight                # the unsharded evaluation path reads the gathered matrix
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """

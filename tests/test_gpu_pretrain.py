@@ -1,5 +1,6 @@
 """GPU parity of the native TSFormer pre-training step (forward + every parameter gradient) against the
 reference's own outputs (tests/golden/tsformer_pretrain_tiny.npz) and the oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -140,3 +141,106 @@ def test_matrix_core_attention_matches_f32_attention(T, p):
     assert e_out < 1.5e-2 and e_g < 2.5e-2 and max(parts.values()) < 3e-2
     assert e_m < 0.1 and e_l < 3e-2
     assert torch.isfinite(g1).all() and torch.isfinite(o1).all()
+
+
+@pytest.mark.parametrize("T", [42, 168, 336])
+def test_attention_kernels_match_fp64_reference_with_their_own_masks(T):
+    """Both attention paths of the pre-training step against an ORACLE (they were only compared with
+    each other above 16 tokens): torch float64 attention + autograd (torch.nn.TransformerEncoderLayer's
+    F.multi_head_attention_forward: softmax(q k^T / sqrt(24)), dropout on the probabilities, times v) at the token counts of
+    config C3's encoder (42), decoder (168) and of the PEMS04 checkpoint recipe (336).  The dropout realisation is the device's:
+    the matrix-core forward hands its keep decisions out as bit masks (one word per (query, key tile)), the f32 kernels draw
+    the same Philox stream; the oracle replays those bits.  f32 kernels: 2e-5; bf16 operands: 1.5e-2 (output) / 2.5e-2 (dqkv)."""
+    from step_amd import _lib as L
+    S, p = 5, 0.1
+    gen = torch.Generator().manual_seed(100 + T)
+    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).cuda()
+    dout = torch.randn(S, T, 96, generator=gen).cuda()
+    seed, site = 0x0BAD_5EED_1234, 16
+    st = L.stream()
+    nkt = (T + 31) // 32
+    res = {}
+    kb = torch.zeros(S * 4 * T * nkt, dtype=torch.int32, device="cuda")
+    for tag in ("_bf16", ""):
+        out = torch.empty(S, T, 96, device="cuda")
+        stats = torch.empty(S * 4 * T, 2, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda")
+        if tag:
+            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_bwd_bf16", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
+        else:
+            L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
+            L.call("step_pt_attention_bwd", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
+        torch.cuda.synchronize()
+        res[tag] = (out.cpu().double(), dqkv.cpu().double())
+    words = kb.cpu().numpy().view(np.uint32).reshape(S, 4, T, nkt)
+    bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(S, 4, T, nkt * 32)[..., :T]
+    keep = torch.from_numpy(bits.astype(np.float64))
+    assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    x = qkv.cpu().double().requires_grad_(True)
+    q, k, v = [t.reshape(S, T, 4, 24).transpose(1, 2) for t in x.split(96, dim=-1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) / 24 ** 0.5, dim=-1) * keep / (1 - p)
+    want = (att @ v).transpose(1, 2).reshape(S, T, 96)
+    want.backward(dout.cpu().double())
+    want, gwant = want.detach(), x.grad
+    for tag, to, tg in (("", 2e-5, 5e-5), ("_bf16", 1.5e-2, 2.5e-2)):
+        eo, eg = rel_l2(res[tag][0], want), rel_l2(res[tag][1], gwant)
+        print(f"T={T} attention{tag or '_f32'} vs float64 oracle with the device's keep bits: out {eo:.2e}, dqkv {eg:.2e}")
+        assert eo < to and eg < tg
+
+
+@pytest.mark.parametrize("mode,t_recon,t_grad", [("f32", 1e-4, 2e-3), ("bf16", 2e-2, 8e-2)])
+def test_pretrain_full_size_c3_matches_oracle(mode, t_recon, t_grad):
+    """Config C3 at its real size -- TSFormer_PEMS-BAY: N = 325 nodes, L = 2016 (168 tokens, 42 unmasked), two windows -- forward,
+    masked MAE and every parameter gradient against the CPU oracle (oracle/step_oracle.py tsformer_pretrain + autograd), dropout
+    off, same mask index lists.  f32 mode is the exact-f32 path; bf16 mode is what `bench.py --config TSFormer_PEMS-BAY` times
+    (bf16 GEMM operands, matrix-core attention): its whole-gradient error is held to 8e-2 here, reconstruction to 2e-2."""
+    import random
+    from step_amd import TSFormer
+    N, L, B = 325, 2016, 2
+    torch.manual_seed(5)
+    model = TSFormer(12, 1, 96, 4, 4, 0.1, L / 12, 0.75, 4, 1, mode="pre-train")
+    with torch.no_grad():                                   # away from the initialisation: zero biases / unit LayerNorms hide mistakes
+        g = torch.Generator().manual_seed(6)
+        for n_, prm in model.named_parameters():
+            if prm.ndim == 1:
+                prm.add_(0.1 * torch.randn(prm.shape, generator=g))
+    sd = {"tsformer." + k: v.detach().clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(1)
+    t = np.arange(L, dtype=np.float32)[:, None]
+    x = np.stack([np.sin(2 * np.pi * t / 288.0 + rng.uniform(0, 6.28, (1, N))) + 0.5 * rng.standard_normal((L, N)) for _ in range(B)]).astype(np.float32)
+    x = torch.from_numpy(x)[..., None]                      # [B, L, N, 1]
+    random.seed(11)
+    um, mk = model.mask()
+    assert len(um) == 42 and len(mk) == 126
+    model = model.cuda()
+    model.train()
+    model.dropout_p = 0.0
+    model.matmul_precision = mode
+    model.mask.forward = lambda: (um, mk)
+    recon, label = model(history_data=x.cuda(), future_data=None, batch_seen=0, epoch=1)
+    loss = O.masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    o_recon, o_label = O.tsformer_pretrain(x, p, um, mk)
+    o_loss = O.masked_mae(o_recon * 150.0 + 200.0, o_label * 150.0 + 200.0, 0.0)
+    o_loss.backward()
+    e_r = rel_l2(recon.detach().cpu(), o_recon.detach())
+    assert max_abs(label.cpu(), o_label) == 0.0
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name, prm in model.named_parameters():
+        want = p["tsformer." + name].grad
+        if want is None or float(want.abs().max()) == 0.0:
+            continue
+        assert prm.grad is not None, name
+        d = (prm.grad.cpu() - want).double()
+        num += float((d ** 2).sum()); den += float((want.double() ** 2).sum())
+        e = rel_l2(prm.grad.cpu(), want)
+        if e > worst[1]:
+            worst = (name, e)
+    e_g = (num / den) ** 0.5
+    print(f"C3 full size [{mode}]: reconstruction rel-L2 {e_r:.2e}, loss {float(loss):.5f} vs {float(o_loss):.5f}, whole gradient {e_g:.2e}, worst tensor {worst}")
+    assert e_r < t_recon and e_g < t_grad
+    assert float(loss) == pytest.approx(float(o_loss), rel=max(10 * t_recon, 1e-4))

@@ -499,14 +499,14 @@ def test_prefetched_frozen_branch_is_bit_identical():
         torch.cuda.synchronize()
         return outs, [p.detach().clone() for p in params], model
 
-    def close(x, y, px, py, what):
+    def close(x, y, px, py, what, params=True):
         worst = 0.0
         for (p0, t0, k0, l0), (p1, t1, k1, l1) in zip(x, y):
             worst = max(worst, rel_l2(p1.cpu(), p0.cpu()), rel_l2(t1.cpu(), t0.cpu()), abs(float(l1 - l0)) / abs(float(l0)))
             assert int((k0 != k1).sum()) <= 4
         wp = max(rel_l2(b_.cpu(), a_.cpu()) for a_, b_ in zip(px, py))
         print(f"{what}: worst prediction / theta / loss difference over 3 steps {worst:.2e}, worst parameter {wp:.2e}")
-        return max(worst, wp)
+        return max(worst, wp) if params else worst
     a, pa, _ = run(False)
     a2, pa2, _ = run(False)
     b, pb, mb = run(True)
@@ -517,4 +517,6 @@ def test_prefetched_frozen_branch_is_bit_identical():
     # dropout seeds, so the comparison is made with dropout off
     d0, pd0, _ = run(False, dropout=False)
     d1, pd1, _ = run(True, wrong_announcement=True, dropout=False)
-    assert close(d0, d1, pd0, pd1, "inline vs mismatching announcements (dropout off)") <= max(10 * noise, 1e-5)
+    # (parameters are not compared here: with dropout off the biases in front of a BatchNorm have an exactly cancelling gradient,
+    # i.e. pure round-off whose SIGN Adam turns into a full +-lr update -- two inline runs differ there just as much)
+    assert close(d0, d1, pd0, pd1, "inline vs mismatching announcements (dropout off)", params=False) <= max(10 * noise, 1e-5)
