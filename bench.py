@@ -392,6 +392,8 @@ class StepBench:
         dt, per_step, loss = timed_loop(self.step, 0, steps, self.barrier, start + warmup)
         if self.world > 1:
             m.collect_reduce_waits()
+            self.reduce_waits, self.small = list(m._reduce_wait_ms), m.collect_small_collectives()
+            m._reduce_wait_ms = None
         dt = max_over_ranks(dt, self.world, self.dev)
         ev = m.tsformer._events
         enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
@@ -477,8 +479,8 @@ class StepBench:
         e1.record()
         torch.cuda.synchronize()
         iso = e0.elapsed_time(e1) / reps
-        exposed = float(np.mean(model._reduce_wait_ms)) if model._reduce_wait_ms else float("nan")
-        small = model.collect_small_collectives() if hasattr(model, "collect_small_collectives") else None
+        exposed = float(np.mean(self.reduce_waits)) if self.reduce_waits else float("nan")
+        small = self.small
         t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(t_ex) for _ in range(world)]
         dist.all_gather(gathered, t_ex)

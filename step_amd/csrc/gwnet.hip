@@ -1060,6 +1060,28 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
     const long BN = (long)B * N;
     float* dx_next = nullptr;
     float* dxbuf[2] = {W.dxa, W.dxb};
+    // dP_s = sum over layers, time steps and channels of x1_s (x) d_x2_s + z (x) d_x1_s: a segmented contraction, K = 3264, cut into
+    // three layer ranges that leave on the auxiliary stream as soon as their layers' hop gradients exist (they accumulate into the
+    // same stack in stream order); only the supports' backward at the very end reads the result
+    {
+        AdjOffsets o;
+        for (int i = 0; i < NL - 1; ++i) { o.cat[i] = S.cat[i] - S.cat[0]; o.dcat[i] = W.dcat[i] - W.dcat[0]; }
+        adj_ktab_kernel<<<3, 128, 0, st>>>(o, N, W.ktab);
+        STEP_LAUNCH_CHECK("adj_ktab");
+    }
+    bool adj_first = true;
+    auto adj_piece = [&](int lo, int hi) -> int {       // layers lo .. hi (inclusive) of the table
+        int seg0 = 0, nseg = 0;
+        for (int i = 0; i < lo; ++i) seg0 += 2 * TOUT[i];
+        for (int i = lo; i <= hi; ++i) nseg += 2 * TOUT[i];
+        StepGemm g = gemm_desc(N, N, 32 * nseg, S.cat[0], 0, 1, W.dcat[0], 1, 0, W.dPstk, N);
+        g.batch = 3 * B; g.batch0 = B;
+        g.scb = (long)N * N; g.scb1 = (long)B * N * N;
+        g.compute_bf16 = BF16;
+        g.accumulate = adj_first ? 0 : 1;
+        adj_first = false;
+        return step_gemm_segmented_launch(g, W.ktab + seg0, ADJ_NSEG, lane.fork());
+    };
     for (int i = NL - 1; i >= 0; --i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
         const long npos = BN * Tout;
@@ -1078,6 +1100,8 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
+            if (i == 4) STEP_TRY(adj_piece(4, 6));          // slots 1..6 of dcat[4..6] are final (tcn_bwd only reads dcat)
+            if (i == 2) STEP_TRY(adj_piece(2, 3));
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
@@ -1098,17 +1122,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         dx_next = dx;
     }
     *dx0 = dx_next;
-    {   // dP_s = sum over layers, time steps and channels of x1_s (x) d_x2_s + z (x) d_x1_s: one segmented contraction, K = 3264
-        AdjOffsets o;
-        for (int i = 0; i < NL - 1; ++i) { o.cat[i] = S.cat[i] - S.cat[0]; o.dcat[i] = W.dcat[i] - W.dcat[0]; }
-        adj_ktab_kernel<<<3, 128, 0, st>>>(o, N, W.ktab);
-        STEP_LAUNCH_CHECK("adj_ktab");
-        StepGemm g = gemm_desc(N, N, 32 * ADJ_NSEG, S.cat[0], 0, 1, W.dcat[0], 1, 0, W.dPstk, N);
-        g.batch = 3 * B; g.batch0 = B;
-        g.scb = (long)N * N; g.scb1 = (long)B * N * N;
-        g.compute_bf16 = BF16;
-        STEP_TRY(step_gemm_segmented_launch(g, W.ktab, ADJ_NSEG, st));
-    }
+    STEP_TRY(adj_piece(0, 1));
     return STEP_OK;
 }
 
@@ -1195,7 +1209,9 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     float* dx0 = nullptr;
     if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane));
     else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane));
-    STEP_TRY(lane.join());          // every leaf is finished from here on: the packed weight gradients are complete
+    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);
+    STEP_LAUNCH_CHECK("start_conv_bwd");
+    STEP_TRY(lane.join());          // every leaf is finished from here on: the packed weight gradients and the adjacency gradients are complete
     {
         GatePtrs gg;
         SkipPtrs sg;
@@ -1206,8 +1222,6 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, st>>>(W.dwcat, W.dbcat, gg);
         unpack_skip_grad_kernel<<<CS, CS, 0, st>>>(W.dwskip, sg);
     }
-    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);
-    STEP_LAUNCH_CHECK("start_conv_bwd");
 
     // ---------------------------------------------------------------- supports
     {   // adaptive adjacency softmax(relu(E1 E2), dim=1); its gradient is the sum over samples of stack slot 2

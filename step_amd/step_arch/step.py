@@ -202,6 +202,7 @@ class _StepFunction(torch.autograd.Function):
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
         fo, fn, _ = layout["items"]["dgl.fc_w"]
         assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
+        assert layout["norm_slot"] == fo - 4
         sh = dgl._shard
         if sh is None:
             L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
@@ -230,6 +231,10 @@ class _StepFunction(torch.autograd.Function):
             # conv1's gradients are per-slice partial sums: summed, not averaged, by the mean all-reduce below
             views["dgl.conv1_w"].mul_(float(world))
             views["dgl.conv1_b"].mul_(float(world))
+            # the squared norm of this rank's fc-slice gradient rides in the spare slot (x world: the reduction below takes the mean)
+            ns = layout["norm_slot"]
+            model._own_slice_norm = torch.linalg.vector_norm(flat[fo:fo + fn]).reshape(1)
+            torch.mul(model._own_slice_norm.square(), float(world), out=flat[ns:ns + 1])
             model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
         model._flat_grad = flat
         model._backward_count = getattr(model, "_backward_count", 0) + 1
@@ -270,6 +275,7 @@ class STEP(nn.Module):
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
         self._reduce_events = []
+        self._small_events = []             # (start, end, bytes) of the time-sliced graph learner's blocking sums (bench.py)
 
     def load_pre_trained_model(self):
         """step.py:27-35: load {"model_state_dict": ...} and freeze."""
@@ -382,12 +388,18 @@ class STEP(nn.Module):
     def _grad_layout(self):
         if self._layout is None:
             off, items, order = 0, {}, []
+            norm_slot = None
             for k, v in self._trainable():
+                if k == "dgl.fc_w":
+                    # four spare floats in front of the fc weight: with time slices the squared norm of this rank's fc-slice gradient
+                    # rides here through the all-reduce of everything before fc_w (the clip norm needs the other ranks' slices)
+                    norm_slot = off
+                    off += 4
                 n = v.numel()
                 items[k] = (off, n, tuple(v.shape))
                 order.append(k)
                 off += (n + 3) & ~3
-            self._layout = {"items": items, "order": order, "total": off}
+            self._layout = {"items": items, "order": order, "total": off, "norm_slot": norm_slot}
         return self._layout
 
     def flatten_parameters(self):
@@ -444,7 +456,14 @@ class STEP(nn.Module):
         """in-place sum of a small device tensor over the data-parallel group, ordered on the current stream"""
         import torch.distributed as dist
         if self._process_group is not None and dist.get_world_size(self._process_group) > 1:
+            timed = self._reduce_wait_ms is not None and t.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(t, group=self._process_group)
+            if timed:
+                e1.record()
+                self._small_events.append((e0, e1, t.numel() * t.element_size()))
 
     def _reduce_finish(self, flat, pending, reduced=None):
         """Wait for the chunks and turn the sums into means.  With ``_reduce_wait_ms`` set to a list (bench.py), the time the
@@ -470,6 +489,17 @@ class STEP(nn.Module):
         if self._reduce_wait_ms is not None:
             self._reduce_wait_ms.extend(out)
         return out
+
+    def collect_small_collectives(self):
+        """{"per_step": n, "exposed_ms_per_step": t, "bytes": [...]} of the blocking sums issued since collect_reduce_waits() was
+        armed (needs a synchronize): each is timed on the stream that waits for it."""
+        ev, self._small_events = self._small_events, []
+        steps = max(len(self._reduce_wait_ms or []), 1)
+        if not ev:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in ev]
+        return {"per_step": len(ev) / steps, "exposed_ms_per_step": float(sum(ms)) / steps,
+                "bytes": sorted({int(n) for _, _, n in ev})}
 
     def _reduce_flat_grads(self, flat):
         self._reduce_finish(flat, self._reduce_begin(flat), flat)
