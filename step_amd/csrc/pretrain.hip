@@ -417,20 +417,31 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
 }
 
 // backward: phase A (wave = query tile) -> dQ and the keep bits, phase B (wave = key tile) -> dK, dV
+// LDS: only the 24 real head dimensions are stored -- row-major rows of 24 (48 B: three 16-byte pieces, the fourth operand piece
+// is a zero constant) and 24 transposed rows plus ONE shared zero row for operand rows 24..31 -- 71 KB at T = 168 (two
+// workgroups per compute unit; 107 KB and one before) and 137 KB at T = 336 (the f32 kernel had to take over above 256 tokens).
+constexpr int MB_RP = 24;                 // row pitch (bf16 elements) of the backward's row-major arrays
+__device__ __forceinline__ bf16x8 mb_row8(const uint16_t* arr, int row, int st, int h) {      // dims 16 st + 8 h .. + 7 of `row`
+    const int off = 16 * st + 8 * h;
+    const uint4 v = *(const uint4*)(arr + row * MB_RP + (off < DH ? off : 0));
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    return __builtin_bit_cast(bf16x8, off < DH ? v : z);
+}
 __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                             const float* __restrict__ dout, const float* __restrict__ stats, int T, int Tp,
                                                             float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ dqkv,
                                                             const uint32_t* __restrict__ keepbits) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp), nt = Tp / 32;
-    uint16_t* Qs = ml;                        // row-major [Tp][MA_RP]: q*scale, k, v, dO
-    uint16_t* Ks = Qs + Tp * MA_RP;
-    uint16_t* Vs = Ks + Tp * MA_RP;
-    uint16_t* Os = Vs + Tp * MA_RP;
-    uint16_t* QT = Os + Tp * MA_RP;           // transposed [32][TPt]: q*scale, k, dO
-    uint16_t* KT = QT + 32 * TPt;
-    uint16_t* OT = KT + 32 * TPt;
-    float* smx = (float*)(OT + 32 * TPt);     // [Tp] row max, 1 / row sum, delta
+    uint16_t* Qs = ml;                        // row-major [Tp][MB_RP]: q*scale, k, v, dO
+    uint16_t* Ks = Qs + Tp * MB_RP;
+    uint16_t* Vs = Ks + Tp * MB_RP;
+    uint16_t* Os = Vs + Tp * MB_RP;
+    uint16_t* QT = Os + Tp * MB_RP;           // transposed [DH][TPt]: q*scale, k, dO
+    uint16_t* KT = QT + DH * TPt;
+    uint16_t* OT = KT + DH * TPt;
+    uint16_t* ZT = OT + DH * TPt;             // [TPt] zeros: the padded head dimensions 24 .. 31 of all three
+    float* smx = (float*)(ZT + TPt);          // [Tp] row max, 1 / row sum, delta
     float* sinv = smx + Tp;
     float* sdl = sinv + Tp;
     uint32_t* bits = (uint32_t*)(sdl + Tp);   // [Tp][nt] keep bits of (query, key tile)
@@ -446,9 +457,12 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
         const uint16_t k = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 96 + hd * DH + d] : 0.f);
         const uint16_t v = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 192 + hd * DH + d] : 0.f);
         const uint16_t g = (uint16_t)f32_to_bf16_bits(ok ? dout[(s * T + t) * D + hd * DH + d] : 0.f);
-        Qs[t * MA_RP + d] = q; Ks[t * MA_RP + d] = k; Vs[t * MA_RP + d] = v; Os[t * MA_RP + d] = g;
-        QT[d * TPt + t] = q; KT[d * TPt + t] = k; OT[d * TPt + t] = g;
+        if (d < DH) {
+            Qs[t * MB_RP + d] = q; Ks[t * MB_RP + d] = k; Vs[t * MB_RP + d] = v; Os[t * MB_RP + d] = g;
+            QT[d * TPt + t] = q; KT[d * TPt + t] = k; OT[d * TPt + t] = g;
+        }
     }
+    for (int i = tid; i < TPt; i += blockDim.x) ZT[i] = 0;
     for (int i = tid; i < Tp; i += blockDim.x) {
         float dl = 0.f, m = 0.f, iv = 0.f;
         if (i < T) {
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
         const float mq = smx[q], iq = sinv[q], dq_ = sdl[q];
         bf16x8 bq[2], bo[2];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) { bq[st] = ma_row8(Qs + q * MA_RP + 16 * st + 8 * h); bo[st] = ma_row8(Os + q * MA_RP + 16 * st + 8 * h); }
+        for (int st = 0; st < 2; ++st) { bq[st] = mb_row8(Qs, q, st, h); bo[st] = mb_row8(Os, q, st, h); }
         f32x16 dqa;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqa[e] = 0.f;
@@ -477,8 +491,8 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Ks + (kt * 32 + col) * MA_RP + 16 * st + 8 * h), bq[st], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Vs + (kt * 32 + col) * MA_RP + 16 * st + 8 * h), bo[st], dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mb_row8(Ks, kt * 32 + col, st, h), bq[st], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mb_row8(Vs, kt * 32 + col, st, h), bo[st], dp, 0, 0, 0);
             }
             float mk[16];
             uint32_t word = 0u;
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(KT + col * TPt, kt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dqa, 0, 0, 0);
+                dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(col < DH ? KT + col * TPt : ZT, kt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dqa, 0, 0, 0);
         }
         if (q < T) {
 #pragma unroll
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
         const int kj = wave * 32 + col;
         bf16x8 bk[2], bv[2];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) { bk[st] = ma_row8(Ks + kj * MA_RP + 16 * st + 8 * h); bv[st] = ma_row8(Vs + kj * MA_RP + 16 * st + 8 * h); }
+        for (int st = 0; st < 2; ++st) { bk[st] = mb_row8(Ks, kj, st, h); bv[st] = mb_row8(Vs, kj, st, h); }
         f32x16 dka, dva;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dka[e] = 0.f; dva[e] = 0.f; }
@@ -530,8 +544,8 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) { sc[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Qs + (qt * 32 + col) * MA_RP + 16 * st + 8 * h), bk[st], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_row8(Os + (qt * 32 + col) * MA_RP + 16 * st + 8 * h), bv[st], dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mb_row8(Qs, qt * 32 + col, st, h), bk[st], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mb_row8(Os, qt * 32 + col, st, h), bv[st], dp, 0, 0, 0);
             }
             float pm[16], ds[16];
 #pragma unroll
@@ -544,8 +558,8 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                dva = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(OT + col * TPt, qt * 32 + 16 * st, h), ma_pack(pm + 8 * st), dva, 0, 0, 0);
-                dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(QT + col * TPt, qt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dka, 0, 0, 0);
+                dva = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(col < DH ? OT + col * TPt : ZT, qt * 32 + 16 * st, h), ma_pack(pm + 8 * st), dva, 0, 0, 0);
+                dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(col < DH ? QT + col * TPt : ZT, qt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dka, 0, 0, 0);
             }
         }
         if (kj < T) {
@@ -680,7 +694,7 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
 }
 // the same attention on the matrix cores (bf16 operands, f32 accumulation) -- what TSFormer(mode="pre-train") uses with matmul_precision = "bf16"
 static size_t ma_fwd_lds(int Tp) { return (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2; }
-static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MA_RP + 3 * 32 * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
+static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MB_RP + (3 * DH + 1) * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
 extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                                           uint32_t* keepbits, void* stream) {
     STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f, "pt_attention_fwd_bf16: bad arguments (T=%d)", T);

@@ -165,8 +165,49 @@ class DiscreteGraphLearning(nn.Module):
         return {k: v for k, v in self.native_tensors().items() if not (k.endswith("_rm") or k.endswith("_rv"))}
 
     def forward(self, long_term_history, tsformer):
-        raise RuntimeError("step_amd.DiscreteGraphLearning is driven through step_amd.STEP (native forward+backward); "
-                           "it has no standalone PyTorch path")
+        """Standalone call with the reference's signature (discrete_graph_learning.py:113-168): long_term_history [B, L, N, C],
+        tsformer = a step_amd.TSFormer -> (bernoulli_unnorm [B, N*N, 2], hidden_states [B, N, P, 96], adj_knn [B, N, N],
+        sampled_adj [B, N, N]).  The native edge kernel produces theta = softmax(logits)[..., 0] rather than both logits; the first
+        output is (log theta, log(1 - theta)), which equals the reference's logits up to a per-edge constant -- every use of them
+        (softmax at step.py:72, the Gumbel sample) is invariant to it.  Forward only (``torch.no_grad()``): training goes through
+        ``step_amd.STEP``.  Not available for a time-sliced (data-parallel sharded) module."""
+        if not long_term_history.is_cuda:
+            raise RuntimeError("step_amd.DiscreteGraphLearning runs only on an AMD GPU: libstep_hip has no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("step_amd.DiscreteGraphLearning.forward is forward-only (wrap the call in torch.no_grad()); training goes "
+                               "through step_amd.STEP")
+        if self._shard is not None:
+            raise RuntimeError("standalone DiscreteGraphLearning.forward is not available for a time-sliced module")
+        import ctypes
+        L = _lib
+        B, Lh, N, _ = long_term_history.shape
+        dev = long_term_history.device
+        P = Lh // 12
+        hidden = tsformer(long_term_history[..., [0]])                      # [B, N, P, 96] (:139)
+        T = self.train_length
+        struct = fill_dgl_struct(self.native_tensors(), int(getattr(self, "matmul_precision", "f32") == "bf16"))
+        gsaved = torch.empty(int(L.lib().step_dgl_global_saved_floats(N, T)), device=dev)
+        gwork = torch.empty(int(L.lib().step_dgl_global_work_floats(N, T, 0)), device=dev)
+        g = torch.empty(N, 100, device=dev)
+        L.call("step_dgl_global_forward", L.ptr(self._series_nt), N, T, ctypes.byref(struct), int(self.training), 0.1,
+               L.ptr(gsaved), L.ptr(gwork), L.ptr(g), L.stream())
+        esaved = torch.empty(int(L.lib().step_dgl_edges_saved_floats(B, N)), device=dev)
+        theta = torch.empty(B, N, N, device=dev)
+        adj = torch.empty(B, N, N, device=dev)
+        u = torch.rand(B, N * N, 2).to(dev)                                 # the reference draws on the host (:12)
+        L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(struct), L.ptr(u), 0, 0.5, L.ptr(esaved), L.ptr(theta), L.ptr(adj),
+               L.stream())
+        hb = hidden.reshape(B * N, P * 96).to(torch.bfloat16).contiguous()
+        sim = torch.empty(B, N, N, device=dev)
+        knn = torch.empty(B, N, N, device=dev)
+        kwork = torch.empty(int(L.lib().step_knn_workspace_bytes(B, N, P * 96)), dtype=torch.uint8, device=dev)
+        L.call("step_knn_graph", L.ptr(hb), None, B, N, P * 96, self.k * N, L.ptr(sim), L.ptr(knn), L.ptr(kwork), kwork.numel(), L.stream())
+        if self.training:
+            for m in (self.bn1, self.bn2, self.bn3):
+                m.num_batches_tracked += 1
+        th = theta.reshape(B, N * N).clamp(1e-30, 1.0)
+        logits = torch.stack([th.log(), torch.log1p(-th.clamp(max=1 - 1e-7))], dim=-1)
+        return logits, hidden, knn, adj
 
 
 def fill_dgl_struct(tensors, gemm_bf16=False):

@@ -106,8 +106,34 @@ class GraphWaveNet(nn.Module):
         return keep
 
     def forward(self, input, hidden_states, sampled_adj):
-        raise RuntimeError("step_amd.GraphWaveNet is driven through step_amd.STEP (native forward+backward); "
-                           "it has no standalone PyTorch path")
+        """Standalone call with the reference's signature (graphwavenet/model.py:132-224): input [B, 12, N, C >= 2] short history,
+        hidden_states [B, N, 96] = TSFormer state of the last patch, sampled_adj [B, N, N] -> prediction [B, N, 12].  One native
+        launch sequence (``step_gwnet_forward``; train mode: batch-statistic BatchNorm with running-stat update and the gcn dropout,
+        like the reference module in train mode).  Forward only: gradients flow through ``step_amd.STEP`` (whose autograd function
+        drives the same kernels plus ``step_gwnet_backward``), so this call must run under ``torch.no_grad()``."""
+        if not input.is_cuda:
+            raise RuntimeError("step_amd.GraphWaveNet runs only on an AMD GPU: libstep_hip has no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("step_amd.GraphWaveNet.forward is forward-only (wrap the call in torch.no_grad()); training goes through step_amd.STEP")
+        L = _lib
+        B, T, N, Cin = input.shape
+        assert T == 12 and N == self.num_nodes and tuple(hidden_states.shape) == (B, N, 96) and tuple(sampled_adj.shape) == (B, N, N)
+        dev = input.device
+        drop = self.dropout if self.training else 0.0
+        bf = int(getattr(self, "matmul_precision", "f32") == "bf16")
+        struct = fill_gwnet_struct(self.native_tensors(), bf)
+        saved = torch.empty(int(L.lib().step_gwnet_saved_floats(B, N, int(drop > 0))), device=dev)
+        work = torch.empty(int(L.lib().step_gwnet_work_floats(B, N, 0)), device=dev)
+        pred = torch.empty(B, 12, N, device=dev)
+        self._seed_ctr = getattr(self, "_seed_ctr", 0) + 1
+        seed = (torch.initial_seed() * 2862933555777941757 + self._seed_ctr * 3037000493) & ((1 << 63) - 1)
+        L.call("step_gwnet_forward", L.ptr(input.contiguous().float()), B, N, Cin, L.ptr(hidden_states.contiguous().float()),
+               L.ptr(sampled_adj.contiguous().float()), ctypes.byref(struct), int(self.training), float(drop), seed, 0.1,
+               L.ptr(saved), L.ptr(work), L.ptr(pred), L.stream())
+        if self.training:
+            for m in list(self.bn)[:7]:
+                m.num_batches_tracked += 1
+        return pred.transpose(1, 2)               # [B, N, 12] (model.py:222-224)
 
 
 def fill_gwnet_struct(tensors, gemm_bf16=False):

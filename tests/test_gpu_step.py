@@ -520,3 +520,35 @@ def test_prefetched_frozen_branch_is_bit_identical():
     # (parameters are not compared here: with dropout off the biases in front of a BatchNorm have an exactly cancelling gradient,
     # i.e. pure round-off whose SIGN Adam turns into a full +-lr update -- two inline runs differ there just as much)
     assert close(d0, d1, pd0, pd1, "inline vs mismatching announcements (dropout off)", params=False) <= max(10 * noise, 1e-5)
+
+
+def test_standalone_submodule_forwards_match_oracle():
+    """The reference's sub-modules are callable on their own (graphwavenet/model.py:132, discrete_graph_learning.py:113); the native
+    ones are too, forward-only: GraphWaveNet(input, hidden_states, sampled_adj) -> [B, N, 12] and DiscreteGraphLearning(long_history,
+    tsformer) -> (logits, hidden, adj_knn, sampled_adj), both against the oracle in eval mode (running statistics, no dropout) with
+    the same host-drawn Gumbel noise; gradients are refused outside torch.no_grad()."""
+    g = load_golden("step_tiny")
+    N, L, T, B, k, epoch, tr = [int(x) for x in g["meta"]]
+    model = build_native(g)
+    model.eval()
+    p = params_of(g, requires_grad=False)
+    hist, long_hist, fut = inputs_of(g)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        model.backend(hist, torch.zeros(B, N, 96, device="cuda"), torch.zeros(B, N, N, device="cuda"))
+    with torch.no_grad():
+        torch.manual_seed(77)
+        logits, hidden, knn, samp = model.discrete_graph_learning(long_hist, model.tsformer)
+        pred = model.backend(hist, hidden[:, :, -1, :].contiguous(), samp)
+    torch.manual_seed(77)
+    u = torch.rand(B, N * N, 2)
+    hid = hidden.cpu()
+    o_logits, _, o_knn, o_samp = O.dgl_forward(g["in.long_hist0"], g["in.node_feats"], p, u, k, training=False, hidden=hid)
+    theta, o_theta = torch.softmax(logits.cpu(), -1)[..., 0], torch.softmax(o_logits, -1)[..., 0]
+    assert logits.shape == (B, N * N, 2) and hidden.shape == (B, N, L // 12, 96) and pred.shape == (B, N, 12)
+    assert max_abs(theta, o_theta) < 2e-5
+    assert torch.equal(samp.cpu(), o_samp)
+    assert int((knn.cpu() != o_knn).sum()) <= 4                                # threshold ties of the bf16 Gram
+    o_pred = O.gwnet_forward(g["in.hist"], hid[:, :, -1, :], o_samp, p, training=False)
+    e = rel_l2(pred.cpu(), o_pred)
+    print(f"standalone sub-modules (eval): theta max-abs {max_abs(theta, o_theta):.1e}, prediction rel-L2 vs oracle {e:.2e}")
+    assert e < 1e-4
