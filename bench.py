@@ -12,10 +12,10 @@ path) on the same synthetic series -- saved in the reference's format and loaded
 softmax schedule is data dependent (units whose scores outrun the fixed shift are redone by the re-shifting loop); the line reports
 how many did (`roofline.fallback_units_per_launch`) and a second figure with random-init weights (`random_init`).
 
-The frozen branch (TSFormer + kNN prior) of batch i+1 is queued on its own stream before the backward pass of batch i
-(`STEP.prefetch`, step_amd/step_arch/step.py): it reads nothing the optimizer updates, so its outputs are bit-identical
-(tests/test_gpu_step.py::test_prefetched_frozen_branch_is_bit_identical); every timed step still contains exactly one encoder
-launch.  `no_prefetch` is the same loop with the branch computed inside forward().
+`prefetch` (second figure of the line): the frozen branch (TSFormer + kNN prior) of batch i+1 queued on its own stream before the
+backward pass of batch i (`STEP.prefetch`, step_amd/step_arch/step.py; it reads nothing the optimizer updates, its outputs are
+bit-identical, tests/test_gpu_step.py::test_prefetched_frozen_branch_is_bit_identical).  Measured neutral on one GPU, hence off
+in the headline loop.
 """
 import argparse
 import json
@@ -347,7 +347,7 @@ class StepBench:
             longh = torch.stack([self.dser[t - Lh:t] for t in ts])
             self.batches.append((hist, longh, fut))
         self.mean, self.std = 200.0, 150.0
-        self.prefetch = not args.no_prefetch
+        self.prefetch = args.prefetch
 
     def barrier(self):
         if self.world > 1:
@@ -517,7 +517,8 @@ def main():
                     "north-star configs at N=1, none at N>1; '-' = none)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic falls back to the committed record)")
     ap.add_argument("--pretrain-steps", type=int, default=300, help="native TSFormer pre-training steps behind the loaded checkpoint (0: random init)")
-    ap.add_argument("--no-prefetch", action="store_true", help="compute the frozen branch inside forward() instead of a step ahead")
+    ap.add_argument("--prefetch", action="store_true", help="queue the frozen branch (encoder + kNN prior) of the next batch on its own stream "
+                    "before this batch's backward (STEP.prefetch); measured neutral on one GPU (the `prefetch` figure of the default line)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -579,14 +580,17 @@ def main():
     no_prefetch, random_init = None, None
     short = max(min(args.steps // 3, 40), 5)
     if extras and not args.forward_only:
-        if bench.prefetch:
-            bench.prefetch = False
-            bench.model._prefetched = None
+        if not bench.prefetch:
+            bench.prefetch = True
             r2 = bench.run(3, short, nxt + 16)
             no_prefetch = {"value": r2["value"], "unit": "windows/s", "ms_per_step": r2["ms_per_step"], "steps": short,
                            "encoder_ms_per_launch": r2["enc_ms"],
-                           "what": "same step with the frozen branch (encoder + kNN prior) launched inside forward(), next to the second stream only"}
-            bench.prefetch = True
+                           "what": "same step with the frozen branch (encoder + kNN prior) of the NEXT batch queued on its own stream before this "
+                                   "batch's backward (STEP.prefetch: bit-identical outputs); not the default because it buys nothing on one GPU -- "
+                                   "the encoder's 704-thread, 147 KB workgroups leave no room for the backward's kernels next to them"}
+            bench.prefetch = False
+            bench.model._prefetched = None
+            torch.cuda.synchronize()
         if ckpt is not None:
             from step_amd import TSFormer
             torch.manual_seed(0)
@@ -643,7 +647,7 @@ def main():
               + (f"pre-trained TSFormer (native C3 path, {ckpt_info['steps']} steps, masked MAE {ckpt_info['first_loss']:.1f} -> {ckpt_info['last_loss']:.1f}) "
                  f"loaded from tsformer_ckpt/, " if ckpt_info else "random-init weights, ")
               + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)")
-              + (", frozen branch of the next batch prefetched on its own stream" if (bench.prefetch and not args.forward_only) else ""))
+              + (", frozen branch of the next batch prefetched on its own stream" if (args.prefetch and not args.forward_only) else ""))
         sfl = step_flops(cfg, B)
         out = {
             "metric": ("validation windows/sec (eval-mode forward + masked MAE)" if args.forward_only else
@@ -669,12 +673,12 @@ def main():
                          "frac_alone": (flops / (enc_alone_ms * 1e-3) / 1e12 / PEAK_TFLOPS) if enc_alone_ms else None,
                          "fallback_units_per_launch": res["fallback_units_per_launch"], "softmax_units_per_launch": units,
                          "note": "achieved / ms_per_launch: events around the kernel on its launch stream inside the timed steps, where it shares "
-                                 "the GPU with the backward pass of the previous batch (prefetch stream) or the second stream's kernels; *_alone: "
+                                 "the GPU with the second stream's kernels (graph learner + WaveNet layers); *_alone: "
                                  "the same kernel in 5 extra steps with nothing next to it; fallback_units: (32-token tile, head, layer, "
                                  "sequence) units whose softmax left the fixed-shift schedule (device counter)"},
         }
         if no_prefetch is not None:
-            out["no_prefetch"] = no_prefetch
+            out["prefetch"] = no_prefetch
         if random_init is not None:
             out["random_init"] = random_init
         if loader_fig is not None:

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream); 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -255,6 +255,14 @@ int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* h
  * rows = sequence-major tokens.  Dropout masks are a pure function of (seed, site, element index), so a
  * backward call with the same arguments replays the forward mask. */
 int step_pt_dropout(const float* x, float* y, long n, float p, uint64_t seed, uint32_t site, void* stream);
+/* bf16 mode: the feed-forward hidden layer with ReLU and dropout in the GEMM epilogue, stored as bf16 (nothing [R,384] is ever written
+ * in f32):  hidden[r][j] = dropout(relu(x[r,:] . w1[j,:] + b1[j])), the keep decisions of step_pt_dropout(seed, site) on [R,384];
+ * and its backward through dropout and ReLU:  dhidden[r][j] = hidden[r][j] != 0 ? (dy[r,:] . w2[:,j]) / (1 - p) : 0.
+ * Replace linear1 + ReLU + dropout of torch.nn.TransformerEncoderLayer (transformer_layers.py:10) and their autograd. */
+int step_pt_ffn_hidden_fwd(const float* x, const float* w1, const float* b1, long R, float p, uint64_t seed, uint32_t site,
+                           uint16_t* hidden, void* stream);
+int step_pt_ffn_hidden_bwd(const float* dy, const float* w2, const uint16_t* hidden, long R, float p, uint16_t* dhidden, void* stream);
+int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void* stream);      /* out[c] += sum_r x[r][c] */
 /* d = dropout(d) * [relu_of > 0] in one pass: the backward of relu -> dropout (same mask stream as step_pt_dropout at `site`) */
 int step_pt_dropout_relu_mask(float* d, const float* relu_of, long n, float p, uint64_t seed, uint32_t site, void* stream);
 int step_pt_add_dropout(const float* a, const float* b, float* out, long n, float p, uint64_t seed, uint32_t site, void* stream);

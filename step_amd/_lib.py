@@ -86,6 +86,9 @@ _SIGS = {
     "step_gwnet_forward_phase": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _i, _vp]),
     "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp, _vp]),
     "step_pt_dropout": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
+    "step_pt_ffn_hidden_fwd": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),
+    "step_pt_colsum_bf16": (_i, [_vp, _l, _i, _vp, _vp]),
     "step_pt_dropout_relu_mask": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_add_dropout": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_add_rows": (_i, [_vp, _l, _i, _vp, _vp, _vp]),

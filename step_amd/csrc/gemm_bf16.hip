@@ -613,6 +613,63 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
         const GemmFused& fu = fa.fu;
         constexpr int PIECES = BM * BN / 4, NPC = PIECES / 256, NB = NPC < 8 ? NPC : 8;
         static_assert(PIECES % 256 == 0 && NPC % NB == 0, "piece loop shape");
+        if (fu.flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ)) {
+            // bf16 hidden layer of the pre-training feed-forward block: a thread's piece = 4 consecutive columns of one row = one
+            // Philox call of the step_pt_dropout stream (element index m * N + n, N % 4 == 0)
+            uint16_t* Ch = (uint16_t*)Cb;
+            const uint16_t* xh = (const uint16_t*)fu.maskx;
+            const bool fwd = (fu.flags & GEMM_FUSED_FFN_FWD) != 0;
+            const float ks = fu.p > 0.f ? 1.f / (1.f - fu.p) : 1.f;
+            const int c4t = (tid % (BN / 4)) * 4;                    // the same 4 columns for all of this thread's pieces
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (fwd && n0 + c4t < g.N) {
+                const float4 t = *(const float4*)(fu.ffn_bias + n0 + c4t);
+                b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+            }
+            for (int pb = 0; pb < NPC; pb += NB) {
+                uint2 x2[NB];
+                long off[NB];
+                bool ok[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int pc = tid + (pb + u) * 256;
+                    const int gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
+                    ok[u] = gm < g.M && gn < g.N;
+                    off[u] = ok[u] ? (long)gm * g.ldc + gn : 0;
+                    if (!fwd) x2[u] = *(const uint2*)(xh + off[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (!ok[u]) continue;
+                    const int pc = tid + (pb + u) * 256;
+                    const float4 t4 = *(const float4*)(tile + (pc / (BN / 4)) * TP + (pc % (BN / 4)) * 4);
+                    const float v[4] = {t4.x, t4.y, t4.z, t4.w};
+                    float o[4];
+                    if (fwd) {
+                        float m[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (fu.p > 0.f) {
+                            const long gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
+                            const long blk = (gm * (long)g.N + gn) >> 2;
+                            uint32_t rr[4];
+                            philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), fu.site, 0xD20Fu, fu.seed_lo, fu.seed_hi, rr);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) m[i] = u32_to_unit(rr[i]) >= fu.p ? ks : 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = fmaxf(v[i] + b4[i], 0.f) * m[i];
+                    } else {
+                        const uint32_t w0 = x2[u].x, w1 = x2[u].y;
+                        // (a stored value of +-0 means "closed": compare the magnitude bits)
+                        o[0] = (w0 & 0x7fffu) ? v[0] * ks : 0.f;
+                        o[1] = (w0 & 0x7fff0000u) ? v[1] * ks : 0.f;
+                        o[2] = (w1 & 0x7fffu) ? v[2] * ks : 0.f;
+                        o[3] = (w1 & 0x7fff0000u) ? v[3] * ks : 0.f;
+                    }
+                    *(uint2*)(Ch + off[u]) = pack4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            return;
+        }
         if (fu.flags & GEMM_FUSED_INTERLEAVED) {
             // channels-last bf16 activations (dgl_conv_mfma.hip): column n belongs to channel n % C, the result and the BatchNorm input
             // are bf16.  Stored: x > 0 ? v - kc (m1 + (x - mean) rstd m2) : 0 with v = alpha A.B (the BatchNorm scale kc is already in B).
@@ -835,6 +892,7 @@ template <int BM, int BN>
 int launch_fast_fused(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
     if (amode == KC_F32 && bmode == MC_BF16) gemm_fast_kernel<BM, BN, KC_F32, MC_BF16, false, false, true><<<grid, 256, 0, st>>>(g, fa);
+    else if (amode == KC_F32 && bmode == KC_F32) gemm_fast_kernel<BM, BN, KC_F32, KC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
     else if (amode == KC_F32 && bmode == MC_F32) gemm_fast_kernel<BM, BN, KC_F32, MC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
     else if (amode == MC_F32 && bmode == MC_F32) gemm_fast_kernel<BM, BN, MC_F32, MC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
     else { step_set_error("step_gemm(fused): operand layout not instantiated"); return STEP_ERR_ARG; }
@@ -884,7 +942,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
                 !(g.a_rowsum && (bmode == KC_BF16 || bmode == MC_BF16)) && !(bmode == MC_BF16 && g.N % 8);
     fa.wide_store = wide_store_ok(g, fused != nullptr);
     if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 &&
-                            ((fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
+                            ((fused->flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ)) ? (g.accumulate == 0 && !fused->dotw && !fused->bnx && !g.c_nscale) :
+                             (fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
                             "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {

@@ -1069,6 +1069,8 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         adj_ktab_kernel<<<3, 128, 0, st>>>(o, N, W.ktab);
         STEP_LAUNCH_CHECK("adj_ktab");
     }
+    // (STEP_ADJ_PIECES=0: one contraction after the loop, A/B measurements)
+    static const bool adj_pieces = []() { const char* e = getenv("STEP_ADJ_PIECES"); return !(e && e[0] == '0'); }();
     bool adj_first = true;
     auto adj_piece = [&](int lo, int hi) -> int {       // layers lo .. hi (inclusive) of the table
         int seg0 = 0, nseg = 0;
@@ -1100,8 +1102,8 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
-            if (i == 4) STEP_TRY(adj_piece(4, 6));          // slots 1..6 of dcat[4..6] are final (tcn_bwd only reads dcat)
-            if (i == 2) STEP_TRY(adj_piece(2, 3));
+            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6));          // slots 1..6 of dcat[4..6] are final (tcn_bwd only reads dcat)
+            if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3));
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
@@ -1122,7 +1124,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         dx_next = dx;
     }
     *dx0 = dx_next;
-    STEP_TRY(adj_piece(0, 1));
+    STEP_TRY(adj_pieces ? adj_piece(0, 1) : adj_piece(0, NL - 2));
     return STEP_OK;
 }
 

@@ -577,6 +577,16 @@ __global__ void relu_mask_kernel(float* __restrict__ d, const float* __restrict_
     if (i < n && !(y[i] > 0.f)) d[i] = 0.f;
 }
 
+// out[c] += sum over rows of x[row][c], x bf16 [rows][cols] (bias gradient of the bf16 hidden-layer gradient)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, long rows, int cols, int slab, float* __restrict__ out) {
+    const long r0 = (long)blockIdx.x * slab, r1 = r0 + slab < rows ? r0 + slab : rows;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = 0.f;
+        for (long r = r0; r < r1; ++r) a += bf16_bits_to_f32(x[r * cols + c]);
+        atomicAdd(out + c, a);
+    }
+}
+
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -722,6 +732,41 @@ extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, co
     attn_mfma_bwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_bwd_lds(Tp), (hipStream_t)stream>>>(qkv, out, dout, stats, T, Tp, p, SEED_LO(seed),
                                                                                                     SEED_HI(seed), site, dqkv, keepbits);
     STEP_LAUNCH_CHECK("pt_attention_bwd_bf16");
+    return STEP_OK;
+}
+// Feed-forward hidden layer with its ReLU and dropout in the GEMM epilogue, stored as bf16 (bf16 contraction mode):
+//   hidden[r][j] = dropout(relu(x[r,:] . w1[j,:] + b1[j]))       x [R,96], w1 [384,96], hidden bf16 [R,384]
+// The keep decisions are those of step_pt_dropout(seed, site) on an [R,384] tensor, so the unfused path replays the same masks.
+extern "C" int step_pt_ffn_hidden_fwd(const float* x, const float* w1, const float* b1, long R, float p, uint64_t seed, uint32_t site,
+                                      uint16_t* hidden, void* stream) {
+    STEP_REQUIRE(x && w1 && b1 && hidden && R > 0 && R < (1L << 31) && p >= 0.f && p < 1.f, "pt_ffn_hidden_fwd: bad arguments");
+    StepGemm g = gemm_desc((int)R, 4 * D, D, x, D, 1, w1, 1, D, (float*)hidden, 4 * D);
+    g.compute_bf16 = 1;
+    GemmFused fu;
+    memset(&fu, 0, sizeof(fu));
+    fu.channels = 1; fu.period = 4 * D; fu.flags = GEMM_FUSED_FFN_FWD;
+    fu.ffn_bias = b1; fu.p = p; fu.seed_lo = SEED_LO(seed); fu.seed_hi = SEED_HI(seed); fu.site = site;
+    return step_gemm_launch_fused(g, fu, (hipStream_t)stream);
+}
+// Its backward through dropout and ReLU: dhidden[r][j] = hidden[r][j] != 0 ? (dy[r,:] . w2[:,j]) / (1 - p) : 0, bf16 [R,384]
+// (dy [R,96] = gradient of the second linear layer's output, w2 [96,384]).
+extern "C" int step_pt_ffn_hidden_bwd(const float* dy, const float* w2, const uint16_t* hidden, long R, float p, uint16_t* dhidden,
+                                      void* stream) {
+    STEP_REQUIRE(dy && w2 && hidden && dhidden && R > 0 && R < (1L << 31) && p >= 0.f && p < 1.f, "pt_ffn_hidden_bwd: bad arguments");
+    StepGemm g = gemm_desc((int)R, 4 * D, D, dy, D, 1, w2, 4 * D, 1, (float*)dhidden, 4 * D);
+    g.compute_bf16 = 1;
+    GemmFused fu;
+    memset(&fu, 0, sizeof(fu));
+    fu.channels = 1; fu.period = 4 * D; fu.flags = GEMM_FUSED_MASKNZ;
+    fu.maskx = hidden; fu.p = p;
+    return step_gemm_launch_fused(g, fu, (hipStream_t)stream);
+}
+// out[c] += sum_r x[r][c] for a bf16 matrix
+extern "C" int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void* stream) {
+    STEP_REQUIRE(x && out && rows > 0 && cols > 0, "pt_colsum_bf16: bad arguments");
+    const int slab = 512;
+    colsum_bf16_kernel<<<(unsigned)((rows + slab - 1) / slab), 256, 0, (hipStream_t)stream>>>(x, rows, cols, slab, out);
+    STEP_LAUNCH_CHECK("pt_colsum_bf16");
     return STEP_OK;
 }
 extern "C" int step_pt_relu_mask(float* d, const float* y, long n, void* stream) {

@@ -13,12 +13,18 @@
 //                coef = [m1 | m2 | gamma*rstd], stat = [scale | shift | mean | rstd], C = channels.
 // flags: GEMM_FUSED_INTERLEAVED -- channels-last bf16 activations (bf16 mode): column n belongs to channel n % channels, C and bnx are bf16
 //        (ldc in bf16 elements), B already carries the BatchNorm scale:  C = x > 0 ? v - kc (m1 + (x - mean) rstd m2) : 0,  kc = coef[2C+c].
-enum { GEMM_FUSED_INTERLEAVED = 1 };
+//        GEMM_FUSED_FFN_FWD -- feed-forward hidden layer of the TSFormer pre-training step (pretrain.hip): C (bf16, ldc in bf16 elements)
+//        = dropout(relu(v + ffn_bias[n])), the keep decisions from the Philox stream of step_pt_dropout at (seed, site) and element
+//        m * N + n -- the ReLU output and its dropped copy are never written in f32.
+//        GEMM_FUSED_MASKNZ -- its backward: C (bf16) = maskx[m][n] != 0 ? v / (1 - p) : 0 with maskx (bf16, laid out like C) the
+//        stored forward value: non-zero exactly where the ReLU was open and the element was kept.
+enum { GEMM_FUSED_INTERLEAVED = 1, GEMM_FUSED_FFN_FWD = 2, GEMM_FUSED_MASKNZ = 4 };
 struct GemmFused {
     const float* dotw; float* dots;
     const float* bnx; const float* bncoef; const float* bnstat;
     int channels, period;
     int flags;
+    const float* ffn_bias; const void* maskx; float p; unsigned seed_lo, seed_hi, site;      // GEMM_FUSED_FFN_FWD / GEMM_FUSED_MASKNZ
 };
 
 // one 32-wide block of a segmented contraction (step_gemm_segmented_launch): element offsets from the A / B base pointers

@@ -56,11 +56,8 @@ class FusedAdamClip(torch.optim.Optimizer):
         sh = self.model.discrete_graph_learning._shard
         if sh is not None and self.max_norm:
             # the fc weight slices of the other ranks belong to the model's gradient norm: the sum of their squared norms came back
-            # in the layout's spare slot with the gradient all-reduce (step.py) -- no collective of its own
-            ns = self.model._grad_layout()["norm_slot"]
-            own = self.model._own_slice_norm
-            extra = torch.addcmul(g[ns:ns + 1] * float(sh["world"]), own, own, value=-1.0)      # (the reduction took the mean of world * own_r^2)
-            g[ns:ns + 1].zero_()          # the slot is not a gradient: keep it out of the norm and the update below
+            # in the layout's spare slot with the gradient all-reduce (step.py backward) -- no collective of its own
+            extra = self.model._other_slices_sumsq
         _lib.call("step_adam_clip_sharded", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                   self.flat.numel(), float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
                   float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(extra), _lib.ptr(self.work),

@@ -233,9 +233,13 @@ class _StepFunction(torch.autograd.Function):
             views["dgl.conv1_b"].mul_(float(world))
             # the squared norm of this rank's fc-slice gradient rides in the spare slot (x world: the reduction below takes the mean)
             ns = layout["norm_slot"]
-            model._own_slice_norm = torch.linalg.vector_norm(flat[fo:fo + fn]).reshape(1)
-            torch.mul(model._own_slice_norm.square(), float(world), out=flat[ns:ns + 1])
+            own = torch.linalg.vector_norm(flat[fo:fo + fn]).reshape(1)
+            torch.mul(own.square(), float(world), out=flat[ns:ns + 1])
             model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
+            # the slot now holds sum_r |g_fc slice of rank r|^2 (mean of world * own_r^2): keep the other ranks' part for the clip norm
+            # (FusedAdamClip) and clear the slot, so that the flat buffer holds gradients only
+            model._other_slices_sumsq = torch.addcmul(flat[ns:ns + 1], own, own, value=-1.0)
+            flat[ns:ns + 1].zero_()
         model._flat_grad = flat
         model._backward_count = getattr(model, "_backward_count", 0) + 1
         ctx.held = None

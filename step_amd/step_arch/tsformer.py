@@ -189,11 +189,19 @@ class _PretrainFunction(torch.autograd.Function):
         h1 = _empty(R, 96, like=x)
         st1 = _empty(R, 2, like=x)
         L.call("step_pt_layernorm_fwd", L.ptr(h1pre), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]), L.ptr(h1), L.ptr(st1), st)
-        f1 = _linear_fwd(h1, P_[pre + "linear1.weight"], P_[pre + "linear1.bias"], relu=True)
-        f1d = f1
-        if p > 0:
-            f1d = _empty(R, 384, like=x)
-            L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
+        if _BF16:
+            # ReLU and dropout in the epilogue of the first linear layer, the hidden layer stored once, as bf16 (the f32 path writes
+            # relu(.) and its dropped copy: 2 x 1.3 GB per decoder layer at config C3); same Philox stream as step_pt_dropout
+            f1 = None
+            f1d = torch.empty(R, 384, device=x.device, dtype=torch.bfloat16)
+            L.call("step_pt_ffn_hidden_fwd", L.ptr(h1), L.ptr(P_[pre + "linear1.weight"]), L.ptr(P_[pre + "linear1.bias"]), R, p, seed,
+                   site + 2, L.ptr(f1d), st)
+        else:
+            f1 = _linear_fwd(h1, P_[pre + "linear1.weight"], P_[pre + "linear1.bias"], relu=True)
+            f1d = f1
+            if p > 0:
+                f1d = _empty(R, 384, like=x)
+                L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
         f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
         h2pre = _empty(R, 96, like=x)
         L.call("step_pt_add_dropout", L.ptr(h1), L.ptr(f2), L.ptr(h2pre), R * 96, p, seed, site + 3, st)
@@ -217,11 +225,26 @@ class _PretrainFunction(torch.autograd.Function):
         if p > 0:
             df2 = _empty(R, 96, like=dh2)
             L.call("step_pt_dropout", L.ptr(dh2pre), L.ptr(df2), R * 96, p, seed, site + 3, st)
-        df1d = _empty(R, 384, like=dh2)
-        _linear_bwd(df2, sv["f1d"], P_[pre + "linear2.weight"], G[pre + "linear2.weight"], G[pre + "linear2.bias"], df1d)
-        L.call("step_pt_dropout_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, p, seed, site + 2, st)      # dropout and ReLU backward in one pass
         dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
-        _linear_bwd(df1d, sv["h1"], P_[pre + "linear1.weight"], G[pre + "linear1.weight"], G[pre + "linear1.bias"], dh1, accumulate_dx=True)
+        if _BF16:
+            # bf16 hidden layer (see _layer_fwd): its gradient is masked in the GEMM epilogue and stored as bf16 as well
+            hid = sv["f1d"]
+            w1, w2 = P_[pre + "linear1.weight"], P_[pre + "linear2.weight"]
+            # dW2[o, j] += sum_r df2[r, o] hid[r, j];  db2 += colsum(df2)
+            _lib.gemm(df2, hid, G[pre + "linear2.weight"], 96, 384, R, 1, 96, 384, 1, 384, accumulate=2, splitk=-1, compute_bf16=True)
+            L.call("step_colsum", L.ptr(df2), R, 96, 96, L.ptr(G[pre + "linear2.bias"]), st)
+            dhid = torch.empty(R, 384, device=dh2.device, dtype=torch.bfloat16)
+            L.call("step_pt_ffn_hidden_bwd", L.ptr(df2), L.ptr(w2), L.ptr(hid), R, p, L.ptr(dhid), st)
+            # dW1[j, i] += sum_r dhid[r, j] h1[r, i]: computed as its transpose (A = h1 with i contiguous, B = dhid with j contiguous)
+            _lib.gemm(sv["h1"], dhid, G[pre + "linear1.weight"], 96, 384, R, 1, 96, 384, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True)
+            L.call("step_pt_colsum_bf16", L.ptr(dhid), R, 384, L.ptr(G[pre + "linear1.bias"]), st)
+            # dh1[r, i] += sum_j dhid[r, j] w1[j, i]
+            _lib.gemm(dhid, w1, dh1, R, 96, 384, 384, 1, 96, 1, 96, accumulate=1, compute_bf16=True)
+        else:
+            df1d = _empty(R, 384, like=dh2)
+            _linear_bwd(df2, sv["f1d"], P_[pre + "linear2.weight"], G[pre + "linear2.weight"], G[pre + "linear2.bias"], df1d)
+            L.call("step_pt_dropout_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, p, seed, site + 2, st)      # dropout and ReLU backward in one pass
+            _linear_bwd(df1d, sv["h1"], P_[pre + "linear1.weight"], G[pre + "linear1.weight"], G[pre + "linear1.bias"], dh1, accumulate_dx=True)
         dh1pre = _empty(R, 96, like=dh2)
         L.call("step_pt_layernorm_bwd", L.ptr(dh1), L.ptr(sv["h1pre"]), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(sv["st1"]), L.ptr(dh1pre),
                L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)

@@ -244,3 +244,41 @@ def test_pretrain_full_size_c3_matches_oracle(mode, t_recon, t_grad):
     print(f"C3 full size [{mode}]: reconstruction rel-L2 {e_r:.2e}, loss {float(loss):.5f} vs {float(o_loss):.5f}, whole gradient {e_g:.2e}, worst tensor {worst}")
     assert e_r < t_recon and e_g < t_grad
     assert float(loss) == pytest.approx(float(o_loss), rel=max(10 * t_recon, 1e-4))
+
+
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_fused_ffn_hidden_layer_matches_unfused_path(p):
+    """step_pt_ffn_hidden_fwd / _bwd (bf16 mode: ReLU + dropout in the epilogue of the first linear layer, hidden layer and its
+    gradient stored as bf16) against the unfused pieces: float32 matmul, ReLU, step_pt_dropout with the same (seed, site) -- the
+    keep decisions must be IDENTICAL (same Philox stream and element index), the values within bf16 operand / storage rounding."""
+    from step_amd import _lib as L
+    R = 128 * 23 + 37
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(R, 96, generator=gen).cuda()
+    w1 = (torch.randn(384, 96, generator=gen) * 0.15).cuda()
+    b1 = (torch.randn(384, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(96, 384, generator=gen) * 0.1).cuda()
+    dy = torch.randn(R, 96, generator=gen).cuda()
+    seed, site, st = 0x1357_9BDF_2468, 18, L.stream()
+    f1 = torch.relu(x.double() @ w1.double().T + b1.double()).float()
+    f1d = torch.empty_like(f1)
+    if p > 0:
+        L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site, st)
+    else:
+        f1d.copy_(f1)
+    hid = torch.empty(R, 384, device="cuda", dtype=torch.bfloat16)
+    L.call("step_pt_ffn_hidden_fwd", L.ptr(x), L.ptr(w1), L.ptr(b1), R, p, seed, site, L.ptr(hid), st)
+    dhid = torch.empty(R, 384, device="cuda", dtype=torch.bfloat16)
+    L.call("step_pt_ffn_hidden_bwd", L.ptr(dy), L.ptr(w2), L.ptr(hid), R, p, L.ptr(dhid), st)
+    bsum = torch.zeros(384, device="cuda")
+    L.call("step_pt_colsum_bf16", L.ptr(dhid), R, 384, L.ptr(bsum), st)
+    torch.cuda.synchronize()
+    clear = f1.abs() > 2e-2                      # away from the ReLU edge, where bf16 operand rounding can flip the sign
+    assert torch.equal((hid != 0) & clear, (f1d != 0) & clear)                          # same keep decisions
+    assert abs(float((f1d[f1 > 0] != 0).float().mean()) - (1 - p)) < 5e-3
+    e_f = rel_l2(hid.float().cpu(), f1d.cpu())
+    want = (dy.double() @ w2.double()).float() * (hid != 0).float() / (1 - p)
+    e_b = rel_l2(dhid.float().cpu(), want.cpu())
+    e_s = rel_l2(bsum.cpu(), dhid.float().sum(0).cpu())
+    print(f"fused feed-forward hidden layer p={p}: forward rel-L2 {e_f:.2e}, backward {e_b:.2e}, bf16 column sums {e_s:.1e}")
+    assert e_f < 6e-3 and e_b < 6e-3 and e_s < 1e-5

@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 rocpd database (--kernel-trace) into a per-kernel table (markdown), the same
 content as `rocprofv3 --stats` kernel_stats: calls, total / average / min / max duration, share.
-usage: python tools/prof_summary.py <results.db> [--skip-first N dispatches per kernel] > profiles/xyz.md"""
+usage: python tools/prof_summary.py <results.db> [--after-last <kernel name substring>] > profiles/xyz.md
+--after-last X: only the dispatches that start after the LAST dispatch of a kernel whose name contains X (bench.py pre-trains the
+TSFormer checkpoint before its timed region: `--after-last attn_mfma_bwd` leaves the training steps only)."""
 import re
 import sqlite3
 import sys
@@ -19,6 +21,11 @@ def main():
                        "d.workgroup_size_x*d.workgroup_size_y*d.workgroup_size_z, s.arch_vgpr_count, s.accum_vgpr_count, "
                        "d.group_segment_size, d.private_segment_size "
                        "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id").fetchall()
+    if "--after-last" in sys.argv:
+        pat = sys.argv[sys.argv.index("--after-last") + 1]
+        cut = max((r[2] for r in rows if pat in r[0]), default=0)
+        rows = [r for r in rows if r[1] > cut]
+        print(f"(dispatches after the last `{pat}` kernel only)\n")
     agg = {}
     for name, st, en, grid, wg, vg, ag, lds, scr in rows:
         a = agg.setdefault(short(name), {"n": 0, "tot": 0, "min": 1 << 62, "max": 0, "vgpr": vg, "agpr": ag, "lds": lds, "scr": scr, "wg": wg})
