@@ -949,7 +949,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         long tiles = fast ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;
-        long want = ((fast ? 768 : 1024) + tiles - 1) / tiles;
+        static const int split_target = []() { const char* e = getenv("STEP_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 768; }();      // (A/B knob)
+        long want = ((fast ? split_target : 1024) + tiles - 1) / tiles;
         long maxs = cdiv(g.K, bk) / 4;
         g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
     }
@@ -959,7 +960,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
     const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
     if (fast && fused) return big ? launch_fast_fused<128, 128>(g, fa, amode, bmode, st) : launch_fast_fused<64, 64>(g, fa, amode, bmode, st);
-    if (fast && !big && bmode != MC_BF16 && g.M >= 1024 && g.N > 64) {
+    static const int tall_m = []() { const char* e = getenv("STEP_GEMM_TALL_M"); return e ? atoi(e) : 1024; }();      // (A/B knob)
+    if (fast && !big && bmode != MC_BF16 && g.M >= tall_m && g.N > 64) {
         // tall products with a short n axis (the diffusion hops of large graphs: 4096 x 32 T x 4096): 128 x 64 tiles -- three workgroups per
         // compute unit and half the A-operand LDS traffic of 64 x 64 -- when they still fill the chip
         const long t = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * g.batch * g.splitk;

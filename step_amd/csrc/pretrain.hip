@@ -577,13 +577,29 @@ __global__ void relu_mask_kernel(float* __restrict__ d, const float* __restrict_
     if (i < n && !(y[i] > 0.f)) d[i] = 0.f;
 }
 
-// out[c] += sum over rows of x[row][c], x bf16 [rows][cols] (bias gradient of the bf16 hidden-layer gradient)
+// out[c] += sum over rows of x[row][c], x bf16 [rows][cols], cols % 8 == 0, cols <= 2048 (bias gradient of the bf16 hidden-layer
+// gradient).  A thread owns 8 consecutive columns (one 16-byte load per row) of every (256 / (cols / 8))-th row of the block's slab;
+// the row lanes are combined through LDS, one atomic per column and block.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, long rows, int cols, int slab, float* __restrict__ out) {
+    __shared__ float part[256 * 8];
+    const int vc = cols >> 3, lanes = 256 / vc;                  // vector columns, row lanes
+    const int cx = threadIdx.x % vc, ry = threadIdx.x / vc;
     const long r0 = (long)blockIdx.x * slab, r1 = r0 + slab < rows ? r0 + slab : rows;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ry < lanes)
+        for (long r = r0 + ry; r < r1; r += lanes) {
+            const uint4 v = *(const uint4*)(x + r * cols + cx * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[2 * j] += __uint_as_float(w[j] << 16); a[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u); }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
     for (int c = threadIdx.x; c < cols; c += 256) {
-        float a = 0.f;
-        for (long r = r0; r < r1; ++r) a += bf16_bits_to_f32(x[r * cols + c]);
-        atomicAdd(out + c, a);
+        float t = 0.f;
+        for (int l = 0; l < lanes; ++l) t += part[(l * vc + (c >> 3)) * 8 + (c & 7)];
+        atomicAdd(out + c, t);
     }
 }
 
@@ -763,8 +779,9 @@ extern "C" int step_pt_ffn_hidden_bwd(const float* dy, const float* w2, const ui
 }
 // out[c] += sum_r x[r][c] for a bf16 matrix
 extern "C" int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void* stream) {
-    STEP_REQUIRE(x && out && rows > 0 && cols > 0, "pt_colsum_bf16: bad arguments");
-    const int slab = 512;
+    STEP_REQUIRE(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 2048 && (((uintptr_t)x) & 15) == 0,
+                 "pt_colsum_bf16: bad arguments (cols must be a multiple of 8, at most 2048, x 16-byte aligned)");
+    const int slab = 1024;
     colsum_bf16_kernel<<<(unsigned)((rows + slab - 1) / slab), 256, 0, (hipStream_t)stream>>>(x, rows, cols, slab, out);
     STEP_LAUNCH_CHECK("pt_colsum_bf16");
     return STEP_OK;
