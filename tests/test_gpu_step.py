@@ -134,9 +134,9 @@ def test_step_training_step_parity(name):
     # ---------------- (b) the reference's own numbers (bf16 encoder error included)
     e_ref = rel_l2(pred.detach().cpu(), g["out.pred"])
     print(name, "pred rel-L2 vs reference", e_ref, "loss vs reference", float(loss), float(g["out.loss"]))
-    assert e_ref < 3e-2
+    assert e_ref < 5e-3                          # measured 1.3 .. 1.5e-3 with the default float16 encoder operands
     assert max_abs(theta.detach().cpu(), g["out.theta"]) < 1e-4
-    assert float(loss) == pytest.approx(float(g["out.loss"]), rel=2e-2)
+    assert float(loss) == pytest.approx(float(g["out.loss"]), rel=1e-3)      # measured 2e-5
     # per-tensor errors are dominated by sign flips of the L1 loss where pred ~ label, so the pass/fail
     # criterion is on the concatenated gradient vector; the worst tensor is reported
     worst, num, den, wname = 0.0, 0.0, 0.0, None
