@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -282,6 +282,13 @@ int step_pt_dec_input_bwd(const float* dout, long S, int P, int Pu, float p, uin
 int step_pt_layernorm_fwd(const float* x, long R, const float* g, const float* b, float* y, float* stats, void* stream);
 int step_pt_layernorm_bwd(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx, float* dgamma,
                           float* dbeta, void* stream);
+/* The same two with their neighbours fused and 16-byte accesses (one row per 32 lanes): forward  pre = a + dropout(b) (the residual
+ * add of transformer_layers.py:10's encoder layer; b may be NULL, then pre is not written), y = LayerNorm(pre), stats = (mean, rstd);
+ * backward  dx as step_pt_layernorm_bwd and, when dx_dropped is given, dropout(dx) with the stream of step_pt_dropout(seed, site). */
+int step_pt_add_layernorm_fwd(const float* a, const float* b, long R, float p, uint64_t seed, uint32_t site, const float* g,
+                              const float* beta, float* pre, float* y, float* stats, void* stream);
+int step_pt_layernorm_bwd_dropout(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx,
+                                  float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream);
 /* 4-head self-attention on qkv [S][T][288] -> out [S][T][96]; stats [S][4][T][2] = row max, row sum (for the backward) */
 int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                           void* stream);

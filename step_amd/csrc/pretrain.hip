@@ -182,6 +182,89 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------------------------ fused residual + LayerNorm, 16-byte accesses
+// One row (96 floats = 24 float4) per 32 lanes, 8 rows per block.  Forward:  pre = a + dropout(b)  (b == nullptr: pre = a, nothing
+// stored for it),  y = LayerNorm(pre), stats = (mean, rstd): the add_dropout pass, its store -> load round trip through HBM and the
+// 4-byte accesses of ln_fwd_kernel in one kernel.  The dropout stream is step_pt_add_dropout's (one Philox call per float4).
+__device__ __forceinline__ float half_sum(float v) {          // sum over the 32 lanes of a half wave
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long R, float p, uint32_t lo,
+                                                         uint32_t hi, uint32_t site, const float* __restrict__ g, const float* __restrict__ beta,
+                                                         float* __restrict__ pre, float* __restrict__ y, float* __restrict__ stats) {
+    const int q = threadIdx.x & 31;
+    const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= R) return;
+    const bool on = q < D / 4;
+    const long k = row * (D / 4) + (on ? q : 0);
+    float4 v = ((const float4*)a)[k];
+    if (b) {
+        const float4 w = ((const float4*)b)[k];
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) keep_scale4(lo, hi, site, k, p, m);
+        v.x += w.x * m[0]; v.y += w.y * m[1]; v.z += w.z * m[2]; v.w += w.w * m[3];
+        if (on) ((float4*)pre)[k] = v;
+    }
+    if (!on) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float mean = half_sum((v.x + v.y) + (v.z + v.w)) * (1.f / D);
+    const float4 d = on ? make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float rstd = rsqrtf(half_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / D) + 1e-5f);
+    if (on) {
+        const float4 g4 = ((const float4*)g)[q], b4 = ((const float4*)beta)[q];
+        ((float4*)y)[k] = make_float4(d.x * rstd * g4.x + b4.x, d.y * rstd * g4.y + b4.y, d.z * rstd * g4.z + b4.z, d.w * rstd * g4.w + b4.w);
+    }
+    if (q == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+// Backward: dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma; optionally dxd = dropout(dx) with the stream of
+// step_pt_dropout at (seed, site) in the same pass (the gradient that continues into the dropped branch); dgamma / dbeta by atomics.
+__global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const float* __restrict__ dy, const float* __restrict__ x, long R,
+                                                          const float* __restrict__ g, const float* __restrict__ stats, float* __restrict__ dx,
+                                                          float* __restrict__ dxd, float p, uint32_t lo, uint32_t hi, uint32_t site,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sg[8][D], sb[8][D];
+    const int q = threadIdx.x & 31, w = threadIdx.x >> 5;
+    const bool on = q < D / 4;
+    const float4 g4 = on ? ((const float4*)g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 8 + w; row < R; row += (long)gridDim.x * 8) {
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        const long k = row * (D / 4) + (on ? q : 0);
+        float4 xv = ((const float4*)x)[k], yv = ((const float4*)dy)[k];
+        if (!on) { xv = make_float4(mean, mean, mean, mean); yv = make_float4(0.f, 0.f, 0.f, 0.f); }
+        const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float qq[4] = {yv.x * g4.x, yv.y * g4.y, yv.z * g4.z, yv.w * g4.w};
+        const float m1 = half_sum((qq[0] + qq[1]) + (qq[2] + qq[3])) * (1.f / D);
+        const float m2 = half_sum((qq[0] * xh[0] + qq[1] * xh[1]) + (qq[2] * xh[2] + qq[3] * xh[3])) * (1.f / D);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = rstd * (qq[i] - m1 - xh[i] * m2); ag[i] += yy[i] * xh[i]; ab[i] += yy[i]; }
+        if (on) {
+            ((float4*)dx)[k] = make_float4(o[0], o[1], o[2], o[3]);
+            if (dxd) {
+                float m[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p > 0.f) keep_scale4(lo, hi, site, k, p, m);
+                ((float4*)dxd)[k] = make_float4(o[0] * m[0], o[1] * m[1], o[2] * m[2], o[3] * m[3]);
+            }
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sg[w][4 * q + i] = ag[i]; sb[w][4 * q + i] = ab[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int f = threadIdx.x;
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { tg += sg[r][f]; tb += sb[r][f]; }
+        atomicAdd(&dgamma[f], tg);
+        atomicAdd(&dbeta[f], tb);
+    }
+}
+
 // ------------------------------------------------------------------------------------ self-attention, one block per (sequence, head)
 // qkv [S][T][288] (q | k | v, head h = columns 24h..24h+23 of each third), out [S][T][96], stats [S][H][T][2] = (row max, row sum)
 // attention-probability dropout uses element index ((s*H + h)*T + i)*T + j
@@ -679,6 +762,29 @@ extern "C" int step_pt_layernorm_fwd(const float* x, long R, const float* g, con
     STEP_REQUIRE(x && g && b && y && stats && R > 0, "pt_layernorm_fwd: bad arguments");
     ln_fwd_kernel<<<(unsigned)((R + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, R, g, b, y, stats);
     STEP_LAUNCH_CHECK("pt_layernorm_fwd");
+    return STEP_OK;
+}
+// pre = a + dropout(b) (b may be NULL: pre is not written), y = LayerNorm(pre), stats = (mean, rstd) per row, in one pass
+extern "C" int step_pt_add_layernorm_fwd(const float* a, const float* b, long R, float p, uint64_t seed, uint32_t site, const float* g,
+                                         const float* beta, float* pre, float* y, float* stats, void* stream) {
+    STEP_REQUIRE(a && g && beta && y && stats && R > 0 && p >= 0.f && p < 1.f && (b == nullptr || pre != nullptr), "pt_add_layernorm_fwd: bad arguments");
+    STEP_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)pre | (uintptr_t)y | (uintptr_t)g | (uintptr_t)beta) & 15) == 0,
+                 "pt_add_layernorm_fwd: 16-byte aligned buffers");
+    add_ln_fwd_kernel<<<(unsigned)((R + 7) / 8), 256, 0, (hipStream_t)stream>>>(a, b, R, p, SEED_LO(seed), SEED_HI(seed), site, g, beta, pre, y, stats);
+    STEP_LAUNCH_CHECK("pt_add_layernorm_fwd");
+    return STEP_OK;
+}
+// LayerNorm backward; dx_dropped (may be NULL) = dropout(dx) with the stream of step_pt_dropout(seed, site), written in the same pass
+extern "C" int step_pt_layernorm_bwd_dropout(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx,
+                                             float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream) {
+    STEP_REQUIRE(dy && x && g && stats && dx && dgamma && dbeta && R > 0 && p >= 0.f && p < 1.f, "pt_layernorm_bwd_dropout: bad arguments");
+    STEP_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_dropped | (uintptr_t)g) & 15) == 0,
+                 "pt_layernorm_bwd_dropout: 16-byte aligned buffers");
+    long blocks = (R + 7) / 8;
+    if (blocks > 4096) blocks = 4096;
+    ln_bwd_drop_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(dy, x, R, g, stats, dx, dx_dropped, p, SEED_LO(seed), SEED_HI(seed), site,
+                                                                         dgamma, dbeta);
+    STEP_LAUNCH_CHECK("pt_layernorm_bwd_dropout");
     return STEP_OK;
 }
 extern "C" int step_pt_layernorm_bwd(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx, float* dgamma,

@@ -136,7 +136,9 @@ class _StepFunction(torch.autograd.Function):
 
         # ---- TSFormer (frozen) and the kNN prior graph (no grad): on the main stream, or already in flight on the prefetch stream
         if frozen is None:
-            frozen = model._frozen_branch(long_hist, B, N)
+            # (the kNN prior is only needed by the loss: with the streams on, its Gram product and top-k selection run next to the
+            #  GraphWaveNet head instead of in front of it)
+            frozen = model._frozen_branch(long_hist, B, N, knn_stream=model._side_stream(dev, "knn") if side is not None else None)
         if side is not None:
             side.wait_event(ready)
             try:
@@ -161,6 +163,8 @@ class _StepFunction(torch.autograd.Function):
             with torch.no_grad():
                 # one multi-tensor launch instead of ten scalar ones
                 torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:7])], 1)
+        if frozen.get("knn_done") is not None:
+            main.wait_event(frozen["knn_done"])          # adj_knn / sim are handed to the caller on the current stream
         ctx.model = model
         ctx.dims = (B, N, Cin, Ttr, float(drop))
         ctx.held = (hist, enc["last"], g, gsaved, esaved, wsaved)
@@ -290,14 +294,14 @@ class STEP(nn.Module):
             p.requires_grad = False
 
     # ------------------------------------------------------------------ helpers
-    def _side_stream(self, dev):
-        key = (dev.type, dev.index)
+    def _side_stream(self, dev, name="side"):
+        key = (name, dev.type, dev.index)
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
-    def _frozen_branch(self, long_hist, B, N):
+    def _frozen_branch(self, long_hist, B, N, knn_stream=None):
         """[B,L,N,C] long history (or a LongHistoryRef) -> TSFormer hidden states -> cosine kNN prior graph, queued on the CURRENT
         stream.  Depends only on the input and the frozen TSFormer (step.py:34-35, discrete_graph_learning.py:139,164-166):
         no parameter the optimizer touches is read, which is what lets prefetch() run it a step ahead."""
@@ -318,9 +322,20 @@ class STEP(nn.Module):
         sim = _f32(B * N * N, dev).view(B, N, N)
         adj_knn = _f32(B * N * N, dev).view(B, N, N)
         kwork = torch.empty(L.lib().step_knn_workspace_bytes(B, N, P * 96), dtype=torch.uint8, device=dev)
-        L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, self.discrete_graph_learning.k * N,
-               L.ptr(sim), L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
-        return {"enc": enc, "sim": sim, "adj_knn": adj_knn, "held": (series, kwork, long_hist), "done": None}
+        knn_done = None
+        if knn_stream is not None:
+            enc_done = torch.cuda.Event()
+            enc_done.record()
+            knn_stream.wait_event(enc_done)
+            with torch.cuda.stream(knn_stream):
+                L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, self.discrete_graph_learning.k * N,
+                       L.ptr(sim), L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), L.stream())
+                knn_done = torch.cuda.Event()
+                knn_done.record()
+        else:
+            L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, self.discrete_graph_learning.k * N,
+                   L.ptr(sim), L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), st)
+        return {"enc": enc, "sim": sim, "adj_knn": adj_knn, "held": (series, kwork, long_hist), "done": None, "knn_done": knn_done}
 
     @staticmethod
     def _batch_key(long_hist):

@@ -150,7 +150,8 @@ class _PretrainFunction(torch.autograd.Function):
             layers.append(sv)
         y = _empty(S * Pu, 96, like=series)
         st_enc = _empty(S * Pu, 2, like=series)
-        L.call("step_pt_layernorm_fwd", L.ptr(x), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(P_["encoder_norm.bias"]), L.ptr(y), L.ptr(st_enc), st)
+        L.call("step_pt_add_layernorm_fwd", L.ptr(x), None, S * Pu, 0.0, 0, 0, L.ptr(P_["encoder_norm.weight"]), L.ptr(P_["encoder_norm.bias"]), None,
+               L.ptr(y), L.ptr(st_enc), st)
         z = _linear_fwd(y, P_["enc_2_dec_emb.weight"], P_["enc_2_dec_emb.bias"])
         d0 = _empty(S * P, 96, like=series)
         L.call("step_pt_dec_input", L.ptr(z), L.ptr(P_["mask_token"]), L.ptr(pos), L.ptr(mk), S, P, Pu, p, seed, 101, L.ptr(d0), st)
@@ -161,7 +162,8 @@ class _PretrainFunction(torch.autograd.Function):
             dec_layers.append(sv)
         d2 = _empty(S * P, 96, like=series)
         st_dec = _empty(S * P, 2, like=series)
-        L.call("step_pt_layernorm_fwd", L.ptr(d), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(P_["decoder_norm.bias"]), L.ptr(d2), L.ptr(st_dec), st)
+        L.call("step_pt_add_layernorm_fwd", L.ptr(d), None, S * P, 0.0, 0, 0, L.ptr(P_["decoder_norm.weight"]), L.ptr(P_["decoder_norm.bias"]), None,
+               L.ptr(d2), L.ptr(st_dec), st)
         r = _linear_fwd(d2, P_["output_layer.weight"], P_["output_layer.bias"])
         saved.update(dict(series=series, um=um, mk=mk, layers=layers, dec_layers=dec_layers, x_enc_out=x, st_enc=st_enc, y=y,
                           d_out=d, st_dec=st_dec, d2=d2, dims=(S, P, Pu, Pm)))
@@ -184,11 +186,10 @@ class _PretrainFunction(torch.autograd.Function):
         else:
             L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
         o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
-        h1pre = _empty(R, 96, like=x)
-        L.call("step_pt_add_dropout", L.ptr(x), L.ptr(o), L.ptr(h1pre), R * 96, p, seed, site + 1, st)
-        h1 = _empty(R, 96, like=x)
-        st1 = _empty(R, 2, like=x)
-        L.call("step_pt_layernorm_fwd", L.ptr(h1pre), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]), L.ptr(h1), L.ptr(st1), st)
+        # residual add (+ dropout of the branch) and LayerNorm in one pass
+        h1pre, h1, st1 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
+        L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]),
+               L.ptr(h1pre), L.ptr(h1), L.ptr(st1), st)
         if _BF16:
             # ReLU and dropout in the epilogue of the first linear layer, the hidden layer stored once, as bf16 (the f32 path writes
             # relu(.) and its dropped copy: 2 x 1.3 GB per decoder layer at config C3); same Philox stream as step_pt_dropout
@@ -203,11 +204,9 @@ class _PretrainFunction(torch.autograd.Function):
                 f1d = _empty(R, 384, like=x)
                 L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
         f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
-        h2pre = _empty(R, 96, like=x)
-        L.call("step_pt_add_dropout", L.ptr(h1), L.ptr(f2), L.ptr(h2pre), R * 96, p, seed, site + 3, st)
-        h2 = _empty(R, 96, like=x)
-        st2 = _empty(R, 2, like=x)
-        L.call("step_pt_layernorm_fwd", L.ptr(h2pre), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]), L.ptr(h2), L.ptr(st2), st)
+        h2pre, h2, st2 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
+        L.call("step_pt_add_layernorm_fwd", L.ptr(h1), L.ptr(f2), R, p, seed, site + 3, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]),
+               L.ptr(h2pre), L.ptr(h2), L.ptr(st2), st)
         return h2, dict(x=x, qkv=qkv, a=a, stats=stats, keepbits=kb, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
                         site=site, T=T)
 
@@ -218,13 +217,13 @@ class _PretrainFunction(torch.autograd.Function):
         st = L.stream()
         pre, site, T = sv["pre"], sv["site"], sv["T"]
         R = S * T
+        # LayerNorm backward and the dropout of the gradient that continues into the branch, one pass
         dh2pre = _empty(R, 96, like=dh2)
-        L.call("step_pt_layernorm_bwd", L.ptr(dh2), L.ptr(sv["h2pre"]), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(sv["st2"]), L.ptr(dh2pre),
-               L.ptr(G[pre + "norm2.weight"]), L.ptr(G[pre + "norm2.bias"]), st)
-        df2 = dh2pre
-        if p > 0:
-            df2 = _empty(R, 96, like=dh2)
-            L.call("step_pt_dropout", L.ptr(dh2pre), L.ptr(df2), R * 96, p, seed, site + 3, st)
+        df2 = _empty(R, 96, like=dh2) if p > 0 else None
+        L.call("step_pt_layernorm_bwd_dropout", L.ptr(dh2), L.ptr(sv["h2pre"]), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(sv["st2"]), L.ptr(dh2pre),
+               L.ptr(df2), p, seed, site + 3, L.ptr(G[pre + "norm2.weight"]), L.ptr(G[pre + "norm2.bias"]), st)
+        if df2 is None:
+            df2 = dh2pre
         dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
         if _BF16:
             # bf16 hidden layer (see _layer_fwd): its gradient is masked in the GEMM epilogue and stored as bf16 as well
@@ -246,12 +245,11 @@ class _PretrainFunction(torch.autograd.Function):
             L.call("step_pt_dropout_relu_mask", L.ptr(df1d), L.ptr(sv["f1"]), R * 384, p, seed, site + 2, st)      # dropout and ReLU backward in one pass
             _linear_bwd(df1d, sv["h1"], P_[pre + "linear1.weight"], G[pre + "linear1.weight"], G[pre + "linear1.bias"], dh1, accumulate_dx=True)
         dh1pre = _empty(R, 96, like=dh2)
-        L.call("step_pt_layernorm_bwd", L.ptr(dh1), L.ptr(sv["h1pre"]), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(sv["st1"]), L.ptr(dh1pre),
-               L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)
-        do = dh1pre
-        if p > 0:
-            do = _empty(R, 96, like=dh2)
-            L.call("step_pt_dropout", L.ptr(dh1pre), L.ptr(do), R * 96, p, seed, site + 1, st)
+        do = _empty(R, 96, like=dh2) if p > 0 else None
+        L.call("step_pt_layernorm_bwd_dropout", L.ptr(dh1), L.ptr(sv["h1pre"]), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(sv["st1"]), L.ptr(dh1pre),
+               L.ptr(do), p, seed, site + 1, L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)
+        if do is None:
+            do = dh1pre
         da = _empty(R, 96, like=dh2)
         _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
                     G[pre + "self_attn.out_proj.bias"], da)
@@ -284,8 +282,8 @@ class _PretrainFunction(torch.autograd.Function):
         dd2 = _empty(S * P, 96, like=dr)
         _linear_bwd(dr, sv["d2"], P_["output_layer.weight"], G["output_layer.weight"], G["output_layer.bias"], dd2)
         dd = _empty(S * P, 96, like=dr)
-        L.call("step_pt_layernorm_bwd", L.ptr(dd2), L.ptr(sv["d_out"]), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(sv["st_dec"]), L.ptr(dd),
-               L.ptr(G["decoder_norm.weight"]), L.ptr(G["decoder_norm.bias"]), st)
+        L.call("step_pt_layernorm_bwd_dropout", L.ptr(dd2), L.ptr(sv["d_out"]), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(sv["st_dec"]), L.ptr(dd),
+               None, 0.0, 0, 0, L.ptr(G["decoder_norm.weight"]), L.ptr(G["decoder_norm.bias"]), st)
         for lsv in reversed(sv["dec_layers"]):
             dd = _PretrainFunction._layer_bwd(dd, lsv, S, P_, G, p, seed)
         # decoder input: split into d z and the mask-token / positional part
@@ -298,8 +296,8 @@ class _PretrainFunction(torch.autograd.Function):
         dy = _empty(S * Pu, 96, like=dr)
         _linear_bwd(dz, sv["y"], P_["enc_2_dec_emb.weight"], G["enc_2_dec_emb.weight"], G["enc_2_dec_emb.bias"], dy)
         dx = _empty(S * Pu, 96, like=dr)
-        L.call("step_pt_layernorm_bwd", L.ptr(dy), L.ptr(sv["x_enc_out"]), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(sv["st_enc"]), L.ptr(dx),
-               L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), st)
+        L.call("step_pt_layernorm_bwd_dropout", L.ptr(dy), L.ptr(sv["x_enc_out"]), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(sv["st_enc"]), L.ptr(dx),
+               None, 0.0, 0, 0, L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), st)
         for lsv in reversed(sv["layers"]):
             dx = _PretrainFunction._layer_bwd(dx, lsv, S, P_, G, p, seed)
         # scatter back to all token positions (zeros at masked ones), dropout, positional and patch embedding

@@ -282,3 +282,40 @@ def test_fused_ffn_hidden_layer_matches_unfused_path(p):
     e_s = rel_l2(bsum.cpu(), dhid.float().sum(0).cpu())
     print(f"fused feed-forward hidden layer p={p}: forward rel-L2 {e_f:.2e}, backward {e_b:.2e}, bf16 column sums {e_s:.1e}")
     assert e_f < 6e-3 and e_b < 6e-3 and e_s < 1e-5
+
+
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_fused_layernorm_kernels_match_unfused(p):
+    """step_pt_add_layernorm_fwd / step_pt_layernorm_bwd_dropout (residual add + dropout + LayerNorm in one pass, 16-byte accesses)
+    against the separate kernels they replace in the pre-training step: identical dropout decisions (same Philox stream), values to
+    float32 summation order; R not a multiple of the 8 rows of a block."""
+    from step_amd import _lib as L
+    R = 8 * 501 + 5
+    gen = torch.Generator().manual_seed(21)
+    a, b, dy = [torch.randn(R, 96, generator=gen).cuda() for _ in range(3)]
+    g = (1 + 0.1 * torch.randn(96, generator=gen)).cuda()
+    beta = (0.1 * torch.randn(96, generator=gen)).cuda()
+    seed, site, st = 0x2468_ACE0_1357, 33, L.stream()
+    e = lambda *sh: torch.empty(*sh, device="cuda")
+    pre0, y0, st0, dx0, dxd0 = e(R, 96), e(R, 96), e(R, 2), e(R, 96), e(R, 96)
+    dg0, db0 = torch.zeros(96, device="cuda"), torch.zeros(96, device="cuda")
+    L.call("step_pt_add_dropout", L.ptr(a), L.ptr(b), L.ptr(pre0), R * 96, p, seed, site, st)
+    L.call("step_pt_layernorm_fwd", L.ptr(pre0), R, L.ptr(g), L.ptr(beta), L.ptr(y0), L.ptr(st0), st)
+    L.call("step_pt_layernorm_bwd", L.ptr(dy), L.ptr(pre0), R, L.ptr(g), L.ptr(st0), L.ptr(dx0), L.ptr(dg0), L.ptr(db0), st)
+    L.call("step_pt_dropout", L.ptr(dx0), L.ptr(dxd0), R * 96, p, seed, site + 1, st)
+    pre1, y1, st1, dx1, dxd1 = e(R, 96), e(R, 96), e(R, 2), e(R, 96), e(R, 96)
+    dg1, db1 = torch.zeros(96, device="cuda"), torch.zeros(96, device="cuda")
+    L.call("step_pt_add_layernorm_fwd", L.ptr(a), L.ptr(b), R, p, seed, site, L.ptr(g), L.ptr(beta), L.ptr(pre1), L.ptr(y1), L.ptr(st1), st)
+    L.call("step_pt_layernorm_bwd_dropout", L.ptr(dy), L.ptr(pre1), R, L.ptr(g), L.ptr(st1), L.ptr(dx1), L.ptr(dxd1), p, seed, site + 1,
+           L.ptr(dg1), L.ptr(db1), st)
+    y2, st2 = e(R, 96), e(R, 2)                      # b = NULL: plain LayerNorm of a
+    L.call("step_pt_add_layernorm_fwd", L.ptr(a), None, R, 0.0, 0, 0, L.ptr(g), L.ptr(beta), None, L.ptr(y2), L.ptr(st2), st)
+    torch.cuda.synchronize()
+    assert torch.equal(pre0, pre1)
+    assert torch.equal(dxd0 != 0, dxd1 != 0) or p == 0.0
+    errs = {k: rel_l2(v1.cpu(), v0.cpu()) for k, (v1, v0) in dict(y=(y1, y0), stats=(st1, st0), dx=(dx1, dx0), dxd=(dxd1, dxd0), dgamma=(dg1, dg0),
+                                                                 dbeta=(db1, db0)).items()}
+    want2 = torch.nn.functional.layer_norm(a.double(), (96,), g.double(), beta.double(), 1e-5)
+    errs["plain"] = rel_l2(y2.cpu().double(), want2.cpu())
+    print(f"fused LayerNorm kernels p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 2e-6
