@@ -136,9 +136,11 @@ class _StepFunction(torch.autograd.Function):
 
         # ---- TSFormer (frozen) and the kNN prior graph (no grad): on the main stream, or already in flight on the prefetch stream
         if frozen is None:
-            # (the kNN prior is only needed by the loss: with the streams on, its Gram product and top-k selection run next to the
-            #  GraphWaveNet head instead of in front of it)
-            frozen = model._frozen_branch(long_hist, B, N, knn_stream=model._side_stream(dev, "knn") if side is not None else None)
+            # (the kNN prior is only needed by the loss; running its Gram product and top-k selection on a third stream next to the
+            #  GraphWaveNet head was measured: 4.72 vs 4.69 ms, the Gram product takes the compute units from the head's small kernels --
+            #  `knn_stream` of _frozen_branch stays available, STEP_KNN_STREAM=1)
+            ks = model._side_stream(dev, "knn") if (side is not None and os.environ.get("STEP_KNN_STREAM", "0") == "1") else None
+            frozen = model._frozen_branch(long_hist, B, N, knn_stream=ks)
         if side is not None:
             side.wait_event(ready)
             try:
@@ -194,7 +196,7 @@ class _StepFunction(torch.autograd.Function):
         dadj = _f32(B * N * N, dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
         # the weight / bias gradients of the WaveNet are leaves of the backward: the library forks them onto the second stream
-        aux = ctypes.c_void_p(model._side_stream(dev).cuda_stream) if (model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1") else None
+        aux = ctypes.c_void_p(model._side_stream(dev, "aux").cuda_stream) if (model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1") else None
         L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
                L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, st)
         del wwork
@@ -295,9 +297,16 @@ class STEP(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _side_stream(self, dev, name="side"):
+        """The model's extra streams.  "side" (forward: graph learner + WaveNet layers next to the encoder) has HIGH priority: the
+        encoder's workgroups fill every compute unit, so a normal-priority kernel of the chain waits ~150 us for room each time it is
+        launched (profiles/r03_f_C2_train_step.md: bn_finalize 182 us next to the encoder, 10 us alone) -- with priority its few
+        workgroups take the next compute unit that frees up.  "aux" (backward: the leaves) has LOW priority: it must not delay the
+        data-gradient chain on the main stream.  STEP_STREAM_PRIO=0 puts both at the default priority (A/B)."""
         key = (name, dev.type, dev.index)
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
+            mode = os.environ.get("STEP_STREAM_PRIO", "1")          # "0": none, "1": both, "side" / "aux": that one only (A/B)
+            prio = {"side": -1, "aux": 1}.get(name, 0) if mode in ("1", name) else 0
+            self._side[key] = torch.cuda.Stream(device=dev, priority=prio)
         return self._side[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
