@@ -221,7 +221,8 @@ typedef struct StepGwnetParams {
 
 /* GraphWaveNet.forward (model.py:132-224) fused with the transposes of step.py:65,72:
  *  hist [B,12,N,Cin] f32 (first two channels used), hidden_last [B*N,96] f32, adj [B,N,N] f32
- *  -> pred [B,12,N] f32.  training!=0: batch-stat BatchNorm (+running-stat update) and, if
+ *  -> pred [B,12,N] f32.  training bit 0: batch-stat BatchNorm (+running-stat update); bit 1 (value 2, with bit 0): also evaluate the
+ *  last layer's gcn, whose output the reference computes and drops (model.py:202-213), for bn.7's running statistics; and, if
  *  dropout_p>0, inverted dropout after each gcn (model.py:47) from the Philox stream `seed`.
  *  saved/work: caller-owned scratch of step_gwnet_{saved,work}_floats floats; `saved` must be
  *  kept unchanged until step_gwnet_backward. */

@@ -354,6 +354,11 @@ __device__ __forceinline__ void bn_fwd_stats(const BnFwd& bn, float* st) {
     }
     __syncthreads();
 }
+// statistics of a BatchNorm whose output nobody reads (bn.7, model.py:210-213): only the running-statistics update of bn_fwd_stats
+__global__ void bn_stats_only_kernel(BnFwd bn) {
+    __shared__ float st[128];
+    bn_fwd_stats(bn, st);
+}
 // BN backward sums S1 = sum dy, S2 = sum dy*xhat -> co[96] = [S1/count | S2/count | gamma*rstd] in LDS; block 0 adds the
 // gradients of gamma / beta
 struct BnBwd { const float *gamma, *stat; float *dgamma, *dbeta; double count; const double* sums; };
@@ -781,7 +786,7 @@ struct Work {
     double* acc64;             // [7 BatchNorms][NCOPY][64] f64 accumulators of the in-kernel BatchNorm sums
     // xcat / dpre / dh: per-layer copies of what the weight-gradient GEMMs read -- those GEMMs are leaves of the backward and run on
     // the auxiliary stream while the data-gradient chain goes on; dcat: one gcn-buffer gradient per layer (all needed at the end)
-    float *xcat[NL], *bsum;
+    float *xcat[NL], *bsum, *y7, *m7;      // y7 / m7: output and dropout mask of the last layer's (dead) gcn, only for its BatchNorm statistics
     float *dcat[NL - 1], *dpre[NL], *dh[NL - 1], *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
     GemmKSeg* ktab;
     float *d_e1, *d_xh, *d_h2, *d_h1;
@@ -799,9 +804,11 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.dwcat = cv.take(NL * 64 * 64);
     w.dbcat = cv.take(NL * 64);
     w.dwskip = cv.take(CS * CS);
-    w.acc64 = (double*)cv.take(2L * 7 * NCOPY * 64);
+    w.acc64 = (double*)cv.take(2L * NL * NCOPY * 64);      // 7 live BatchNorms + the dead bn.7 (only with STEP_GWNET_DEAD_BN7)
     for (int i = 0; i < NL; ++i) w.xcat[i] = backward ? cv.take(BN * TOUT[i] * 64) : nullptr;
     w.bsum = cv.take(CS);
+    w.y7 = cv.take(BN * TOUT[NL - 1] * C);
+    w.m7 = cv.take(BN * TOUT[NL - 1] * C);
     if (backward) {
         for (int i = 0; i < NL - 1; ++i) w.dcat[i] = cv.take(BN * TOUT[i] * CAT);
         w.ktab = (GemmKSeg*)cv.take(3L * ADJ_NSEG * sizeof(GemmKSeg) / sizeof(float));
@@ -930,7 +937,7 @@ extern "C" long step_gwnet_saved_offset(int B, int N, int dropout, int item, int
 
 template <bool BF16>
 static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const Work& W, int B, int N, bool training, float drop_p,
-                                uint64_t seed, float momentum, hipStream_t st) {
+                                uint64_t seed, float momentum, bool dead_bn7, hipStream_t st) {
     const long BN = (long)B * N;
     for (int i = 0; i < NL; ++i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
@@ -944,14 +951,20 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
         tcn_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(i == 0 ? S.x0 : S.y[i - 1], bn, npos, Tin, Tout, dil, W.wcat + i * 4096,
                                                                         W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
         STEP_LAUNCH_CHECK("tcn_fwd");
-        if (i == NL - 1) break;
+        if (i == NL - 1 && !(dead_bn7 && training)) break;
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, st));      // slots 1,3,5 = P_s z
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, st));      // slots 2,4,6 = P_s (P_s z)
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
+        const bool dead = i == NL - 1;              // the reference evaluates gconv[7] / bn[7] and drops the result (model.py:202-213)
         mix_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 64), 256, 0, st>>>(S.cat[i], p->gconv_w[i], p->gconv_b[i], xin, npos, Tin, Tout, dil, drop_p,
-                                                                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, S.mask[i], S.y[i],
-                                                                       W.acc64 + (long)i * NCOPY * 64);
+                                                                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, dead ? W.m7 : S.mask[i],
+                                                                       dead ? W.y7 : S.y[i], W.acc64 + (long)i * NCOPY * 64);
         STEP_LAUNCH_CHECK("mix_fwd");
+        if (dead) {
+            const BnFwd b7 = {p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], 1, momentum, S.bnstat[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
+            bn_stats_only_kernel<<<1, 64, 0, st>>>(b7);
+            STEP_LAUNCH_CHECK("bn7_stats");
+        }
     }
     return STEP_OK;
 }
@@ -985,14 +998,15 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_forward: bad sizes B=%d N=%d C=%d", B, N, Cin);
     const bool do_layers = phase != 2, do_head = phase != 1;
     hipStream_t st = (hipStream_t)stream;
-    const bool use_drop = training && dropout_p > 0.f;
+    const bool train = (training & 1) != 0;          // bit 1 (value 2): also the dead bn.7 statistics, see the header
+    const bool use_drop = train && dropout_p > 0.f;
     Saved S = carve_saved(saved, B, N, use_drop);
     Work W = carve_work(work, B, N, false);
     const long BN = (long)B * N;
     const int allbf16 = p->gemm_bf16;      // bf16 mode: every contraction of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
 
     if (do_layers) {
-    STEP_TRY(zero((float*)W.acc64, 2L * 7 * NCOPY * 64, st));
+    STEP_TRY(zero((float*)W.acc64, 2L * NL * NCOPY * 64, st));
     start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
     STEP_LAUNCH_CHECK("start_conv");
     // supports (model.py:160-166)
@@ -1024,8 +1038,9 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
 
     // 8 layers: gated TCN (one kernel), two diffusion hops (the three supports per launch), gcn mix + dropout + residual + BatchNorm
     // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
-    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
-    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, training != 0, use_drop ? dropout_p : 0.f, seed, momentum, st));
+    const bool dead_bn7 = (training & 2) != 0;
+    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, st));
+    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, st));
     }
 
     // head (model.py:215-220): the only part that needs the TSFormer's hidden state
@@ -1142,7 +1157,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
     STEP_TRY(pack_weights(p, W, st));
-    STEP_TRY(zero(W.dwcat, (long)((float*)W.acc64 - W.dwcat) + 2L * 7 * NCOPY * 64, st));       // dwcat, dbcat, dwskip, acc64
+    STEP_TRY(zero(W.dwcat, (long)((float*)W.acc64 - W.dwcat) + 2L * NL * NCOPY * 64, st));       // dwcat, dbcat, dwskip, acc64
     const long NN = (long)N * N;
 
     // ---------------------------------------------------------------- head (model.py:215-220)

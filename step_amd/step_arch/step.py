@@ -131,7 +131,8 @@ class _StepFunction(torch.autograd.Function):
                         model._sum_over_ranks(exchange[phase])
             L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
                    TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), sst)
-            L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct), int(training),
+            L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct),
+                   int(training) | (2 if (training and model.track_dead_bn7) else 0),
                    float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, sst)
 
         # ---- TSFormer (frozen) and the kNN prior graph (no grad): on the main stream, or already in flight on the prefetch stream
@@ -164,7 +165,7 @@ class _StepFunction(torch.autograd.Function):
         if training:
             with torch.no_grad():
                 # one multi-tensor launch instead of ten scalar ones
-                torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:7])], 1)
+                torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:8 if model.track_dead_bn7 else 7])], 1)
         if frozen.get("knn_done") is not None:
             main.wait_event(frozen["knn_done"])          # adj_knn / sim are handed to the caller on the current stream
         ctx.model = model
@@ -271,6 +272,11 @@ class STEP(nn.Module):
         # "bf16": every GEMM-shaped contraction of the GraphWaveNet and the DGL (hops, 1x1 / gate / mix / head layers and their
         # weight gradients, DGL conv and fc) runs on the bf16 matrix cores with f32 accumulation (BASELINE config "bf16")
         self.matmul_precision = "f32"
+        # The last WaveNet layer's gcn + BatchNorm output is dead code in the reference (model.py:202-213), but its forward still runs
+        # there and moves bn.7's running statistics.  True: evaluate that layer's gcn for its batch statistics as well (two hop
+        # launches, the mix kernel and a finalize: ~40 us per step) so that a checkpoint written after training round-trips all of
+        # the reference's buffers; False (default): skip the dead work, bn.7's three buffers stay at their initial values.
+        self.track_dead_bn7 = False
         self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
         self._seed_ctr = 0
         self._process_group = None
@@ -297,16 +303,13 @@ class STEP(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _side_stream(self, dev, name="side"):
-        """The model's extra streams.  "side" (forward: graph learner + WaveNet layers next to the encoder) has HIGH priority: the
-        encoder's workgroups fill every compute unit, so a normal-priority kernel of the chain waits ~150 us for room each time it is
-        launched (profiles/r03_f_C2_train_step.md: bn_finalize 182 us next to the encoder, 10 us alone) -- with priority its few
-        workgroups take the next compute unit that frees up.  "aux" (backward: the leaves) has LOW priority: it must not delay the
-        data-gradient chain on the main stream.  STEP_STREAM_PRIO=0 puts both at the default priority (A/B)."""
+        """The model's extra streams: "side" (forward: graph learner + WaveNet layers next to the encoder), "aux" (backward: the leaves).
+        Stream priorities were measured and change nothing here (the device offers two levels; 4.683 vs 4.686 ms with the side chain at
+        high priority, profiles/r03_g_stream_priority_ab.log): next to the encoder a small kernel still waits ~150 us for a compute
+        unit, because a freed unit goes back to the encoder's queue as often as to the other one."""
         key = (name, dev.type, dev.index)
         if key not in self._side:
-            mode = os.environ.get("STEP_STREAM_PRIO", "1")          # "0": none, "1": both, "side" / "aux": that one only (A/B)
-            prio = {"side": -1, "aux": 1}.get(name, 0) if mode in ("1", name) else 0
-            self._side[key] = torch.cuda.Stream(device=dev, priority=prio)
+            self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
@@ -396,10 +399,7 @@ class STEP(nn.Module):
         return rec
 
     def _prefetch_stream(self, dev):
-        key = ("prefetch", dev.type, dev.index)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        return self._side_stream(dev, "prefetch")
 
     def _next_seed(self):
         self._seed_ctr += 1
