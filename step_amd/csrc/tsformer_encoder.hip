@@ -78,6 +78,12 @@ constexpr int parked_frags() { return PARK ? 6 : (MAXW == 12 && TSF_PARK1) ? 1 :
 #ifndef TSF_STATIC_PRIO
 #define TSF_STATIC_PRIO 0   // 1: the later-dispatched half of the workgroup's waves runs at s_setprio 1 for the whole kernel (A/B builds; 1.994 vs 2.002 ms)
 #endif
+#ifndef TSF_PERSIST
+#define TSF_PERSIST 0       // N > 0: persistent launch of at most N workgroups, each looping over sequences blockIdx.x, + gridDim.x, ...; the next
+#endif                      // sequence's first weight block is requested during the last feed-forward stage of the current one (A/B builds).
+                            // Measured (profiles/r03_i_persistent_encoder_ab.log): alone 1.882 vs 1.871 ms at N = 256 (no gain: the 4 % tail
+                            // of 2456 workgroups over 256 compute units is not where the time goes); whole step 4.78 (256), 4.88 (240),
+                            // 4.70 (224: 32 compute units left to the second stream, encoder 2.41 ms) against 4.73 ms
 #ifndef TSF_BATCH_FRAGS
 #define TSF_BATCH_FRAGS 0   // 1: scheduling fences around the batched weight-fragment reads (measured: forces the operand copy into scratch, 1.93 -> 2.22 ms)
 #endif
@@ -103,7 +109,6 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int seq = blockIdx.x;
     const int P = A.P, nkt = A.nkt;
     const int tok = wave * 32 + c;
     const bool tok_ok = tok < P;
@@ -150,23 +155,39 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         return slot_of(g);
     };
 
-    issue_fill(0);
     if (TSF_STATIC_PRIO && wave * 2 >= nkt) __builtin_amdgcn_s_setprio(1);
+    bool first_block_requested = false;       // (persistent launch) block 0 of this sequence was requested during the previous one
+#if TSF_PERSIST
+#pragma unroll 1
+    for (int seq = blockIdx.x; seq < A.S; seq += gridDim.x) {
+#else
+    const int seq = blockIdx.x;
+    {
+#endif
+    // no barrier between sequences: the first stage_begin() of a sequence is one, and ring slot 0 was released two stages before the end
+    if (!first_block_requested) issue_fill(0);
+    issued = 1;
+    first_block_requested = false;
 
     // ------------------------------------------------------------------ patch embedding + pos
     f32x16 xT[3];
     {
         float xin[12];
-        const float4* src = (const float4*)(A.series + (long)seq * A.L + (long)tokc * TSF_PATCH);
+        // (per-lane addresses of this block are derived from a fresh lane id: as loop invariants of the persistent variant they
+        //  would be kept alive -- in scratch memory -- across the whole sequence)
+        const int lane_p = fresh_lane_id(), h_p = lane_p >> 5, tok_p = wave * 32 + (lane_p & 31);
+        const bool tok_ok_p = tok_p < P;
+        const int tokc_p = tok_ok_p ? tok_p : 0;
+        const float4* src = (const float4*)(A.series + (long)seq * A.L + (long)tokc_p * TSF_PATCH);
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            float4 t4 = tok_ok ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 t4 = tok_ok_p ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
             xin[4 * v] = t4.x; xin[4 * v + 1] = t4.y; xin[4 * v + 2] = t4.z; xin[4 * v + 3] = t4.w;
         }
         // x W_pe^T on the matrix cores in full f32 (v_mfma_f32_32x32x2_f32, K = 12 in six steps): A = W_pe rows (features) of
         // block t, stored per lane by the packer ([3][6][64] floats, one coalesced dword load each), B = this token's inputs
         // 2s + h; the accumulators start from pos + b_pe (pre-added by the packer) and come out in the layout of every other tile
-        const float4* pos = (const float4*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc * 2 + h) * 12;
+        const float4* pos = (const float4*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc_p * 2 + h_p) * 12;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -174,11 +195,11 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 const float4 p4 = pos[t * 4 + q4];
                 xT[t][4 * q4] = p4.x; xT[t][4 * q4 + 1] = p4.y; xT[t][4 * q4 + 2] = p4.z; xT[t][4 * q4 + 3] = p4.w;
             }
-        const float* wpe = (const float*)(W + TSF_G_WPE) + lane;
+        const float* wpe = (const float*)(W + TSF_G_WPE) + lane_p;
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
             // (a plain `h ? odd : even` is turned into a dynamically indexed private array, i.e. scratch memory)
-            const uint32_t hm = 0u - (uint32_t)h;
+            const uint32_t hm = 0u - (uint32_t)h_p;
             const float xb = __uint_as_float((__float_as_uint(xin[2 * ks]) & ~hm) | (__float_as_uint(xin[2 * ks + 1]) & hm));
 #pragma unroll
             for (int t = 0; t < 3; ++t) xT[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpe[(t * 6 + ks) * 64], xb, xT[t], 0, 0, 0);
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                     if (h == 0) qb[1][5] = (ope)0.0f;
                 }
             }
-            slow_units += redo ? 1 : 0;
+            slow_units = __builtin_amdgcn_readfirstlane(slow_units + (redo ? 1 : 0));
             if (!redo) {
             } else if (TSF_ABLATE & 32) {
             } else if constexpr (PIPE == 2) {
@@ -576,6 +597,10 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
             if (j > 0) {
                 blk = (PAIR && (j & 1)) ? slot_of(g) : stage_begin(g, PAIR ? 3 : 1);      // PAIR: odd blocks arrived with their predecessor
                 tail = (const float*)(blk + TSF_TAIL);
+                if (TSF_PERSIST && PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                    issue_fill(0);            // slot 0 (block g - 2) is free since this stage's barrier: the next sequence's first block
+                    first_block_requested = true;
+                }
             }
             TSF_PRIO_CHAIN(1);
 #pragma unroll
@@ -672,6 +697,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
         if (lane_e == 0) A.sqn[(long)seq * 16 + wave] = sq;
         if (wave == 0 && lane_e >= nkt && lane_e < 16) A.sqn[(long)seq * 16 + lane_e] = 0.f;
     }
+    }   // sequences of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------
@@ -741,7 +767,8 @@ int launch_enc_t(const EncArgs& a, hipStream_t st) {
         step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
         return STEP_ERR_HIP;
     }
-    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE><<<a.S, a.nkt * 64, lds, st>>>(a);
+    const int grid = (TSF_PERSIST > 0 && a.S > TSF_PERSIST) ? TSF_PERSIST : a.S;
+    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE><<<grid, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
 }
