@@ -112,7 +112,7 @@ def static_pmc_traffic(config, B):
         return None
 
 
-def live_pmc_traffic(config, B, ckpt, timeout=240):
+def live_pmc_traffic(config, B, ckpt, timeout=150):
     """HBM bytes of the encoder launch measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE -- they do
     not fit one pass; --kernel-trace only, no other trace domain) over a child process that loads the same checkpoint and launches
     the training-mode encoder at this config's size (bench.py --pmc-child).  Units and the gfx950 correction as
