@@ -75,14 +75,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#ifndef STEP_PHILOX_MUL64
+#define STEP_PHILOX_MUL64 1     // 0: __umulhi + low product (two quarter-rate multiplies per round half; identical results)
+#endif
 // ---- counter-based RNG (Philox4x32-10) --------------------------------------------------
 // Used for on-device Gumbel noise and dropout masks; deterministic in (seed, counter).
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                            uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
+#if STEP_PHILOX_MUL64
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;      // one v_mad_u64_u32 each
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
         uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

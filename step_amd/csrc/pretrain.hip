@@ -265,9 +265,28 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------ dropout stream of the attention probabilities
+// One Philox4x32 call = eight 16-bit fields = eight keep decisions (field >= p * 2^16; 16 bits resolve p to 1.5e-5, and the fields of
+// a Philox output are as independent as its words).  Decision of (row, key k), row = (s H + head) T + query: field number
+//     row * T32 + 32 (k >> 5) + sigma(k & 31),   sigma(8 g + 4 h + j) = 16 h + 4 g + j,   T32 = T rounded up to 32
+// -- sigma makes the 16 keys one lane of a matrix-core score tile holds (keys 8 g + 4 h + j, g = 0..3, j = 0..3) 16 CONSECUTIVE
+// fields, i.e. two Philox calls per lane and tile (the element-per-word stream of step_pt_dropout needed four, and they were half
+// of the forward kernel's time: profiles/r03_l_pretrain_attention_ablations.log).  The f32 kernels evaluate the same stream.
+__device__ __forceinline__ uint32_t attn_keep_thr(float p) { return (uint32_t)(p * 65536.f); }
+__device__ __forceinline__ long attn_keep_index(long row, int T32, int k) {
+    const int k32 = k & 31;
+    return row * T32 + (k & ~31) + 16 * ((k32 >> 2) & 1) + 4 * (k32 >> 3) + (k32 & 3);
+}
+__device__ __forceinline__ float attn_keep(uint32_t lo, uint32_t hi, uint32_t site, long row, int T32, int k, float p) {
+    const long f = attn_keep_index(row, T32, k), blk = f >> 3;
+    const int sub = (int)(f & 7);
+    uint32_t r[4];
+    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), site, 0xD20Fu, lo, hi, r);
+    return ((r[sub >> 1] >> (16 * (sub & 1))) & 0xffffu) >= attn_keep_thr(p) ? 1.f / (1.f - p) : 0.f;
+}
+
 // ------------------------------------------------------------------------------------ self-attention, one block per (sequence, head)
 // qkv [S][T][288] (q | k | v, head h = columns 24h..24h+23 of each third), out [S][T][96], stats [S][H][T][2] = (row max, row sum)
-// attention-probability dropout uses element index ((s*H + h)*T + i)*T + j
 template <bool BWD>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, long S, int T, float p, uint32_t lo, uint32_t hi,
                                                    uint32_t site, float* __restrict__ out, float* __restrict__ stats,
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 for (int d = 0; d < DH; ++d) a += q[d] * sk[j * DH + d];
                 float e = __expf(a - mx);
                 l += e;
-                if (p > 0.f) e *= keep_scale(lo, hi, site, (srow + i) * T + j, p);
+                if (p > 0.f) e *= attn_keep(lo, hi, site, srow + i, (T + 31) & ~31, j, p);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) o[d] += e * sv[j * DH + d];
             }
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 #pragma unroll
                 for (int d = 0; d < DH; ++d) { a += q[d] * sk[j * DH + d]; dp += dout_i[d] * sv[j * DH + d]; }
                 const float pij = __expf(a - smx[i]) * sinv[i];
-                if (p > 0.f) dp *= keep_scale(lo, hi, site, (srow + i) * T + j, p);
+                if (p > 0.f) dp *= attn_keep(lo, hi, site, srow + i, (T + 31) & ~31, j, p);
                 const float ds = pij * (dp - sdl[i]);
 #pragma unroll
                 for (int d = 0; d < DH; ++d) dq[d] += ds * sk[j * DH + d];
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 for (int d = 0; d < DH; ++d) { a += sq[i * DH + d] * kj[d]; dp += sdo[i * DH + d] * vj[d]; }
                 const float pij = __expf(a * scale - smx[i]) * sinv[i];
                 float m = 1.f;
-                if (p > 0.f) m = keep_scale(lo, hi, site, (srow + i) * T + j, p);
+                if (p > 0.f) m = attn_keep(lo, hi, site, srow + i, (T + 31) & ~31, j, p);
                 const float ds = pij * (dp * m - sdl[i]);
                 const float pm = pij * m;
 #pragma unroll
@@ -387,6 +406,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 // takes accumulator registers [8s, 8s+8), i.e. keys {16s+4h+0..3, 16s+8+4h+0..3} of lane half h, and the A operand (rows of a
 // transposed LDS copy) reads exactly those keys (any pairing of k is a valid contraction order).
 // Dropout of the attention probabilities: the same Philox stream and element index as attn_kernel (one call covers 4 keys).
+#ifndef MA_ABLATE
+#define MA_ABLATE 0       // timing experiments only (WRONG results): 1 no Philox in the forward, 2 no global loads in the fills, 4 no output stores
+#endif
 constexpr int MA_DP = 32;                 // head dim padded to two k steps
 constexpr int MA_RP = 40;                 // row pitch of the row-major LDS arrays (bf16 elements): 80 B, conflict-free 16-byte reads
 __device__ __forceinline__ int ma_tpitch(int Tp) { return Tp + 8; }      // pitch of the transposed arrays
@@ -396,21 +418,48 @@ __device__ __forceinline__ bf16x8 ma_tr8(const uint16_t* trow, int k0, int h) { 
     return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
 }
 __device__ __forceinline__ bf16x8 ma_pack(const float* v) { return pack8(v); }
-// keep decisions (as multipliers 1/(1-p) or 0) of elements elem0 .. elem0+3 of the attention-dropout stream
-__device__ __forceinline__ void ma_keep4(uint32_t lo, uint32_t hi, uint32_t site, long elem0, float p, float ks, float* m) {
-    uint32_t r[8];
-    const long blk = elem0 >> 2;
-    const int off = (int)(elem0 & 3);
-    philox4x32((uint32_t)blk, (uint32_t)(blk >> 32), site, 0xD20Fu, lo, hi, r);
-    if (off) philox4x32((uint32_t)(blk + 1), (uint32_t)((blk + 1) >> 32), site, 0xD20Fu, lo, hi, r + 4);
+// the 16 keep decisions (as multipliers 1/(1-p) or 0) of one lane of a score tile -- keys 8 g + 4 h + j of the tile, m[4 g + j] --
+// from the attention-dropout stream (attn_keep_index): fields 16 h .. 16 h + 15 of the tile = two Philox calls
+__device__ __forceinline__ void ma_keep16(uint32_t lo, uint32_t hi, uint32_t site, long row, int T32, int kt, int h, float p, float ks, float* m) {
+    const long blk = (row * T32 + kt * 32 + 16 * h) >> 3;
+    const uint32_t thr = attn_keep_thr(p);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t v = r[j];
-        if (off == 1) v = r[j + 1]; else if (off == 2) v = r[j + 2]; else if (off == 3) v = r[j + 3];
-        m[j] = u32_to_unit(v) >= p ? ks : 0.f;
+    for (int b = 0; b < 2; ++b) {
+        uint32_t r[4];
+        philox4x32((uint32_t)(blk + b), (uint32_t)((blk + b) >> 32), site, 0xD20Fu, lo, hi, r);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) m[8 * b + f] = ((r[f >> 1] >> (16 * (f & 1))) & 0xffffu) >= thr ? ks : 0.f;
     }
 }
 __device__ __forceinline__ int ma_key(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }     // accumulator register -> row of the tile
+
+// Global <-> LDS traffic of both kernels moves 16 bytes per lane: a fill item is (token t, 4 head dimensions), 8 items per token
+// (6 real + 2 padding), so the 24 values of a (token, head) are six float4 of one 96-byte run, and results leave through an f32
+// staging tile [Tp][MA_SP] as float4 pieces of those runs.  (With one 4-byte access per lane the loads were 30 % and the stores 30 %
+// (forward) / 65 % (backward) of the kernel time: profiles/r03_l_pretrain_attention_ablations.log.)
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); this hands XCD x a CONTIGUOUS range of (sequence, head)
+// units, so the four heads of a sequence -- which share every 128-byte line of the sequence's qkv / out / dqkv rows -- run
+// back to back on one L2.
+__device__ __forceinline__ unsigned ma_unit(unsigned b, unsigned n) {
+    const unsigned per = n >> 3, rem = n & 7u, x = b & 7u;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+constexpr int MA_SP = 28;                 // row pitch (floats) of the staging tile: 112 B, 16-byte aligned, 2-way conflicts at most
+__device__ __forceinline__ void ma_stage_rows(float* stage, int q, int h, const f32x16& v, float scale) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int d = ma_key(e, h);
+        if (d < DH) stage[q * MA_SP + d] = v[e] * scale;
+    }
+}
+// rows [0, T) of the staging tile -> dst[t * ld + (0..23)], float4 pieces
+__device__ __forceinline__ void ma_store_rows(const float* stage, int T, float* __restrict__ dst, long ld, int tid, int nthreads) {
+    if (MA_ABLATE & 4) return;
+    for (int e = tid; e < T * 6; e += nthreads) {
+        const int t = e / 6, d4 = e - 6 * t;
+        *(float4*)(dst + (long)t * ld + d4 * 4) = *(const float4*)(stage + t * MA_SP + d4 * 4);
+    }
+}
 
 // forward: out [S][T][96], stats [S][H][T][2] = (row max, row sum) like attn_kernel
 __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
@@ -421,18 +470,22 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
     uint16_t* Qs = ml;                       // [Tp][MA_RP]  q * scale
     uint16_t* Ks = Qs + Tp * MA_RP;          // [Tp][MA_RP]
     uint16_t* VT = Ks + Tp * MA_RP;          // [32][TPt]
-    const long s = blockIdx.x / H;
-    const int hd = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const unsigned unit = ma_unit(blockIdx.x, gridDim.x);
+    const long s = unit / H;
+    const int hd = unit % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
     const float scale = 0.20412414523193154f;
-    const float* base = qkv + s * (long)T * 288;
-    for (int e = tid; e < Tp * MA_DP; e += blockDim.x) {
-        const int t = e >> 5, d = e & 31;
-        const bool ok = t < T && d < DH;
-        const float q = ok ? base[(long)t * 288 + hd * DH + d] * scale : 0.f, k = ok ? base[(long)t * 288 + 96 + hd * DH + d] : 0.f;
-        const float v = ok ? base[(long)t * 288 + 192 + hd * DH + d] : 0.f;
-        Qs[t * MA_RP + d] = (uint16_t)f32_to_bf16_bits(q);
-        Ks[t * MA_RP + d] = (uint16_t)f32_to_bf16_bits(k);
-        VT[d * TPt + t] = (uint16_t)f32_to_bf16_bits(v);
+    const float* base = qkv + s * (long)T * 288 + hd * DH;
+    for (int e = tid; e < Tp * 8; e += blockDim.x) {
+        const int t = e >> 3, d4 = e & 7;
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
+        if (t < T && d4 < 6 && !(MA_ABLATE & 2)) {
+            const float* r = base + (long)t * 288 + d4 * 4;
+            q4 = *(const float4*)r; k4 = *(const float4*)(r + 96); v4 = *(const float4*)(r + 192);
+        }
+        *(uint2*)(Qs + t * MA_RP + d4 * 4) = make_uint2(pack_bf16x2(q4.x * scale, q4.y * scale), pack_bf16x2(q4.z * scale, q4.w * scale));
+        *(uint2*)(Ks + t * MA_RP + d4 * 4) = make_uint2(pack_bf16x2(k4.x, k4.y), pack_bf16x2(k4.z, k4.w));
+        VT[(d4 * 4 + 0) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.x); VT[(d4 * 4 + 1) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.y);
+        VT[(d4 * 4 + 2) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.z); VT[(d4 * 4 + 3) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.w);
     }
     __syncthreads();
     const int q = wave * 32 + col, nkt = Tp / 32;
@@ -471,13 +524,12 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
         if (p > 0.f) {
             uint32_t word = 0u;
             if (q < T) {
+                float m[16];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float m4[4];
-                    ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+                for (int e = 0; e < 16; ++e) m[e] = ks;
+                if (!(MA_ABLATE & 1)) ma_keep16(lo, hi, site, srow + q, Tp, kt, h, p, ks, m);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { pv[4 * g + j] *= m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
-                }
+                for (int e = 0; e < 16; ++e) { pv[e] *= m[e]; if (m[e] > 0.f) word |= 1u << ma_key(e, h); }
             }
             // the keep decisions of (query, key tile) as one word: the backward reads them instead of re-running Philox
             word |= __shfl_xor(word, 32, 64);
@@ -488,15 +540,13 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(VT + col * TPt, kt * 32 + 16 * st, h), ma_pack(pv + 8 * st), o, 0, 0, 0);
     }
     l += __shfl_xor(l, 32, 64);
-    if (q < T) {
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int d = ma_key(e, h);
-            if (d < DH) out[(s * T + q) * D + hd * DH + d] = o[e] * inv;
-        }
-        if (h == 0) { stats[(srow + q) * 2] = mx; stats[(srow + q) * 2 + 1] = l; }
-    }
+    if (q < T && h == 0) { stats[(srow + q) * 2] = mx; stats[(srow + q) * 2 + 1] = l; }
+    // the output tile leaves through LDS (the operand arrays are dead) as float4 pieces of each token's 96-byte run
+    __syncthreads();
+    float* stage = (float*)ml;
+    ma_stage_rows(stage, q, h, o, 1.f / l);
+    __syncthreads();
+    ma_store_rows(stage, T, out + s * (long)T * D + hd * DH, D, tid, blockDim.x);
 }
 
 // backward: phase A (wave = query tile) -> dQ and the keep bits, phase B (wave = key tile) -> dK, dV
@@ -528,37 +578,63 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
     float* sinv = smx + Tp;
     float* sdl = sinv + Tp;
     uint32_t* bits = (uint32_t*)(sdl + Tp);   // [Tp][nt] keep bits of (query, key tile)
-    const long s = blockIdx.x / H;
-    const int hd = blockIdx.x % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const unsigned unit = ma_unit(blockIdx.x, gridDim.x);
+    const long s = unit / H;
+    const int hd = unit % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
     const float scale = 0.20412414523193154f;
     const float* base = qkv + s * (long)T * 288;
     const long srow = (s * H + hd) * (long)T;
-    for (int e = tid; e < Tp * MA_DP; e += blockDim.x) {
-        const int t = e >> 5, d = e & 31;
-        const bool ok = t < T && d < DH;
-        const uint16_t q = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + hd * DH + d] * scale : 0.f);
-        const uint16_t k = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 96 + hd * DH + d] : 0.f);
-        const uint16_t v = (uint16_t)f32_to_bf16_bits(ok ? base[(long)t * 288 + 192 + hd * DH + d] : 0.f);
-        const uint16_t g = (uint16_t)f32_to_bf16_bits(ok ? dout[(s * T + t) * D + hd * DH + d] : 0.f);
-        if (d < DH) {
-            Qs[t * MB_RP + d] = q; Ks[t * MB_RP + d] = k; Vs[t * MB_RP + d] = v; Os[t * MB_RP + d] = g;
-            QT[d * TPt + t] = q; KT[d * TPt + t] = k; OT[d * TPt + t] = g;
+    // fill: item = (token, 4 head dimensions), 8 lanes per token, float4 loads; blockDim = 2 Tp, so every thread owns exactly four
+    // items -- all twenty loads are issued before the first is consumed
+    float4 q4[4], k4[4], v4[4], g4[4], o4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = tid + it * blockDim.x, t = e >> 3, d4 = e & 7;
+        q4[it] = make_float4(0.f, 0.f, 0.f, 0.f); k4[it] = q4[it]; v4[it] = q4[it]; g4[it] = q4[it]; o4[it] = q4[it];
+        if (t < T && d4 < 6 && !(MA_ABLATE & 2)) {
+            const float* r = base + (long)t * 288 + hd * DH + d4 * 4;
+            const long oi = (s * T + t) * D + hd * DH + d4 * 4;
+            q4[it] = *(const float4*)r; k4[it] = *(const float4*)(r + 96); v4[it] = *(const float4*)(r + 192);
+            g4[it] = *(const float4*)(dout + oi); o4[it] = *(const float4*)(out + oi);
+        }
+    }
+    if (keepbits && p > 0.f)                 // the forward's keep decisions of this (sequence, head): one contiguous run of T nt words
+        for (int i = tid; i < Tp * nt; i += blockDim.x) bits[i] = i < T * nt ? keepbits[srow * nt + i] : 0u;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = tid + it * blockDim.x, t = e >> 3, d4 = e & 7;
+        float dl = g4[it].x * o4[it].x + g4[it].y * o4[it].y + g4[it].z * o4[it].z + g4[it].w * o4[it].w;
+        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);     // delta_t = sum_d dO O (8 adjacent lanes)
+        if (d4 == 0) sdl[t] = dl;
+        if (d4 < 6) {
+            const float qv[4] = {q4[it].x * scale, q4[it].y * scale, q4[it].z * scale, q4[it].w * scale};
+            const float kv[4] = {k4[it].x, k4[it].y, k4[it].z, k4[it].w}, vv[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
+            const float gv[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
+            uint16_t qb[4], kb[4], vb[4], gb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                qb[c] = (uint16_t)f32_to_bf16_bits(qv[c]); kb[c] = (uint16_t)f32_to_bf16_bits(kv[c]);
+                vb[c] = (uint16_t)f32_to_bf16_bits(vv[c]); gb[c] = (uint16_t)f32_to_bf16_bits(gv[c]);
+                const int d = d4 * 4 + c;
+                QT[d * TPt + t] = qb[c]; KT[d * TPt + t] = kb[c]; OT[d * TPt + t] = gb[c];
+            }
+            const int ro = t * MB_RP + d4 * 4;
+            *(uint2*)(Qs + ro) = make_uint2(qb[0] | ((uint32_t)qb[1] << 16), qb[2] | ((uint32_t)qb[3] << 16));
+            *(uint2*)(Ks + ro) = make_uint2(kb[0] | ((uint32_t)kb[1] << 16), kb[2] | ((uint32_t)kb[3] << 16));
+            *(uint2*)(Vs + ro) = make_uint2(vb[0] | ((uint32_t)vb[1] << 16), vb[2] | ((uint32_t)vb[3] << 16));
+            *(uint2*)(Os + ro) = make_uint2(gb[0] | ((uint32_t)gb[1] << 16), gb[2] | ((uint32_t)gb[3] << 16));
         }
     }
     for (int i = tid; i < TPt; i += blockDim.x) ZT[i] = 0;
     for (int i = tid; i < Tp; i += blockDim.x) {
-        float dl = 0.f, m = 0.f, iv = 0.f;
-        if (i < T) {
-#pragma unroll
-            for (int d = 0; d < DH; ++d) dl += dout[(s * T + i) * D + hd * DH + d] * out[(s * T + i) * D + hd * DH + d];
-            m = stats[(srow + i) * 2];
-            iv = 1.f / stats[(srow + i) * 2 + 1];
-        }
-        sdl[i] = dl; smx[i] = m; sinv[i] = iv;
+        float2 st2 = make_float2(0.f, 1.f);
+        if (i < T) st2 = *(const float2*)(stats + (srow + i) * 2);
+        smx[i] = i < T ? st2.x : 0.f; sinv[i] = i < T ? 1.f / st2.y : 0.f;
     }
     __syncthreads();
     const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
     float* db = dqkv + s * (long)T * 288;
+    f32x16 dq_keep;
     {   // ---- phase A: this wave's 32 queries against every key tile (keys in registers, query = lane)
         const int q = wave * 32 + col;
         const float mq = smx[q], iq = sinv[q], dq_ = sdl[q];
@@ -580,22 +656,20 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             float mk[16];
             uint32_t word = 0u;
             if (keepbits && p > 0.f) {               // the forward's keep decisions
-                word = q < T ? keepbits[(srow + q) * nt + kt] : 0u;
+                word = q < T ? bits[q * nt + kt] : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mk[4 * g + j] = (word >> (8 * g + 4 * h + j)) & 1u ? ks : 0.f;
             } else {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float m4[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (p > 0.f && q < T) ma_keep4(lo, hi, site, (srow + q) * T + kt * 32 + 8 * g + 4 * h, p, ks, m4);
+                for (int e = 0; e < 16; ++e) mk[e] = p > 0.f && q >= T ? 0.f : ks;
+                if (p > 0.f && q < T) ma_keep16(lo, hi, site, srow + q, Tp, kt, h, p, ks, mk);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { mk[4 * g + j] = m4[j]; if (m4[j] > 0.f) word |= 1u << (8 * g + 4 * h + j); }
-                }
+                for (int e = 0; e < 16; ++e) if (mk[e] > 0.f) word |= 1u << ma_key(e, h);
                 word |= __shfl_xor(word, 32, 64);
             }
-            if (h == 0) bits[q * nt + kt] = word;
+            if (h == 0 && !(keepbits && p > 0.f)) bits[q * nt + kt] = word;
             float ds[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -607,10 +681,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             for (int st = 0; st < 2; ++st)
                 dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(col < DH ? KT + col * TPt : ZT, kt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dqa, 0, 0, 0);
         }
-        if (q < T) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const int d = ma_key(e, h); if (d < DH) db[(long)q * 288 + hd * DH + d] = dqa[e] * scale; }
-        }
+        dq_keep = dqa;                         // leaves with dK and dV through the staging tile, after phase B is done with the operands
     }
     __syncthreads();
     {   // ---- phase B: this wave's 32 keys against every query tile (queries in registers, key = lane)
@@ -645,13 +716,19 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
                 dka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(col < DH ? QT + col * TPt : ZT, qt * 32 + 16 * st, h), ma_pack(ds + 8 * st), dka, 0, 0, 0);
             }
         }
-        if (kj < T) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int d = ma_key(e, h);
-                if (d < DH) { db[(long)kj * 288 + 96 + hd * DH + d] = dka[e]; db[(long)kj * 288 + 192 + hd * DH + d] = dva[e]; }
+        // dQ | dK | dV of this wave's 32 tokens -> staging tile [Tp][3 MA_SP] over the dead operands -> float4 pieces of the three
+        // 96-byte runs each token owns in dqkv
+        __syncthreads();
+        float* stage = (float*)ml;
+        ma_stage_rows(stage, 3 * kj, h, dq_keep, scale);
+        ma_stage_rows(stage + MA_SP, 3 * kj, h, dka, 1.f);
+        ma_stage_rows(stage + 2 * MA_SP, 3 * kj, h, dva, 1.f);
+        __syncthreads();
+        if (!(MA_ABLATE & 4))
+            for (int e = tid; e < T * 18; e += blockDim.x) {
+                const int t = e / 18, r = e - 18 * t, sec = r / 6, d4 = r - 6 * sec;
+                *(float4*)(db + (long)t * 288 + sec * 96 + hd * DH + d4 * 4) = *(const float4*)(stage + (3 * t + sec) * MA_SP + d4 * 4);
             }
-        }
     }
 }
 
@@ -825,7 +902,10 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
     return STEP_OK;
 }
 // the same attention on the matrix cores (bf16 operands, f32 accumulation) -- what TSFormer(mode="pre-train") uses with matmul_precision = "bf16"
-static size_t ma_fwd_lds(int Tp) { return (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2; }
+static size_t ma_fwd_lds(int Tp) {      // operands, re-used by the f32 staging tile of the output
+    const size_t ops = (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2, stage = (size_t)Tp * MA_SP * 4;
+    return ops > stage ? ops : stage;
+}
 static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MB_RP + (3 * DH + 1) * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
 extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                                           uint32_t* keepbits, void* stream) {

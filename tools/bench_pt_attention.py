@@ -1,0 +1,46 @@
+"""Micro-benchmark of the pre-training attention kernels (matrix-core path) at config C3's decoder / encoder sizes.
+usage: [STEP_HIP_LIB=...] python tools/bench_pt_attention.py [S]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from step_amd import _lib as L  # noqa: E402
+
+
+def main():
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 5200
+    tag = os.environ.get("STEP_HIP_LIB", "default")
+    for T in (168, 42):
+        gen = torch.Generator().manual_seed(T)
+        qkv = (torch.randn(S, T, 288, generator=gen) * 1.0).cuda()
+        dout = torch.randn(S, T, 96, generator=gen).cuda()
+        out = torch.empty(S, T, 96, device="cuda")
+        stats = torch.empty(S * 4 * T, 2, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda")
+        kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda")
+        st = L.stream()
+        for p in (0.1, 0.0):
+            def fwd():
+                L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, 1234, 7, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+
+            def bwd():
+                L.call("step_pt_attention_bwd_bf16", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, 1234, 7, L.ptr(dqkv), L.ptr(kb), st)
+            res = []
+            for f in (fwd, bwd):
+                for _ in range(3):
+                    f()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                res.append(e0.elapsed_time(e1) / 10)
+            print(f"{tag} S={S} T={T} p={p}: forward {res[0] * 1e3:.0f} us, backward {res[1] * 1e3:.0f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
