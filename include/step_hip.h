@@ -295,14 +295,22 @@ int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t see
                           void* stream);
 int step_pt_attention_bwd(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
                           uint64_t seed, uint32_t site, float* dqkv, void* stream);
-/* The same attention with bf16 operands on the matrix cores (f32 accumulation, same statistics layout, same dropout stream); what the
- * pre-training module uses when matmul_precision == "bf16".  T <= 336; the backward needs 0.44 T + 0.03 T^2/32 KB of LDS (T > 256 falls
- * back to the f32 kernel).  keepbits (nullable): [S][4][T][ceil(T/32)] words -- the forward stores the keep decisions of every (query,
- * key tile), a backward given the same buffer reads them instead of regenerating the Philox stream. */
-int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
+/* The same attention on the matrix cores with the activations stored as bfloat16 (f32 accumulation and statistics, same statistics
+ * layout; the probability dropout draws the 16-bit-field stream of csrc/pretrain.hip `attn_keep_index`, which the f32 kernels above
+ * evaluate too): qkv bf16 [S][T][288], out / dout bf16 [S][T][96], dqkv bf16 [S][T][288], all 16-byte aligned; what the pre-training
+ * module uses when matmul_precision == "bf16" (the producing / consuming GEMMs write / read bf16: step_pt_linear_bf16out, step_gemm
+ * with a_bf16 / b_bf16).  T <= 352 (the backward holds seven operand copies and the keep bits in LDS: 139 KB at 352 tokens).
+ * keepbits (nullable): [S][4][T][ceil(T/32)] words -- the forward stores the keep decisions of every (query, key tile), a backward
+ * given the same buffer reads them instead of regenerating the Philox stream. */
+int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats,
                                uint32_t* keepbits, void* stream);
-int step_pt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
-                               uint64_t seed, uint32_t site, float* dqkv, const uint32_t* keepbits, void* stream);
+int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* stats, long S, int T, float p,
+                               uint64_t seed, uint32_t site, uint16_t* dqkv, const uint32_t* keepbits, void* stream);
+/* out[r][n] = bf16(sum_k x[r][k] w(k, n) + bias[n]), x f32 [R][K] rows (16-byte aligned, K % 4 == 0), w(k, n) at w + k * swk + n * swn
+ * with swk == 1 (a torch Linear weight [N][K]) or swn == 1 (its transpose: the data gradient of that layer), bias nullable, N % 4 == 0,
+ * out bf16 [R][N]: a linear layer whose result is only ever read as a matrix-core operand, stored in that type (bf16 contraction). */
+int step_pt_linear_bf16out(const float* x, const float* w, long swk, long swn, const float* bias, long R, int N, int K, uint16_t* out,
+                           void* stream);
 int step_pt_relu_mask(float* d, const float* y, long n, void* stream);      /* d *= (y > 0) */
 int step_colsum(const float* x, long rows, int cols, long ld, float* out, void* stream);   /* out[c] += sum_r x[r*ld + c] */
 
@@ -325,6 +333,14 @@ int step_adam_clip_sharded(float* params, const float* grads, float* exp_avg, fl
  * Writes the scalar loss and d loss/d pred, d loss/d theta.  work: 3 doubles of scratch. */
 int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const float* theta, const float* prior, long n_adj,
                       float null_val, float coef, double* work, float* loss, float* dpred, float* dtheta, void* stream);
+/* The same on NORMALISED tensors: the loss is taken on x * scale + shift (the runner's inverse scaling, base_tsf_runner.py:240-250,
+ * step_runner.py:86-92, folded into the two kernels); dpred is the gradient w.r.t. the normalised prediction.  real is read with an
+ * element stride (real_stride = C reads feature 0 of a contiguous [..., C] batch tensor in place). */
+int step_loss_scaled_fwd_bwd(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
+                             const float* theta, const float* prior, long n_adj, float null_val, float coef, double* work, float* loss,
+                             float* dpred, float* dtheta, void* stream);
+/* out_a = a * *g, out_b = b * *g with g a device scalar (autograd's incoming gradient of the loss applied to both gradients). */
+int step_scale2(const float* a, long na, const float* b, long nb, const float* g, float* out_a, float* out_b, void* stream);
 
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on

@@ -105,9 +105,12 @@ _SIGS = {
     "step_pt_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
     "step_pt_attention_fwd_bf16": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
     "step_pt_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
+    "step_pt_linear_bf16out": (_i, [_vp, _vp, _l, _l, _vp, _l, _i, _i, _vp, _vp]),
     "step_pt_relu_mask": (_i, [_vp, _vp, _l, _vp]),
     "step_colsum": (_i, [_vp, _l, _i, _l, _vp, _vp]),
     "step_loss_fwd_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "step_loss_scaled_fwd_bwd": (_i, [_vp, _vp, _l, _l, _f, _f, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "step_scale2": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp]),
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     "step_adam_clip_sharded": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp]),
@@ -116,7 +119,7 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
 
 

@@ -613,16 +613,16 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
         const GemmFused& fu = fa.fu;
         constexpr int PIECES = BM * BN / 4, NPC = PIECES / 256, NB = NPC < 8 ? NPC : 8;
         static_assert(PIECES % 256 == 0 && NPC % NB == 0, "piece loop shape");
-        if (fu.flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ)) {
-            // bf16 hidden layer of the pre-training feed-forward block: a thread's piece = 4 consecutive columns of one row = one
+        if (fu.flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ | GEMM_FUSED_BF16OUT)) {
+            // GEMM_FUSED_BF16OUT: v + bias stored as bf16.  The other two: bf16 hidden layer of the pre-training feed-forward block: a thread's piece = 4 consecutive columns of one row = one
             // Philox call of the step_pt_dropout stream (element index m * N + n, N % 4 == 0)
             uint16_t* Ch = (uint16_t*)Cb;
             const uint16_t* xh = (const uint16_t*)fu.maskx;
-            const bool fwd = (fu.flags & GEMM_FUSED_FFN_FWD) != 0;
+            const bool fwd = (fu.flags & GEMM_FUSED_FFN_FWD) != 0, plain = (fu.flags & GEMM_FUSED_BF16OUT) != 0;
             const float ks = fu.p > 0.f ? 1.f / (1.f - fu.p) : 1.f;
             const int c4t = (tid % (BN / 4)) * 4;                    // the same 4 columns for all of this thread's pieces
             float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (fwd && n0 + c4t < g.N) {
+            if ((fwd || plain) && fu.ffn_bias && n0 + c4t < g.N) {
                 const float4 t = *(const float4*)(fu.ffn_bias + n0 + c4t);
                 b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
             }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
                     const int gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
                     ok[u] = gm < g.M && gn < g.N;
                     off[u] = ok[u] ? (long)gm * g.ldc + gn : 0;
-                    if (!fwd) x2[u] = *(const uint2*)(xh + off[u]);
+                    if (!fwd && !plain) x2[u] = *(const uint2*)(xh + off[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
@@ -645,7 +645,10 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
                     const float4 t4 = *(const float4*)(tile + (pc / (BN / 4)) * TP + (pc % (BN / 4)) * 4);
                     const float v[4] = {t4.x, t4.y, t4.z, t4.w};
                     float o[4];
-                    if (fwd) {
+                    if (plain) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = v[i] + b4[i];
+                    } else if (fwd) {
                         float m[4] = {1.f, 1.f, 1.f, 1.f};
                         if (fu.p > 0.f) {
                             const long gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
@@ -942,7 +945,7 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
                 !(g.a_rowsum && (bmode == KC_BF16 || bmode == MC_BF16)) && !(bmode == MC_BF16 && g.N % 8);
     fa.wide_store = wide_store_ok(g, fused != nullptr);
     if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 &&
-                            ((fused->flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ)) ? (g.accumulate == 0 && !fused->dotw && !fused->bnx && !g.c_nscale) :
+                            ((fused->flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ | GEMM_FUSED_BF16OUT)) ? (g.accumulate == 0 && !fused->dotw && !fused->bnx && !g.c_nscale) :
                              (fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
                             "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
     const int bk = fast ? FBK : BK;

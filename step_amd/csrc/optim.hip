@@ -97,15 +97,16 @@ extern "C" int step_adam_clip_sharded(float* params, const float* grads, float* 
 // step_loss (reference step/step_loss/step_loss.py:5-16 + basicts/metrics/mae.py:5-28), forward value and both
 // gradients in two launches:  loss = sum(|p - y| m) / sum(m) + coef * mean(BCE(theta, prior)),  m = |y - null| > 5e-5.
 namespace {
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1,
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1, long rs,
+                                                          float scale, float shift,
                                                           const float* __restrict__ theta, const float* __restrict__ prior, long n2,
                                                           float null_val, double* __restrict__ acc /*[3]*/) {
     __shared__ double red[4][3];
     double s_abs = 0.0, s_cnt = 0.0, s_bce = 0.0;
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
-        const float y = real[i];
-        if (fabsf(y - null_val) > 5e-5f) { s_abs += fabsf(pred[i] - y); s_cnt += 1.0; }
+        const float y = real[i * rs] * scale + shift;
+        if (fabsf(y - null_val) > 5e-5f) { s_abs += fabsf((pred[i] * scale + shift) - y); s_cnt += 1.0; }
     }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
         const float t = theta[i], y = prior[i];
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x < 3) atomicAdd(&acc[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1,
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ pred, const float* __restrict__ real, long n1, long rs,
+                                                          float scale, float shift,
                                                           const float* __restrict__ theta, const float* __restrict__ prior, long n2,
                                                           float null_val, float coef, const double* __restrict__ acc,
                                                           float* __restrict__ loss, float* __restrict__ dpred, float* __restrict__ dtheta) {
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
         *loss = (cnt > 0.0 ? (float)(acc[0] / cnt) : 0.f) + coef * (float)(acc[2] / (double)n2);
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
-        const float y = real[i], d = pred[i] - y;
-        const float m = fabsf(y - null_val) > 5e-5f ? inv_cnt : 0.f;
+        const float y = real[i * rs] * scale + shift, d = (pred[i] * scale + shift) - y;
+        const float m = fabsf(y - null_val) > 5e-5f ? inv_cnt * scale : 0.f;      // d/d pred of the loss on pred * scale + shift
         dpred[i] = d > 0.f ? m : (d < 0.f ? -m : 0.f);
     }
     const float sc = coef / (float)n2;
@@ -140,20 +142,44 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
         dtheta[i] = sc * (t - y) / fmaxf(t * (1.f - t), 1e-12f);
     }
 }
+__global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb,
+                                                     const float* __restrict__ g, float* __restrict__ oa, float* __restrict__ ob) {
+    const float s = *g;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) oa[i] = a[i] * s;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) ob[i] = b[i] * s;
+}
 }  // namespace
 
-extern "C" int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const float* theta, const float* prior, long n_adj,
-                                 float null_val, float coef, double* work /*3 doubles*/, float* loss, float* dpred, float* dtheta,
-                                 void* stream) {
-    STEP_REQUIRE(pred && real && theta && prior && work && loss && dpred && dtheta && n_pred > 0 && n_adj > 0, "step_loss: bad arguments");
+extern "C" int step_loss_scaled_fwd_bwd(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
+                                        const float* theta, const float* prior, long n_adj, float null_val, float coef,
+                                        double* work /*3 doubles*/, float* loss, float* dpred, float* dtheta, void* stream) {
+    STEP_REQUIRE(pred && real && theta && prior && work && loss && dpred && dtheta && n_pred > 0 && n_adj > 0 && real_stride >= 1,
+                 "step_loss: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(work, 0, 3 * sizeof(double), st) != hipSuccess) { step_set_error("step_loss: memset failed"); return STEP_ERR_HIP; }
     long nmax = n_pred > n_adj ? n_pred : n_adj;
     int blocks = (int)((nmax + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    loss_reduce_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, theta, prior, n_adj, null_val, work);
+    loss_reduce_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, work);
     STEP_LAUNCH_CHECK("loss_reduce");
-    loss_finish_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, theta, prior, n_adj, null_val, coef, work, loss, dpred, dtheta);
+    loss_finish_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, coef, work, loss,
+                                               dpred, dtheta);
     STEP_LAUNCH_CHECK("loss_finish");
+    return STEP_OK;
+}
+extern "C" int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const float* theta, const float* prior, long n_adj,
+                                 float null_val, float coef, double* work /*3 doubles*/, float* loss, float* dpred, float* dtheta,
+                                 void* stream) {
+    return step_loss_scaled_fwd_bwd(pred, real, n_pred, 1, 1.f, 0.f, theta, prior, n_adj, null_val, coef, work, loss, dpred, dtheta, stream);
+}
+// out_a = a * *g, out_b = b * *g (g a device scalar): both gradients of step_loss times the incoming gradient of the loss, one launch
+extern "C" int step_scale2(const float* a, long na, const float* b, long nb, const float* g, float* out_a, float* out_b, void* stream) {
+    STEP_REQUIRE(a && b && g && out_a && out_b && na > 0 && nb > 0, "step_scale2: bad arguments");
+    long nmax = na > nb ? na : nb;
+    int blocks = (int)((nmax + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    scale2_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a, na, b, nb, g, out_a, out_b);
+    STEP_LAUNCH_CHECK("scale2");
     return STEP_OK;
 }

@@ -433,9 +433,10 @@ __device__ __forceinline__ void ma_keep16(uint32_t lo, uint32_t hi, uint32_t sit
 }
 __device__ __forceinline__ int ma_key(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }     // accumulator register -> row of the tile
 
-// Global <-> LDS traffic of both kernels moves 16 bytes per lane: a fill item is (token t, 4 head dimensions), 8 items per token
-// (6 real + 2 padding), so the 24 values of a (token, head) are six float4 of one 96-byte run, and results leave through an f32
-// staging tile [Tp][MA_SP] as float4 pieces of those runs.  (With one 4-byte access per lane the loads were 30 % and the stores 30 %
+// Activations in HBM are bf16 (qkv [S][T][288], out / d out [S][T][96], d qkv [S][T][288]: the GEMM epilogues write them and the
+// GEMM loaders read them in that type -- the rounding is the one the matrix-core operands get anyway).  Global <-> LDS traffic moves
+// 16 bytes per lane: a fill item is (token t, 8 head dimensions), 4 items per token (3 real + 1 padding) = three uint4 of one 48-byte
+// run, copied to LDS as they are; results leave through an f32 staging tile [Tp][MA_SP] and are packed to uint4 pieces of those runs.  (With one 4-byte access per lane the loads were 30 % and the stores 30 %
 // (forward) / 65 % (backward) of the kernel time: profiles/r03_l_pretrain_attention_ablations.log.)
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); this hands XCD x a CONTIGUOUS range of (sequence, head)
 // units, so the four heads of a sequence -- which share every 128-byte line of the sequence's qkv / out / dqkv rows -- run
@@ -452,40 +453,48 @@ __device__ __forceinline__ void ma_stage_rows(float* stage, int q, int h, const 
         if (d < DH) stage[q * MA_SP + d] = v[e] * scale;
     }
 }
-// rows [0, T) of the staging tile -> dst[t * ld + (0..23)], float4 pieces
-__device__ __forceinline__ void ma_store_rows(const float* stage, int T, float* __restrict__ dst, long ld, int tid, int nthreads) {
+// rows [0, T) of the staging tile -> dst[t * ld + (0..23)] as bf16, uint4 pieces (8 values)
+__device__ __forceinline__ uint4 ma_pack8(const float* v) {
+    const float4 a = *(const float4*)v, b = *(const float4*)(v + 4);
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+__device__ __forceinline__ void ma_store_rows(const float* stage, int T, uint16_t* __restrict__ dst, long ld, int tid, int nthreads) {
     if (MA_ABLATE & 4) return;
-    for (int e = tid; e < T * 6; e += nthreads) {
-        const int t = e / 6, d4 = e - 6 * t;
-        *(float4*)(dst + (long)t * ld + d4 * 4) = *(const float4*)(stage + t * MA_SP + d4 * 4);
+    for (int e = tid; e < T * 3; e += nthreads) {
+        const int t = e / 3, d8 = e - 3 * t;
+        *(uint4*)(dst + (long)t * ld + d8 * 8) = ma_pack8(stage + t * MA_SP + d8 * 8);
     }
+}
+__device__ __forceinline__ uint16_t ma_half(const uint4& v, int c) {      // element c (0..7) of 8 packed bf16
+    const uint32_t w = c < 2 ? v.x : (c < 4 ? v.y : (c < 6 ? v.z : v.w));
+    return (uint16_t)(w >> (16 * (c & 1)));
 }
 
 // forward: out [S][T][96], stats [S][H][T][2] = (row max, row sum) like attn_kernel
-__global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
-                                                            uint32_t site, float* __restrict__ out, float* __restrict__ stats,
+__global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
+                                                            uint32_t site, uint16_t* __restrict__ out, float* __restrict__ stats,
                                                             uint32_t* __restrict__ keepbits) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp);
-    uint16_t* Qs = ml;                       // [Tp][MA_RP]  q * scale
+    uint16_t* Qs = ml;                       // [Tp][MA_RP]  q (the 1/sqrt(24) of the scores is applied to the f32 products)
     uint16_t* Ks = Qs + Tp * MA_RP;          // [Tp][MA_RP]
     uint16_t* VT = Ks + Tp * MA_RP;          // [32][TPt]
     const unsigned unit = ma_unit(blockIdx.x, gridDim.x);
     const long s = unit / H;
     const int hd = unit % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
     const float scale = 0.20412414523193154f;
-    const float* base = qkv + s * (long)T * 288 + hd * DH;
-    for (int e = tid; e < Tp * 8; e += blockDim.x) {
-        const int t = e >> 3, d4 = e & 7;
-        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4;
-        if (t < T && d4 < 6 && !(MA_ABLATE & 2)) {
-            const float* r = base + (long)t * 288 + d4 * 4;
-            q4 = *(const float4*)r; k4 = *(const float4*)(r + 96); v4 = *(const float4*)(r + 192);
+    const uint16_t* base = qkv + s * (long)T * 288 + hd * DH;
+    for (int e = tid; e < Tp * 4; e += blockDim.x) {             // (token, 8 head dimensions): q | k rows copied as they are, v transposed
+        const int t = e >> 2, d8 = e & 3;
+        uint4 q8 = make_uint4(0u, 0u, 0u, 0u), k8 = q8, v8 = q8;
+        if (t < T && d8 < 3 && !(MA_ABLATE & 2)) {
+            const uint16_t* r = base + (long)t * 288 + d8 * 8;
+            q8 = *(const uint4*)r; k8 = *(const uint4*)(r + 96); v8 = *(const uint4*)(r + 192);
         }
-        *(uint2*)(Qs + t * MA_RP + d4 * 4) = make_uint2(pack_bf16x2(q4.x * scale, q4.y * scale), pack_bf16x2(q4.z * scale, q4.w * scale));
-        *(uint2*)(Ks + t * MA_RP + d4 * 4) = make_uint2(pack_bf16x2(k4.x, k4.y), pack_bf16x2(k4.z, k4.w));
-        VT[(d4 * 4 + 0) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.x); VT[(d4 * 4 + 1) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.y);
-        VT[(d4 * 4 + 2) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.z); VT[(d4 * 4 + 3) * TPt + t] = (uint16_t)f32_to_bf16_bits(v4.w);
+        *(uint4*)(Qs + t * MA_RP + d8 * 8) = q8;
+        *(uint4*)(Ks + t * MA_RP + d8 * 8) = k8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) VT[(d8 * 8 + c) * TPt + t] = ma_half(v8, c);
     }
     __syncthreads();
     const int q = wave * 32 + col, nkt = Tp / 32;
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
         scores(kt, acc);
         float pv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { pv[e] = __expf(acc[e] - mx); l += pv[e]; }
+        for (int e = 0; e < 16; ++e) { pv[e] = __expf((acc[e] - mx) * scale); l += pv[e]; }
         if (p > 0.f) {
             uint32_t word = 0u;
             if (q < T) {
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const float* __restr
             o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma_tr8(VT + col * TPt, kt * 32 + 16 * st, h), ma_pack(pv + 8 * st), o, 0, 0, 0);
     }
     l += __shfl_xor(l, 32, 64);
-    if (q < T && h == 0) { stats[(srow + q) * 2] = mx; stats[(srow + q) * 2 + 1] = l; }
+    if (q < T && h == 0) { stats[(srow + q) * 2] = mx * scale; stats[(srow + q) * 2 + 1] = l; }
     // the output tile leaves through LDS (the operand arrays are dead) as float4 pieces of each token's 96-byte run
     __syncthreads();
     float* stage = (float*)ml;
@@ -560,17 +569,17 @@ __device__ __forceinline__ bf16x8 mb_row8(const uint16_t* arr, int row, int st, 
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     return __builtin_bit_cast(bf16x8, off < DH ? v : z);
 }
-__global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                            const float* __restrict__ dout, const float* __restrict__ stats, int T, int Tp,
-                                                            float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ dqkv,
+__global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ dout, const float* __restrict__ stats, int T, int Tp,
+                                                            float p, uint32_t lo, uint32_t hi, uint32_t site, uint16_t* __restrict__ dqkv,
                                                             const uint32_t* __restrict__ keepbits) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp), nt = Tp / 32;
-    uint16_t* Qs = ml;                        // row-major [Tp][MB_RP]: q*scale, k, v, dO
+    uint16_t* Qs = ml;                        // row-major [Tp][MB_RP]: q, k, v, dO
     uint16_t* Ks = Qs + Tp * MB_RP;
     uint16_t* Vs = Ks + Tp * MB_RP;
     uint16_t* Os = Vs + Tp * MB_RP;
-    uint16_t* QT = Os + Tp * MB_RP;           // transposed [DH][TPt]: q*scale, k, dO
+    uint16_t* QT = Os + Tp * MB_RP;           // transposed [DH][TPt]: q, k, dO
     uint16_t* KT = QT + DH * TPt;
     uint16_t* OT = KT + DH * TPt;
     uint16_t* ZT = OT + DH * TPt;             // [TPt] zeros: the padded head dimensions 24 .. 31 of all three
@@ -582,58 +591,52 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
     const long s = unit / H;
     const int hd = unit % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
     const float scale = 0.20412414523193154f;
-    const float* base = qkv + s * (long)T * 288;
+    const uint16_t* base = qkv + s * (long)T * 288 + hd * DH;
     const long srow = (s * H + hd) * (long)T;
-    // fill: item = (token, 4 head dimensions), 8 lanes per token, float4 loads; blockDim = 2 Tp, so every thread owns exactly four
-    // items -- all twenty loads are issued before the first is consumed
-    float4 q4[4], k4[4], v4[4], g4[4], o4[4];
+    // fill: item = (token, 8 head dimensions), 4 lanes per token, uint4 loads; blockDim = 2 Tp, so every thread owns exactly two
+    // items -- all ten loads are issued before the first is consumed
+    uint4 q8[2], k8[2], v8[2], g8[2], o8[2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = tid + it * blockDim.x, t = e >> 3, d4 = e & 7;
-        q4[it] = make_float4(0.f, 0.f, 0.f, 0.f); k4[it] = q4[it]; v4[it] = q4[it]; g4[it] = q4[it]; o4[it] = q4[it];
-        if (t < T && d4 < 6 && !(MA_ABLATE & 2)) {
-            const float* r = base + (long)t * 288 + hd * DH + d4 * 4;
-            const long oi = (s * T + t) * D + hd * DH + d4 * 4;
-            q4[it] = *(const float4*)r; k4[it] = *(const float4*)(r + 96); v4[it] = *(const float4*)(r + 192);
-            g4[it] = *(const float4*)(dout + oi); o4[it] = *(const float4*)(out + oi);
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + it * blockDim.x, t = e >> 2, d8 = e & 3;
+        q8[it] = make_uint4(0u, 0u, 0u, 0u); k8[it] = q8[it]; v8[it] = q8[it]; g8[it] = q8[it]; o8[it] = q8[it];
+        if (t < T && d8 < 3 && !(MA_ABLATE & 2)) {
+            const uint16_t* r = base + (long)t * 288 + d8 * 8;
+            const long oi = (s * T + t) * D + hd * DH + d8 * 8;
+            q8[it] = *(const uint4*)r; k8[it] = *(const uint4*)(r + 96); v8[it] = *(const uint4*)(r + 192);
+            g8[it] = *(const uint4*)(dout + oi); o8[it] = *(const uint4*)(out + oi);
         }
     }
     if (keepbits && p > 0.f)                 // the forward's keep decisions of this (sequence, head): one contiguous run of T nt words
         for (int i = tid; i < Tp * nt; i += blockDim.x) bits[i] = i < T * nt ? keepbits[srow * nt + i] : 0u;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = tid + it * blockDim.x, t = e >> 3, d4 = e & 7;
-        float dl = g4[it].x * o4[it].x + g4[it].y * o4[it].y + g4[it].z * o4[it].z + g4[it].w * o4[it].w;
-        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);     // delta_t = sum_d dO O (8 adjacent lanes)
-        if (d4 == 0) sdl[t] = dl;
-        if (d4 < 6) {
-            const float qv[4] = {q4[it].x * scale, q4[it].y * scale, q4[it].z * scale, q4[it].w * scale};
-            const float kv[4] = {k4[it].x, k4[it].y, k4[it].z, k4[it].w}, vv[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w};
-            const float gv[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w};
-            uint16_t qb[4], kb[4], vb[4], gb[4];
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + it * blockDim.x, t = e >> 2, d8 = e & 3;
+        const uint32_t gw[4] = {g8[it].x, g8[it].y, g8[it].z, g8[it].w}, ow[4] = {o8[it].x, o8[it].y, o8[it].z, o8[it].w};
+        float dl = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                qb[c] = (uint16_t)f32_to_bf16_bits(qv[c]); kb[c] = (uint16_t)f32_to_bf16_bits(kv[c]);
-                vb[c] = (uint16_t)f32_to_bf16_bits(vv[c]); gb[c] = (uint16_t)f32_to_bf16_bits(gv[c]);
-                const int d = d4 * 4 + c;
-                QT[d * TPt + t] = qb[c]; KT[d * TPt + t] = kb[c]; OT[d * TPt + t] = gb[c];
+        for (int j = 0; j < 4; ++j)
+            dl += __uint_as_float(gw[j] << 16) * __uint_as_float(ow[j] << 16) + __uint_as_float(gw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64);                    // delta_t = sum_d dO O (4 adjacent lanes)
+        if (d8 == 0) sdl[t] = dl;
+        if (d8 < 3) {
+            const int ro = t * MB_RP + d8 * 8;
+            *(uint4*)(Qs + ro) = q8[it]; *(uint4*)(Ks + ro) = k8[it]; *(uint4*)(Vs + ro) = v8[it]; *(uint4*)(Os + ro) = g8[it];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int d = d8 * 8 + c;
+                QT[d * TPt + t] = ma_half(q8[it], c); KT[d * TPt + t] = ma_half(k8[it], c); OT[d * TPt + t] = ma_half(g8[it], c);
             }
-            const int ro = t * MB_RP + d4 * 4;
-            *(uint2*)(Qs + ro) = make_uint2(qb[0] | ((uint32_t)qb[1] << 16), qb[2] | ((uint32_t)qb[3] << 16));
-            *(uint2*)(Ks + ro) = make_uint2(kb[0] | ((uint32_t)kb[1] << 16), kb[2] | ((uint32_t)kb[3] << 16));
-            *(uint2*)(Vs + ro) = make_uint2(vb[0] | ((uint32_t)vb[1] << 16), vb[2] | ((uint32_t)vb[3] << 16));
-            *(uint2*)(Os + ro) = make_uint2(gb[0] | ((uint32_t)gb[1] << 16), gb[2] | ((uint32_t)gb[3] << 16));
         }
     }
     for (int i = tid; i < TPt; i += blockDim.x) ZT[i] = 0;
     for (int i = tid; i < Tp; i += blockDim.x) {
         float2 st2 = make_float2(0.f, 1.f);
         if (i < T) st2 = *(const float2*)(stats + (srow + i) * 2);
-        smx[i] = i < T ? st2.x : 0.f; sinv[i] = i < T ? 1.f / st2.y : 0.f;
+        smx[i] = i < T ? st2.x * (1.f / scale) : 0.f; sinv[i] = i < T ? 1.f / st2.y : 0.f;       // row max in the unscaled-score domain
     }
     __syncthreads();
     const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    float* db = dqkv + s * (long)T * 288;
     f32x16 dq_keep;
     {   // ---- phase A: this wave's 32 queries against every key tile (keys in registers, query = lane)
         const int q = wave * 32 + col;
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const bool kok = kt * 32 + ma_key(e, h) < T;
-                const float pij = kok ? __expf(sc[e] - mq) * iq : 0.f;
+                const float pij = kok ? __expf((sc[e] - mq) * scale) * iq : 0.f;
                 ds[e] = pij * (dp[e] * mk[e] - dq_);
             }
 #pragma unroll
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
             for (int e = 0; e < 16; ++e) {
                 const int qi = qt * 32 + ma_key(e, h);
                 const float mkv = (bits[qi * nt + wave] >> col) & 1u ? ks : 0.f;
-                const float pij = kj < T ? __expf(sc[e] - smx[qi]) * sinv[qi] : 0.f;      // rows qi >= T: sinv = 0
+                const float pij = kj < T ? __expf((sc[e] - smx[qi]) * scale) * sinv[qi] : 0.f;      // rows qi >= T: sinv = 0
                 pm[e] = pij * mkv;
                 ds[e] = pij * (dp[e] * mkv - sdl[qi]);
             }
@@ -721,14 +724,16 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const float* __restr
         __syncthreads();
         float* stage = (float*)ml;
         ma_stage_rows(stage, 3 * kj, h, dq_keep, scale);
-        ma_stage_rows(stage + MA_SP, 3 * kj, h, dka, 1.f);
+        ma_stage_rows(stage + MA_SP, 3 * kj, h, dka, scale);
         ma_stage_rows(stage + 2 * MA_SP, 3 * kj, h, dva, 1.f);
         __syncthreads();
-        if (!(MA_ABLATE & 4))
-            for (int e = tid; e < T * 18; e += blockDim.x) {
-                const int t = e / 18, r = e - 18 * t, sec = r / 6, d4 = r - 6 * sec;
-                *(float4*)(db + (long)t * 288 + sec * 96 + hd * DH + d4 * 4) = *(const float4*)(stage + (3 * t + sec) * MA_SP + d4 * 4);
+        if (!(MA_ABLATE & 4)) {
+            uint16_t* db = dqkv + s * (long)T * 288 + hd * DH;
+            for (int e = tid; e < T * 9; e += blockDim.x) {
+                const int t = e / 9, r = e - 9 * t, sec = r / 3, d8 = r - 3 * sec;
+                *(uint4*)(db + (long)t * 288 + sec * 96 + d8 * 8) = ma_pack8(stage + (3 * t + sec) * MA_SP + d8 * 8);
             }
+        }
     }
 }
 
@@ -907,9 +912,10 @@ static size_t ma_fwd_lds(int Tp) {      // operands, re-used by the f32 staging 
     return ops > stage ? ops : stage;
 }
 static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MB_RP + (3 * DH + 1) * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
-extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
+extern "C" int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats,
                                           uint32_t* keepbits, void* stream) {
-    STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f, "pt_attention_fwd_bf16: bad arguments (T=%d)", T);
+    STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 352 && p >= 0.f && p < 1.f && ((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0,
+                 "pt_attention_fwd_bf16: bad arguments (T=%d; at most 352 tokens, 16-byte aligned bf16 tensors)", T);
     const int Tp = (T + 31) & ~31;
     if (hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         step_set_error("pt_attention_fwd_bf16: cannot raise the dynamic LDS limit");
@@ -920,13 +926,13 @@ extern "C" int step_pt_attention_fwd_bf16(const float* qkv, long S, int T, float
     STEP_LAUNCH_CHECK("pt_attention_fwd_bf16");
     return STEP_OK;
 }
-extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, const float* dout, const float* stats, long S, int T, float p,
-                                          uint64_t seed, uint32_t site, float* dqkv, const uint32_t* keepbits, void* stream) {
-    STEP_REQUIRE(qkv && out && dout && stats && dqkv && S > 0 && T > 0 && T <= 336 && p >= 0.f && p < 1.f,
-                 "pt_attention_bwd_bf16: bad arguments (T=%d)", T);
+extern "C" int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* stats, long S, int T, float p,
+                                          uint64_t seed, uint32_t site, uint16_t* dqkv, const uint32_t* keepbits, void* stream) {
+    STEP_REQUIRE(qkv && out && dout && stats && dqkv && S > 0 && T > 0 && T <= 352 && p >= 0.f && p < 1.f &&
+                 ((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0,
+                 "pt_attention_bwd_bf16: bad arguments (T=%d; at most 352 tokens, 16-byte aligned bf16 tensors)", T);
     const int Tp = (T + 31) & ~31;
-    if (ma_bwd_lds(Tp) > 160 * 1024)        // (T > 256: seven operand copies + keep bits no longer fit the LDS -- the f32 kernel takes over)
-        return step_pt_attention_bwd(qkv, out, dout, stats, S, T, p, seed, site, dqkv, stream);
+    STEP_REQUIRE(ma_bwd_lds(Tp) <= 160 * 1024, "pt_attention_bwd_bf16: %d tokens do not fit the LDS", T);
     if (hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         step_set_error("pt_attention_bwd_bf16: cannot raise the dynamic LDS limit");
         return STEP_ERR_HIP;
@@ -935,6 +941,19 @@ extern "C" int step_pt_attention_bwd_bf16(const float* qkv, const float* out, co
                                                                                                     SEED_HI(seed), site, dqkv, keepbits);
     STEP_LAUNCH_CHECK("pt_attention_bwd_bf16");
     return STEP_OK;
+}
+// Linear layer whose result is stored as bf16 (GEMM_FUSED_BF16OUT epilogue of the staged GEMM): out = x w + bias
+extern "C" int step_pt_linear_bf16out(const float* x, const float* w, long swk, long swn, const float* bias, long R, int N, int K, uint16_t* out,
+                                      void* stream) {
+    STEP_REQUIRE(x && w && out && R > 0 && R < (1L << 31) && N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0 && (swk == 1 || swn == 1),
+                 "pt_linear_bf16out: bad arguments");
+    StepGemm g = gemm_desc((int)R, N, K, x, K, 1, w, swk, swn, (float*)out, N);
+    g.compute_bf16 = 1;
+    GemmFused fu;
+    memset(&fu, 0, sizeof(fu));
+    fu.channels = 1; fu.period = N; fu.flags = GEMM_FUSED_BF16OUT;
+    fu.ffn_bias = bias;
+    return step_gemm_launch_fused(g, fu, (hipStream_t)stream);
 }
 // Feed-forward hidden layer with its ReLU and dropout in the GEMM epilogue, stored as bf16 (bf16 contraction mode):
 //   hidden[r][j] = dropout(relu(x[r,:] . w1[j,:] + b1[j]))       x [R,96], w1 [384,96], hidden bf16 [R,384]

@@ -18,7 +18,9 @@
 //        m * N + n -- the ReLU output and its dropped copy are never written in f32.
 //        GEMM_FUSED_MASKNZ -- its backward: C (bf16) = maskx[m][n] != 0 ? v / (1 - p) : 0 with maskx (bf16, laid out like C) the
 //        stored forward value: non-zero exactly where the ReLU was open and the element was kept.
-enum { GEMM_FUSED_INTERLEAVED = 1, GEMM_FUSED_FFN_FWD = 2, GEMM_FUSED_MASKNZ = 4 };
+//        GEMM_FUSED_BF16OUT -- C (bf16, ldc in bf16 elements) = v + ffn_bias[n] (ffn_bias nullable): a linear layer whose output is stored as
+//        the matrix-core operand type of its consumers (qkv and the attention-output gradient of the pre-training step).
+enum { GEMM_FUSED_INTERLEAVED = 1, GEMM_FUSED_FFN_FWD = 2, GEMM_FUSED_MASKNZ = 4, GEMM_FUSED_BF16OUT = 8 };
 struct GemmFused {
     const float* dotw; float* dots;
     const float* bnx; const float* bncoef; const float* bnstat;

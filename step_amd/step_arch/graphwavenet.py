@@ -70,7 +70,18 @@ class GraphWaveNet(nn.Module):
         self.receptive_field = 13
 
     # names of the tensors the native forward reads, in C-struct order
+    def _apply(self, fn, recurse=True):
+        self._nt_cache = None                # .to() / .float() replace the BatchNorm buffers by new tensors
+        return super()._apply(fn, recurse)
+
     def native_tensors(self):
+        """name -> tensor, in C-struct order.  The dict is built once (it is a walk over ~110 module attributes, 0.15 ms of host
+        time per call and two calls per step) and dropped whenever the module is converted (``_apply``); the pointers are read from
+        the tensors at every call of ``fill_gwnet_struct``, so in-place updates, ``load_state_dict`` and re-homing into the flat
+        parameter buffer need no invalidation."""
+        c = getattr(self, "_nt_cache", None)
+        if c is not None:
+            return c
         t = {"nodevec1": self.nodevec1, "nodevec2": self.nodevec2,
              "start_w": self.start_conv.weight, "start_b": self.start_conv.bias,
              "fc_his0_w": self.fc_his[0].weight, "fc_his0_b": self.fc_his[0].bias,
@@ -90,11 +101,15 @@ class GraphWaveNet(nn.Module):
             t[f"bn_rv.{i}"] = self.bn[i].running_var
             t[f"gconv_w.{i}"] = self.gconv[i].mlp.mlp.weight
             t[f"gconv_b.{i}"] = self.gconv[i].mlp.mlp.bias
+        self._nt_cache = t
         return t
 
     # parameters that receive a gradient (the reference leaves the others at grad=None:
     # residual_convs.*, gconv.7, bn.7 -- SURVEY.md section 5)
     def trainable_native(self):
+        c = getattr(self, "_tn_cache", None)
+        if c is not None and c[0] is getattr(self, "_nt_cache", None):
+            return c[1]
         t = self.native_tensors()
         keep = {}
         for k, v in t.items():
@@ -103,6 +118,7 @@ class GraphWaveNet(nn.Module):
             if k.split(".")[0] in ("gconv_w", "gconv_b", "bn_w", "bn_b") and k.endswith(".7"):
                 continue
             keep[k] = v
+        self._tn_cache = (t, keep)
         return keep
 
     def forward(self, input, hidden_states, sampled_adj):

@@ -94,6 +94,7 @@ def _empty(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+MC_ATTENTION_MAX_TOKENS = 352        # step_pt_attention_{fwd,bwd}_bf16: the backward's LDS footprint (include/step_hip.h)
 _BF16 = False        # operand precision of the pre-training GEMMs, set from TSFormer.matmul_precision by _PretrainFunction
 
 
@@ -176,14 +177,22 @@ class _PretrainFunction(torch.autograd.Function):
         L = _lib
         st = L.stream()
         R = S * T
-        qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
-        a = _empty(R, 96, like=x)
         stats = _empty(S * 4 * T, 2, like=x)
         kb = None
-        if _BF16:       # matrix-core attention; the keep decisions of the probability dropout are handed to the backward as bit masks
+        mc = _BF16 and T <= MC_ATTENTION_MAX_TOKENS
+        if mc:
+            # matrix-core attention with bf16 activations: qkv leaves its GEMM as bf16 (the type its only readers -- the attention
+            # kernels -- would round it to), the attention output likewise (read by the out-projection and its weight gradient as a
+            # matrix-core operand); the keep decisions of the probability dropout are handed to the backward as bit masks
+            qkv = torch.empty(R, 288, device=x.device, dtype=torch.bfloat16)
+            L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(P_[pre + "self_attn.in_proj_weight"]), 1, 96, L.ptr(P_[pre + "self_attn.in_proj_bias"]),
+                   R, 288, 96, L.ptr(qkv), st)
+            a = torch.empty(R, 96, device=x.device, dtype=torch.bfloat16)
             kb = torch.empty(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device=x.device) if p > 0 else None
             L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), L.ptr(kb), st)
         else:
+            qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
+            a = _empty(R, 96, like=x)
             L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
         o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
         # residual add (+ dropout of the branch) and LayerNorm in one pass
@@ -250,16 +259,28 @@ class _PretrainFunction(torch.autograd.Function):
                L.ptr(do), p, seed, site + 1, L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)
         if do is None:
             do = dh1pre
+        dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
+        if sv["qkv"].dtype == torch.bfloat16:
+            # bf16 activations (see _layer_fwd): the gradients that are only read as matrix-core operands are stored as bf16 too
+            wo, wi = P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.in_proj_weight"]
+            # dWo[j, i] += sum_r do[r, j] a[r, i];  dbo += colsum(do)
+            _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True)
+            L.call("step_colsum", L.ptr(do), R, 96, 96, L.ptr(G[pre + "self_attn.out_proj.bias"]), st)
+            da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
+            L.call("step_pt_linear_bf16out", L.ptr(do), L.ptr(wo), 96, 1, None, R, 96, 96, L.ptr(da), st)          # da = do @ Wo
+            dqkv = torch.empty(R, 288, device=dh2.device, dtype=torch.bfloat16)
+            L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
+                   L.ptr(sv["keepbits"]), st)
+            # dWi[j, i] += sum_r dqkv[r, j] x[r, i], computed as its transpose (A = x with i contiguous, B = dqkv with j contiguous)
+            _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True)
+            L.call("step_pt_colsum_bf16", L.ptr(dqkv), R, 288, L.ptr(G[pre + "self_attn.in_proj_bias"]), st)
+            _lib.gemm(dqkv, wi, dx, R, 96, 288, 288, 1, 96, 1, 96, accumulate=1, compute_bf16=True)                   # dx += dqkv @ Wi
+            return dx
         da = _empty(R, 96, like=dh2)
         _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
                     G[pre + "self_attn.out_proj.bias"], da)
         dqkv = _empty(R, 288, like=dh2)
-        if _BF16:
-            L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
-                   L.ptr(sv["keepbits"]), st)
-        else:
-            L.call("step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
-        dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
+        L.call("step_pt_attention_bwd", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv), st)
         _linear_bwd(dqkv, sv["x"], P_[pre + "self_attn.in_proj_weight"], G[pre + "self_attn.in_proj_weight"],
                     G[pre + "self_attn.in_proj_bias"], dx, accumulate_dx=True)
         return dx
@@ -347,6 +368,7 @@ class TSFormer(nn.Module):
         self._seed_ctr2 = 0
         self._packed = None
         self._packed_key = None
+        self._plist = None
         # 16-bit operand type of the fused forecasting encoder: "f16" (default) or "bf16".  Same MFMA rate and kernel time; on
         # MI355X float16 fragments bring the hidden-state error vs the fp32 reference from 1.2-1.9e-2 (bf16) down to 2.2e-3 and
         # the prediction error from 7.5e-3 to 8e-4 (profiles/r01_x_encoder_f16_lcg_ab.log, tests/test_gpu_kernels.py).  float16
@@ -367,8 +389,15 @@ class TSFormer(nn.Module):
         self.fallback_counter = None # bench.py / tests: int32 cuda tensor [64] whose sum the kernel raises by its slow-path softmax units
 
     # ------------------------------------------------------------------ packed operand cache
+    def _apply(self, fn, recurse=True):
+        self._plist = None
+        return super()._apply(fn, recurse)
+
     def _pack_key(self, P):
-        return (P, self.encoder_operand, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        ps = self._plist                      # the Parameter objects of the tree, listed once (the walk costs 0.1 ms per step)
+        if ps is None:
+            ps = self._plist = list(self.parameters())
+        return (P, self.encoder_operand, tuple((p.data_ptr(), p._version) for p in ps))
 
     def packed_weights(self, P, device):
         key = self._pack_key(P)

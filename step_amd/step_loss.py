@@ -4,6 +4,8 @@ gsl_coefficient, null_val)``.  The reference runner calls it on RESCALED predict
 (``base_tsf_runner.py:240-250``); it is caller-side code, a handful of element-wise torch ops on
 ``[B,12,N,1]`` / ``[B,N,N]`` tensors whose autograd feeds ``dpred`` / ``dtheta`` into the native backward.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -20,34 +22,67 @@ def masked_mae(preds, labels, null_val=np.nan):
     return torch.mean(torch.nan_to_num(loss, nan=0.0))
 
 
+def _flat_stride(x):
+    """element stride s such that the logical elements of x, in C order, sit at x.data_ptr() + 4 * s * i (x contiguous: 1; one
+    feature of a contiguous [..., C] tensor, ``y[..., :1]``: C); None when x has no such stride."""
+    if x.is_contiguous():
+        return 1
+    if x.dim() < 2 or x.shape[-1] != 1:
+        return None
+    s = x.stride(-2)
+    exp = s
+    for d in range(x.dim() - 2, -1, -1):
+        if x.shape[d] != 1 and x.stride(d) != exp:
+            return None
+        exp *= x.shape[d]
+    return s
+
+
 class _NativeStepLoss(torch.autograd.Function):
-    """Loss value + both gradients from two HIP launches (libstep_hip step_loss_fwd_bwd)."""
+    """Loss value + both gradients from two HIP launches (libstep_hip step_loss_scaled_fwd_bwd); the backward multiplies both by the
+    incoming gradient in one more."""
 
     @staticmethod
-    def forward(ctx, prediction, real_value, theta, priori_adj, coef, null_val):
+    def forward(ctx, prediction, real_value, theta, priori_adj, coef, null_val, scale, shift):
         from . import _lib
         p = prediction.contiguous().float()
-        r = real_value.contiguous().float()
+        r = real_value.float()
+        rs = _flat_stride(r)
+        if rs is None:
+            r, rs = r.contiguous(), 1
         t = theta.contiguous().float()
         a = priori_adj.contiguous().float()
         loss = torch.empty((), device=p.device, dtype=torch.float32)
         dp, dt = torch.empty_like(p), torch.empty_like(t)
         work = torch.empty(3, device=p.device, dtype=torch.float64)
-        _lib.call("step_loss_fwd_bwd", _lib.ptr(p), _lib.ptr(r), p.numel(), _lib.ptr(t), _lib.ptr(a), t.numel(), float(null_val),
-                  float(coef), _lib.ptr(work), _lib.ptr(loss), _lib.ptr(dp), _lib.ptr(dt), _lib.stream())
+        assert r.is_cuda and r.dtype == torch.float32
+        _lib.call("step_loss_scaled_fwd_bwd", _lib.ptr(p), ctypes.c_void_p(r.data_ptr()), p.numel(), rs, float(scale), float(shift), _lib.ptr(t), _lib.ptr(a),
+                  t.numel(), float(null_val), float(coef), _lib.ptr(work), _lib.ptr(loss), _lib.ptr(dp), _lib.ptr(dt), _lib.stream())
         ctx.save_for_backward(dp, dt)
         ctx.shapes = (prediction.shape, theta.shape)
         return loss
 
     @staticmethod
     def backward(ctx, g):
+        from . import _lib
         dp, dt = ctx.saved_tensors
-        return (dp * g).view(ctx.shapes[0]), None, (dt * g).view(ctx.shapes[1]), None, None, None
+        if g.is_cuda and g.dtype == torch.float32 and g.numel() == 1:
+            op, ot = torch.empty_like(dp), torch.empty_like(dt)
+            _lib.call("step_scale2", _lib.ptr(dp), dp.numel(), _lib.ptr(dt), dt.numel(), _lib.ptr(g.contiguous()), _lib.ptr(op), _lib.ptr(ot),
+                      _lib.stream())
+        else:
+            op, ot = dp * g, dt * g
+        return op.view(ctx.shapes[0]), None, ot.view(ctx.shapes[1]), None, None, None, None, None
 
 
-def step_loss_native(prediction, real_value, theta, priori_adj, gsl_coefficient, null_val=0.0):
-    """Same signature and value as ``step_loss`` (finite ``null_val``), computed by libstep_hip."""
-    return _NativeStepLoss.apply(prediction, real_value, theta, priori_adj, gsl_coefficient, null_val)
+def step_loss_native(prediction, real_value, theta, priori_adj, gsl_coefficient, null_val=0.0, rescale=None):
+    """Same signature and value as ``step_loss`` (finite ``null_val``), computed by libstep_hip.
+    ``rescale=(mean, std)``: ``prediction`` / ``real_value`` are the NORMALISED tensors and the loss is taken on ``x * std + mean`` --
+    the runner's inverse scaling (base_tsf_runner.py:240-250, step_runner.py:86-92) done inside the loss kernels instead of four
+    element-wise launches before them and their autograd nodes after; ``real_value`` may be one feature of the batch tensor
+    (``future[..., :1]``), it is read in place."""
+    mean, std = (0.0, 1.0) if rescale is None else rescale
+    return _NativeStepLoss.apply(prediction, real_value, theta, priori_adj, gsl_coefficient, null_val, std, mean)
 
 
 def step_loss(prediction, real_value, theta, priori_adj, gsl_coefficient, null_val=np.nan):

@@ -108,30 +108,33 @@ def test_pretrain_bf16_mode_close_to_f32_mode():
 
 @pytest.mark.parametrize("T,p", [(42, 0.1), (168, 0.1), (40, 0.0), (77, 0.25), (336, 0.1)])
 def test_matrix_core_attention_matches_f32_attention(T, p):
-    """step_pt_attention_{fwd,bwd}_bf16 (bf16 operands on the matrix cores, what the pre-training module uses in bf16 mode) against
-    the exact-f32 kernels: same row statistics, same dropout stream (identical keep masks for identical seed / site), outputs and
-    gradients within bf16 operand rounding.  T = 336 exercises the backward's fall-back (LDS), T = 77 an unaligned mask stream."""
+    """step_pt_attention_{fwd,bwd}_bf16 (bf16 activations in HBM, bf16 operands on the matrix cores: what the pre-training module uses
+    in bf16 mode) against the exact-f32 kernels on the same (bf16-representable) inputs: same row statistics, same dropout stream
+    (identical keep masks for identical seed / site), outputs and gradients within bf16 operand / storage rounding.  T = 336 is the
+    largest token count of the reference's configs (the backward's LDS footprint), T = 77 an unaligned mask stream."""
     from step_amd import _lib as L
     S = 6
     gen = torch.Generator().manual_seed(T)
-    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).cuda()
-    dout = torch.randn(S, T, 96, generator=gen).cuda()
+    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).bfloat16().cuda()
+    dout = torch.randn(S, T, 96, generator=gen).bfloat16().cuda()
     seed, site = 0x1234_5678_9ABC, 7
     st = L.stream()
     res = {}
     for tag in ("", "_bf16"):
-        out = torch.empty(S, T, 96, device="cuda")
+        dt = torch.bfloat16 if tag else torch.float32
+        qkv_t, dout_t = qkv.to(dt), dout.to(dt)
+        out = torch.empty(S, T, 96, device="cuda", dtype=dt)
         stats = torch.empty(S * 4 * T, 2, device="cuda")
-        dqkv = torch.zeros(S, T, 288, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda", dtype=dt)
         if tag:
             kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda") if T != 77 else None      # (T = 77: the backward regenerates the masks)
-            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
-            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
+            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
         else:
-            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
-            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
+            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
+            L.call("step_pt_attention_bwd" + tag, L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
         torch.cuda.synchronize()
-        res[tag] = (out.cpu(), stats.cpu(), dqkv.cpu())
+        res[tag] = (out.float().cpu(), stats.cpu(), dqkv.float().cpu())
     (o0, s0, g0), (o1, s1, g1) = res[""], res["_bf16"]
     e_out, e_g = rel_l2(o1, o0), rel_l2(g1, g0)
     e_m = float((s1[:, 0] - s0[:, 0]).abs().max())
@@ -150,29 +153,31 @@ def test_attention_kernels_match_fp64_reference_with_their_own_masks(T):
     F.multi_head_attention_forward: softmax(q k^T / sqrt(24)), dropout on the probabilities, times v) at the token counts of
     config C3's encoder (42), decoder (168) and of the PEMS04 checkpoint recipe (336).  The dropout realisation is the device's:
     the matrix-core forward hands its keep decisions out as bit masks (one word per (query, key tile)), the f32 kernels draw
-    the same Philox stream; the oracle replays those bits.  f32 kernels: 2e-5; bf16 operands: 1.5e-2 (output) / 2.5e-2 (dqkv)."""
+    the same Philox stream; the oracle replays those bits.  f32 kernels: 2e-5; bf16 activations / operands: 1.5e-2 (output) / 2.5e-2 (dqkv)."""
     from step_amd import _lib as L
     S, p = 5, 0.1
     gen = torch.Generator().manual_seed(100 + T)
-    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).cuda()
-    dout = torch.randn(S, T, 96, generator=gen).cuda()
+    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).bfloat16().float().cuda()          # bf16-representable: both paths and the
+    dout = torch.randn(S, T, 96, generator=gen).bfloat16().float().cuda()                  # oracle see the same numbers
     seed, site = 0x0BAD_5EED_1234, 16
     st = L.stream()
     nkt = (T + 31) // 32
     res = {}
     kb = torch.zeros(S * 4 * T * nkt, dtype=torch.int32, device="cuda")
     for tag in ("_bf16", ""):
-        out = torch.empty(S, T, 96, device="cuda")
+        dt = torch.bfloat16 if tag else torch.float32
+        qkv_t, dout_t = qkv.to(dt), dout.to(dt)
+        out = torch.empty(S, T, 96, device="cuda", dtype=dt)
         stats = torch.empty(S * 4 * T, 2, device="cuda")
-        dqkv = torch.zeros(S, T, 288, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda", dtype=dt)
         if tag:
-            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
-            L.call("step_pt_attention_bwd_bf16", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
+            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_bwd_bf16", L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
         else:
-            L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
-            L.call("step_pt_attention_bwd", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
+            L.call("step_pt_attention_fwd", L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
+            L.call("step_pt_attention_bwd", L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), st)
         torch.cuda.synchronize()
-        res[tag] = (out.cpu().double(), dqkv.cpu().double())
+        res[tag] = (out.float().cpu().double(), dqkv.float().cpu().double())
     words = kb.cpu().numpy().view(np.uint32).reshape(S, 4, T, nkt)
     bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(S, 4, T, nkt * 32)[..., :T]
     keep = torch.from_numpy(bits.astype(np.float64))
@@ -319,3 +324,32 @@ def test_fused_layernorm_kernels_match_unfused(p):
     errs["plain"] = rel_l2(y2.cpu().double(), want2.cpu())
     print(f"fused LayerNorm kernels p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 2e-6
+
+
+@pytest.mark.parametrize("R", [4099, 130_000])
+def test_linear_with_bf16_output(R):
+    """step_pt_linear_bf16out (the qkv projection and the attention-output gradient of the bf16 pre-training step: a linear layer
+    whose result is stored as bf16) against float32 matmul of the bf16-rounded operands, rounded to bf16: both weight layouts
+    (a Linear weight [N, K]; its transpose use, the data gradient), with and without bias, N = 288 and 96 (a partial 128-wide tile).
+    The products are exact in f32 (8-bit x 8-bit mantissas), so only the summation order and the final rounding differ: at most one
+    bf16 ulp on a few elements."""
+    from step_amd import _lib as L
+    gen = torch.Generator().manual_seed(R)
+    st = L.stream()
+    for N, K, transposed, with_bias in ((288, 96, False, True), (96, 96, True, False), (96, 288, True, True)):
+        x = torch.randn(R, K, generator=gen).cuda()
+        w = (torch.randn(K, N, generator=gen) if transposed else torch.randn(N, K, generator=gen)).cuda() * 0.2
+        b = torch.randn(N, generator=gen).cuda() if with_bias else None
+        out = torch.empty(R, N, device="cuda", dtype=torch.bfloat16)
+        swk, swn = (N, 1) if transposed else (1, K)
+        L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(w), swk, swn, L.ptr(b) if b is not None else None, R, N, K, L.ptr(out), st)
+        torch.cuda.synchronize()
+        xr, wr = x.bfloat16().float(), w.bfloat16().float()
+        want = xr @ (wr if transposed else wr.t())
+        if b is not None:
+            want = want + b
+        got = out.float()
+        err = (got - want).abs() / want.abs().clamp_min(1e-2)
+        frac_off = float((got != want.bfloat16().float()).float().mean())
+        print(f"linear_bf16out R={R} N={N} K={K} transposed={transposed}: max rel err {float(err.max()):.2e}, elements off by an ulp {frac_off:.2e}")
+        assert float(err.max()) < 1.2e-2 and frac_off < 2e-2          # one bf16 ulp = 2^-8 relative at most

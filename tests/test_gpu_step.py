@@ -302,6 +302,37 @@ def test_native_step_loss_matches_reference_loss():
             assert float(nt_.abs().max()) == 0.0
 
 
+def test_native_step_loss_with_inverse_scaling_inside():
+    """step_loss_native(..., rescale=(mean, std)): the runner's inverse scaling (base_tsf_runner.py:240-250) folded into the loss
+    kernels, the target read in place as feature 0 of the [B, 12, N, C] batch tensor -- against the oracle's step_loss on the rescaled
+    tensors (value, gradient w.r.t. the NORMALISED prediction, gradient w.r.t. theta); also through retain_graph (the backward
+    must not scale its saved gradients in place)."""
+    from step_amd.step_loss import step_loss_native, _flat_stride
+    g = torch.Generator().manual_seed(6)
+    B, N, C = 3, 23, 3
+    mean, std = 200.0, 150.0
+    pred = torch.randn(B, 12, N, 1, generator=g).cuda().requires_grad_(True)
+    fut = torch.randn(B, 12, N, C, generator=g)
+    fut[0, :, 3, 0] = -mean / std                                # rescales to the null value 0
+    fut = fut.cuda()
+    theta = torch.rand(B, N, N, generator=g).clamp(1e-4, 1 - 1e-4).cuda().requires_grad_(True)
+    prior = (torch.rand(B, N, N, generator=g) < 0.1).float().cuda()
+    assert _flat_stride(fut[..., :1]) == C and _flat_stride(fut) == 1 and _flat_stride(fut[:, :, ::2, :1]) is None
+    pred_c = pred.detach().cpu().requires_grad_(True)
+    theta_c = theta.detach().cpu().requires_grad_(True)
+    l_ref = O.step_loss(O.rescale(pred_c, mean, std), O.rescale(fut.cpu()[..., :1], mean, std), theta_c, prior.cpu(), 0.7, null_val=0.0)
+    gp, gt = torch.autograd.grad(l_ref, [pred_c, theta_c])
+    for target in (fut[..., :1], fut[..., :1].contiguous(), fut[:, :, :, [0]]):
+        l_nat = step_loss_native(pred, target, theta, prior, 0.7, null_val=0.0, rescale=(mean, std))
+        a1 = torch.autograd.grad(l_nat * 3.0, [pred, theta], retain_graph=True)
+        a2 = torch.autograd.grad(l_nat * 3.0, [pred, theta])
+        assert float(l_nat) == pytest.approx(float(l_ref), rel=1e-5)
+        for a in (a1, a2):
+            assert rel_l2(a[0].cpu() / 3.0, gp) < 1e-5 and rel_l2(a[1].cpu() / 3.0, gt) < 1e-5
+    n_null = int((O.rescale(fut.cpu()[..., :1], mean, std).abs() <= 5e-5).sum())
+    assert n_null == 12 and float((a2[0][0, :, 3] != 0).sum()) == 0           # the masked targets carry no gradient
+
+
 @pytest.mark.parametrize("name", ["step_tiny", "step_small"])
 def test_step_bf16_matmul_mode(name):
     """matmul_precision="bf16": diffusion hops, their adjoints and the DGL fc on the bf16 matrix cores.  Operand rounding

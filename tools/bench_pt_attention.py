@@ -14,11 +14,11 @@ def main():
     tag = os.environ.get("STEP_HIP_LIB", "default")
     for T in (168, 42):
         gen = torch.Generator().manual_seed(T)
-        qkv = (torch.randn(S, T, 288, generator=gen) * 1.0).cuda()
-        dout = torch.randn(S, T, 96, generator=gen).cuda()
-        out = torch.empty(S, T, 96, device="cuda")
+        qkv = (torch.randn(S, T, 288, generator=gen) * 1.0).bfloat16().cuda()
+        dout = torch.randn(S, T, 96, generator=gen).bfloat16().cuda()
+        out = torch.empty(S, T, 96, device="cuda", dtype=torch.bfloat16)
         stats = torch.empty(S * 4 * T, 2, device="cuda")
-        dqkv = torch.zeros(S, T, 288, device="cuda")
+        dqkv = torch.zeros(S, T, 288, device="cuda", dtype=torch.bfloat16)
         kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda")
         st = L.stream()
         for p in (0.1, 0.0):
