@@ -65,6 +65,11 @@ typedef struct StepGemm {
        columns into a weight-gradient GEMM (the DGL fc weight gradient w.r.t. the normalised conv2 output). */
     const float *c_nscale, *c_nshift, *c_mvec;
     int c_nperiod;
+    /* optional scratch for split-K (accumulate == 2, compute_bf16, staged path): with at least splitk * batch * M * N floats here the
+       splits store their partial tiles (plain 16-byte stores) and a second launch adds their sum to C, instead of every split adding
+       every element of its tile with an atomic -- 256 splits of a 96 x 384 weight gradient are 9.4 M atomics, which took longer than
+       streaming the two operands (profiles/r03_w_split_target_ab_C3.log).  NULL / too small: atomics as before. */
+    float* splitk_ws; long splitk_ws_floats;
 } StepGemm;
 int step_gemm(const StepGemm* g, void* stream);
 

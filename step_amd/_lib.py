@@ -24,7 +24,7 @@ class StepGemm(ctypes.Structure):
                 ("b_nblk", _i), ("b_nstride", _l), ("c_nblk", _i), ("c_nstride", _l),
                 ("a_kscale", _vp), ("a_kshift", _vp), ("a_kperiod", _i),
                 ("batch0", _i), ("sab1", _l), ("sbb1", _l), ("scb1", _l), ("compute_bf16", _i), ("a_rowsum", _vp), ("c_nscale", _vp), ("c_nshift", _vp), ("c_mvec", _vp),
-                ("c_nperiod", _i)]
+                ("c_nperiod", _i), ("splitk_ws", _vp), ("splitk_ws_floats", _l)]
 
 
 class StepDglParams(ctypes.Structure):
@@ -171,7 +171,7 @@ def call(name, *args):
 def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0, scn=1, alpha=1.0,
          accumulate=0, bias=None, relu=False, splitk=1, a_off=0, b_off=0, c_off=0, a_k=(0, 0), b_k=(0, 0),
          b_n=(0, 0), c_n=(0, 0), a_kscale=None, a_kshift=None, a_kperiod=0, batch0=0, sab1=0, sbb1=0, scb1=0, compute_bf16=False, a_rowsum=None, c_nscale=None, c_nshift=None, c_mvec=None,
-         c_nperiod=0):
+         c_nperiod=0, splitk_ws=None):
     """Thin descriptor builder around step_gemm; a/b/c are device tensors (f32 or bf16 for a, b),
     offsets are in elements."""
     g = StepGemm()
@@ -195,6 +195,8 @@ def gemm(a, b, c, M, N, K, sam, sak, sbk, sbn, ldc, batch=1, sab=0, sbb=0, scb=0
     g.c_nscale, g.c_nshift, g.c_mvec = (ptr(c_nscale) if c_nscale is not None else None, ptr(c_nshift) if c_nshift is not None else None,
                                          ptr(c_mvec) if c_mvec is not None else None)
     g.c_nperiod = c_nperiod
+    if splitk_ws is not None:           # scratch for the partial tiles of a split-K product (summed by a second launch instead of atomics)
+        g.splitk_ws, g.splitk_ws_floats = ptr(splitk_ws), splitk_ws.numel()
     if a_kscale is not None:
         g.a_kscale, g.a_kshift, g.a_kperiod = a_kscale.data_ptr(), a_kshift.data_ptr(), a_kperiod
     check(lib().step_gemm(ctypes.byref(g), stream()), "step_gemm")

@@ -245,6 +245,7 @@ struct FastArgs {
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
     int xcd_swizzle;                   // remap block ids so that the n tiles of an m tile share an XCD (see gemm_fast_kernel)
     int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
+    long split_stride;                 // split-K through a workspace: split zs writes its partial tiles at C + zs * split_stride (0: off)
     GemmFused fu;                      // fused epilogues of the DGL fc backward (step_internal.h); all-null = off
 };
 
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
         }
     }
 
-    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1;
+    float* Cb = g.C + (long)i0 * g.scb + (long)i1 * g.scb1 + (long)zs * fa.split_stride;
     if constexpr (FUSED) {
         // Wide-store epilogue with the fused pieces of the DGL BatchNorm2 backward (GemmFused, step_internal.h).  The RAW
         // alpha * A.B tile is staged; the column-block affine, the per-channel reductions against W and the BatchNorm-backward
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
         }
         return;
     }
+    if constexpr (BM * (BN + 4) * 4 <= 2 * BUF)
     if (fa.wide_store) {
         // Store / read-modify-write epilogue through LDS: the accumulator layout has 32 consecutive columns per wave
         // instruction (128-byte runs); staged as a [BM][BN] f32 tile, every thread instead moves 16-byte pieces of whole rows
@@ -933,6 +935,34 @@ int launch_bf16(const StepGemm& g, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// second launch of a split-K product that went through a workspace: C(b, m, n) += sum over `chunk` splits of ws[z][b][m][n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int chunk, long mn, int N, int batch,
+                                                            int batch0, float* __restrict__ C, long ldc, long scn, long scb, long scb1) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x, total = mn * batch;
+    if (e >= total) return;
+    const int z0 = blockIdx.y * chunk, z1 = z0 + chunk < splits ? z0 + chunk : splits;
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = z0; z < z1; ++z) s += ws[(long)z * total + e];
+    const long b = e / mn, r = e - b * mn;
+    const long m = r / N, n = r - m * N;
+    const long i0 = batch0 ? b % batch0 : b, i1 = batch0 ? b / batch0 : 0;
+    atomicAdd(C + i0 * scb + i1 * scb1 + m * ldc + n * scn, s);
+}
+}  // namespace
+
+static int auto_splitk(int M, int N, int K, int batch, bool fast) {
+    const int bk = fast ? FBK : BK;
+    long tiles = fast ? (long)cdiv(M, 128) * cdiv(N, 128) * batch : (long)cdiv(M, 64) * cdiv(N, 64) * batch;
+    static const int split_target = []() { const char* e = getenv("STEP_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 768; }();      // (A/B knob)
+    long want = ((fast ? split_target : 1024) + tiles - 1) / tiles;
+    long maxs = cdiv(K, bk) / 4;
+    return (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
+}
+// the number of splits step_gemm chooses for splitk = -1 on the staged path (callers size StepGemm.splitk_ws with it)
+int step_gemm_auto_splitk(int M, int N, int K, int batch) { return auto_splitk(M, N, K, batch, true); }
+
 int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     FastArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -951,26 +981,45 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
-        long tiles = fast ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * g.batch;
-        static const int split_target = []() { const char* e = getenv("STEP_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 768; }();      // (A/B knob)
-        long want = ((fast ? split_target : 1024) + tiles - 1) / tiles;
-        long maxs = cdiv(g.K, bk) / 4;
-        g.splitk = (int)(want < 1 ? 1 : (want > maxs ? (maxs < 1 ? 1 : maxs) : want));
+        g.splitk = auto_splitk(g.M, g.N, g.K, g.batch, fast);
     }
     if (g.splitk < 1) g.splitk = 1;
     if (g.splitk > 1) STEP_REQUIRE(g.accumulate == 2, "step_gemm: split-K needs accumulate==2");
     STEP_REQUIRE(!(g.accumulate == 2 && (g.bias || g.relu)), "step_gemm: bias/relu epilogue not available with atomic accumulate");
     long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * g.batch * g.splitk;
     const bool big = g.M > 64 && g.N > 64 && tiles128 >= 512;
+    // split-K through the caller's workspace: partial tiles stored, summed into C by splitk_reduce_kernel
+    static const bool use_ws = []() { const char* e = getenv("STEP_GEMM_SPLITK_WS"); return !e || atoi(e) != 0; }();      // (A/B knob)
+    const StepGemm orig = g;
+    bool ws_reduce = false;
+    if (use_ws && fast && !fused && g.splitk > 1 && g.splitk_ws && !g.c_nblk && !g.c_nscale && (((uintptr_t)g.splitk_ws) & 15) == 0 &&
+        (long)g.M * g.N * g.batch * g.splitk <= g.splitk_ws_floats) {
+        const long mn = (long)g.M * g.N;
+        ws_reduce = true;
+        fa.split_stride = mn * g.batch;
+        g.C = g.splitk_ws; g.ldc = g.N; g.scn = 1; g.accumulate = 0;
+        g.scb = mn; g.scb1 = (long)g.batch0 * mn;
+        fa.wide_store = wide_store_ok(g, true);
+    }
+    auto finish = [&](int rc) -> int {
+        if (rc != STEP_OK || !ws_reduce) return rc;
+        const long total = (long)orig.M * orig.N * orig.batch;
+        const int chunk = 16;
+        dim3 grid((unsigned)((total + 255) / 256), (unsigned)cdiv(orig.splitk, chunk));
+        splitk_reduce_kernel<<<grid, 256, 0, st>>>(orig.splitk_ws, orig.splitk, chunk, (long)orig.M * orig.N, orig.N, orig.batch, orig.batch0, orig.C,
+                                                  orig.ldc, orig.scn ? orig.scn : 1, orig.scb, orig.scb1);
+        STEP_LAUNCH_CHECK("step_gemm(split-K reduce)");
+        return STEP_OK;
+    };
     if (fast && fused) return big ? launch_fast_fused<128, 128>(g, fa, amode, bmode, st) : launch_fast_fused<64, 64>(g, fa, amode, bmode, st);
     static const int tall_m = []() { const char* e = getenv("STEP_GEMM_TALL_M"); return e ? atoi(e) : 1024; }();      // (A/B knob)
     if (fast && !big && bmode != MC_BF16 && g.M >= tall_m && g.N > 64) {
         // tall products with a short n axis (the diffusion hops of large graphs: 4096 x 32 T x 4096): 128 x 64 tiles -- three workgroups per
         // compute unit and half the A-operand LDS traffic of 64 x 64 -- when they still fill the chip
         const long t = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * g.batch * g.splitk;
-        if (t >= 256) return launch_fast<128, 64>(g, fa, amode, bmode, st);
+        if (t >= 256) return finish(launch_fast<128, 64>(g, fa, amode, bmode, st));
     }
-    if (fast) return big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st);
+    if (fast) return finish(big ? launch_fast<128, 128>(g, fa, amode, bmode, st) : launch_fast<64, 64>(g, fa, amode, bmode, st));
     STEP_TRY(step_gemm_rowsum_separate(&g, st));
     if (big) return launch_bf16<128, 128>(g, st);
     return launch_bf16<64, 64>(g, st);

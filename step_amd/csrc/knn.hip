@@ -203,9 +203,16 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mask_kernel(const float* __rest
 
 static long tk_slices(int N) { return ((long)N * N + TK_SLICE - 1) / TK_SLICE; }
 
+static long tk_bytes(int B, int N) { return (long)B * (3 * TK_BINS + tk_slices(N) + 2) * (long)sizeof(uint32_t); }
+// F > 0 (step_knn_graph): the selection state, then -- 256-byte aligned -- the partial tiles of the split-K Gram product
+// (StepGemm.splitk_ws: 33 MB at PEMS04, where 11 splits x 8 x 307^2 f32 atomics were most of the launch)
+static long gram_ws_floats(int B, int N, int F) {
+    const int splits = step_gemm_auto_splitk(N, N, F, B);
+    return splits > 1 ? (long)splits * B * N * N : 0;
+}
 extern "C" long step_knn_workspace_bytes(int B, int N, int F) {
-    (void)F;
-    return (long)B * (3 * TK_BINS + tk_slices(N) + 2) * (long)sizeof(uint32_t);
+    const long base = tk_bytes(B, N);
+    return F > 0 ? ((base + 255) & ~255L) + gram_ws_floats(B, N, F) * (long)sizeof(float) : base;
 }
 
 extern "C" int step_topk_mask(const float* sim, int B, int N, int k_total, float* adj, void* work, long work_bytes,
@@ -220,7 +227,7 @@ extern "C" int step_topk_mask(const float* sim, int B, int N, int k_total, float
     w.hist = (uint32_t*)work;
     w.ties = w.hist + (long)B * 3 * TK_BINS;
     w.sel = w.ties + (long)B * slices;
-    if (hipMemsetAsync(work, 0, (size_t)step_knn_workspace_bytes(B, N, 0), st) != hipSuccess) {
+    if (hipMemsetAsync(work, 0, (size_t)tk_bytes(B, N), st) != hipSuccess) {
         step_set_error("topk_mask: memset failed");
         return STEP_ERR_HIP;
     }
@@ -257,6 +264,10 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
         g.B = hidden; g.sbk = 1; g.sbn = F; g.sbb = (long)N * F; g.b_bf16 = 1;
         g.C = sim; g.ldc = N; g.scn = 1; g.scb = (long)N * N;
         g.alpha = 1.f; g.accumulate = 2; g.splitk = -1; g.compute_bf16 = 1;
+        if (work && work_bytes >= step_knn_workspace_bytes(B, N, F) && gram_ws_floats(B, N, F) > 0) {
+            g.splitk_ws = (float*)((char*)work + ((tk_bytes(B, N) + 255) & ~255L));
+            g.splitk_ws_floats = gram_ws_floats(B, N, F);
+        }
         STEP_TRY(step_gemm_launch(g, st));
     }
     dim3 grid(cdiv(N, 256) > 4 ? 4 : cdiv(N, 256), N, B);

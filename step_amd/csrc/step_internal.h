@@ -35,6 +35,7 @@ constexpr int GEMM_KSEG_MAX = 128;
 int step_gemm_segmented_launch(StepGemm g, const GemmKSeg* ktab, int ktab_per, hipStream_t st);
 
 int step_gemm_launch(StepGemm g, hipStream_t st);
+int step_gemm_auto_splitk(int M, int N, int K, int batch);      // splits chosen for splitk = -1 on the staged bf16 path
 int step_gemm_launch_fused(StepGemm g, const GemmFused& fused, hipStream_t st);      // STEP_ERR_ARG (message set) when the operands do not qualify
 int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused = nullptr);
 int step_gemm_f32_fast_launch(StepGemm g, hipStream_t st, const GemmFused* fused = nullptr);      // -1: operands do not qualify

@@ -98,6 +98,18 @@ MC_ATTENTION_MAX_TOKENS = 352        # step_pt_attention_{fwd,bwd}_bf16: the bac
 _BF16 = False        # operand precision of the pre-training GEMMs, set from TSFormer.matmul_precision by _PretrainFunction
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_ws(dev):
+    """Scratch for the partial tiles of the split-K weight-gradient GEMMs (StepGemm.splitk_ws): the staged path aims at 768
+    workgroups of 128 x 128 tiles, i.e. at most 768 * 128 * 128 floats of partial results (50 MB), whatever the shape."""
+    t = _SPLITK_WS.get(dev)
+    if t is None:
+        t = _SPLITK_WS[dev] = torch.empty(768 * 128 * 128, device=dev, dtype=torch.float32)
+    return t
+
+
 def _linear_fwd(x, w, b, relu=False):
     """y[R,N] = x[R,K] @ w[N,K]^T + b   (step_gemm: exact-f32 matrix cores, or bf16 operands in the bf16 mode)."""
     R, K = x.shape
@@ -111,7 +123,7 @@ def _linear_bwd(dy, x, w, dw, db, dx=None, accumulate_dx=False):
     """dw[N,K] += dy^T x ; db[N] += colsum(dy) (as the all-ones column of the same GEMM) ; dx[R,K] (=|+=) dy @ w."""
     R, N = dy.shape
     K = x.shape[1]
-    _lib.gemm(dy, x, dw, N, K, R, 1, N, K, 1, K, accumulate=2, splitk=-1, a_rowsum=db, compute_bf16=_BF16)
+    _lib.gemm(dy, x, dw, N, K, R, 1, N, K, 1, K, accumulate=2, splitk=-1, a_rowsum=db, compute_bf16=_BF16, splitk_ws=_splitk_ws(dy.device))
     if dx is not None:
         _lib.gemm(dy, w, dx, R, K, N, N, 1, K, 1, K, accumulate=1 if accumulate_dx else 0, compute_bf16=_BF16)
     return dx
@@ -239,12 +251,12 @@ class _PretrainFunction(torch.autograd.Function):
             hid = sv["f1d"]
             w1, w2 = P_[pre + "linear1.weight"], P_[pre + "linear2.weight"]
             # dW2[o, j] += sum_r df2[r, o] hid[r, j];  db2 += colsum(df2)
-            _lib.gemm(df2, hid, G[pre + "linear2.weight"], 96, 384, R, 1, 96, 384, 1, 384, accumulate=2, splitk=-1, compute_bf16=True)
+            _lib.gemm(df2, hid, G[pre + "linear2.weight"], 96, 384, R, 1, 96, 384, 1, 384, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             L.call("step_colsum", L.ptr(df2), R, 96, 96, L.ptr(G[pre + "linear2.bias"]), st)
             dhid = torch.empty(R, 384, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_ffn_hidden_bwd", L.ptr(df2), L.ptr(w2), L.ptr(hid), R, p, L.ptr(dhid), st)
             # dW1[j, i] += sum_r dhid[r, j] h1[r, i]: computed as its transpose (A = h1 with i contiguous, B = dhid with j contiguous)
-            _lib.gemm(sv["h1"], dhid, G[pre + "linear1.weight"], 96, 384, R, 1, 96, 384, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True)
+            _lib.gemm(sv["h1"], dhid, G[pre + "linear1.weight"], 96, 384, R, 1, 96, 384, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             L.call("step_pt_colsum_bf16", L.ptr(dhid), R, 384, L.ptr(G[pre + "linear1.bias"]), st)
             # dh1[r, i] += sum_j dhid[r, j] w1[j, i]
             _lib.gemm(dhid, w1, dh1, R, 96, 384, 384, 1, 96, 1, 96, accumulate=1, compute_bf16=True)
@@ -264,7 +276,7 @@ class _PretrainFunction(torch.autograd.Function):
             # bf16 activations (see _layer_fwd): the gradients that are only read as matrix-core operands are stored as bf16 too
             wo, wi = P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.in_proj_weight"]
             # dWo[j, i] += sum_r do[r, j] a[r, i];  dbo += colsum(do)
-            _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True)
+            _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             L.call("step_colsum", L.ptr(do), R, 96, 96, L.ptr(G[pre + "self_attn.out_proj.bias"]), st)
             da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_linear_bf16out", L.ptr(do), L.ptr(wo), 96, 1, None, R, 96, 96, L.ptr(da), st)          # da = do @ Wo
@@ -272,7 +284,7 @@ class _PretrainFunction(torch.autograd.Function):
             L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
                    L.ptr(sv["keepbits"]), st)
             # dWi[j, i] += sum_r dqkv[r, j] x[r, i], computed as its transpose (A = x with i contiguous, B = dqkv with j contiguous)
-            _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True)
+            _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             L.call("step_pt_colsum_bf16", L.ptr(dqkv), R, 288, L.ptr(G[pre + "self_attn.in_proj_bias"]), st)
             _lib.gemm(dqkv, wi, dx, R, 96, 288, 288, 1, 96, 1, 96, accumulate=1, compute_bf16=True)                   # dx += dqkv @ Wi
             return dx

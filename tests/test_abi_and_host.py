@@ -241,7 +241,12 @@ def test_workspace_size_queries_are_pure_host_functions():
     lib = _lib.lib()
     N, T, B = 307, 13599, 8
     slices = (N * N + 4095) // 4096
-    assert lib.step_knn_workspace_bytes(B, N, 96 * 336) == B * (3 * 2048 + slices + 2) * 4
+    sel = B * (3 * 2048 + slices + 2) * 4                                      # selection state of the top-k
+    assert lib.step_knn_workspace_bytes(B, N, 0) == sel                        # step_topk_mask alone
+    # step_knn_graph: + the partial tiles of the split-K Gram product (9 tiles of 128 x 128 per sample, 72 in all: 11 splits to reach
+    # 768 workgroups), 256-byte aligned
+    assert lib.step_knn_workspace_bytes(B, N, 96 * 336) == ((sel + 255) & ~255) + 11 * B * N * N * 4
+    assert lib.step_knn_workspace_bytes(1, 4096, 96 * 168) == ((1 * (3 * 2048 + 4096 + 2) * 4 + 255) & ~255)     # 1024 tiles: no split, no scratch
     assert lib.step_dgl_edges_saved_floats(B, N) == 2 * N * 100 + N * N + 2 * B * N * N
     assert lib.step_dgl_edges_work_floats(N) == N * N + 2 * N * 100
     assert lib.step_dgl_global_saved_floats(N, T) > N * 8 * (T - 9)           # at least the conv1 activations

@@ -353,3 +353,29 @@ def test_linear_with_bf16_output(R):
         frac_off = float((got != want.bfloat16().float()).float().mean())
         print(f"linear_bf16out R={R} N={N} K={K} transposed={transposed}: max rel err {float(err.max()):.2e}, elements off by an ulp {frac_off:.2e}")
         assert float(err.max()) < 1.2e-2 and frac_off < 2e-2          # one bf16 ulp = 2^-8 relative at most
+
+
+@pytest.mark.parametrize("N,K", [(384, 131_072 + 37), (288, 70_001), (384, 873_600)])
+def test_weight_gradient_contraction_split_k_workspace(N, K):
+    """The weight gradients of the pre-training step: C [96 x N] += A^T B with A f32 [K][96], B bf16 [K][N], K = number of activation
+    rows, result written transposed like the module does, split-K over up to 256 workgroups per column tile.  With StepGemm.splitk_ws the
+    splits store partial tiles and a second launch sums them (per-element atomics from 256 splits were slower than streaming the operands,
+    profiles/r03_w_*, r03_x_*); without, atomics.  Both against torch float64 of the bf16-rounded operands: sums of K products of
+    magnitude ~1 in f32, 1e-5 relative to the result's norm."""
+    from step_amd import _lib as L
+    gen = torch.Generator().manual_seed(N + K)
+    a = torch.randn(K, 96, generator=gen).cuda()
+    b = torch.randn(K, N, generator=gen).bfloat16().cuda()
+    want = (b.float().double().t() @ a.bfloat16().double()).cpu()          # [N, 96]
+    ws = torch.empty(768 * 128 * 128, device="cuda")
+    for tag, w in (("atomics", None), ("workspace", ws), ("workspace too small -> atomics", ws[:1000])):
+        c = torch.zeros(N, 96, device="cuda")                  # C(m = i, n = j) at j * 96 + i: the transposed result, as for dW1 / dWi
+        L.gemm(a, b, c, 96, N, K, 1, 96, N, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=w)
+        torch.cuda.synchronize()
+        e = rel_l2(c.cpu().double(), want)
+        print(f"weight-gradient contraction N={N} K={K} [{tag}]: rel-L2 {e:.2e}")
+        assert e < 2e-5
+    # accumulate semantics: a second product into the same C adds to it
+    L.gemm(a, b, c, 96, N, K, 1, 96, N, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=ws)
+    torch.cuda.synchronize()
+    assert rel_l2(c.cpu().double(), 2 * want) < 2e-5
