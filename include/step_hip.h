@@ -290,11 +290,14 @@ int step_pt_layernorm_bwd(const float* dy, const float* x, long R, const float* 
                           float* dbeta, void* stream);
 /* The same two with their neighbours fused and 16-byte accesses (one row per 32 lanes): forward  pre = a + dropout(b) (the residual
  * add of transformer_layers.py:10's encoder layer; b may be NULL, then pre is not written), y = LayerNorm(pre), stats = (mean, rstd);
- * backward  dx as step_pt_layernorm_bwd and, when dx_dropped is given, dropout(dx) with the stream of step_pt_dropout(seed, site). */
+ * backward  dx as step_pt_layernorm_bwd and, when dx_dropped is given, dropout(dx) with the stream of step_pt_dropout(seed, site);
+ * out_colsum (nullable, [96]) += column sums of dx_dropped (of dx without it): the bias gradient of the linear layer that gradient
+ * enters next. */
 int step_pt_add_layernorm_fwd(const float* a, const float* b, long R, float p, uint64_t seed, uint32_t site, const float* g,
                               const float* beta, float* pre, float* y, float* stats, void* stream);
 int step_pt_layernorm_bwd_dropout(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx,
-                                  float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream);
+                                  float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta,
+                                  float* out_colsum, void* stream);
 /* 4-head self-attention on qkv [S][T][288] -> out [S][T][96]; stats [S][4][T][2] = row max, row sum (for the backward) */
 int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                           void* stream);

@@ -90,7 +90,7 @@ _SIGS = {
     "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),
     "step_pt_colsum_bf16": (_i, [_vp, _l, _i, _vp, _vp]),
     "step_pt_add_layernorm_fwd": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "step_pt_layernorm_bwd_dropout": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
+    "step_pt_layernorm_bwd_dropout": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
     "step_pt_dropout_relu_mask": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_add_dropout": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_add_rows": (_i, [_vp, _l, _i, _vp, _vp, _vp]),

@@ -744,11 +744,17 @@ extern "C" long step_dgl_global_saved_floats(int N, int T) {
     // ... + the BatchNorm2-scaled, (t, c)-ordered f32 copy of fc.weight and its shift term (channels-last bf16 storage, bf16 mode)
     return (long)N * 8 * T1 + (long)N * 16 * T2 + (long)N * EMB + 4 * 8 + 4 * 16 + 4 * EMB + (long)EMB * 16 * T2 + 128;
 }
+// partial tiles of the split-K fc product (StepGemm.splitk_ws): N x 100 results from K = 16 (T - 18) -- 3 tiles at PEMS04, 256 splits, whose
+// 7.9 M atomics into gpre were most of that launch
+static long fc_splitk_ws_floats(int N, int T2) {
+    const int splits = step_gemm_auto_splitk(N, EMB, 16 * T2, 1);
+    return splits > 1 ? (long)splits * N * EMB + 4 : 0;
+}
 extern "C" long step_dgl_global_work_floats(int N, int T, int backward) {
     long T1 = T - 9, T2 = T - 18;
     long nb1 = (long)N * cdiv(T1, 1024), nb2 = (long)N * cdiv(T2, 1024);
     long part = (nb1 > nb2 ? nb1 : nb2) * 32 + 64;
-    if (!backward) return part + dgl_conv2_pack_floats() + 64;
+    if (!backward) return part + dgl_conv2_pack_floats() + 64 + fc_splitk_ws_floats(N, (int)T2);
     return part + (long)N * 16 * T2 + (long)N * 8 * T1 + (long)EMB * 16 * T2 + 2L * N * EMB + DGL_SMALL + dgl_conv2_wgrad_scratch_floats(N, (int)T1);
 }
 
@@ -850,6 +856,11 @@ static int dgl_global_forward_impl(const float* series_nt, int N, int T, const S
         gm.accumulate = 2;
         gm.splitk = -1;
         gm.compute_bf16 = p->gemm_bf16;
+        if (fc_splitk_ws_floats(N, T2) > 0) {          // (the work buffer of step_dgl_global_work_floats(N, T, 0) ends with this scratch)
+            float* ws = work + part_floats + dgl_conv2_pack_floats() + 64;
+            gm.splitk_ws = (float*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+            gm.splitk_ws_floats = fc_splitk_ws_floats(N, T2) - 4;
+        }
         STEP_TRY(step_gemm_launch(gm, st));
     }
     if (all || phase == 4) {

@@ -222,12 +222,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const float* __restrict__ dy, const float* __restrict__ x, long R,
                                                           const float* __restrict__ g, const float* __restrict__ stats, float* __restrict__ dx,
                                                           float* __restrict__ dxd, float p, uint32_t lo, uint32_t hi, uint32_t site,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sg[8][D], sb[8][D];
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ocol) {
+    __shared__ float sg[8][D], sb[8][D], sc[8][D];
     const int q = threadIdx.x & 31, w = threadIdx.x >> 5;
     const bool on = q < D / 4;
     const float4 g4 = on ? ((const float4*)g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ac[4] = {0.f, 0.f, 0.f, 0.f};
     for (long row = (long)blockIdx.x * 8 + w; row < R; row += (long)gridDim.x * 8) {
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
         const long k = row * (D / 4) + (on ? q : 0);
@@ -243,25 +243,28 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const float* __restric
         for (int i = 0; i < 4; ++i) { o[i] = rstd * (qq[i] - m1 - xh[i] * m2); ag[i] += yy[i] * xh[i]; ab[i] += yy[i]; }
         if (on) {
             ((float4*)dx)[k] = make_float4(o[0], o[1], o[2], o[3]);
+            float m[4] = {1.f, 1.f, 1.f, 1.f};
             if (dxd) {
-                float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (p > 0.f) keep_scale4(lo, hi, site, k, p, m);
                 ((float4*)dxd)[k] = make_float4(o[0] * m[0], o[1] * m[1], o[2] * m[2], o[3] * m[3]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ac[i] += o[i] * m[i];          // column sums of the gradient that continues (dxd, or dx without it)
         }
     }
     if (on) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sg[w][4 * q + i] = ag[i]; sb[w][4 * q + i] = ab[i]; }
+        for (int i = 0; i < 4; ++i) { sg[w][4 * q + i] = ag[i]; sb[w][4 * q + i] = ab[i]; sc[w][4 * q + i] = ac[i]; }
     }
     __syncthreads();
     if (threadIdx.x < D) {
         const int f = threadIdx.x;
-        float tg = 0.f, tb = 0.f;
+        float tg = 0.f, tb = 0.f, tc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { tg += sg[r][f]; tb += sb[r][f]; }
+        for (int r = 0; r < 8; ++r) { tg += sg[r][f]; tb += sb[r][f]; tc += sc[r][f]; }
         atomicAdd(&dgamma[f], tg);
         atomicAdd(&dbeta[f], tb);
+        if (ocol) atomicAdd(&ocol[f], tc);
     }
 }
 
@@ -858,14 +861,15 @@ extern "C" int step_pt_add_layernorm_fwd(const float* a, const float* b, long R,
 }
 // LayerNorm backward; dx_dropped (may be NULL) = dropout(dx) with the stream of step_pt_dropout(seed, site), written in the same pass
 extern "C" int step_pt_layernorm_bwd_dropout(const float* dy, const float* x, long R, const float* g, const float* stats, float* dx,
-                                             float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream) {
+                                             float* dx_dropped, float p, uint64_t seed, uint32_t site, float* dgamma, float* dbeta,
+                                             float* out_colsum, void* stream) {
     STEP_REQUIRE(dy && x && g && stats && dx && dgamma && dbeta && R > 0 && p >= 0.f && p < 1.f, "pt_layernorm_bwd_dropout: bad arguments");
     STEP_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_dropped | (uintptr_t)g) & 15) == 0,
                  "pt_layernorm_bwd_dropout: 16-byte aligned buffers");
     long blocks = (R + 7) / 8;
     if (blocks > 4096) blocks = 4096;
     ln_bwd_drop_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(dy, x, R, g, stats, dx, dx_dropped, p, SEED_LO(seed), SEED_HI(seed), site,
-                                                                         dgamma, dbeta);
+                                                                         dgamma, dbeta, out_colsum);
     STEP_LAUNCH_CHECK("pt_layernorm_bwd_dropout");
     return STEP_OK;
 }

@@ -242,7 +242,8 @@ class _PretrainFunction(torch.autograd.Function):
         dh2pre = _empty(R, 96, like=dh2)
         df2 = _empty(R, 96, like=dh2) if p > 0 else None
         L.call("step_pt_layernorm_bwd_dropout", L.ptr(dh2), L.ptr(sv["h2pre"]), R, L.ptr(P_[pre + "norm2.weight"]), L.ptr(sv["st2"]), L.ptr(dh2pre),
-               L.ptr(df2), p, seed, site + 3, L.ptr(G[pre + "norm2.weight"]), L.ptr(G[pre + "norm2.bias"]), st)
+               L.ptr(df2), p, seed, site + 3, L.ptr(G[pre + "norm2.weight"]), L.ptr(G[pre + "norm2.bias"]),
+               L.ptr(G[pre + "linear2.bias"]) if _BF16 else None, st)          # (bf16 mode: db2 = colsum(df2) rides along)
         if df2 is None:
             df2 = dh2pre
         dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
@@ -250,9 +251,8 @@ class _PretrainFunction(torch.autograd.Function):
             # bf16 hidden layer (see _layer_fwd): its gradient is masked in the GEMM epilogue and stored as bf16 as well
             hid = sv["f1d"]
             w1, w2 = P_[pre + "linear1.weight"], P_[pre + "linear2.weight"]
-            # dW2[o, j] += sum_r df2[r, o] hid[r, j];  db2 += colsum(df2)
+            # dW2[o, j] += sum_r df2[r, o] hid[r, j]  (db2 = colsum(df2) came out of the LayerNorm backward above)
             _lib.gemm(df2, hid, G[pre + "linear2.weight"], 96, 384, R, 1, 96, 384, 1, 384, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
-            L.call("step_colsum", L.ptr(df2), R, 96, 96, L.ptr(G[pre + "linear2.bias"]), st)
             dhid = torch.empty(R, 384, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_ffn_hidden_bwd", L.ptr(df2), L.ptr(w2), L.ptr(hid), R, p, L.ptr(dhid), st)
             # dW1[j, i] += sum_r dhid[r, j] h1[r, i]: computed as its transpose (A = h1 with i contiguous, B = dhid with j contiguous)
@@ -268,16 +268,16 @@ class _PretrainFunction(torch.autograd.Function):
         dh1pre = _empty(R, 96, like=dh2)
         do = _empty(R, 96, like=dh2) if p > 0 else None
         L.call("step_pt_layernorm_bwd_dropout", L.ptr(dh1), L.ptr(sv["h1pre"]), R, L.ptr(P_[pre + "norm1.weight"]), L.ptr(sv["st1"]), L.ptr(dh1pre),
-               L.ptr(do), p, seed, site + 1, L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]), st)
+               L.ptr(do), p, seed, site + 1, L.ptr(G[pre + "norm1.weight"]), L.ptr(G[pre + "norm1.bias"]),
+               L.ptr(G[pre + "self_attn.out_proj.bias"]) if sv["qkv"].dtype == torch.bfloat16 else None, st)       # (dbo = colsum(do))
         if do is None:
             do = dh1pre
         dx = dh1pre if p > 0 else dh1pre.clone()            # residual branch of H1pre = X + dropout(O)
         if sv["qkv"].dtype == torch.bfloat16:
             # bf16 activations (see _layer_fwd): the gradients that are only read as matrix-core operands are stored as bf16 too
             wo, wi = P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.in_proj_weight"]
-            # dWo[j, i] += sum_r do[r, j] a[r, i];  dbo += colsum(do)
+            # dWo[j, i] += sum_r do[r, j] a[r, i]  (dbo = colsum(do) came out of the LayerNorm backward above)
             _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
-            L.call("step_colsum", L.ptr(do), R, 96, 96, L.ptr(G[pre + "self_attn.out_proj.bias"]), st)
             da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_linear_bf16out", L.ptr(do), L.ptr(wo), 96, 1, None, R, 96, 96, L.ptr(da), st)          # da = do @ Wo
             dqkv = torch.empty(R, 288, device=dh2.device, dtype=torch.bfloat16)
@@ -316,7 +316,7 @@ class _PretrainFunction(torch.autograd.Function):
         _linear_bwd(dr, sv["d2"], P_["output_layer.weight"], G["output_layer.weight"], G["output_layer.bias"], dd2)
         dd = _empty(S * P, 96, like=dr)
         L.call("step_pt_layernorm_bwd_dropout", L.ptr(dd2), L.ptr(sv["d_out"]), S * P, L.ptr(P_["decoder_norm.weight"]), L.ptr(sv["st_dec"]), L.ptr(dd),
-               None, 0.0, 0, 0, L.ptr(G["decoder_norm.weight"]), L.ptr(G["decoder_norm.bias"]), st)
+               None, 0.0, 0, 0, L.ptr(G["decoder_norm.weight"]), L.ptr(G["decoder_norm.bias"]), None, st)
         for lsv in reversed(sv["dec_layers"]):
             dd = _PretrainFunction._layer_bwd(dd, lsv, S, P_, G, p, seed)
         # decoder input: split into d z and the mask-token / positional part
@@ -330,7 +330,7 @@ class _PretrainFunction(torch.autograd.Function):
         _linear_bwd(dz, sv["y"], P_["enc_2_dec_emb.weight"], G["enc_2_dec_emb.weight"], G["enc_2_dec_emb.bias"], dy)
         dx = _empty(S * Pu, 96, like=dr)
         L.call("step_pt_layernorm_bwd_dropout", L.ptr(dy), L.ptr(sv["x_enc_out"]), S * Pu, L.ptr(P_["encoder_norm.weight"]), L.ptr(sv["st_enc"]), L.ptr(dx),
-               None, 0.0, 0, 0, L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), st)
+               None, 0.0, 0, 0, L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), None, st)
         for lsv in reversed(sv["layers"]):
             dx = _PretrainFunction._layer_bwd(dx, lsv, S, P_, G, p, seed)
         # scatter back to all token positions (zeros at masked ones), dropout, positional and patch embedding

@@ -311,8 +311,9 @@ def test_fused_layernorm_kernels_match_unfused(p):
     pre1, y1, st1, dx1, dxd1 = e(R, 96), e(R, 96), e(R, 2), e(R, 96), e(R, 96)
     dg1, db1 = torch.zeros(96, device="cuda"), torch.zeros(96, device="cuda")
     L.call("step_pt_add_layernorm_fwd", L.ptr(a), L.ptr(b), R, p, seed, site, L.ptr(g), L.ptr(beta), L.ptr(pre1), L.ptr(y1), L.ptr(st1), st)
+    col1 = torch.zeros(96, device="cuda")
     L.call("step_pt_layernorm_bwd_dropout", L.ptr(dy), L.ptr(pre1), R, L.ptr(g), L.ptr(st1), L.ptr(dx1), L.ptr(dxd1), p, seed, site + 1,
-           L.ptr(dg1), L.ptr(db1), st)
+           L.ptr(dg1), L.ptr(db1), L.ptr(col1), st)
     y2, st2 = e(R, 96), e(R, 2)                      # b = NULL: plain LayerNorm of a
     L.call("step_pt_add_layernorm_fwd", L.ptr(a), None, R, 0.0, 0, 0, L.ptr(g), L.ptr(beta), None, L.ptr(y2), L.ptr(st2), st)
     torch.cuda.synchronize()
@@ -322,8 +323,9 @@ def test_fused_layernorm_kernels_match_unfused(p):
                                                                  dbeta=(db1, db0)).items()}
     want2 = torch.nn.functional.layer_norm(a.double(), (96,), g.double(), beta.double(), 1e-5)
     errs["plain"] = rel_l2(y2.cpu().double(), want2.cpu())
+    errs["colsum"] = rel_l2(col1.cpu().double(), dxd0.double().sum(0).cpu())         # the bias gradient of the next linear layer
     print(f"fused LayerNorm kernels p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
-    assert max(errs.values()) < 2e-6
+    assert max(v for k, v in errs.items() if k != "colsum") < 2e-6 and errs["colsum"] < 2e-5       # (f32 atomics of ~R / 8 partial sums)
 
 
 @pytest.mark.parametrize("R", [4099, 130_000])
