@@ -201,9 +201,12 @@ long step_dgl_edges_saved_floats(int B, int N);
 long step_dgl_edges_work_floats(int N);
 int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
                            float temperature, float* saved, float* theta_out, float* adj_out, void* stream);
+/* aux_stream (nullable): the fc_out weight / bias gradients are queued there, ordered after the kernels that produce their inputs and
+ * NOT joined (same contract as step_gwnet_backward: order the first reader of `grads` and the release of `work` after aux_stream);
+ * dg is ordered on `stream`. */
 int step_dgl_edges_backward(const float* g, int N, int B, const StepDglParams* p, const float* saved,
                             const float* dtheta, const float* dadj, float temperature, float* work,
-                            const StepDglParams* grads, float* dg, void* stream);
+                            const StepDglParams* grads, float* dg, void* aux_stream, void* stream);
 
 /* ---------------------------------------------------------------- GraphWaveNet backbone ----
  * Device pointers named after the reference state_dict keys of `backend.*`
@@ -247,8 +250,11 @@ int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const flo
  * through both random-walk normalisations, model.py:121-130,160).
  * aux_stream (may be NULL or equal to stream: everything on `stream`): a second stream of the same device for the LEAVES of the
  * backward -- the weight / bias gradients of every layer and the whole fc_his branch, which nothing else in the backward reads.
- * They are forked after the kernels that produce their inputs (event on `stream`, wait on aux_stream) and joined before the
- * call's last kernels, so on return all work of the call is ordered before whatever the caller queues on `stream` next. */
+ * They are forked after the kernels that produce their inputs (event on `stream`, wait on aux_stream).  On return dadj is ordered
+ * on `stream`; the last leaves (unpacking the gate / skip gradients, the adaptive adjacency's backward with the two node-embedding
+ * gradients) may still be queued on aux_stream: the caller orders the first reader of `grads` -- and the release of `work` -- after
+ * aux_stream (one stream-wait before the gradient all-reduce / the optimizer; step_arch/step.py does it after the graph learner's
+ * backward, by when the leaves have long finished). */
 int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                         const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
                         float* dadj, int dropout, void* aux_stream, void* stream);

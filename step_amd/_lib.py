@@ -78,7 +78,7 @@ _SIGS = {
     "step_dgl_edges_saved_floats": (_l, [_i, _i]),
     "step_dgl_edges_work_floats": (_l, [_i]),
     "step_dgl_edges_forward": (_i, [_vp, _i, _i, _PD, _vp, _u64, _f, _vp, _vp, _vp, _vp]),
-    "step_dgl_edges_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _f, _vp, _PD, _vp, _vp]),
+    "step_dgl_edges_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _f, _vp, _PD, _vp, _vp, _vp]),
     "step_gwnet_saved_floats": (_l, [_i, _i, _i]),
     "step_gwnet_work_floats": (_l, [_i, _i, _i]),
     "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),

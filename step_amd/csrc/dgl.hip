@@ -1119,9 +1119,10 @@ extern "C" long step_dgl_edges_work_floats(int N) { return (long)N * N + 2L * N 
 
 extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepDglParams* p, const float* saved,
                                        const float* dtheta, const float* dadj, float temperature, float* work,
-                                       const StepDglParams* grads, float* dg, void* stream) {
+                                       const StepDglParams* grads, float* dg, void* aux_stream, void* stream) {
     STEP_REQUIRE(g && p && saved && work && grads && dg && N > 0 && B > 0, "dgl_edges_backward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    AuxLane lane(st, (hipStream_t)aux_stream);
     const float* sndT = saved;
     const float* rcv = sndT + (long)N * EMB;
     const float* theta = rcv + (long)N * EMB + (long)N * N;
@@ -1146,13 +1147,17 @@ extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepD
     StepGemm g2 = gemm_desc(N, EMB, EMB, dsndT, 1, N, p->fc_out_w, 2 * EMB, 1, dg, EMB);
     g2.accumulate = 1;
     STEP_TRY(step_gemm_launch(g2, st));
-    // dW[:, 100:] += drcv^T @ g ;  dW[:, :100] += dsnd^T @ g ;  db += colsum(drcv)
+    // dW[:, 100:] += drcv^T @ g ;  dW[:, :100] += dsnd^T @ g ;  db += colsum(drcv): leaves (K = N products with 100 x 100 results, 57 us at
+    // PEMS04 and 130 us at PEMS07 on four workgroups each) -- to the auxiliary stream, NOT joined here: the caller orders the first reader
+    // of `grads` (and the release of `work`) after aux_stream
+    static const bool tail_leaves = []() { const char* e = getenv("STEP_TAIL_LEAVES"); return !(e && e[0] == '0'); }();      // (A/B knob)
+    hipStream_t leaf = tail_leaves ? lane.fork() : st;
     StepGemm g3 = gemm_desc(EMB, EMB, N, drcv, 1, EMB, g, EMB, 1, grads->fc_out_w + EMB, 2 * EMB);
     g3.accumulate = 1;
-    STEP_TRY(step_gemm_launch(g3, st));
+    STEP_TRY(step_gemm_launch(g3, leaf));
     StepGemm g4 = gemm_desc(EMB, EMB, N, dsndT, N, 1, g, EMB, 1, grads->fc_out_w, 2 * EMB);
     g4.accumulate = 1;
-    STEP_TRY(step_gemm_launch(g4, st));
-    STEP_TRY(step_colsum_launch(drcv, N, EMB, EMB, grads->fc_out_b, st));
+    STEP_TRY(step_gemm_launch(g4, leaf));
+    STEP_TRY(step_colsum_launch(drcv, N, EMB, EMB, grads->fc_out_b, leaf));
     return STEP_OK;
 }

@@ -834,42 +834,6 @@ Work carve_work(float* base, int B, int N, bool backward) {
 
 // Fork / join between the caller's stream and its auxiliary stream with re-usable events (one small pool per host thread and device:
 // a wait captures the state of its event when it is queued, so re-recording an event for a later fork is safe).
-struct AuxLane {
-    hipStream_t main, aux;
-    bool on;
-    int next = 0;
-    AuxLane(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr && a != m) {}
-    static hipEvent_t event(int k) {
-        thread_local std::vector<hipEvent_t> pool[16];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::vector<hipEvent_t>& v = pool[dev & 15];
-        while ((int)v.size() <= k) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            v.push_back(e);
-        }
-        return v[k];
-    }
-    // the stream leaf work goes to, ordered after everything queued on the main stream so far
-    hipStream_t fork() {
-        if (!on) return main;
-        hipEvent_t e = event(next++ & 63);
-        if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
-        return aux;
-    }
-    // the main stream waits for everything queued on the auxiliary stream so far
-    int join() {
-        if (!on) return STEP_OK;
-        hipEvent_t e = event(next++ & 63);
-        if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
-            step_set_error("gwnet_backward: stream join failed");
-            return STEP_ERR_HIP;
-        }
-        return STEP_OK;
-    }
-};
-
 int zero(float* p, long n, hipStream_t st) {
     if (hipMemsetAsync(p, 0, (size_t)n * sizeof(float), st) != hipSuccess) {
         step_set_error("gwnet: memset failed");
@@ -1228,7 +1192,18 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane));
     start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);
     STEP_LAUNCH_CHECK("start_conv_bwd");
-    STEP_TRY(lane.join());          // every leaf is finished from here on: the packed weight gradients and the adjacency gradients are complete
+    STEP_TRY(lane.join());          // every leaf queued so far is finished from here on: the packed weight gradients and the adjacency gradients are complete
+    // ---------------------------------------------------------------- supports
+    // What the caller's next kernels wait for is dadj alone: the random-walk normalisations' backward stays on the main stream.  The
+    // rest of the tail only writes parameter gradients -- unpacking the gate / skip gradients and the adaptive adjacency's chain
+    // (softmax(relu(E1 E2)) backward + the two node-embedding gradients: 88 us at PEMS04, 180 us at PEMS07 of badly shaped K = N products)
+    // -- and goes to the auxiliary stream WITHOUT a join: the caller orders the first reader of `grads` after aux_stream.
+    static const bool tail_leaves = []() { const char* e = getenv("STEP_TAIL_LEAVES"); return !(e && e[0] == '0'); }();      // (A/B knob)
+    hipStream_t leaf = tail_leaves ? lane.fork() : st;
+    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk, S.Pstk, N, W.rf);
+    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk + B * NN, S.Pstk + B * NN, N, W.rb);
+    rw_bwd_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(W.dPstk, W.dPstk + B * NN, N, S.rs, S.cs, W.rf, W.rb, dadj);
+    STEP_LAUNCH_CHECK("rw_bwd");
     {
         GatePtrs gg;
         SkipPtrs sg;
@@ -1236,26 +1211,22 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             gg.wf[i] = grads->filter_w[i]; gg.bf[i] = grads->filter_b[i]; gg.wg[i] = grads->gate_w[i]; gg.bg[i] = grads->gate_b[i];
             sg.w[i] = grads->skip_w[i]; sg.b[i] = nullptr;
         }
-        unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, st>>>(W.dwcat, W.dbcat, gg);
-        unpack_skip_grad_kernel<<<CS, CS, 0, st>>>(W.dwskip, sg);
+        unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, leaf>>>(W.dwcat, W.dbcat, gg);
+        unpack_skip_grad_kernel<<<CS, CS, 0, leaf>>>(W.dwskip, sg);
     }
-
-    // ---------------------------------------------------------------- supports
     {   // adaptive adjacency softmax(relu(E1 E2), dim=1); its gradient is the sum over samples of stack slot 2
-        sum_batches_kernel<<<g1(NN), 256, 0, st>>>(W.dPstk + 2 * B * NN, NN, B, W.dPa);
-        row_dot_kernel<<<N, 256, 0, st>>>(W.dPa, S.Pa, N, W.rf);
-        softmax_relu_bwd_kernel<<<g1(NN), 256, 0, st>>>(S.Madp, S.Pa, W.dPa, W.rf, N, W.dM);
+        float* rdot = W.y7;          // [N] row dots (y7 is a forward-only buffer: B N 32 floats, free here; rf / rb belong to the chain above)
+        sum_batches_kernel<<<g1(NN), 256, 0, leaf>>>(W.dPstk + 2 * B * NN, NN, B, W.dPa);
+        row_dot_kernel<<<N, 256, 0, leaf>>>(W.dPa, S.Pa, N, rdot);
+        softmax_relu_bwd_kernel<<<g1(NN), 256, 0, leaf>>>(S.Madp, S.Pa, W.dPa, rdot, N, W.dM);
         STEP_LAUNCH_CHECK("adp_bwd");
         StepGemm g1_ = gemm_desc(N, 10, N, W.dM, N, 1, p->nodevec2, 1, N, grads->nodevec1, 10);
         g1_.accumulate = 1;
-        STEP_TRY(step_gemm_launch(g1_, st));
+        STEP_TRY(step_gemm_launch(g1_, leaf));
         StepGemm g2_ = gemm_desc(10, N, N, p->nodevec1, 1, 10, W.dM, N, 1, grads->nodevec2, N);
         g2_.accumulate = 1;
-        STEP_TRY(step_gemm_launch(g2_, st));
+        STEP_TRY(step_gemm_launch(g2_, leaf));
     }
-    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk, S.Pstk, N, W.rf);
-    row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk + B * NN, S.Pstk + B * NN, N, W.rb);
-    rw_bwd_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(W.dPstk, W.dPstk + B * NN, N, S.rs, S.cs, W.rf, W.rb, dadj);
     STEP_LAUNCH_CHECK("rw_bwd");
     return STEP_OK;
 }

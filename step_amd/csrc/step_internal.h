@@ -1,6 +1,7 @@
 // Internal C++ declarations shared by the translation units of libstep_hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "../../include/step_hip.h"
 
 // Fused epilogues of the DiscreteGraphLearning fc backward, internal to the library (wide-store epilogue of the staged GEMM).
@@ -78,3 +79,41 @@ int dgl_conv2_wgrad_mfma(const float* dz, const float* a1, const float* sc, cons
                          int T1, hipStream_t st);
 int dgl_conv1_wgrad_mfma(const float* dz, const float* x, float* scratch, float* dw, float* db, int N, int T, hipStream_t st);
 int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out, hipStream_t st);
+
+// Fork / join of leaf work onto a second stream (events from a per-thread, per-device pool): the data-gradient chain of a backward
+// stays on `main`, launches whose results nothing in the chain reads go to fork().
+struct AuxLane {
+    hipStream_t main, aux;
+    bool on;
+    int next = 0;
+    AuxLane(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr && a != m) {}
+    static hipEvent_t event(int k) {
+        thread_local std::vector<hipEvent_t> pool[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::vector<hipEvent_t>& v = pool[dev & 15];
+        while ((int)v.size() <= k) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            v.push_back(e);
+        }
+        return v[k];
+    }
+    // the stream leaf work goes to, ordered after everything queued on the main stream so far
+    hipStream_t fork() {
+        if (!on) return main;
+        hipEvent_t e = event(next++ & 63);
+        if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
+        return aux;
+    }
+    // the main stream waits for everything queued on the auxiliary stream so far
+    int join() {
+        if (!on) return STEP_OK;
+        hipEvent_t e = event(next++ & 63);
+        if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
+            step_set_error("backward: stream join failed");
+            return STEP_ERR_HIP;
+        }
+        return STEP_OK;
+    }
+};

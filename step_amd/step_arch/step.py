@@ -200,12 +200,18 @@ class _StepFunction(torch.autograd.Function):
         aux = ctypes.c_void_p(model._side_stream(dev, "aux").cuda_stream) if (model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1") else None
         L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
                L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, st)
-        del wwork
+        # (wwork / ework stay referenced until the auxiliary stream is joined below: its last leaves still read them)
         ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
         dgv = _f32(N * 100, dev)
         dth = dtheta.contiguous().float() if dtheta is not None else None
         L.call("step_dgl_edges_backward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(esaved), L.ptr(dth) if dth is not None else None,
-               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), st)
+               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), aux, st)
+
+        def join_aux():
+            # the leaves the two calls above left on the auxiliary stream (parameter gradients only) must be finished before the first
+            # reader of the flat gradient buffer: the all-reduce of everything in front of fc_w, or the optimizer
+            if aux is not None:
+                torch.cuda.current_stream().wait_stream(model._side_stream(dev, "aux"))
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
         fo, fn, _ = layout["items"]["dgl.fc_w"]
         assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
@@ -217,6 +223,7 @@ class _StepFunction(torch.autograd.Function):
             pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
             L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
                    L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
+            join_aux()
             pending += model._reduce_begin(flat[:fo])
             model._reduce_finish(flat, pending, flat)
         else:
@@ -235,6 +242,7 @@ class _StepFunction(torch.autograd.Function):
                        L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase, st)
                 if phase in exchange:
                     model._sum_over_ranks(exchange[phase])
+            join_aux()
             # conv1's gradients are per-slice partial sums: summed, not averaged, by the mean all-reduce below
             views["dgl.conv1_w"].mul_(float(world))
             views["dgl.conv1_b"].mul_(float(world))
@@ -247,6 +255,7 @@ class _StepFunction(torch.autograd.Function):
             # (FusedAdamClip) and clear the slot, so that the flat buffer holds gradients only
             model._other_slices_sumsq = torch.addcmul(flat[ns:ns + 1], own, own, value=-1.0)
             flat[ns:ns + 1].zero_()
+        del wwork, ework
         model._flat_grad = flat
         model._backward_count = getattr(model, "_backward_count", 0) + 1
         ctx.held = None
