@@ -199,6 +199,7 @@ long step_dgl_global_offset(int N, int T, int item);
  *  (step.py:72) and the sampled adjacency [B,N,N] with the diagonal cleared. */
 long step_dgl_edges_saved_floats(int B, int N);
 long step_dgl_edges_work_floats(int N);
+long step_dgl_edges_theta_offset(int N);      /* theta_out == saved + this offset (floats): theta is written once, in place (no copy) */
 int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
                            float temperature, float* saved, float* theta_out, float* adj_out, void* stream);
 /* aux_stream (nullable): the fc_out weight / bias gradients are queued there, ordered after the kernels that produce their inputs and
@@ -248,16 +249,18 @@ int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const flo
                              float* saved, float* work, float* pred, int phase, void* stream);
 /* dpred [B,12,N] -> parameter gradients (+=) and dadj [B,N,N] (gradient w.r.t. the sampled adjacency,
  * through both random-walk normalisations, model.py:121-130,160).
- * aux_stream (may be NULL or equal to stream: everything on `stream`): a second stream of the same device for the LEAVES of the
- * backward -- the weight / bias gradients of every layer and the whole fc_his branch, which nothing else in the backward reads.
- * They are forked after the kernels that produce their inputs (event on `stream`, wait on aux_stream).  On return dadj is ordered
- * on `stream`; the last leaves (unpacking the gate / skip gradients, the adaptive adjacency's backward with the two node-embedding
- * gradients) may still be queued on aux_stream: the caller orders the first reader of `grads` -- and the release of `work` -- after
- * aux_stream (one stream-wait before the gradient all-reduce / the optimizer; step_arch/step.py does it after the graph learner's
- * backward, by when the leaves have long finished). */
+ * aux_stream, leaf_stream (each may be NULL or equal to stream: that work stays on `stream`; leaf_stream NULL: aux_stream takes its
+ * work too): two more streams of the same device.  aux_stream runs the adjacency-gradient contractions of the layer ranges next to
+ * the data-gradient chain and is joined inside the call (dadj needs them).  leaf_stream runs the LEAVES of the backward -- the
+ * weight / bias gradients of every layer, the fc_his branch, unpacking the gate / skip gradients, the adaptive adjacency's backward
+ * with the two node-embedding gradients, the start convolution's gradients -- forked after the kernels that produce their inputs
+ * (event on `stream`, wait on leaf_stream) and NOT joined: on return dadj is ordered on `stream`, the leaves may still be running, and
+ * the caller orders the first reader of `grads` -- and the release of `work` -- after leaf_stream and aux_stream (one stream-wait
+ * before the gradient all-reduce / the optimizer; step_arch/step.py does it after the graph learner's backward, by when the leaves
+ * have long finished). */
 int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                         const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
-                        float* dadj, int dropout, void* aux_stream, void* stream);
+                        float* dadj, int dropout, void* aux_stream, void* leaf_stream, void* stream);
 
 /* ---------------------------------------------------------------- TSFormer pre-training -----
  * Building blocks (exact f32) of the masked-autoencoder stage, forward and backward; the contractions

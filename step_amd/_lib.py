@@ -77,6 +77,7 @@ _SIGS = {
     "step_dgl_global_offset": (_l, [_i, _i, _i]),
     "step_dgl_edges_saved_floats": (_l, [_i, _i]),
     "step_dgl_edges_work_floats": (_l, [_i]),
+    "step_dgl_edges_theta_offset": (_l, [_i]),
     "step_dgl_edges_forward": (_i, [_vp, _i, _i, _PD, _vp, _u64, _f, _vp, _vp, _vp, _vp]),
     "step_dgl_edges_backward": (_i, [_vp, _i, _i, _PD, _vp, _vp, _vp, _f, _vp, _PD, _vp, _vp, _vp]),
     "step_gwnet_saved_floats": (_l, [_i, _i, _i]),
@@ -84,7 +85,7 @@ _SIGS = {
     "step_gwnet_saved_offset": (_l, [_i, _i, _i, _i, _i]),
     "step_gwnet_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _vp]),
     "step_gwnet_forward_phase": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _i, _vp]),
-    "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp, _vp]),
+    "step_gwnet_backward": (_i, [_vp, _i, _i, _i, _vp, _PG, _vp, _vp, _vp, _PG, _vp, _i, _vp, _vp, _vp]),
     "step_pt_dropout": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
     "step_pt_ffn_hidden_fwd": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp]),
     "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),

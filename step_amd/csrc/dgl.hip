@@ -1077,6 +1077,8 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
 }
 
 extern "C" long step_dgl_edges_saved_floats(int B, int N) { return 2L * N * EMB + (long)N * N + 2L * B * N * N; }
+// where theta [B][N*N] lives inside `saved` (floats): pass saved + this as theta_out and the forward writes it once, in place
+extern "C" long step_dgl_edges_theta_offset(int N) { return 2L * N * EMB + (long)N * N; }
 
 // saved layout: sndT [EMB][N] | rcv [N][EMB] | z [N*N] | theta [B][N*N] | y0 [B][N*N]
 extern "C" int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,

@@ -1035,7 +1035,7 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
 
 template <bool BF16>
 static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams* grads, const Saved& S, const Work& W, int B, int N,
-                                 float** dx0, hipStream_t st, AuxLane& lane) {
+                                 float** dx0, hipStream_t st, AuxLane& lane, AuxLane& leaves) {
     const long BN = (long)B * N;
     float* dx_next = nullptr;
     float* dxbuf[2] = {W.dxa, W.dxb};
@@ -1076,13 +1076,19 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh[i], 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = -1;
             gw.a_rowsum = grads->gconv_b[i];
-            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, lane.fork()));          // leaf: nothing in the backward reads it
+            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, leaves.fork()));          // leaf: nothing in the backward reads it
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
-            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6));          // slots 1..6 of dcat[4..6] are final (tcn_bwd only reads dcat)
+            // slots 1..6 of dcat[i..] are final here (tcn_bwd only reads dcat): the adjacency-gradient contraction of the finished layers
+            // starts now, on the auxiliary stream.  The LAST piece is what the supports' backward waits for after the loop, so it is the
+            // smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers 0..1 as one piece after the loop the
+            // main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
+            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6));
             if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3));
+            if (adj_pieces && i == 1) STEP_TRY(adj_piece(1, 1));
+            if (adj_pieces && i == 0) STEP_TRY(adj_piece(0, 0));
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
@@ -1093,7 +1099,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
                                                                                 i > 0 ? W.acc64 + (long)(i - 1) * NCOPY * 64 : nullptr);
         STEP_LAUNCH_CHECK("tcn_bwd");
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
-        hipStream_t leaf = lane.fork();           // gate / filter weight gradient of this layer: a leaf as well
+        hipStream_t leaf = leaves.fork();           // gate / filter weight gradient of this layer: a leaf as well
         im2col_kernel<<<g1(npos * 64), 256, 0, leaf>>>(xin, BN, Tin, Tout, dil, W.xcat[i]);
         STEP_LAUNCH_CHECK("im2col");
         StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre[i], 1, 64, W.xcat[i], 64, 1, W.dwcat + i * 4096, 64);
@@ -1103,17 +1109,21 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         dx_next = dx;
     }
     *dx0 = dx_next;
-    STEP_TRY(adj_pieces ? adj_piece(0, 1) : adj_piece(0, NL - 2));
+    if (!adj_pieces) STEP_TRY(adj_piece(0, NL - 2));
     return STEP_OK;
 }
 
 extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, const float* hidden_last, const StepGwnetParams* p,
                                    const float* saved, float* work, const float* dpred, const StepGwnetParams* grads,
-                                   float* dadj, int dropout, void* aux_stream, void* stream) {
+                                   float* dadj, int dropout, void* aux_stream, void* leaf_stream, void* stream) {
     STEP_REQUIRE(hist && hidden_last && p && saved && work && dpred && grads && dadj, "gwnet_backward: null argument");
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_backward: bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    // two lanes: the adjacency-gradient contractions (`lane`, joined before the supports' backward needs their result) and the pure
+    // leaves (`leaves`: parameter gradients only, joined by the caller).  On ONE in-order stream the contractions queued behind the weight
+    // gradients of the same layers and the join waited 136 us for them at PEMS04 (profiles/r03_ab_C2_step_timeline.md)
     AuxLane lane(st, (hipStream_t)aux_stream);
+    AuxLane leaves(st, leaf_stream ? (hipStream_t)leaf_stream : (hipStream_t)aux_stream, 64);
     Saved S = carve_saved((float*)saved, B, N, dropout != 0);
     Work W = carve_work(work, B, N, true);
     const long BN = (long)B * N;
@@ -1126,14 +1136,14 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
 
     // ---------------------------------------------------------------- head (model.py:215-220)
     // Main stream: the data-gradient chain d_e1 -> d_xh -> d zlast (what the layers need).  Everything else here -- the weight and
-    // bias gradients and the whole fc_his branch -- is a leaf of the backward and goes to the auxiliary stream (lane.fork()).
+    // bias gradients and the whole fc_his branch -- is a leaf of the backward and goes to the auxiliary stream (leaves.fork()).
     {
         // d_e1[b,n,:] = sum_o dpred[b][o][n] W2[o,:], masked by relu(e1)
         StepGemm g = gemm_desc(N, CE, OUT, dpred, 1, N, p->end2_w, CE, 1, W.d_e1, CE);
         g.batch = B; g.sab = (long)OUT * N; g.scb = (long)N * CE;
         STEP_TRY(step_gemm_launch(g, st));
         {
-            hipStream_t leaf = lane.fork();
+            hipStream_t leaf = leaves.fork();
             // dW2[o,:] += sum_{b,n} dpred[b][o][n] e1[b,n,:]   (batches accumulate atomically)
             StepGemm gw = gemm_desc(OUT, CE, N, dpred, N, 1, S.e1, CE, 1, grads->end2_w, CE);
             gw.batch = B; gw.sab = (long)OUT * N; gw.sbb = (long)N * CE; gw.scb = 0; gw.accumulate = 2;
@@ -1146,13 +1156,13 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
             gw1.accumulate = 2; gw1.splitk = split_for(BN);
             gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
-            gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, lane.fork()));
+            gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, leaves.fork()));
         }
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
         gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_xh, S.xh, BN * CS);       // = d skip = d h2 (pre-mask)
         {   // the 8 skip convolutions, data side: d zlast = d skip @ Wskip (every layer's last-step gradient)
-            hipStream_t leaf = lane.fork();
+            hipStream_t leaf = leaves.fork();
             StepGemm gz = gemm_desc((int)BN, CS, CS, W.d_xh, CS, 1, W.wskip, CS, 1, W.dskip, CS);
             gz.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gz, st));
             // ---- leaves that read d_xh
@@ -1188,10 +1198,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
 
     // ---------------------------------------------------------------- WaveNet layers, reversed
     float* dx0 = nullptr;
-    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane));
-    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane));
-    start_conv_bwd_kernel<<<128, 256, 0, st>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);
-    STEP_LAUNCH_CHECK("start_conv_bwd");
+    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane, leaves));
+    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane, leaves));
     STEP_TRY(lane.join());          // every leaf queued so far is finished from here on: the packed weight gradients and the adjacency gradients are complete
     // ---------------------------------------------------------------- supports
     // What the caller's next kernels wait for is dadj alone: the random-walk normalisations' backward stays on the main stream.  The
@@ -1199,7 +1207,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     // (softmax(relu(E1 E2)) backward + the two node-embedding gradients: 88 us at PEMS04, 180 us at PEMS07 of badly shaped K = N products)
     // -- and goes to the auxiliary stream WITHOUT a join: the caller orders the first reader of `grads` after aux_stream.
     static const bool tail_leaves = []() { const char* e = getenv("STEP_TAIL_LEAVES"); return !(e && e[0] == '0'); }();      // (A/B knob)
-    hipStream_t leaf = tail_leaves ? lane.fork() : st;
+    if (!tail_leaves) STEP_TRY(leaves.join());
+    hipStream_t leaf = tail_leaves ? leaves.fork() : st;
     row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk, S.Pstk, N, W.rf);
     row_dot_kernel<<<(unsigned)BN, 256, 0, st>>>(W.dPstk + B * NN, S.Pstk + B * NN, N, W.rb);
     rw_bwd_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(W.dPstk, W.dPstk + B * NN, N, S.rs, S.cs, W.rf, W.rb, dadj);
@@ -1211,6 +1220,8 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
             gg.wf[i] = grads->filter_w[i]; gg.bf[i] = grads->filter_b[i]; gg.wg[i] = grads->gate_w[i]; gg.bg[i] = grads->gate_b[i];
             sg.w[i] = grads->skip_w[i]; sg.b[i] = nullptr;
         }
+        start_conv_bwd_kernel<<<128, 256, 0, leaf>>>(hist, B, N, Cin, dx0, grads->start_w, grads->start_b);      // (a leaf too: 37 us at PEMS04)
+        STEP_LAUNCH_CHECK("start_conv_bwd");
         unpack_gate_grad_kernel<<<dim3(16, NL), 256, 0, leaf>>>(W.dwcat, W.dbcat, gg);
         unpack_skip_grad_kernel<<<CS, CS, 0, leaf>>>(W.dwskip, sg);
     }

@@ -85,8 +85,8 @@ int step_colsum_launch(const float* x, long rows, int cols, long ld, float* out,
 struct AuxLane {
     hipStream_t main, aux;
     bool on;
-    int next = 0;
-    AuxLane(hipStream_t m, hipStream_t a) : main(m), aux(a), on(a != nullptr && a != m) {}
+    int next = 0, base = 0;            // base: first event of this lane in the pool (two lanes of one call use disjoint events)
+    AuxLane(hipStream_t m, hipStream_t a, int base_ = 0) : main(m), aux(a), on(a != nullptr && a != m), base(base_) {}
     static hipEvent_t event(int k) {
         thread_local std::vector<hipEvent_t> pool[16];
         int dev = 0;
@@ -102,14 +102,14 @@ struct AuxLane {
     // the stream leaf work goes to, ordered after everything queued on the main stream so far
     hipStream_t fork() {
         if (!on) return main;
-        hipEvent_t e = event(next++ & 63);
+        hipEvent_t e = event(base + (next++ & 63));
         if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
         return aux;
     }
     // the main stream waits for everything queued on the auxiliary stream so far
     int join() {
         if (!on) return STEP_OK;
-        hipEvent_t e = event(next++ & 63);
+        hipEvent_t e = event(base + (next++ & 63));
         if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
             step_set_error("backward: stream join failed");
             return STEP_ERR_HIP;

@@ -101,7 +101,10 @@ class _StepFunction(torch.autograd.Function):
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 0), dev)
         g = _f32(N * 100, dev).view(N, 100)
         esaved = _f32(L.lib().step_dgl_edges_saved_floats(B, N), dev)
-        theta = _f32(B * N * N, dev).view(B, N, N)
+        # theta is one of the tensors the edge backward reads from `esaved`: returned as a view of it, written once (a separate output
+        # tensor cost a 3 MB device copy on the second stream's chain, 217 us next to the encoder)
+        to = int(L.lib().step_dgl_edges_theta_offset(N))
+        theta = esaved[to:to + B * N * N].view(B, N, N)
         adj = _f32(B * N * N, dev).view(B, N, N)
         wsaved = _f32(L.lib().step_gwnet_saved_floats(B, N, int(drop > 0)), dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 0), dev)
@@ -197,21 +200,25 @@ class _StepFunction(torch.autograd.Function):
         dadj = _f32(B * N * N, dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
         # the weight / bias gradients of the WaveNet are leaves of the backward: the library forks them onto the second stream
-        aux = ctypes.c_void_p(model._side_stream(dev, "aux").cuda_stream) if (model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1") else None
+        use_aux = model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1"
+        aux = ctypes.c_void_p(model._side_stream(dev, "aux").cuda_stream) if use_aux else None
+        leaf = ctypes.c_void_p(model._side_stream(dev, "leaf").cuda_stream) if (use_aux and os.environ.get("STEP_NO_LEAF_STREAM", "0") != "1") else None
         L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
-               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, st)
+               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, leaf, st)
         # (wwork / ework stay referenced until the auxiliary stream is joined below: its last leaves still read them)
         ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
         dgv = _f32(N * 100, dev)
         dth = dtheta.contiguous().float() if dtheta is not None else None
         L.call("step_dgl_edges_backward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(esaved), L.ptr(dth) if dth is not None else None,
-               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), aux, st)
+               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), leaf if leaf is not None else aux, st)
 
         def join_aux():
             # the leaves the two calls above left on the auxiliary stream (parameter gradients only) must be finished before the first
             # reader of the flat gradient buffer: the all-reduce of everything in front of fc_w, or the optimizer
             if aux is not None:
                 torch.cuda.current_stream().wait_stream(model._side_stream(dev, "aux"))
+            if leaf is not None:
+                torch.cuda.current_stream().wait_stream(model._side_stream(dev, "leaf"))
         gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
         fo, fn, _ = layout["items"]["dgl.fc_w"]
         assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
