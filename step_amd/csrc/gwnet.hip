@@ -1051,7 +1051,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
     // (STEP_ADJ_PIECES=0: one contraction after the loop, A/B measurements)
     static const bool adj_pieces = []() { const char* e = getenv("STEP_ADJ_PIECES"); return !(e && e[0] == '0'); }();
     bool adj_first = true;
-    auto adj_piece = [&](int lo, int hi) -> int {       // layers lo .. hi (inclusive) of the table
+    auto adj_piece = [&](int lo, int hi, hipStream_t on_stream) -> int {       // layers lo .. hi (inclusive) of the table
         int seg0 = 0, nseg = 0;
         for (int i = 0; i < lo; ++i) seg0 += 2 * TOUT[i];
         for (int i = lo; i <= hi; ++i) nseg += 2 * TOUT[i];
@@ -1061,7 +1061,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         g.compute_bf16 = BF16;
         g.accumulate = adj_first ? 0 : 1;
         adj_first = false;
-        return step_gemm_segmented_launch(g, W.ktab + seg0, ADJ_NSEG, lane.fork());
+        return step_gemm_segmented_launch(g, W.ktab + seg0, ADJ_NSEG, on_stream);
     };
     for (int i = NL - 1; i >= 0; --i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
@@ -1073,22 +1073,14 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh[i],
                                                                             W.dcat[i]);
             STEP_LAUNCH_CHECK("mix_bwd");
-            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh[i], 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
-            gw.accumulate = 2; gw.splitk = -1;
-            gw.a_rowsum = grads->gconv_b[i];
-            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, leaves.fork()));          // leaf: nothing in the backward reads it
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
-            // slots 1..6 of dcat[i..] are final here (tcn_bwd only reads dcat): the adjacency-gradient contraction of the finished layers
-            // starts now, on the auxiliary stream.  The LAST piece is what the supports' backward waits for after the loop, so it is the
-            // smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers 0..1 as one piece after the loop the
-            // main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
-            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6));
-            if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3));
-            if (adj_pieces && i == 1) STEP_TRY(adj_piece(1, 1));
-            if (adj_pieces && i == 0) STEP_TRY(adj_piece(0, 0));
+            // slots 1..6 of dcat[i] are final here (tcn_bwd only reads dcat).  The LAST adjacency-gradient piece is what the supports' backward
+            // waits for after the loop, so it is the smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers
+            // 0..1 as one piece after the loop the main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
+            if (adj_pieces && i == 0) STEP_TRY(adj_piece(0, 0, lane.fork()));
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
@@ -1099,7 +1091,20 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
                                                                                 i > 0 ? W.acc64 + (long)(i - 1) * NCOPY * 64 : nullptr);
         STEP_LAUNCH_CHECK("tcn_bwd");
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
-        hipStream_t leaf = leaves.fork();           // gate / filter weight gradient of this layer: a leaf as well
+        // ONE event on the main stream per layer (each record costs the dependent chain ~6 us between two kernels): the leaves of this
+        // layer -- mix weight gradient, gate / filter weight gradient -- and the adjacency-gradient piece of the layers finished so far
+        // all wait for it
+        hipEvent_t ev = leaves.on ? leaves.mark() : lane.mark();
+        hipStream_t leaf = leaves.after(ev);
+        if (i < NL - 1) {
+            StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh[i], 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
+            gw.accumulate = 2; gw.splitk = -1;
+            gw.a_rowsum = grads->gconv_b[i];
+            gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, leaf));          // leaf: nothing in the backward reads it
+            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6, lane.after(ev)));
+            if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3, lane.after(ev)));
+            if (adj_pieces && i == 1) STEP_TRY(adj_piece(1, 1, lane.after(ev)));
+        }
         im2col_kernel<<<g1(npos * 64), 256, 0, leaf>>>(xin, BN, Tin, Tout, dil, W.xcat[i]);
         STEP_LAUNCH_CHECK("im2col");
         StepGemm gw = gemm_desc(64, 64, (int)npos, W.dpre[i], 1, 64, W.xcat[i], 64, 1, W.dwcat + i * 4096, 64);
@@ -1109,7 +1114,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         dx_next = dx;
     }
     *dx0 = dx_next;
-    if (!adj_pieces) STEP_TRY(adj_piece(0, NL - 2));
+    if (!adj_pieces) STEP_TRY(adj_piece(0, NL - 2, lane.fork()));
     return STEP_OK;
 }
 

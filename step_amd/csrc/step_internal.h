@@ -106,6 +106,19 @@ struct AuxLane {
         if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
         return aux;
     }
+    // One record on the main stream for several waiters (an event record costs the main stream's dependent chain ~6 us of packet
+    // processing between two kernels): mark() records, after(e) makes this lane's stream wait for it.
+    hipEvent_t mark() {
+        if (!on) return nullptr;
+        hipEvent_t e = event(base + (next++ & 63));
+        if (!e || hipEventRecord(e, main) != hipSuccess) { on = false; return nullptr; }
+        return e;
+    }
+    hipStream_t after(hipEvent_t e) {
+        if (!on || !e) return main;
+        if (hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
+        return aux;
+    }
     // the main stream waits for everything queued on the auxiliary stream so far
     int join() {
         if (!on) return STEP_OK;
