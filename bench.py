@@ -393,7 +393,9 @@ class StepBench:
         m.tsformer.fallback_counter = torch.zeros(64, dtype=torch.int32, device=self.dev)
         if self.world > 1:
             m._reduce_wait_ms = []
+        allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
         dt, per_step, loss = timed_loop(self.step, 0, steps, self.barrier, start + warmup)
+        allocs = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0
         if self.world > 1:
             m.collect_reduce_waits()
             self.reduce_waits, self.small = list(m._reduce_wait_ms), m.collect_small_collectives()
@@ -407,7 +409,7 @@ class StepBench:
         B = self.cfg["B"]
         return {"value": B * self.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                 "p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)), "p90": float(np.percentile(per_step, 90)),
-                "host_enqueue_ms_per_step": HOST["enqueue_s"] / steps * 1e3, "enc_ms": enc_ms, "enc_launches": len(ev), "fallback_units_per_launch": slow / launches, "final_loss": float(loss.detach())}
+                "host_enqueue_ms_per_step": HOST["enqueue_s"] / steps * 1e3, "device_allocs": int(allocs), "enc_ms": enc_ms, "enc_launches": len(ev), "fallback_units_per_launch": slow / launches, "final_loss": float(loss.detach())}
 
     def softmax_units(self):
         P = self.cfg["L"] // 12
@@ -618,6 +620,11 @@ def main():
         others = {}
         for name in [n for n in names.split(",") if n]:
             try:
+                # a fresh allocator cache per config: with the blocks the previous config left cached, the first steps of a larger config kept
+                # going back to hipMalloc / hipFree inside the timed region (PEMS07 6.83 ms here against 6.07 ms in its own process,
+                # profiles/r03_ag_*)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
                 c2 = dict(CONFIGS[name])
                 if c2.get("pretrain"):
                     r = pretrain_run(args, c2, world, rank, dev, 5, 15)
@@ -632,6 +639,7 @@ def main():
                     fl = step_flops(c2, c2["B"])
                     others[name] = {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": 20,
                                     "encoder_ms_per_launch": r["enc_ms"], "fallback_units_per_launch": r["fallback_units_per_launch"],
+                                    "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "device_allocs_in_timed_region": r["device_allocs"],
                                     "whole_step_tflops": fl / (r["ms_per_step"] * 1e-3) / 1e12,
                                     "whole_step_frac_of_mfma_peak": fl / (r["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS,
                                     "workload": f"{name}: N={c2['N']}, L={c2['L']}, batch {c2['B']}/GPU, full train step, natively pre-trained TSFormer"}

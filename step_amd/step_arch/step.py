@@ -202,7 +202,9 @@ class _StepFunction(torch.autograd.Function):
         # the weight / bias gradients of the WaveNet are leaves of the backward: the library forks them onto the second stream
         use_aux = model.overlap_streams and os.environ.get("STEP_NO_AUX", "0") != "1"
         aux = ctypes.c_void_p(model._side_stream(dev, "aux").cuda_stream) if use_aux else None
-        leaf = ctypes.c_void_p(model._side_stream(dev, "leaf").cuda_stream) if (use_aux and os.environ.get("STEP_NO_LEAF_STREAM", "0") != "1") else None
+        # (a stream of their own for the pure leaves was measured and changes nothing -- 4.51 vs 4.51 ms at PEMS04, profiles/r03_ac_* -- so
+        #  the library's leaf_stream stays NULL and they share "aux": one hardware queue fewer in use; STEP_LEAF_STREAM=1 turns it on)
+        leaf = ctypes.c_void_p(model._side_stream(dev, "leaf").cuda_stream) if (use_aux and os.environ.get("STEP_LEAF_STREAM", "0") == "1") else None
         L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
                L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, leaf, st)
         # (wwork / ework stay referenced until the auxiliary stream is joined below: its last leaves still read them)
@@ -272,6 +274,9 @@ class _StepFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in (layout["items"][k] for k in layout["order"]))
 
 
+_STREAMS = {}        # (name, device type, device index) -> torch.cuda.Stream, see STEP._side_stream
+
+
 class STEP(nn.Module):
     """Pre-training Enhanced Spatial-temporal Graph Neural Network -- MI355X-native drop-in."""
 
@@ -324,10 +329,14 @@ class STEP(nn.Module):
         Stream priorities were measured and change nothing here (the device offers two levels; 4.683 vs 4.686 ms with the side chain at
         high priority, profiles/r03_g_stream_priority_ab.log): next to the encoder a small kernel still waits ~150 us for a compute
         unit, because a freed unit goes back to the encoder's queue as often as to the other one."""
+        # One set of streams per PROCESS and device, shared by every model: the runtime multiplexes streams onto a handful of hardware
+        # queues (four by default), and two streams that land on one queue serialise.  With per-model streams a second model built in the
+        # same process (bench.py's other configs) ran its "side" / "aux" work on queues its own main stream was using: PEMS07 6.83 ms
+        # instead of 6.07 ms (profiles/r03_ag_*, r03_ah_*).
         key = (name, dev.type, dev.index)
-        if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=dev)
-        return self._side[key]
+        if key not in _STREAMS:
+            _STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _STREAMS[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
     def _frozen_branch(self, long_hist, B, N, knn_stream=None):
