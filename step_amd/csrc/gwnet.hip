@@ -1147,29 +1147,25 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
         StepGemm g = gemm_desc(N, CE, OUT, dpred, 1, N, p->end2_w, CE, 1, W.d_e1, CE);
         g.batch = B; g.sab = (long)OUT * N; g.scb = (long)N * CE;
         STEP_TRY(step_gemm_launch(g, st));
-        {
-            hipStream_t leaf = leaves.fork();
-            // dW2[o,:] += sum_{b,n} dpred[b][o][n] e1[b,n,:]   (batches accumulate atomically)
-            StepGemm gw = gemm_desc(OUT, CE, N, dpred, N, 1, S.e1, CE, 1, grads->end2_w, CE);
-            gw.batch = B; gw.sab = (long)OUT * N; gw.sbb = (long)N * CE; gw.scb = 0; gw.accumulate = 2;
-            STEP_TRY(step_gemm_launch(gw, leaf));
-            rowsum_mod_kernel<<<B * OUT, 256, 0, leaf>>>(dpred, N, OUT, grads->end2_b);
-            STEP_LAUNCH_CHECK("end2_bias_grad");
-        }
         relu_bwd_kernel<<<g1(BN * CE), 256, 0, st>>>(W.d_e1, S.e1, BN * CE);
-        {
-            StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
-            gw1.accumulate = 2; gw1.splitk = split_for(BN);
-            gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
-            gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, leaves.fork()));
-        }
         StepGemm gx = gemm_desc((int)BN, CS, CE, W.d_e1, CE, 1, p->end1_w, CS, 1, W.d_xh, CS);
         gx.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gx, st));
         relu_bwd_kernel<<<g1(BN * CS), 256, 0, st>>>(W.d_xh, S.xh, BN * CS);       // = d skip = d h2 (pre-mask)
         {   // the 8 skip convolutions, data side: d zlast = d skip @ Wskip (every layer's last-step gradient)
-            hipStream_t leaf = leaves.fork();
+            hipStream_t leaf = leaves.fork();          // ONE event for all leaves of the head (each record is a ~6 us bubble on the main chain)
             StepGemm gz = gemm_desc((int)BN, CS, CS, W.d_xh, CS, 1, W.wskip, CS, 1, W.dskip, CS);
             gz.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gz, st));
+            {   // dW2[o,:] += sum_{b,n} dpred[b][o][n] e1[b,n,:]   (batches accumulate atomically)
+                StepGemm gw = gemm_desc(OUT, CE, N, dpred, N, 1, S.e1, CE, 1, grads->end2_w, CE);
+                gw.batch = B; gw.sab = (long)OUT * N; gw.sbb = (long)N * CE; gw.scb = 0; gw.accumulate = 2;
+                STEP_TRY(step_gemm_launch(gw, leaf));
+                rowsum_mod_kernel<<<B * OUT, 256, 0, leaf>>>(dpred, N, OUT, grads->end2_b);
+                STEP_LAUNCH_CHECK("end2_bias_grad");
+                StepGemm gw1 = gemm_desc(CE, CS, (int)BN, W.d_e1, 1, CE, S.xh, CS, 1, grads->end1_w, CS);
+                gw1.accumulate = 2; gw1.splitk = split_for(BN);
+                gw1.a_rowsum = grads->end1_b;                         // bias gradient = row sums of the same A
+                gw1.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(gw1, leaf));
+            }
             // ---- leaves that read d_xh
             // the 8 skip biases all receive colsum(d skip)
             STEP_TRY(zero(W.bsum, CS, leaf));
