@@ -171,7 +171,10 @@ int step_dgl_global_backward(const float* series_nt, int N, int T, const StepDgl
                              const float* dg, float* work, const StepDglParams* grads, void* stream);
 /* The same backward in two calls: phase 1 ends with the finished fc weight gradient (87 MB at PEMS04, the bulk of the
    data-parallel all-reduce, which the caller starts while phase 2 -- conv / BatchNorm backward, same `work` -- runs);
-   phase 0 = both. */
+   phase 0 = both.  phase | STEP_DGL_FRESH_FC_GRAD (also for step_dgl_global_backward_shard): grads->fc_w holds no previous value --
+   the fc weight gradient (98 % of the gradient bytes) is STORED instead of accumulated, so the caller need not zero that buffer and
+   the kernel does not read it. */
+#define STEP_DGL_FRESH_FC_GRAD 16
 int step_dgl_global_backward_phase(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                              const float* dg, float* work, const StepDglParams* grads, int phase, void* stream);
 

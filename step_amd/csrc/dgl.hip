@@ -688,7 +688,7 @@ __global__ void gpre_init_kernel(float* __restrict__ gpre, const float* __restri
 }
 __global__ __launch_bounds__(256) void fc_unpermute_kernel(const float* __restrict__ graw, const float* __restrict__ fc_w,
                                                            const float* __restrict__ st2, const float* __restrict__ colsum,
-                                                           float* __restrict__ dfc_w, float* __restrict__ dots_o, int T2) {
+                                                           float* __restrict__ dfc_w, float* __restrict__ dots_o, int T2, int overwrite) {
     // one thread = one time step of one output row: its 64-byte row of G, 16 coalesced loads of fc_w and of the gradient
     __shared__ float red[4][32];
     const int o = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, tid = threadIdx.x;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void fc_unpermute_kernel(const float* __restri
         const float g[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
         float w[16], old[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { const long idx = ((long)o * 16 + c) * T2 + t; w[c] = fc_w[idx]; old[c] = dfc_w[idx]; }
+        for (int c = 0; c < 16; ++c) { const long idx = ((long)o * 16 + c) * T2 + t; w[c] = fc_w[idx]; old[c] = overwrite ? 0.f : dfc_w[idx]; }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             dfc_w[((long)o * 16 + c) * T2 + t] = old[c] + st2[c] * g[c] + st2[16 + c] * cso;
@@ -911,8 +911,8 @@ extern "C" int step_dgl_global_backward(const float* series_nt, int N, int T, co
 // data-parallel all-reduce, which the caller can start right away); phase 2: the rest, with the same `work` buffer
 extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved,
                                               const float* dg, float* work, const StepDglParams* grads, int phase, void* stream) {
-    STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18 && phase >= 0 && phase <= 2,
-                 "dgl_global_backward: bad arguments");
+    STEP_REQUIRE(series_nt && p && saved && dg && work && grads && N > 0 && T > 18 && (phase & ~STEP_DGL_FRESH_FC_GRAD) >= 0 &&
+                 (phase & ~STEP_DGL_FRESH_FC_GRAD) <= 2, "dgl_global_backward: bad arguments");
     return dgl_global_backward_impl(series_nt, N, T, p, saved, dg, work, grads, nullptr, phase, stream);
 }
 
@@ -924,7 +924,8 @@ extern "C" int step_dgl_global_backward_phase(const float* series_nt, int N, int
 extern "C" int step_dgl_global_backward_shard(const float* series_slice, int N, int Ts, const StepDglParams* p, const float* saved,
                                               const float* dg, float* work, const StepDglParams* grads, const StepDglShard* shard,
                                               int phase, void* stream) {
-    STEP_REQUIRE(series_slice && p && saved && dg && work && grads && shard && N > 0 && Ts > 18 && (phase == 1 || phase == 3 || phase == 4),
+    const int ph = phase & ~STEP_DGL_FRESH_FC_GRAD;
+    STEP_REQUIRE(series_slice && p && saved && dg && work && grads && shard && N > 0 && Ts > 18 && (ph == 1 || ph == 3 || ph == 4),
                  "dgl_global_backward_shard: bad arguments");
     STEP_REQUIRE(p->gemm_bf16 && Ts - 18 >= 128, "dgl_global_backward_shard: needs the bf16 contraction mode and a slice of >= 128 conv2 columns");
     return dgl_global_backward_impl(series_slice, N, Ts, p, saved, dg, work, grads, shard, phase, stream);
@@ -932,6 +933,8 @@ extern "C" int step_dgl_global_backward_shard(const float* series_slice, int N, 
 
 static int dgl_global_backward_impl(const float* series_nt, int N, int T, const StepDglParams* p, const float* saved, const float* dg,
                                     float* work, const StepDglParams* grads, const StepDglShard* shard, int phase, void* stream) {
+    const int fresh_fc = (phase & STEP_DGL_FRESH_FC_GRAD) ? 1 : 0;      // grads->fc_w holds no previous value: store, do not read-modify-write
+    phase &= ~STEP_DGL_FRESH_FC_GRAD;
     const bool do_fc = phase == 0 || phase == 1, do_mid = phase == 0 || phase == 2 || phase == 3, do_tail = phase == 0 || phase == 2 || phase == 4;
     hipStream_t st = (hipStream_t)stream;
     const int T1 = T - 9, T2 = T - 18;
@@ -967,7 +970,7 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
             gm.compute_bf16 = 1;
             STEP_TRY(step_gemm_launch(gm, st));
             if (hipMemsetAsync(dots_o, 0, EMB * 32 * sizeof(float), st) != hipSuccess) { step_set_error("memset failed"); return STEP_ERR_HIP; }
-            fc_unpermute_kernel<<<dim3(cdiv(T2, 256), EMB), 256, 0, st>>>(wraw, p->fc_w, st2, colsum, grads->fc_w, dots_o, T2);
+            fc_unpermute_kernel<<<dim3(cdiv(T2, 256), EMB), 256, 0, st>>>(wraw, p->fc_w, st2, colsum, grads->fc_w, dots_o, T2, fresh_fc);
             dots_reduce_kernel<<<1, 64, 0, st>>>(dots_o, dots);
             STEP_LAUNCH_CHECK("fc_unpermute");
         }
@@ -999,7 +1002,7 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
         {
             // d fc_w[o][k] += sc[c(k)] * (dgpre^T a2)[o][k] + sh[c(k)] * colsum(dgpre)[o]: BN2's affine rides in the GEMM epilogue
             StepGemm gm = gemm_desc(EMB, (int)K, N, dgpre, 1, EMB, a2, K, 1, grads->fc_w, K);
-            gm.accumulate = 1;
+            gm.accumulate = fresh_fc ? 0 : 1;
             gm.c_nscale = st2; gm.c_nshift = st2 + 16; gm.c_nperiod = T2; gm.c_mvec = colsum;
             gm.compute_bf16 = p->gemm_bf16;
             if (fuse2) {

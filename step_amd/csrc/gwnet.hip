@@ -1035,7 +1035,7 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
 
 template <bool BF16>
 static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams* grads, const Saved& S, const Work& W, int B, int N,
-                                 float** dx0, hipStream_t st, AuxLane& lane, AuxLane& leaves) {
+                                 float** dx0, hipStream_t st, AuxLane& lane, AuxLane& leaves, hipEvent_t* adj_done) {
     const long BN = (long)B * N;
     float* dx_next = nullptr;
     float* dxbuf[2] = {W.dxa, W.dxb};
@@ -1080,7 +1080,7 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             // slots 1..6 of dcat[i] are final here (tcn_bwd only reads dcat).  The LAST adjacency-gradient piece is what the supports' backward
             // waits for after the loop, so it is the smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers
             // 0..1 as one piece after the loop the main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
-            if (adj_pieces && i == 0) STEP_TRY(adj_piece(0, 0, lane.fork()));
+            if (adj_pieces && i == 0) { STEP_TRY(adj_piece(0, 0, lane.fork())); *adj_done = lane.done(); }       // (what the supports' backward waits for)
         }
         // gated TCN (+ the skip branch's gradient at the last step, + col2im, + BatchNorm_{i-1}'s backward sums)
         float* dx = dxbuf[i & 1];
@@ -1095,15 +1095,16 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         // layer -- mix weight gradient, gate / filter weight gradient -- and the adjacency-gradient piece of the layers finished so far
         // all wait for it
         hipEvent_t ev = leaves.on ? leaves.mark() : lane.mark();
+        // (the adjacency piece first: the pieces are what the backward waits for at the end, the leaves behind them on the same stream are not)
+        if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6, lane.after(ev)));
+        if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3, lane.after(ev)));
+        if (adj_pieces && i == 1) STEP_TRY(adj_piece(1, 1, lane.after(ev)));
         hipStream_t leaf = leaves.after(ev);
         if (i < NL - 1) {
             StepGemm gw = gemm_desc(C, CAT, (int)npos, W.dh[i], 1, C, cat, CAT, 1, grads->gconv_w[i], CAT);
             gw.accumulate = 2; gw.splitk = -1;
             gw.a_rowsum = grads->gconv_b[i];
             gw.compute_bf16 = BF16; STEP_TRY(step_gemm_launch(gw, leaf));          // leaf: nothing in the backward reads it
-            if (adj_pieces && i == 4) STEP_TRY(adj_piece(4, 6, lane.after(ev)));
-            if (adj_pieces && i == 2) STEP_TRY(adj_piece(2, 3, lane.after(ev)));
-            if (adj_pieces && i == 1) STEP_TRY(adj_piece(1, 1, lane.after(ev)));
         }
         im2col_kernel<<<g1(npos * 64), 256, 0, leaf>>>(xin, BN, Tin, Tout, dil, W.xcat[i]);
         STEP_LAUNCH_CHECK("im2col");
@@ -1199,9 +1200,12 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
 
     // ---------------------------------------------------------------- WaveNet layers, reversed
     float* dx0 = nullptr;
-    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane, leaves));
-    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane, leaves));
-    STEP_TRY(lane.join());          // every leaf queued so far is finished from here on: the packed weight gradients and the adjacency gradients are complete
+    hipEvent_t adj_done = nullptr;
+    if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane, leaves, &adj_done));
+    else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane, leaves, &adj_done));
+    // the adjacency gradients are complete from here on (the event behind the last piece; leaves queued on that stream after it -- layer
+    // 0's gate gradient -- no longer hold the main stream back: 100 us at PEMS07, profiles/r03_ai_C4_step_timeline.md)
+    STEP_TRY(lane.wait_done(adj_done));
     // ---------------------------------------------------------------- supports
     // What the caller's next kernels wait for is dadj alone: the random-walk normalisations' backward stays on the main stream.  The
     // rest of the tail only writes parameter gradients -- unpacking the gate / skip gradients and the adaptive adjacency's chain

@@ -119,6 +119,20 @@ struct AuxLane {
         if (hipStreamWaitEvent(aux, e, 0) != hipSuccess) { on = false; return main; }
         return aux;
     }
+    // done(): an event on the AUXILIARY stream after what is queued on it so far; wait_done(e): the main stream waits for that point
+    // only -- later leaves on the same stream do not delay it (join() = wait for everything queued so far).
+    hipEvent_t done() {
+        if (!on) return nullptr;
+        hipEvent_t e = event(base + (next++ & 63));
+        if (!e || hipEventRecord(e, aux) != hipSuccess) return nullptr;
+        return e;
+    }
+    int wait_done(hipEvent_t e) {
+        if (!on) return STEP_OK;
+        if (!e) return join();
+        if (hipStreamWaitEvent(main, e, 0) != hipSuccess) { step_set_error("backward: stream join failed"); return STEP_ERR_HIP; }
+        return STEP_OK;
+    }
     // the main stream waits for everything queued on the auxiliary stream so far
     int join() {
         if (!on) return STEP_OK;

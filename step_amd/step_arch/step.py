@@ -137,6 +137,11 @@ class _StepFunction(torch.autograd.Function):
             L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct),
                    int(training) | (2 if (training and model.track_dead_bn7) else 0),
                    float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, sst)
+            if training:
+                with torch.no_grad():
+                    # the BatchNorm step counters: one multi-tensor launch instead of ten scalar ones, on this (the second) stream -- on the
+                    # main stream it sat between the head and the loss
+                    torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:8 if model.track_dead_bn7 else 7])], 1)
 
         # ---- TSFormer (frozen) and the kNN prior graph (no grad): on the main stream, or already in flight on the prefetch stream
         if frozen is None:
@@ -165,10 +170,6 @@ class _StepFunction(torch.autograd.Function):
         # ---- GraphWaveNet head: the only consumer of the TSFormer's last hidden state
         L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), None, ctypes.byref(bstruct), int(training),
                float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), 2, st)
-        if training:
-            with torch.no_grad():
-                # one multi-tensor launch instead of ten scalar ones
-                torch._foreach_add_([m.num_batches_tracked for m in (dgl.bn1, dgl.bn2, dgl.bn3, *list(be.bn)[:8 if model.track_dead_bn7 else 7])], 1)
         if frozen.get("knn_done") is not None:
             main.wait_event(frozen["knn_done"])          # adj_knn / sim are handed to the caller on the current stream
         ctx.model = model
@@ -189,7 +190,14 @@ class _StepFunction(torch.autograd.Function):
         st = L.stream()
         be, dgl = model.backend, model.discrete_graph_learning
         layout = model._grad_layout()
-        flat = torch.zeros(layout["total"], device=dev, dtype=torch.float32)
+        # the flat gradient buffer: everything in front of the fc weight (gradients accumulate into zeros, 18 MB at PEMS04) is cleared; the fc
+        # weight's 87 MB are STORED by the graph learner's backward (STEP_DGL_FRESH_FC_GRAD), neither cleared here nor read there
+        fo, fn, _ = layout["items"]["dgl.fc_w"]
+        flat = torch.empty(layout["total"], device=dev, dtype=torch.float32)
+        flat[:fo].zero_()
+        if fo + fn < layout["total"]:
+            flat[fo + fn:].zero_()
+        FRESH = 16          # include/step_hip.h STEP_DGL_FRESH_FC_GRAD
         views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
         gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
         dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
@@ -228,7 +236,7 @@ class _StepFunction(torch.autograd.Function):
         sh = dgl._shard
         if sh is None:
             L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-                   L.ptr(gwork), ctypes.byref(dg_grads), 1, st)
+                   L.ptr(gwork), ctypes.byref(dg_grads), 1 | FRESH, st)
             pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
             L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
                    L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
@@ -248,7 +256,7 @@ class _StepFunction(torch.autograd.Function):
             exchange = {1: gwork[o_dots:o_dots + 32], 3: gwork[o_graw:o_graw + 1296]}
             for phase in (1, 3, 4):
                 L.call("step_dgl_global_backward_shard", L.ptr(dgl._series_slice), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-                       L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase, st)
+                       L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase | FRESH, st)
                 if phase in exchange:
                     model._sum_over_ranks(exchange[phase])
             join_aux()
