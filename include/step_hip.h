@@ -246,7 +246,9 @@ int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hi
                        float* saved, float* work, float* pred, void* stream);
 /* The same in two calls, so that the caller can run the part that does not depend on the TSFormer on another stream while
  * the encoder is busy: phase 1 = supports + the 8 WaveNet layers (hidden_last / pred unused), phase 2 = head (hist / adj
- * unused; same saved / work buffers, after phase 1 in stream order), phase 0 = both. */
+ * unused; same saved / work buffers, after phase 1 in stream order), phase 0 = both.  The head in two: phase 3 = the fc_his branch
+ * (needs hidden_last only: it can be queued behind the encoder before phase 1 has finished elsewhere), phase 4 = the rest of the
+ * head (after phases 1 and 3; needs pred). */
 int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                              const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                              float* saved, float* work, float* pred, int phase, void* stream);

@@ -1141,6 +1141,9 @@ extern "C" int step_dgl_edges_backward(const float* g, int N, int B, const StepD
     STEP_LAUNCH_CHECK("edge_dz");
     edge_bwd_row_kernel<<<N, 256, (size_t)N * sizeof(float), st>>>(dz, sndT, rcv, p->fc_cat_w, N, drcv, grads->fc_cat_w, grads->fc_cat_b);
     STEP_LAUNCH_CHECK("edge_bwd_row");
+    // (the column pass only shares its input with the row pass, but the auxiliary stream is the wrong place for it: the unjoined leaves of
+    //  the WaveNet backward are still queued there -- 0.2 ms of them at PEMS07 -- and the main stream would wait behind them: measured
+    //  6.13 vs 6.01 ms at PEMS07, 17.5 vs 17.0 at N = 4096, profiles/r03_ak_bench.log)
     if (N % 4 == 0 && N >= 1024 && (((uintptr_t)dz | (uintptr_t)sndT | (uintptr_t)dsndT) & 15) == 0)
         edge_bwd_col_kernel<4><<<dim3(cdiv(N, 256), cdiv(EMB, 4)), 256, 0, st>>>(dz, sndT, rcv, p->fc_cat_w, N, dsndT);
     else

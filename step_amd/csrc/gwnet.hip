@@ -956,11 +956,12 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
 extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                                         const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                                         float* saved, float* work, float* pred, int phase, void* stream) {
-    STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 2, "gwnet_forward: null argument / bad phase");
-    STEP_REQUIRE(phase == 2 || (hist && adj), "gwnet_forward: the layer phase needs hist and adj");
-    STEP_REQUIRE(phase == 1 || (hidden_last && pred), "gwnet_forward: the head phase needs hidden_last and pred");
+    STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 4, "gwnet_forward: null argument / bad phase");
+    const bool do_layers = phase == 0 || phase == 1, do_his = phase == 0 || phase == 2 || phase == 3, do_head = phase == 0 || phase == 2 || phase == 4;
+    STEP_REQUIRE(!do_layers || (hist && adj), "gwnet_forward: the layer phase needs hist and adj");
+    STEP_REQUIRE(!do_his || hidden_last, "gwnet_forward: the fc_his phase needs hidden_last");
+    STEP_REQUIRE(!do_head || pred, "gwnet_forward: the head phase needs pred");
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_forward: bad sizes B=%d N=%d C=%d", B, N, Cin);
-    const bool do_layers = phase != 2, do_head = phase != 1;
     hipStream_t st = (hipStream_t)stream;
     const bool train = (training & 1) != 0;          // bit 1 (value 2): also the dead bn.7 statistics, see the header
     const bool use_drop = train && dropout_p > 0.f;
@@ -1007,14 +1008,17 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
     else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, st));
     }
 
-    // head (model.py:215-220): the only part that needs the TSFormer's hidden state
-    if (do_head) {
+    // head (model.py:215-220).  fc_his (phase 3) is the only part that needs the TSFormer's hidden state, and needs nothing else: the
+    // caller can queue it behind the encoder while the layers still run on another stream, and the rest (phase 4) after both
+    if (do_his) {
         StepGemm g = gemm_desc((int)BN, CE, HID, hidden_last, HID, 1, p->fc_his0_w, 1, HID, S.h1, CE);
         g.bias = p->fc_his0_b; g.relu = 1;
         g.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g, st));
         StepGemm g2 = gemm_desc((int)BN, CS, CE, S.h1, CE, 1, p->fc_his2_w, 1, CE, S.h2, CS);
         g2.bias = p->fc_his2_b; g2.relu = 1;
         g2.compute_bf16 = allbf16; STEP_TRY(step_gemm_launch(g2, st));
+    }
+    if (do_head) {
         // skip = sum_i Wskip_i z_i[last step] + sum_i b_i: the 8 skip convolutions as one K = 256 contraction
         StepGemm gs = gemm_desc((int)BN, CS, CS, S.zlast, CS, 1, W.wskip, 1, CS, S.skip, CS);
         gs.bias = W.bsum;

@@ -161,7 +161,10 @@ extern "C" int step_loss_scaled_fwd_bwd(const float* pred, const float* real, lo
     long nmax = n_pred > n_adj ? n_pred : n_adj;
     int blocks = (int)((nmax + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    loss_reduce_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, work);
+    // three f64 atomics per block onto three addresses: at least 16 elements per thread (191 blocks at PEMS04, 1024 at N = 4096)
+    int rblocks = (int)(nmax / 4096);
+    rblocks = rblocks < 1 ? 1 : (rblocks > 1024 ? 1024 : rblocks);
+    loss_reduce_kernel<<<rblocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, work);
     STEP_LAUNCH_CHECK("loss_reduce");
     loss_finish_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, coef, work, loss,
                                                dpred, dtheta);

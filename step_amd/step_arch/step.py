@@ -158,18 +158,26 @@ class _StepFunction(torch.autograd.Function):
                     if u is not None:
                         u.record_stream(side)
                     graph_and_layers(L.stream())
-            finally:
+            except BaseException:
                 # the join is queued even when a launch above raised: buffers handed back to the allocator must not be
                 # re-used by main-stream work while side-stream kernels may still write them
                 main.wait_stream(side)
+                raise
         else:
             graph_and_layers(st)
         if frozen["done"] is not None:
             main.wait_event(frozen["done"])
         enc, sim, adj_knn = frozen["enc"], frozen["sim"], frozen["adj_knn"]
-        # ---- GraphWaveNet head: the only consumer of the TSFormer's last hidden state
-        L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), None, ctypes.byref(bstruct), int(training),
-               float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), 2, st)
+        # ---- GraphWaveNet head.  The fc_his branch is the only consumer of the TSFormer's last hidden state and needs nothing else: it is
+        # queued behind the encoder (and the kNN prior) BEFORE the main stream waits for the layers on the second stream
+        try:
+            L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, L.ptr(enc["last"]), None, ctypes.byref(bstruct), int(training),
+                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 3, st)
+        finally:
+            if side is not None:
+                main.wait_stream(side)
+        L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, None, ctypes.byref(bstruct), int(training),
+               float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), L.ptr(pred), 4, st)
         if frozen.get("knn_done") is not None:
             main.wait_event(frozen["knn_done"])          # adj_knn / sim are handed to the caller on the current stream
         ctx.model = model
