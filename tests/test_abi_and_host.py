@@ -268,3 +268,47 @@ def test_mask_generator_seeded_matches_reference():
     um, mk = MaskGenerator(P, 0.75)()
     assert um == g["in.unmasked"].tolist() and mk == g["in.masked"].tolist()
     assert sorted(um + mk) == list(range(P)) and len(mk) == int(P * 0.75)
+
+
+def test_host_side_caches_follow_the_module():
+    """The per-step host work that is cached (round 3: C1 was bound by it) must notice when its inputs change: the parameter list of
+    zero_grad and of the TSFormer's packed-weight key, the WaveNet's tensor dictionary (BatchNorm buffers are REPLACED by module
+    conversions), the process-wide streams."""
+    from step_amd.step_arch import step as step_mod
+    model, g = _tiny_model()
+    for p in model.parameters():
+        if p.requires_grad:
+            p.grad = torch.ones_like(p)
+    model.zero_grad()
+    assert all(p.grad is None for p in model.parameters()) and model._zg_params is not None
+    model._flat_grad, model._backward_count = object(), 3
+    model.zero_grad()
+    assert model._flat_grad is None and model._backward_count == 0              # the flat-gradient bookkeeping is reset too
+    nt = model.backend.native_tensors()
+    assert model.backend.native_tensors() is nt                                  # built once ...
+    rm_before = nt["bn_rm.0"]
+    model.double().float()                                                       # ... dropped by a conversion (buffers become new tensors)
+    nt2 = model.backend.native_tensors()
+    assert nt2 is not nt and nt2["bn_rm.0"] is model.backend.bn[0].running_mean and nt2["bn_rm.0"] is not rm_before
+    assert model._zg_params is None and model.tsformer._plist is None            # and so are the parameter lists
+    k1 = model.tsformer._pack_key(14)
+    with torch.no_grad():
+        next(model.tsformer.parameters()).add_(1.0)                              # an in-place update changes the key (version counter)
+    assert model.tsformer._pack_key(14) != k1
+    assert model.backend.trainable_native() is model.backend.trainable_native()
+    assert set(model.backend.trainable_native()) < set(nt2)
+    # streams are per process and device, not per model (hardware queues are few)
+    assert step_mod._STREAMS is not None and isinstance(step_mod._STREAMS, dict)
+
+
+def test_loss_target_stride_detection():
+    """step_loss_native reads the target in place when it is one feature of the batch tensor (`future[..., :1]`): the stride helper must
+    accept exactly the layouts that are a constant element stride apart and nothing else."""
+    from step_amd.step_loss import _flat_stride
+    x = torch.zeros(3, 12, 23, 3)
+    assert _flat_stride(x) == 1 and _flat_stride(x[..., :1]) == 3 and _flat_stride(x[..., 1:2]) == 3
+    assert _flat_stride(x[..., :1].contiguous()) == 1
+    assert _flat_stride(x[:, :, ::2, :1]) is None and _flat_stride(x[..., :2]) is None and _flat_stride(x.transpose(1, 2)) is None
+    assert _flat_stride(x[:, :6, :, :1]) is None                                 # rows skipped between samples
+    assert _flat_stride(x[:1, :, :, :1]) == 3                                    # a single sample: the batch stride does not matter
+    assert _flat_stride(torch.zeros(5, 1)) == 1
