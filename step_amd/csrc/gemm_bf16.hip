@@ -245,6 +245,7 @@ struct FastArgs {
     int a_klog, b_klog, b_nlog;        // log2 of the remap block along k / n, 30 = no remap
     int xcd_swizzle;                   // remap block ids so that the n tiles of an m tile share an XCD (see gemm_fast_kernel)
     int wide_store;                    // epilogue through LDS with 16-byte row pieces (plain store / += of a dense, aligned C)
+    int m_fast;                        // block order with the m tiles of one n tile adjacent (they share that n tile's B columns), see launch_fast_fused
     long split_stride;                 // split-K through a workspace: split zs writes its partial tiles at C + zs * split_stride (0: off)
     GemmFused fu;                      // fused epilogues of the DGL fc backward (step_internal.h); all-null = off
 };
@@ -487,6 +488,12 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
         const unsigned gx = gridDim.x, lin = bx + gx * (by + gridDim.y * bz);
         const unsigned q = lin >> 3, j = q / gx, grp = (lin & 7u) + 8u * j;
         bx = q - j * gx; by = grp % gridDim.y; bz = grp / gridDim.y;
+    } else if (fa.m_fast) {
+        // few m tiles over a B operand far larger than the caches (d_a2 of the graph learner: 7 row tiles x 2114 column tiles of a 54 MB
+        // weight copy at PEMS07): in the default order the m tiles of one n tile are a whole grid row apart and each re-reads its B columns
+        // from HBM; adjacent, they meet in the memory-side cache
+        const unsigned lin = bx + gridDim.x * by;
+        by = lin % gridDim.y; bx = lin / gridDim.y;
     }
     const int zb = bz / g.splitk, zs = bz % g.splitk;
     const int m0 = by * BM, n0 = bx * BN;
@@ -894,8 +901,11 @@ int launch_fast(const StepGemm& g, const FastArgs& fa_in, int amode, int bmode, 
 }
 // the fused DGL epilogues: only the operand combinations dgl.hip uses
 template <int BM, int BN>
-int launch_fast_fused(const StepGemm& g, const FastArgs& fa, int amode, int bmode, hipStream_t st) {
+int launch_fast_fused(const StepGemm& g, const FastArgs& fa_in, int amode, int bmode, hipStream_t st) {
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), 1);
+    FastArgs fa = fa_in;
+    static const bool m_fast_on = []() { const char* e = getenv("STEP_GEMM_M_FAST"); return !e || atoi(e) != 0; }();      // (A/B knob)
+    fa.m_fast = m_fast_on && grid.y >= 2 && grid.y <= 64 && (long)g.N * g.K * (g.b_bf16 ? 2 : 4) >= (16L << 20);
     if (amode == KC_F32 && bmode == MC_BF16) gemm_fast_kernel<BM, BN, KC_F32, MC_BF16, false, false, true><<<grid, 256, 0, st>>>(g, fa);
     else if (amode == KC_F32 && bmode == KC_F32) gemm_fast_kernel<BM, BN, KC_F32, KC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
     else if (amode == KC_F32 && bmode == MC_F32) gemm_fast_kernel<BM, BN, KC_F32, MC_F32, false, false, true><<<grid, 256, 0, st>>>(g, fa);
