@@ -26,8 +26,16 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  This step uses three streams
+# (main; "side": graph learner + WaveNet layers next to the encoder; "aux": the leaves of the backward) of which at most two carry work
+# at a time, and runs 1.6 % faster at PEMS04 / 0.8 % at PEMS07 with TWO queues than with three or four (one queue: no overlap at all,
+# 5.27 ms; profiles/r03_ar_hw_queues_ab.log, r03_as_*).  It has to be in the environment before the runtime initialises, i.e. before
+# torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -675,6 +683,7 @@ def main():
                        "final_loss": res["final_loss"]},
             "step_ms": {"p10": res["p10"], "p50": res["p50"], "p90": res["p90"]},
             "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+            "runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "whole_step": {"algorithmic_flop": sfl, "tflops": sfl / (res["ms_per_step"] * 1e-3) / 1e12,
                            "frac_of_mfma_peak": sfl / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS,
