@@ -324,7 +324,6 @@ class STEP(nn.Module):
         self._flat_grad = None
         self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
-        self._side = {}
         self._prefetched = None             # record of the frozen branch queued by prefetch() for the next batch
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
