@@ -312,3 +312,23 @@ def test_loss_target_stride_detection():
     assert _flat_stride(x[:, :6, :, :1]) is None                                 # rows skipped between samples
     assert _flat_stride(x[:1, :, :, :1]) == 3                                    # a single sample: the batch stride does not matter
     assert _flat_stride(torch.zeros(5, 1)) == 1
+
+
+def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
+    """bench.py puts GPU_MAX_HW_QUEUES=2 into the environment before torch (the HIP runtime) is imported -- for single-process runs, unless
+    the caller set it; multi-process runs (WORLD_SIZE > 1: the collective library has its own stream) keep the runtime's default."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.argv = ['bench.py']; import bench; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE")}
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-1]
+    assert run({}) == "2"
+    assert run({"WORLD_SIZE": "1"}) == "2"
+    assert run({"WORLD_SIZE": "8"}) == "None"
+    assert run({"GPU_MAX_HW_QUEUES": "4"}) == "4"
