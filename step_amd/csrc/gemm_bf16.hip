@@ -988,7 +988,6 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
                             ((fused->flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ | GEMM_FUSED_BF16OUT)) ? (g.accumulate == 0 && !fused->dotw && !fused->bnx && !g.c_nscale) :
                              (fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
                             "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
-    const int bk = fast ? FBK : BK;
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");
         g.splitk = auto_splitk(g.M, g.N, g.K, g.batch, fast);

@@ -872,20 +872,6 @@ int nconv_bwd_data3(const float* PTstk, const uint16_t* P16, float* dcat, int sr
     g.compute_bf16 = bf16;
     return step_gemm_launch(g, st);
 }
-// dP_s[b][v][w] += sum_n X_s[b][v][n] * dOut_s[b][w][n]   (x from cat slot xs0 + xstep*s, dOut from dcat slot ds0 + 2*s)
-int nconv_bwd_adj3(const float* cat, int xs0, int xstep, const float* dcat, int ds0, float* dPstk, int B, int N, int T,
-                   int bf16, hipStream_t st) {
-    StepGemm g = gemm_desc(N, N, T * C, cat + xs0 * C, (long)T * CAT, 1, dcat + ds0 * C, 1, (long)T * CAT, dPstk, N);
-    g.batch = 3 * B; g.batch0 = B;
-    g.sab = (long)N * T * CAT; g.sab1 = (long)xstep * C;
-    g.sbb = (long)N * T * CAT; g.sbb1 = 2L * C;
-    g.scb = (long)N * N; g.scb1 = (long)B * N * N;
-    g.a_kblk = C; g.a_kstride = CAT; g.b_kblk = C; g.b_kstride = CAT;
-    g.accumulate = 1;
-    g.compute_bf16 = bf16;
-    return step_gemm_launch(g, st);
-}
-
 }  // namespace
 
 // =========================================================================================== C ABI

@@ -412,7 +412,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 #ifndef MA_ABLATE
 #define MA_ABLATE 0       // timing experiments only (WRONG results): 1 no Philox in the forward, 2 no global loads in the fills, 4 no output stores
 #endif
-constexpr int MA_DP = 32;                 // head dim padded to two k steps
 constexpr int MA_RP = 40;                 // row pitch of the row-major LDS arrays (bf16 elements): 80 B, conflict-free 16-byte reads
 __device__ __forceinline__ int ma_tpitch(int Tp) { return Tp + 8; }      // pitch of the transposed arrays
 __device__ __forceinline__ bf16x8 ma_row8(const uint16_t* row) { return __builtin_bit_cast(bf16x8, *(const uint4*)row); }
@@ -885,8 +884,9 @@ extern "C" int step_pt_layernorm_bwd(const float* dy, const float* x, long R, co
 static void attn_attrs() {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // (a failure shows up as a launch error of the first call that needs more than the default limit)
+        (void)hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
 }
