@@ -31,7 +31,7 @@ import time
 # at a time, and runs 1.6 % faster at PEMS04 / 0.8 % at PEMS07 with TWO queues than with three or four (one queue: no overlap at all,
 # 5.27 ms; profiles/r03_ar_hw_queues_ab.log, r03_as_*).  It has to be in the environment before the runtime initialises, i.e. before
 # torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np  # noqa: E402
@@ -269,8 +269,11 @@ def timed_loop(step, warmup, steps, barrier, start=0):
     return dt, per_step, out
 
 
+DIST = {"on": False}        # a process group exists (world > 1, or --force-process-group on one rank)
+
+
 def max_over_ranks(dt, world, dev):
-    if world > 1:
+    if DIST["on"]:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t)
@@ -310,7 +313,7 @@ def pretrain_run(args, cfg, world, rank, dev, warmup, steps):
         return loss
 
     def barrier():
-        if world > 1:
+        if DIST["on"]:
             torch.distributed.barrier()
         torch.cuda.synchronize()
     dt, per_step, loss = timed_loop(step, warmup, steps, barrier)
@@ -339,9 +342,10 @@ class StepBench:
         if args.eval_dropout_off:
             self.model.backend.dropout = 0.0
             self.model.tsformer.dropout_p = 0.0
-        if world > 1:
+        if DIST["on"]:
             # each rank keeps one time slice of the graph learner's global branch and of fc.weight (bf16 mode)
-            self.model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim)
+            self.model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim,
+                                                   single_rank_collectives=world == 1)
         self.sharded = self.model.discrete_graph_learning._shard is not None
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         if args.torch_optim:
@@ -362,7 +366,7 @@ class StepBench:
         self.prefetch = args.prefetch
 
     def barrier(self):
-        if self.world > 1:
+        if DIST["on"]:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -399,12 +403,12 @@ class StepBench:
             self.step(start + i)
         m.tsformer._events = []
         m.tsformer.fallback_counter = torch.zeros(64, dtype=torch.int32, device=self.dev)
-        if self.world > 1:
+        if DIST["on"]:
             m._reduce_wait_ms = []
         allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
         dt, per_step, loss = timed_loop(self.step, 0, steps, self.barrier, start + warmup)
         allocs = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0) - allocs0
-        if self.world > 1:
+        if DIST["on"]:
             m.collect_reduce_waits()
             self.reduce_waits, self.small = list(m._reduce_wait_ms), m.collect_small_collectives()
             m._reduce_wait_ms = None
@@ -428,7 +432,7 @@ class StepBench:
         m = self.model
         keep = (m.overlap_streams, self.prefetch)
         m.overlap_streams, self.prefetch = False, False
-        m._prefetched = None
+        m.cancel_prefetch()
         m.tsformer._events = []
         for i in range(6):
             self.step(start + i)
@@ -464,10 +468,10 @@ class StepBench:
                 torch.nn.utils.clip_grad_norm_(self.params, max_norm=3.0)
             self.opt.step()
             return loss
-        self.model._prefetched = None
+        self.model.cancel_prefetch()
         dtl, _, _ = timed_loop(loader_step, 3, steps, self.barrier)
         dtl = max_over_ranks(dtl, self.world, self.dev)
-        self.model._prefetched = None
+        self.model.cancel_prefetch()
         return {"value": B * self.world * steps / dtl, "unit": "windows/s", "ms_per_step": dtl / steps * 1e3, "steps": steps,
                 "zero_history_fraction": zero_frac,
                 "what": "same training step, windows gathered on the device from the resident series by forecast origin "
@@ -510,7 +514,7 @@ class StepBench:
                         "count and exposed ms per step of the time-sliced graph learner's blocking sums"}
 
     def close(self):
-        self.model._prefetched = None
+        self.model.cancel_prefetch()
         del self.model, self.opt, self.batches, self.dser, self.params
         import gc
         gc.collect()
@@ -540,6 +544,11 @@ def main():
                     help="validation / test path (SURVEY 8f-4): eval-mode forward + metric under no_grad, no backward / optimizer")
     ap.add_argument("--no-shard", action="store_true", help="--gpus > 1: keep the whole graph learner (and fc.weight) on every rank")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="--gpus 1 only: create a one-rank process group and issue every collective of the data-parallel path (parameter "
+                         "broadcast, chunked async all-reduce, the time-sliced graph learner's small sums) through it, so that RCCL, its "
+                         "stream and the event ordering against the step's streams run on a one-GPU box; leaves GPU_MAX_HW_QUEUES at the "
+                         "runtime default unless set explicitly")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child is not None:
@@ -554,8 +563,14 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)          # (test rigs with fewer devices than ranks share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    DIST["on"] = world > 1 or args.force_process_group
+    if DIST["on"]:
         import torch.distributed as dist
+        if world == 1:          # --force-process-group: a group of one rank, rendezvous on the loopback address
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29581")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
         else:
@@ -575,7 +590,7 @@ def main():
                               "config": {"workload": r["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
                                          "final_loss": r["final_loss"]},
                               "whole_step": {"tflops": r["whole_step_tflops"], "frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"]}}), flush=True)
-        if world > 1:
+        if DIST["on"]:
             torch.distributed.destroy_process_group()
         return
 
@@ -589,7 +604,7 @@ def main():
     extras = not args.no_extras
     enc_alone_ms = bench.encoder_alone_ms(nxt) if (not args.forward_only and extras) else None
     loader_fig = bench.loader_figure(max(args.steps // 2, 10)) if (not args.forward_only and not args.no_loader_figure and extras) else None
-    comm = bench.comm_figure() if (world > 1 and not args.forward_only) else None
+    comm = bench.comm_figure() if (DIST["on"] and not args.forward_only) else None
     # ---- secondary figures of the same config: frozen branch inside forward(); random-init TSFormer
     no_prefetch, random_init = None, None
     short = max(min(args.steps // 3, 40), 5)
@@ -603,7 +618,7 @@ def main():
                                    "batch's backward (STEP.prefetch: bit-identical outputs); not the default because it buys nothing on one GPU -- "
                                    "the encoder's 704-thread, 147 KB workgroups leave no room for the backward's kernels next to them"}
             bench.prefetch = False
-            bench.model._prefetched = None
+            bench.model.cancel_prefetch()
             torch.cuda.synchronize()
         if ckpt is not None:
             from step_amd import TSFormer
@@ -713,7 +728,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, data)
         print(json.dumps(out), flush=True)
     shutil.rmtree(workdir, ignore_errors=True)
-    if world > 1:
+    if DIST["on"]:
         torch.distributed.destroy_process_group()
 
 

@@ -174,16 +174,31 @@ def dgl_global_feature(node_feats, p, pre="discrete_graph_learning.", training=T
     return bn(g, "bn3", (0,), 1)
 
 
-def dgl_edge_logits(g, p, pre="discrete_graph_learning."):
+def dgl_edge_logits(g, p, pre="discrete_graph_learning.", row_chunk=None):
     """discrete_graph_learning.py:148-153 with the one-hot matmuls (rel_rec / rel_send,
     :81-89) replaced by their meaning: edge e = i*N + j has receiver i and sender j, and
-    the concat order is [sender, receiver].  g[N,100] -> logits[N*N, 2] (batch-invariant)."""
+    the concat order is [sender, receiver].  g[N,100] -> logits[N*N, 2] (batch-invariant).
+    ``row_chunk``: evaluate ``row_chunk`` receiver rows at a time and re-compute each block in the
+    backward pass (torch.utils.checkpoint), so that the [N, N, 100] hidden tensor -- 6.7 GB at
+    N = 4096, several copies of it under autograd -- never exists; same arithmetic per edge."""
     N, E = g.shape
     w = p[pre + "fc_out.weight"]
     snd = g @ w[:, :E].T                    # indexed by j
     rcv = g @ w[:, E:].T                    # indexed by i
-    hid = torch.relu(rcv.unsqueeze(1) + snd.unsqueeze(0) + p[pre + "fc_out.bias"])   # [i, j, 100]
-    return (hid @ p[pre + "fc_cat.weight"].T + p[pre + "fc_cat.bias"]).reshape(N * N, 2)
+
+    def rows(rcv_rows, snd_all, b_out, w_cat, b_cat):
+        hid = torch.relu(rcv_rows.unsqueeze(1) + snd_all.unsqueeze(0) + b_out)        # [i, j, 100]
+        return hid @ w_cat.T + b_cat
+    args = (p[pre + "fc_out.bias"], p[pre + "fc_cat.weight"], p[pre + "fc_cat.bias"])
+    if row_chunk is None or row_chunk >= N:
+        return rows(rcv, snd, *args).reshape(N * N, 2)
+    from torch.utils.checkpoint import checkpoint
+    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (rcv, snd) + args)
+    out = []
+    for i0 in range(0, N, row_chunk):
+        blk = rcv[i0:i0 + row_chunk]
+        out.append(checkpoint(rows, blk, snd, *args, use_reentrant=False) if need_grad else rows(blk, snd, *args))
+    return torch.cat(out, 0).reshape(N * N, 2)
 
 
 def gumbel_hard_sample(logits, u, temperature=0.5, eps=1e-10):
@@ -212,16 +227,17 @@ def cosine_knn_graph(hidden, k_total):
 
 
 def dgl_forward(long_hist0, node_feats, p, u, k, training=True, stats=None,
-                pre="discrete_graph_learning.", hidden=None):
+                pre="discrete_graph_learning.", hidden=None, edge_row_chunk=None, g=None):
     """DiscreteGraphLearning.forward (discrete_graph_learning.py:113-168).
     long_hist0[B, L, N] is channel 0 of the long history; u is the uniform noise the
     reference draws with torch.rand at :12.  Returns (logits[B,N*N,2], hidden[B,N,P,96],
     adj_knn[B,N,N], sampled_adj[B,N,N])."""
     B, _, N = long_hist0.shape
-    g = dgl_global_feature(node_feats, p, pre, training, stats)
+    if g is None:             # (tests of very large graphs pass the global feature in, e.g. computed without autograd)
+        g = dgl_global_feature(node_feats, p, pre, training, stats)
     if hidden is None:        # tests may inject the device encoder's (bf16) hidden states instead
         hidden = tsformer_encode(long_hist0, p).detach()
-    logits = dgl_edge_logits(g, p, pre).unsqueeze(0).expand(B, N * N, 2)
+    logits = dgl_edge_logits(g, p, pre, row_chunk=edge_row_chunk).unsqueeze(0).expand(B, N * N, 2)
     samp = gumbel_hard_sample(logits, u)[..., 0].reshape(B, N, N)
     samp = samp * (1.0 - torch.eye(N, dtype=samp.dtype))
     adj_knn, _ = cosine_knn_graph(hidden.reshape(B, N, -1), k * N)
@@ -306,11 +322,12 @@ def gwnet_forward(hist, hidden_last, sampled_adj, p, pre="backend.", training=Tr
 
 # ----------------------------------------------------------------------------- STEP + loss
 def step_forward(hist, long_hist, node_feats, p, u, k, epoch, training=True,
-                 drop_masks=None, stats=None, hidden=None, hidden_last=None, aux=None):
+                 drop_masks=None, stats=None, hidden=None, hidden_last=None, aux=None, edge_row_chunk=None, g=None):
     """STEP.forward (step/step_arch/step.py:37-72).  Returns
     (prediction[B,12,N,1], theta[B,N,N], adj_knn[B,N,N], gsl_coefficient)."""
     B, _, N, _ = hist.shape
-    logits, hidden, adj_knn, samp = dgl_forward(long_hist[..., 0], node_feats, p, u, k, training, stats, hidden=hidden)
+    logits, hidden, adj_knn, samp = dgl_forward(long_hist[..., 0], node_feats, p, u, k, training, stats, hidden=hidden,
+                                                edge_row_chunk=edge_row_chunk, g=g)
     if aux is not None:
         aux["sampled_adj"] = samp.detach()
     last = hidden[:, :, -1, :] if hidden_last is None else hidden_last

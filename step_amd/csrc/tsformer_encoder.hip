@@ -59,6 +59,9 @@ namespace {
 #define TSF_MASK_EARLY 1    // fetch a tile's keep-mask words at the top of its step instead of next to their use
 #endif
 
+#ifndef TSF_INTERLEAVE
+#define TSF_INTERLEAVE 0    // 1: fast attention step issues score(k-step 0), P V (half 0), score(k-step 1), P V (half 1) with each half's selects / packs in between
+#endif
 #ifndef TSF_RING12
 #define TSF_RING12 4        // ring slots of the 9..12 tile variant without the parked operand copy (2: one barrier per block, A/B builds)
 #endif
@@ -70,7 +73,7 @@ constexpr int ring_slots() { return (MAXW == 12 && !PARK) ? TSF_RING12 : 2; }
 // number of operand-copy fragments (of 6) parked in LDS while the attention loops run: all of them (PARK), or just the one the
 // register allocator would otherwise put into scratch memory in the 9..12 tile variant
 template <int MAXW, bool PARK>
-constexpr int parked_frags() { return PARK ? 6 : (MAXW == 12 && TSF_PARK1) ? 1 : 0; }
+constexpr int parked_frags() { return PARK ? 6 : ((MAXW == 12 || MAXW == 8) && TSF_PARK1) ? 1 : 0; }
 
 #ifndef TSF_SUM_SCALAR
 #define TSF_SUM_SCALAR 0    // 1: softmax row sums as four chains of plain v_add_f32 instead of two chains of v_pk_add_f32 (A/B builds; measured 1.986 vs 2.002 ms, within noise)
@@ -100,8 +103,13 @@ __device__ __forceinline__ typename Opnd<F16>::v8 relu_packed(typename Opnd<F16>
 struct Yes { static constexpr bool value = true; };
 struct No { static constexpr bool value = false; };
 
+// waves per SIMD the register allocation has to admit: the unparked 5..8 tile variant is launched with <= 6-7 waves per workgroup and
+// wants two workgroups per compute unit (12-14 waves = 3-4 per SIMD -> 168 registers, like the twelve-wave variant gets by itself)
+template <int MAXW, bool PARK>
+constexpr int min_waves_per_simd() { return (MAXW == 8 && !PARK) ? 3 : 1; }
+
 template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE>
-__global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) {
+__global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
     typedef typename Opnd<F16>::v8 op8;            // one MFMA operand: 8 x bfloat16 or 8 x float16
@@ -459,6 +467,31 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 exp_tile(cur, cur);
                 if constexpr (drop) row_sums(cur);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (TSF_INTERLEAVE != 0) {
+                    // the two dependent pairs (score k-steps of the NEXT tile, the two halves of this tile's P V product) alternate, each
+                    // half's selects and packs in between: no matrix instruction is issued right behind the one it depends on
+                    if constexpr (NEXT) nxt = mfma16<F16>(k0, qb[0], zero);
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
+                    }
+                    const bf16x8 p0 = pack_half<false>(cur, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    o = mfma16<false>(v0, p0, o);
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 8; i < 16; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (NEXT) nxt = mfma16<F16>(k1, qb[1], nxt);
+                    const bf16x8 p1 = pack_half<false>(cur, 1);
+                    if constexpr (drop && NEXT) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        tm = load_mask(kt + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    o = mfma16<false>(v1, p1, o);
+                } else {
                 if constexpr (NEXT) {
                     nxt = mfma16<F16>(k0, qb[0], zero);
                     nxt = mfma16<F16>(k1, qb[1], nxt);
@@ -475,6 +508,7 @@ __global__ __launch_bounds__(MAXW * 64) void tsformer_encoder_kernel(EncArgs A) 
                 const bf16x8 p0 = pack_half<false>(cur, 0), p1 = pack_half<false>(cur, 1);
                 o = mfma16<false>(v0, p0, o);
                 o = mfma16<false>(v1, p1, o);
+                }
             };
             auto denominator = [&]() -> float {
                 if constexpr (drop) {
@@ -851,7 +885,15 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     hipStream_t st = (hipStream_t)stream;
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
     if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);
-    if (a.nkt <= 8) return dr ? launch_enc<8, true, true>(a, st) : launch_enc<8, false, true>(a, st);
+    if (a.nkt <= 8) {
+        // 5..8 token tiles (P = 168: six).  Unparked, a workgroup needs nkt * 5 KB + 50 KB of LDS -- 80 KB at P = 168, so TWO
+        // workgroups (sequences) share a compute unit (12 waves x 168 registers fit the register file) and run out of phase; parked
+        // it is 110 KB, one workgroup of six waves per compute unit.  STEP_ENC_PARK=1 / 0 forces either (A/B measurements).
+        const char* e = getenv("STEP_ENC_PARK");
+        const bool park = e ? e[0] == '1' : a.nkt * (4 + parked_frags<8, false>()) * TSF_FRAG + 2 * TSF_BLOCK > 80 * 1024;
+        if (!park) return dr ? launch_enc<8, true, false>(a, st) : launch_enc<8, false, false>(a, st);
+        return dr ? launch_enc<8, true, true>(a, st) : launch_enc<8, false, true>(a, st);
+    }
     if (a.nkt > 8 && a.nkt <= 11) {
         // 9..11 token tiles (P = 336): the operand copy stays in registers -- same kernel time as parking it in LDS (2.54 vs 2.55 ms at
         // C2), but 66 KB of LDS per compute unit stay free for the second stream's kernels (step 5.39 -> 5.37 ms).  STEP_ENC_PARK=1

@@ -183,6 +183,7 @@ class _StepFunction(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (B, N, Cin, Ttr, float(drop))
         ctx.held = (hist, enc["last"], g, gsaved, esaved, wsaved)
+        ctx.esaved_version = esaved._version
         ctx.mark_non_differentiable(adj_knn)
         model._last = {"sampled_adj": adj, "sim": sim, "hidden_bf16": enc["hidden_bf16"], "saved_gwnet": wsaved, "g": g,
                        "hidden_last": enc["last"]}
@@ -205,7 +206,6 @@ class _StepFunction(torch.autograd.Function):
         flat[:fo].zero_()
         if fo + fn < layout["total"]:
             flat[fo + fn:].zero_()
-        FRESH = 16          # include/step_hip.h STEP_DGL_FRESH_FC_GRAD
         views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
         gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
         dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
@@ -221,65 +221,79 @@ class _StepFunction(torch.autograd.Function):
         # (a stream of their own for the pure leaves was measured and changes nothing -- 4.51 vs 4.51 ms at PEMS04, profiles/r03_ac_* -- so
         #  the library's leaf_stream stays NULL and they share "aux": one hardware queue fewer in use; STEP_LEAF_STREAM=1 turns it on)
         leaf = ctypes.c_void_p(model._side_stream(dev, "leaf").cuda_stream) if (use_aux and os.environ.get("STEP_LEAF_STREAM", "0") == "1") else None
-        L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
-               L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, leaf, st)
-        # (wwork / ework stay referenced until the auxiliary stream is joined below: its last leaves still read them)
-        ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
-        dgv = _f32(N * 100, dev)
-        dth = dtheta.contiguous().float() if dtheta is not None else None
-        L.call("step_dgl_edges_backward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(esaved), L.ptr(dth) if dth is not None else None,
-               L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), leaf if leaf is not None else aux, st)
+        joined = [False]
 
         def join_aux():
-            # the leaves the two calls above left on the auxiliary stream (parameter gradients only) must be finished before the first
-            # reader of the flat gradient buffer: the all-reduce of everything in front of fc_w, or the optimizer
+            # the leaves the two library calls below leave on the auxiliary stream (parameter gradients only) must be finished before the
+            # first reader of the flat gradient buffer: the all-reduce of everything in front of fc_w, or the optimizer
             if aux is not None:
                 torch.cuda.current_stream().wait_stream(model._side_stream(dev, "aux"))
             if leaf is not None:
                 torch.cuda.current_stream().wait_stream(model._side_stream(dev, "leaf"))
-        gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
-        fo, fn, _ = layout["items"]["dgl.fc_w"]
-        assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
-        assert layout["norm_slot"] == fo - 4
-        sh = dgl._shard
-        if sh is None:
-            L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-                   L.ptr(gwork), ctypes.byref(dg_grads), 1 | FRESH, st)
-            pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
-            L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-                   L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
-            join_aux()
-            pending += model._reduce_begin(flat[:fo])
-            model._reduce_finish(flat, pending, flat)
-        else:
-            # time slices: the gradient of g is averaged over the ranks first, every rank then back-propagates its slice; the slices
-            # meet in two small sums (BatchNorm2's 32 "dots", the 1296 raw conv2 weight-gradient sums).  The fc weight slice's
-            # gradient stays on its rank -- 98 % of the gradient bytes never enter a collective.
-            world = sh["world"]
-            model._sum_over_ranks(dgv)
-            dgv.mul_(1.0 / world)
-            dgl._slice_dirty = True          # the optimizer is about to change the slices: fc.weight / state_dict() are stale until a gather
-            sstruct = dgl.shard_struct()
-            o_dots, o_graw = L.lib().step_dgl_global_offset(N, Ttr, 10), L.lib().step_dgl_global_offset(N, Ttr, 11)
-            exchange = {1: gwork[o_dots:o_dots + 32], 3: gwork[o_graw:o_graw + 1296]}
-            for phase in (1, 3, 4):
-                L.call("step_dgl_global_backward_shard", L.ptr(dgl._series_slice), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
-                       L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase | FRESH, st)
-                if phase in exchange:
-                    model._sum_over_ranks(exchange[phase])
-            join_aux()
-            # conv1's gradients are per-slice partial sums: summed, not averaged, by the mean all-reduce below
-            views["dgl.conv1_w"].mul_(float(world))
-            views["dgl.conv1_b"].mul_(float(world))
-            # the squared norm of this rank's fc-slice gradient rides in the spare slot (x world: the reduction below takes the mean)
-            ns = layout["norm_slot"]
-            own = torch.linalg.vector_norm(flat[fo:fo + fn]).reshape(1)
-            torch.mul(own.square(), float(world), out=flat[ns:ns + 1])
-            model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
-            # the slot now holds sum_r |g_fc slice of rank r|^2 (mean of world * own_r^2): keep the other ranks' part for the clip norm
-            # (FusedAdamClip) and clear the slot, so that the flat buffer holds gradients only
-            model._other_slices_sumsq = torch.addcmul(flat[ns:ns + 1], own, own, value=-1.0)
-            flat[ns:ns + 1].zero_()
+            joined[0] = True
+        if esaved._version != ctx.esaved_version:
+            # theta is returned as a view of this buffer (forward); the edge backward reads it -- an in-place edit by user code (e.g.
+            # theta.clamp_() in a custom loss) would silently corrupt the gradients, and autograd cannot see it (ctx.held, not save_for_backward)
+            raise RuntimeError("step_amd.STEP: the returned edge probabilities (theta) were modified in place after forward(); the native "
+                               "backward reads that buffer -- use an out-of-place op (theta.clamp(...)) or theta.clone()")
+        FRESH = 16          # include/step_hip.h STEP_DGL_FRESH_FC_GRAD
+        try:
+            L.call("step_gwnet_backward", L.ptr(hist), B, N, Cin, L.ptr(last), ctypes.byref(bstruct), L.ptr(wsaved), L.ptr(wwork),
+                   L.ptr(dpred), ctypes.byref(gw_grads), L.ptr(dadj), int(drop > 0), aux, leaf, st)
+            # (wwork / ework stay referenced until the auxiliary stream is joined below: its last leaves still read them)
+            ework = _f32(L.lib().step_dgl_edges_work_floats(N), dev)
+            dgv = _f32(N * 100, dev)
+            dth = dtheta.contiguous().float() if dtheta is not None else None
+            L.call("step_dgl_edges_backward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(esaved), L.ptr(dth) if dth is not None else None,
+                   L.ptr(dadj), TEMPERATURE, L.ptr(ework), ctypes.byref(dg_grads), L.ptr(dgv), leaf if leaf is not None else aux, st)
+            gwork = _f32(L.lib().step_dgl_global_work_floats(N, Ttr, 1), dev)
+            fo, fn, _ = layout["items"]["dgl.fc_w"]
+            assert fo + fn == layout["total"] or fo + ((fn + 3) & ~3) == layout["total"]
+            assert layout["norm_slot"] == fo - 4
+            sh = dgl._shard
+            if sh is None:
+                L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                       L.ptr(gwork), ctypes.byref(dg_grads), 1 | FRESH, st)
+                pending = model._reduce_begin(flat[fo:fo + fn])          # overlaps with the conv / BatchNorm backward below
+                L.call("step_dgl_global_backward_phase", L.ptr(dgl._series_nt), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                       L.ptr(gwork), ctypes.byref(dg_grads), 2, st)
+                join_aux()
+                pending += model._reduce_begin(flat[:fo])
+                model._reduce_finish(flat, pending, flat)
+            else:
+                # time slices: the gradient of g is averaged over the ranks first, every rank then back-propagates its slice; the slices
+                # meet in two small sums (BatchNorm2's 32 "dots", the 1296 raw conv2 weight-gradient sums).  The fc weight slice's
+                # gradient stays on its rank -- 98 % of the gradient bytes never enter a collective.
+                world = sh["world"]
+                model._sum_over_ranks(dgv)
+                dgv.mul_(1.0 / world)
+                dgl._slice_dirty = True          # the optimizer is about to change the slices: fc.weight / state_dict() are stale until a gather
+                sstruct = dgl.shard_struct()
+                o_dots, o_graw = L.lib().step_dgl_global_offset(N, Ttr, 10), L.lib().step_dgl_global_offset(N, Ttr, 11)
+                exchange = {1: gwork[o_dots:o_dots + 32], 3: gwork[o_graw:o_graw + 1296]}
+                for phase in (1, 3, 4):
+                    L.call("step_dgl_global_backward_shard", L.ptr(dgl._series_slice), N, Ttr, ctypes.byref(dstruct), L.ptr(gsaved), L.ptr(dgv),
+                           L.ptr(gwork), ctypes.byref(dg_grads), ctypes.byref(sstruct), phase | FRESH, st)
+                    if phase in exchange:
+                        model._sum_over_ranks(exchange[phase])
+                join_aux()
+                # conv1's gradients are per-slice partial sums: summed, not averaged, by the mean all-reduce below
+                views["dgl.conv1_w"].mul_(float(world))
+                views["dgl.conv1_b"].mul_(float(world))
+                # the squared norm of this rank's fc-slice gradient rides in the spare slot (x world: the reduction below takes the mean)
+                ns = layout["norm_slot"]
+                own = torch.linalg.vector_norm(flat[fo:fo + fn]).reshape(1)
+                torch.mul(own.square(), float(world), out=flat[ns:ns + 1])
+                model._reduce_finish(flat, model._reduce_begin(flat[:fo]), flat[:fo])
+                # the slot now holds sum_r |g_fc slice of rank r|^2 (mean of world * own_r^2): keep the other ranks' part for the clip norm
+                # (FusedAdamClip) and clear the slot, so that the flat buffer holds gradients only
+                model._other_slices_sumsq = torch.addcmul(flat[ns:ns + 1], own, own, value=-1.0)
+                flat[ns:ns + 1].zero_()
+        finally:
+            # also on the error path: the unjoined leaves still read wwork / ework / wsaved / g / hidden_last and write `flat`; once this frame's
+            # locals go back to the caching allocator, main-stream work must be ordered behind them (mirrors the forward's guard)
+            if not joined[0]:
+                join_aux()
         del wwork, ework
         model._flat_grad = flat
         model._backward_count = getattr(model, "_backward_count", 0) + 1
@@ -317,8 +331,10 @@ class STEP(nn.Module):
         self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
         self._seed_ctr = 0
         self._process_group = None
+        self._min_world = 1                 # collectives are issued for groups larger than this (0: also for a single rank)
         self._layout = None
         self._zg_params = None
+        self._zg_key = None
         self._last = {}
         self._flat_param = None
         self._flat_grad = None
@@ -428,6 +444,15 @@ class STEP(nn.Module):
         rec["key"], rec["training"] = self._batch_key(long_history_data), mode
         self._prefetched = rec
 
+    def cancel_prefetch(self):
+        """Drop a frozen branch queued by ``prefetch()`` that will not be consumed.  The prefetch stream's encoder reads the TSFormer's
+        keep-mask pool, which the next encoder launch refills: the CURRENT stream is made to wait for the queued branch first, so no
+        later launch -- a forward() of another batch, a direct ``model.tsformer(...)`` / ``DiscreteGraphLearning.forward`` call -- can
+        refill the pool under a running kernel (that would make the dropout masks irreproducible)."""
+        rec, self._prefetched = self._prefetched, None
+        if rec is not None and rec.get("done") is not None:
+            torch.cuda.current_stream().wait_event(rec["done"])
+
     def _take_prefetched(self, long_hist):
         rec, self._prefetched = self._prefetched, None
         if rec is None:
@@ -485,13 +510,18 @@ class STEP(nn.Module):
         self._flat_param = flat
         return flat
 
-    def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False):
+    def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False, single_rank_collectives=False):
         """Average the flat gradient buffer over ranks inside backward (RCCL all-reduce of the flat buffer, in two asynchronous
         chunks; replaces DDP's bucketed reducer -- do not also wrap the module in DistributedDataParallel).  Like DDP's
-        constructor, it first broadcasts rank 0's parameters and buffers (``sync_module_states``)."""
+        constructor, it first broadcasts rank 0's parameters and buffers (``sync_module_states``).
+        ``single_rank_collectives``: issue every collective of the data-parallel path even in a group of ONE rank (the parameter
+        broadcast, the chunked asynchronous all-reduce, the time-sliced graph learner's small sums with a single slice), so that
+        the collective library, its stream and the event ordering against the step's three streams run on a one-GPU box
+        (`bench.py --gpus 1 --force-process-group`); arithmetically a no-op."""
         import torch.distributed as dist
         self._process_group = process_group if process_group is not None else dist.group.WORLD
-        if sync_module_states and dist.get_world_size(self._process_group) > 1:
+        self._min_world = 0 if single_rank_collectives else 1
+        if sync_module_states and dist.get_world_size(self._process_group) > self._min_world:
             # what DistributedDataParallel does when it wraps a module: every rank starts from rank 0's parameters and buffers
             src = dist.get_global_rank(self._process_group, 0)
             with torch.no_grad():
@@ -503,7 +533,7 @@ class STEP(nn.Module):
                         c = d.contiguous()
                         dist.broadcast(c, src, group=self._process_group)
                         d.copy_(c)
-        if shard_graph_learner and dist.get_world_size(self._process_group) > 1:
+        if shard_graph_learner and dist.get_world_size(self._process_group) > self._min_world:
             # every rank keeps one time slice of the graph learner's global branch and of fc.weight
             if self.matmul_precision != "bf16":
                 raise ValueError("shard_graph_learner needs matmul_precision = 'bf16' (the sliced backward uses the fused BatchNorm backward)")
@@ -518,14 +548,14 @@ class STEP(nn.Module):
         if self._process_group is None:
             return []
         import torch.distributed as dist
-        if dist.get_world_size(self._process_group) <= 1 or chunk.numel() == 0:
+        if dist.get_world_size(self._process_group) <= self._min_world or chunk.numel() == 0:
             return []
         return [dist.all_reduce(chunk, group=self._process_group, async_op=True)]
 
     def _sum_over_ranks(self, t):
         """in-place sum of a small device tensor over the data-parallel group, ordered on the current stream"""
         import torch.distributed as dist
-        if self._process_group is not None and dist.get_world_size(self._process_group) > 1:
+        if self._process_group is not None and dist.get_world_size(self._process_group) > self._min_world:
             timed = self._reduce_wait_ms is not None and t.is_cuda
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -580,9 +610,14 @@ class STEP(nn.Module):
         if set_to_none:
             # nn.Module.zero_grad walks the module tree for its parameters (0.3 ms of host time per step); the Parameter objects
             # of the tree do not change between steps, so the list is kept (dropped by _apply / load_state_dict / time slicing)
+            # and re-checked against the identity of the sub-modules and of the graph learner's slice parameter, which is what
+            # shard_time_slices() / a replaced sub-module change without going through _apply / load_state_dict)
+            dgl = self.discrete_graph_learning
+            key = (id(self.tsformer), id(self.backend), id(dgl), id(getattr(dgl, "fc_weight_slice", None)), len(self._parameters))
             ps = self._zg_params
-            if ps is None:
+            if ps is None or self._zg_key != key:
                 ps = self._zg_params = list(self.parameters())
+                self._zg_key = key
             for q in ps:
                 q.grad = None
         else:

@@ -299,6 +299,24 @@ def test_host_side_caches_follow_the_module():
     assert set(model.backend.trainable_native()) < set(nt2)
     # streams are per process and device, not per model (hardware queues are few)
     assert step_mod._STREAMS is not None and isinstance(step_mod._STREAMS, dict)
+    # parameters that appear WITHOUT _apply / load_state_dict: a direct shard_time_slices() creates the slice
+    # parameter, a replaced sub-module brings new ones -- zero_grad must clear their gradients too
+    model.zero_grad()
+    model.discrete_graph_learning.fc_weight_slice = torch.nn.Parameter(torch.zeros(100, 16))      # what shard_time_slices() registers
+    sl = model.discrete_graph_learning.fc_weight_slice
+    sl.grad = torch.ones_like(sl)
+    model.zero_grad()
+    assert sl.grad is None
+    from step_amd import TSFormer
+    model.tsformer = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=14,
+                              mask_ratio=0.75, encoder_depth=4, decoder_depth=1, mode="forecasting")
+    q = next(model.tsformer.parameters())
+    q.grad = torch.ones_like(q)
+    model.zero_grad()
+    assert q.grad is None
+    # a prefetch record can be dropped safely (no device in this test: no record, nothing to wait for)
+    model.cancel_prefetch()
+    assert model._prefetched is None
 
 
 def test_loss_target_stride_detection():

@@ -525,3 +525,46 @@ def test_gemm_wide_store_epilogue(L, M, N, K, ta, bf16):
     ch = torch.arange(N) // period
     want = C0.double() + raw * sc.double()[ch][None, :] + mv.double()[:, None] * sh.double()[ch][None, :]
     assert rel_l2(C2.cpu(), want) < 2e-5
+
+
+@pytest.mark.parametrize("steps", [300, 3000])
+def test_timed_encoder_on_the_benchmark_checkpoint_matches_oracle(L, steps):
+    """The encoder exactly as bench.py runs it: the instantiation with dropout (DROP = true, float16 operands, P = 336) on the
+    checkpoint `bench.native_checkpoint` makes -- `steps` native masked-pre-training steps of tools/pretrain_checkpoint.py on the
+    synthetic PEMS04 series (300 = the default of `bench.py --pretrain-steps`; 3000 = ten times further from the initialisation)
+    -- on real windows of that series, against the oracle replaying the same keep masks.  SURVEY 8c's bound for the 16-bit path:
+    hidden rel-L2 <= 1e-2.  Prints how many softmax units left the fixed-shift schedule (the kernel's data-dependent slow path)
+    and how sharp the attention of the checkpoint is."""
+    import bench as Bn
+    from step_amd import tsformer_pack as TP
+    from tests import enc_dropout_host as DH
+    from tools.pretrain_checkpoint import pretrain, attention_sharpness
+    cfg = Bn.CONFIGS["STEP_PEMS04"]
+    N, Lh = cfg["N"], cfg["L"]
+    P, S = Lh // 12, 4
+    data = Bn.synth_series(cfg["T_all"], N)
+    sd, losses = pretrain(data, Lh, steps=steps, batch=6, device="cuda", matmul="bf16", seed=0)       # = bench.native_checkpoint
+    p = {"tsformer." + k: v for k, v in sd.items()}
+    rng = np.random.default_rng(steps)
+    ts, ns = rng.integers(Lh, cfg["T_all"] - 12, size=S), rng.integers(0, N, size=S)
+    x = torch.from_numpy(np.stack([data[t - Lh:t, n, 0] for t, n in zip(ts, ns)]).astype(np.float32))      # [S, L]
+    packed = TP.pack_tsformer({k: v for k, v in sd.items()}, P, operand="f16")
+    keep, seed = 0.9, 0xB16B00B5 + steps
+    pool = _host_pool(1 << 16, keep, 11)
+    masks = _masks_to_torch(DH.encoder_masks(pool, seed, S, P))
+    xo = x.T.contiguous()[None]                                                                            # [1, L, S]
+    want = O.tsformer_encode(xo, p, drop=masks, keep=keep).reshape(S, P, 96)
+    clean = O.tsformer_encode(xo, p).reshape(S, P, 96)
+    cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+    h1, _, _, _ = _encode(L, x.cuda(), packed, drop=1.0 - keep, seed=seed, f16=1, pool=torch.from_numpy(pool.view(np.int64)).cuda(), fallback=cnt)
+    slow1 = int(cnt.sum().item())
+    cnt.zero_()
+    h0, _, _, _ = _encode(L, x.cuda(), packed, f16=1, fallback=cnt)
+    slow0 = int(cnt.sum().item())
+    e1, e0 = rel_l2(h1.cpu(), want), rel_l2(h0.cpu(), clean)
+    sharp = attention_sharpness(sd, x)
+    print(f"checkpoint of {steps} pre-training steps (masked MAE {losses[0]:.1f} -> {losses[-1]:.1f}; mean top attention probability per layer "
+          f"{[round(v, 4) for v in sharp]}, uniform = {1.0 / P:.4f}): DROP=true kernel vs oracle with the same masks {e1:.3e}, dropout off {e0:.3e}; "
+          f"softmax units on the re-shifting path {slow1} (dropout on) / {slow0} (off) of {S * 4 * 4 * 11}")
+    assert torch.isfinite(h1).all()
+    assert e1 < 1e-2 and e0 < 1e-2

@@ -40,12 +40,20 @@ static std::vector<char> slurp(const char* path) {
 
 struct Lib {
     std::string tag;
+    std::string env_key, env_val;            // optional `tag=path@KEY=VAL`: KEY is set to VAL around every launch of this entry (the library reads its knobs per launch)
     int abi;
     enc4_fn e4; enc3_fn e3; enc5_fn e5; fill_fn fill; err_fn err;
     unsigned int* counter = nullptr;         // ABI 5: device counter of softmax units on the re-shifting (slow) path
     // unified call: flags bit0 f16, bit1 always-reshift (ABI 4 only)
     int run(const float* x, int S, int L, const void* pk, long pkb, int flags, uint16_t* h16, float* h32, float* last, float* sqn, float p,
             const uint64_t* pool, long words, uint64_t seed, hipStream_t st) const {
+        if (!env_key.empty()) setenv(env_key.c_str(), env_val.c_str(), 1);
+        const int rc = run_(x, S, L, pk, pkb, flags, h16, h32, last, sqn, p, pool, words, seed, st);
+        if (!env_key.empty()) unsetenv(env_key.c_str());
+        return rc;
+    }
+    int run_(const float* x, int S, int L, const void* pk, long pkb, int flags, uint16_t* h16, float* h32, float* last, float* sqn, float p,
+             const uint64_t* pool, long words, uint64_t seed, hipStream_t st) const {
         if (abi >= 5) return e5(x, S, L, pk, pkb, 4, flags, h16, h32, last, sqn, p, pool, words, seed, counter, st);
         if (abi >= 4) return e4(x, S, L, pk, pkb, 4, flags, h16, h32, last, sqn, p, pool, words, seed, st);
         return e3(x, S, L, pk, pkb, 4, flags & 1, h16, h32, last, sqn, p, seed, st);
@@ -68,7 +76,16 @@ int main(int argc, char** argv) {
         size_t eq = a.find('=');
         if (eq == std::string::npos) { printf("argument %s is not tag=path\n", argv[i]); return 1; }
         Lib l; l.tag = a.substr(0, eq);
-        void* h = dlopen(a.substr(eq + 1).c_str(), RTLD_NOW | RTLD_LOCAL);
+        std::string path = a.substr(eq + 1);
+        const size_t at = path.find('@');
+        if (at != std::string::npos) {
+            const std::string kv = path.substr(at + 1);
+            path = path.substr(0, at);
+            const size_t e2 = kv.find('=');
+            if (e2 == std::string::npos) { printf("argument %s: expected tag=path@KEY=VAL\n", argv[i]); return 1; }
+            l.env_key = kv.substr(0, e2); l.env_val = kv.substr(e2 + 1);
+        }
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
         abi_fn abi = (abi_fn)dlsym(h, "step_abi_version");
         l.err = (err_fn)dlsym(h, "step_last_error");
@@ -81,13 +98,18 @@ int main(int argc, char** argv) {
         libs.push_back(l);
     }
     if (libs.empty()) { printf("no libraries\n"); return 1; }
-    const int P = 336, L = 12 * P, S0 = 12, S = 2456;
-    std::vector<char> series = slurp("series_small.bin"), want = slurp("want_hidden.bin"), wantd = slurp("want_hidden_drop.bin");
+    // ENC_AB_P / ENC_AB_S: tokens per sequence and sequences of the timed launch (defaults: the PEMS04 launch, 336 x 2456; PEMS07 is
+    // 168 x 3532, the 4096-node graph 168 x 4096); the fixtures of another P carry the suffix _p<P> (tools/enc_ab_prepare.py)
+    const int P = getenv("ENC_AB_P") ? atoi(getenv("ENC_AB_P")) : 336, L = 12 * P, S0 = 12;
+    const int S = getenv("ENC_AB_S") ? atoi(getenv("ENC_AB_S")) : 2456;
+    const std::string sfx = P == 336 ? "" : "_p" + std::to_string(P);
+    auto fx = [&](const char* stem) { return slurp((std::string(stem) + sfx + ".bin").c_str()); };
+    std::vector<char> series = fx("series_small"), want = fx("want_hidden"), wantd = fx("want_hidden_drop");
     std::vector<char> poolf = slurp("drop_pool.bin"), seedf = slurp("drop_seed.bin");
     // [2]: float16 fragments of the UNSCALED initialisation (bench.py's model), used for timing only: the softmax schedule of
     // the kernel is data dependent (heads whose scores outrun the fixed shift are redone), and the sharpened weights of
     // packs [0] / [1] make a whole layer take that path
-    std::vector<char> pack[3] = {slurp("pack_bf16.bin"), slurp("pack_f16.bin"), slurp("pack_f16_plain.bin")};
+    std::vector<char> pack[3] = {fx("pack_bf16"), fx("pack_f16"), fx("pack_f16_plain")};
     const long pool_words = (long)poolf.size() / 8;
     uint64_t drop_seed; memcpy(&drop_seed, seedf.data(), 8);
     hipStream_t st;
@@ -200,7 +222,7 @@ int main(int argc, char** argv) {
             HIPCK(hipMemcpy(hb.data(), d_hid16, hb.size() * 2, hipMemcpyDeviceToHost));
             printf("[%s] %s%s dropout %.1f: median %.3f ms, min %.3f, max %.3f (%zu launches, S=%d P=%d) = %.1f TFLOP/s algorithmic, %.1f %% of 2.5 PF; slow-path softmax units %u of %d\n",
                    libs[li].tag.c_str(), fl ? "f16 " : "bf16", mode >= 3 ? " bench-like data" : "", p, med, v.front(), v.back(), v.size(), S, P, flop / med / 1e9, flop / med / 1e9 / 25.0,
-                   slow[li], S * 4 * 4 * 11);
+                   slow[li], S * 4 * 4 * ((P + 31) / 32));
         }
     }
     // sanity of the last dropout-on output of the last library: LayerNorm output, mean square ~1 per feature

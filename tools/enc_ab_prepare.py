@@ -52,14 +52,30 @@ def main():
     from step_amd.step_arch.tsformer import TSFormer
     from tests import enc_dropout_host as DH
     os.makedirs(OUT, exist_ok=True)
-    P, S0 = 336, 12
+    for P in (336, 168):
+        fixtures(O, TP, TSFormer, DH, P)
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-o", os.path.join(OUT, "enc_ab"), os.path.join(ROOT, "tools", "enc_ab.cpp"), "-ldl"])
+    for spec in sys.argv[1:] or ["default"]:
+        if "@" in spec:
+            name, rev = spec.split("@", 1)
+            print(build_variant(name, [], rev))
+        else:
+            name, _, d = spec.partition(":")
+            print(build_variant(name, [x for x in d.split(",") if x]))
+    print(sorted(os.listdir(OUT)))
+
+
+def fixtures(O, TP, TSFormer, DH, P):
+    """weights, series, oracle outputs for P tokens per sequence; files of P != 336 carry the suffix _p<P> (ENC_AB_P of the harness)"""
+    S0 = 12
+    sfx = "" if P == 336 else f"_p{P}"
     L = 12 * P
     torch.manual_seed(0)
     m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=P, mask_ratio=0.75,
                  encoder_depth=4, decoder_depth=1, mode="forecasting")
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     # the untouched initialisation (what bench.py's random-init model holds): timing only, see enc_ab.cpp
-    TP.pack_tsformer(sd, P, operand="f16").numpy().tofile(os.path.join(OUT, "pack_f16_plain.bin"))
+    TP.pack_tsformer(sd, P, operand="f16").numpy().tofile(os.path.join(OUT, f"pack_f16_plain{sfx}.bin"))
     g = torch.Generator().manual_seed(1)
     for k, v in sd.items():                       # sharper attention than the 0.02-std initialisation, no exactly-zero biases
         if v.ndim >= 2 and "position" not in k and "mask_token" not in k:
@@ -81,22 +97,13 @@ def main():
     tt = torch.from_numpy
     md = {"pos": tt(masks["pos"]), "layers": [{k: tt(v) for k, v in Lr.items()} for Lr in masks["layers"]]}
     wantd = O.tsformer_encode(x, p, drop=md, keep=keep).reshape(S0, P, 96).numpy().astype(np.float32)
-    series.tofile(os.path.join(OUT, "series_small.bin"))
-    want.tofile(os.path.join(OUT, "want_hidden.bin"))
-    wantd.tofile(os.path.join(OUT, "want_hidden_drop.bin"))
+    series.tofile(os.path.join(OUT, f"series_small{sfx}.bin"))
+    want.tofile(os.path.join(OUT, f"want_hidden{sfx}.bin"))
+    wantd.tofile(os.path.join(OUT, f"want_hidden_drop{sfx}.bin"))
     pool.tofile(os.path.join(OUT, "drop_pool.bin"))
     np.array([seed], dtype=np.uint64).tofile(os.path.join(OUT, "drop_seed.bin"))
     for op in ("bf16", "f16"):
-        TP.pack_tsformer(sd, P, operand=op).numpy().tofile(os.path.join(OUT, f"pack_{op}.bin"))
-    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-o", os.path.join(OUT, "enc_ab"), os.path.join(ROOT, "tools", "enc_ab.cpp"), "-ldl"])
-    for spec in sys.argv[1:] or ["default"]:
-        if "@" in spec:
-            name, rev = spec.split("@", 1)
-            print(build_variant(name, [], rev))
-        else:
-            name, _, d = spec.partition(":")
-            print(build_variant(name, [x for x in d.split(",") if x]))
-    print(sorted(os.listdir(OUT)))
+        TP.pack_tsformer(sd, P, operand=op).numpy().tofile(os.path.join(OUT, f"pack_{op}{sfx}.bin"))
 
 
 if __name__ == "__main__":
