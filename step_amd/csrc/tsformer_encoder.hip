@@ -59,8 +59,8 @@ namespace {
 #define TSF_MASK_EARLY 1    // fetch a tile's keep-mask words at the top of its step instead of next to their use
 #endif
 
-#ifndef TSF_INTERLEAVE
-#define TSF_INTERLEAVE 0    // 1: fast attention step issues score(k-step 0), P V (half 0), score(k-step 1), P V (half 1) with each half's selects / packs in between
+#ifndef TSF_TAIL_GROUPS
+#define TSF_TAIL_GROUPS 1   // 0: the last key tile runs the full step even when most of its keys are padding (A/B builds)
 #endif
 #ifndef TSF_RING12
 #define TSF_RING12 4        // ring slots of the 9..12 tile variant without the parked operand copy (2: one barrier per block, A/B builds)
@@ -102,13 +102,17 @@ __device__ __forceinline__ typename Opnd<F16>::v8 relu_packed(typename Opnd<F16>
 
 struct Yes { static constexpr bool value = true; };
 struct No { static constexpr bool value = false; };
+struct G1 { static constexpr int value = 1; };
+struct G2 { static constexpr int value = 2; };
+struct G3 { static constexpr int value = 3; };
 
 // waves per SIMD the register allocation has to admit: the unparked 5..8 tile variant is launched with <= 6-7 waves per workgroup and
 // wants two workgroups per compute unit (12-14 waves = 3-4 per SIMD -> 168 registers, like the twelve-wave variant gets by itself)
 template <int MAXW, bool PARK>
 constexpr int min_waves_per_simd() { return (MAXW == 8 && !PARK) ? 3 : 1; }
 
-template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE>
+// TG: groups of 8 keys that exist in the LAST key tile when the launch is known to have that many (P = 168: 1, P = 336: 2); 4 = any P
+template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE, int TG>
 __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
@@ -455,6 +459,10 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // (behind the exponentials); the keep-mask words are loop carried, the next tile's being fetched into the same
             // scalar registers right after this tile's selects have consumed them -- nothing waits on that counter again
             // before the next step's exponentials are done.
+            // (Measured and not kept, round 4: issuing score(k-step 0), P V (half 0), score(k-step 1), P V (half 1) with each half's selects and
+            //  packs in between -- no matrix instruction right behind the one it depends on -- costs 20 spilled registers in the unparked
+            //  variants and is 1 % SLOWER in the parked ones: 1.922 vs 1.905 ms at P = 336, 1.648 vs 1.652 at P = 168,
+            //  profiles/r04_a_enc_ab_*.log.)
             auto fast_step = [&](f32x16& cur, f32x16& nxt, int kt, TileMask& tm, auto has_next) {
                 constexpr bool NEXT = decltype(has_next)::value;
                 const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
@@ -467,31 +475,6 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 exp_tile(cur, cur);
                 if constexpr (drop) row_sums(cur);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (TSF_INTERLEAVE != 0) {
-                    // the two dependent pairs (score k-steps of the NEXT tile, the two halves of this tile's P V product) alternate, each
-                    // half's selects and packs in between: no matrix instruction is issued right behind the one it depends on
-                    if constexpr (NEXT) nxt = mfma16<F16>(k0, qb[0], zero);
-                    if constexpr (drop) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
-                    }
-                    const bf16x8 p0 = pack_half<false>(cur, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    o = mfma16<false>(v0, p0, o);
-                    if constexpr (drop) {
-#pragma unroll
-                        for (int i = 8; i < 16; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (NEXT) nxt = mfma16<F16>(k1, qb[1], nxt);
-                    const bf16x8 p1 = pack_half<false>(cur, 1);
-                    if constexpr (drop && NEXT) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        tm = load_mask(kt + 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    o = mfma16<false>(v1, p1, o);
-                } else {
                 if constexpr (NEXT) {
                     nxt = mfma16<F16>(k0, qb[0], zero);
                     nxt = mfma16<F16>(k1, qb[1], nxt);
@@ -508,7 +491,36 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 const bf16x8 p0 = pack_half<false>(cur, 0), p1 = pack_half<false>(cur, 1);
                 o = mfma16<false>(v0, p0, o);
                 o = mfma16<false>(v1, p1, o);
+            };
+            // The LAST key tile when only its first 8 * NG keys exist (P = 168: 8 of 32, NG = 1; P = 336: 16, NG = 2).  Keys 8 g .. 8 g + 7 are
+            // accumulator registers 4 g .. 4 g + 3 of both lane halves (tsformer_layout.h), and the probability of a padded key is exactly 0
+            // (its score carries the -30000 of slot 26), so their exponentials, row sums, selects and packs -- and, from NG <= 2, the whole second
+            // k-step of the P V product -- are skipped: same bits, 3/4 (1/2) of this tile's vector work less.
+            auto fast_last = [&](f32x16& cur, int kt, TileMask& tm, auto groups) {
+                constexpr int NG = decltype(groups)::value;
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane);
+                bf16x8 v1;
+                if constexpr (NG > 2) v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cur[i] = i < 4 * NG ? ((TSF_ABLATE & 1) ? cur[i] : __builtin_amdgcn_exp2f(cur[i])) : 0.f;
+                if constexpr (drop) {
+#pragma unroll
+                    for (int i = 0; i < 4 * NG; i += 4) {
+                        lsum2 += f32x2{cur[i], cur[i + 1]};
+                        lsum2b += f32x2{cur[i + 2], cur[i + 3]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4 * NG; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
                 }
+                o = mfma16<false>(v0, pack_half<false>(cur, 0), o);
+                if constexpr (NG > 2) o = mfma16<false>(v1, pack_half<false>(cur, 1), o);
+            };
+            auto last_step = [&](f32x16& cur, f32x16& other, int kt, TileMask& tm) {
+                if constexpr (TG == 1) fast_last(cur, kt, tm, G1{});
+                else if constexpr (TG == 2) fast_last(cur, kt, tm, G2{});
+                else if constexpr (TG == 3) fast_last(cur, kt, tm, G3{});
+                else fast_step(cur, other, kt, tm, No{});
             };
             auto denominator = [&]() -> float {
                 if constexpr (drop) {
@@ -536,9 +548,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 }
                 if (kt + 1 < nkt) {
                     fast_step(sa, sb, kt, tm, Yes{});
-                    fast_step(sb, sa, kt + 1, tm, No{});
+                    last_step(sb, sa, kt + 1, tm);
                 } else {
-                    fast_step(sa, sb, kt, tm, No{});
+                    last_step(sa, sb, kt, tm);
                 }
                 den = denominator();
                 redo = __builtin_amdgcn_ballot_w64(!(den < TSF_LIMIT)) != 0;
@@ -791,20 +803,29 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
 #define TSF_PIPE 2          // attention loop schedule (A/B knob): 0 plain, 1 next tile's score MFMAs in flight during this tile's
 #endif                      // VALU work (one tile copy per iteration), 2 the same over two alternating tiles (no copies)
 
-template <int MAXW, bool DROP, bool PARK, bool F16>
-int launch_enc_t(const EncArgs& a, hipStream_t st) {
+template <int MAXW, bool DROP, bool PARK, bool F16, int TG>
+int launch_enc_tg(const EncArgs& a, hipStream_t st) {
     size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (size_t)a.nkt * parked_frags<MAXW, PARK>() * TSF_FRAG;
     // per launch, not once per process: the attribute is per device and setting it is cheap
-    hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE>,
+    hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
         return STEP_ERR_HIP;
     }
     const int grid = (TSF_PERSIST > 0 && a.S > TSF_PERSIST) ? TSF_PERSIST : a.S;
-    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE><<<grid, a.nkt * 64, lds, st>>>(a);
+    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
+}
+// The last key tile's shortcut is instantiated where the reference's configurations land: 8 keys (P = 168: METR-LA, PEMS-BAY, PEMS07) in
+// the 5..8 tile variants, 16 keys (P = 336: PEMS03 / 04 / 08) in the 9..12 tile variants; every other P runs the generic last step.
+template <int MAXW, bool DROP, bool PARK, bool F16>
+int launch_enc_t(const EncArgs& a, hipStream_t st) {
+    constexpr int TGX = !TSF_TAIL_GROUPS ? 4 : MAXW == 8 ? 1 : MAXW == 12 ? 2 : 4;
+    const int tail_keys = a.P - (a.nkt - 1) * 32;
+    if (TGX != 4 && tail_keys == 8 * TGX) return launch_enc_tg<MAXW, DROP, PARK, F16, TGX>(a, st);
+    return launch_enc_tg<MAXW, DROP, PARK, F16, 4>(a, st);
 }
 template <int MAXW, bool DROP, bool PARK>
 int launch_enc(const EncArgs& a, hipStream_t st) {

@@ -1,80 +1,120 @@
-"""Per-kernel roofline table for config C2 (STEP_PEMS04, B=8) from a tools/prof_summary.py markdown summary.
+"""Per-kernel roofline table of one STEP config from a tools/prof_summary.py markdown summary (rocprofv3 --kernel-trace --stats of
+`bench.py --config <name>` with STEP_NO_OVERLAP=1, so that durations are the kernels' own).
 
-Algorithmic bytes / FLOPs per launch are analytic (shapes of the config); durations are the rocprofv3 averages of the summary.
-usage: python tools/roofline_table.py profiles/r02_w_C2_train_step_no_overlap.md > profiles/r02_w_roofline_table.md
-(rows describe the round-2 kernels; the round-1 table profiles/r01_u_roofline_table.md was made by the round-1 version of this file)"""
+Algorithmic bytes / FLOPs per launch are analytic (shapes of the config, bench.CONFIGS); durations are the rocprofv3 averages.
+usage: python tools/roofline_table.py <summary.md> [--config STEP_PEMS04] [--json profiles/kernel_roofline.json] > table.md
+`--json` also records the rows (and the dominant kernels by time per step) under the config's name in that file, which is what
+bench.py quotes as `other_configs[*].dominant_kernels` (marked static, with the summary's path as source)."""
+import argparse
+import json
+import os
 import re
 import sys
 
-N, T, B, P, EMB = 307, 13599, 8, 336, 100
-T1, T2 = T - 9, T - 18
-K = 16 * T2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 MB = 1e6
-a1, a2 = N * 8 * T1 * 4, N * 16 * T2 * 4
-fcw = EMB * K * 4
-npar = 25.3e6
 HBM, MFMA_BF16 = 8000.0, 2500.0          # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+EMB = 100
 
-# kernel-name substring -> (label, bound, algorithmic bytes per launch or None, algorithmic FLOP per launch or None)
-a1h, a2h = a1 // 2, a2 // 2               # round 2, bf16 mode: channels-last bf16 rows
-wp = EMB * K * 2                          # the per-step bf16 fc weight copy
 
-# kernel-name substring -> (label, bound, algorithmic bytes per launch or None, algorithmic FLOP per launch or None)
-ROWS = [
-    ("tsformer_encoder_kernel", "fused TSFormer encoder (2456 sequences x 336 tokens)", "mfma", 39.6e6 + 158.4e6, B * N * P * (4 * (221184 + 384 * P) + 2304)),
-    ("gemm_fast_kernelILi128ELi128ELi1ELi1ELb0", "cosine Gram (8 x 307^2 x 32256) and DGL fc forward (bf16 rows x bf16 weight copy), averaged", "hbm/L2", (B * N * P * 96 * 2 + B * N * N * 4 + a2h + wp) / 2, (2.0 * B * N * N * P * 96 + 2.0 * N * EMB * K) / 2),
-    ("gemm_fast_kernelILi128ELi128ELi2ELi3ELb0", "DGL fc weight gradient G = dgpre^T a2 (n-contiguous bf16 loader, writes 87 MB)", "hbm", a2h + fcw, 2.0 * N * EMB * K),
-    ("fc_unpermute_kernel", "G -> fc.weight layout, BN2 affine, += into the gradient, BN2 backward sums", "hbm", 4 * fcw, None),
-    ("fc_prep_kernel", "per-step bf16 (t,c)-ordered copy of fc.weight with BN2's scale", "hbm", fcw + wp, None),
-    ("gemm_fast_kernelILi128ELi128ELi0ELi3ELb0ELb0ELb1", "DGL fc input gradient + fused BN2 backward / ReLU mask (reads a2h, writes dz2h)", "hbm", wp + 2 * a2h, 2.0 * N * EMB * K),
-    ("conv1_fwd_cl_kernel", "DGL conv1 forward (series -> a1h)", "hbm", N * T * 4 + a1h, 2.0 * N * T1 * 8 * 10),
-    ("conv2_fwd_cl_kernel", "DGL conv2 forward (a1h -> a2h)", "hbm", a1h + a2h, 2.0 * N * T2 * 16 * 80),
-    ("conv2_dgrad_cl_kernel", "DGL conv2 input gradient + fused BN1 backward (dz2h, a1h -> dz1h)", "hbm", a2h + 2 * a1h, 2.0 * N * T2 * 16 * 80),
-    ("conv2_wgrad_cl_kernel", "DGL conv2 weight-gradient sums (reads dz2h and a1h)", "hbm", a2h + a1h, 2.0 * N * T2 * 16 * 80),
-    ("conv1_wgrad_cl_kernel", "DGL conv1 weight gradient (reads dz1h and the series)", "hbm", a1h + N * T * 4, 2.0 * N * T1 * 8 * 10),
-    ("adam_clip_kernel", "fused clip + Adam (25.3 M parameters, 28 B each)", "hbm", npar * 28, None),
-    ("pack_long_history_kernel", "long history [B,L,N,3] -> [B*N, L] (reads all three channels' lines)", "hbm", B * 4032 * N * 3 * 4 + B * 4032 * N * 4, None),
-    ("gemm_fast_kernelILi64ELi64ELi1ELi2ELb0", "diffusion hop, 3 supports x 8 samples per launch (bf16 stack x f32 slots)", "latency", 24 * (N * 312 * 2 + 2 * N * 12 * 32 * 4), 2.0 * 24 * N * N * 12 * 32),
-    ("ELb0ELb1ELb0", "adjacency gradients of all layers, one segmented contraction (K = 3264, 24 x 307^2 outputs)", "mfma/L2", 24 * (2 * N * 3264 * 4 + N * N * 4), 2.0 * 24 * N * N * 3264),
-]
+def rows_of(N, T, B, P, L):
+    """kernel-name substring -> (label, bound, algorithmic bytes per launch or None, algorithmic FLOP per launch or None)"""
+    T1, T2 = T - 9, T - 18
+    K = 16 * T2
+    a1h, a2h = N * 8 * T1 * 2, N * 16 * T2 * 2           # bf16 mode: channels-last bf16 rows
+    fcw = EMB * K * 4
+    wp = EMB * K * 2                                      # the per-step bf16 fc weight copy
+    npar = 486252 + 20 * N + EMB * K + 21934 + 300        # parameters the optimizer touches
+    S = B * N
+    Np = (N + 7) // 8 * 8
+    big = N >= 2048                                       # (the hop GEMM takes 128 x 64 tiles on the large graphs, 64 x 64 otherwise)
+    hop_key = ("gemm_fast_kernelILi128ELi64ELi1ELi2ELb0", "gemm_fast_kernelILi64ELi64ELi1ELi2ELb0")
+    return [
+        ("tsformer_encoder_kernel", f"fused TSFormer encoder ({S} sequences x {P} tokens)", "mfma", S * L * 4 + S * P * 96 * 2, S * P * (4 * (221184 + 384 * P) + 2304)),
+        ("gemm_fast_kernelILi128ELi128ELi1ELi1ELb0", f"cosine Gram ({B} x {N}^2 x {P * 96}) and DGL fc forward (bf16 rows x bf16 weight copy), averaged", "hbm/L2", (S * P * 96 * 2 + B * N * N * 4 + a2h + wp) / 2, (2.0 * B * N * N * P * 96 + 2.0 * N * EMB * K) / 2),
+        ("gemm_fast_kernelILi128ELi128ELi2ELi3ELb0", "DGL fc weight gradient G = dgpre^T a2 (n-contiguous bf16 loader)", "hbm", a2h + fcw, 2.0 * N * EMB * K),
+        ("fc_unpermute_kernel", "G -> fc.weight layout, BN2 affine, stored into the gradient, BN2 backward sums", "hbm", 3 * fcw, None),
+        ("fc_prep_kernel", "per-step bf16 (t,c)-ordered copy of fc.weight with BN2's scale", "hbm", fcw + wp, None),
+        ("gemm_fast_kernelILi128ELi128ELi0ELi3ELb0ELb0ELb1", "DGL fc input gradient + fused BN2 backward / ReLU mask (reads a2h, writes dz2h)", "hbm", wp + 2 * a2h, 2.0 * N * EMB * K),
+        ("conv1_fwd_cl_kernel", "DGL conv1 forward (series -> a1h)", "hbm", N * T * 4 + a1h, 2.0 * N * T1 * 8 * 10),
+        ("conv2_fwd_cl_kernel", "DGL conv2 forward (a1h -> a2h)", "hbm", a1h + a2h, 2.0 * N * T2 * 16 * 80),
+        ("conv2_dgrad_cl_kernel", "DGL conv2 input gradient + fused BN1 backward (dz2h, a1h -> dz1h)", "hbm", a2h + 2 * a1h, 2.0 * N * T2 * 16 * 80),
+        ("conv2_wgrad_cl_kernel", "DGL conv2 weight-gradient sums (reads dz2h and a1h)", "hbm", a2h + a1h, 2.0 * N * T2 * 16 * 80),
+        ("conv1_wgrad_cl_kernel", "DGL conv1 weight gradient (reads dz1h and the series)", "hbm", a1h + N * T * 4, 2.0 * N * T1 * 8 * 10),
+        ("adam_clip_kernel", f"fused clip + Adam ({npar / 1e6:.1f} M parameters, 28 B each)", "hbm", npar * 28, None),
+        ("pack_long_history_kernel", "long history [B,L,N,3] -> [B*N, L] (reads all three channels' lines)", "hbm", B * L * N * 3 * 4 + B * L * N * 4, None),
+        (hop_key, f"diffusion hop, 3 supports x {B} samples per launch (bf16 adjacency stack x 32-channel slots; T = 12 here, it shrinks per layer)", "hbm/L2" if big else "latency", 3 * B * (N * Np * 2 + 2 * N * 12 * 32 * 4), 2.0 * 3 * B * N * N * 12 * 32),
+        ("ELb0ELb1ELb0", f"adjacency gradients of all layers, one segmented contraction (K = 3264, {3 * B} x {N}^2 outputs)", "mfma/L2", 3 * B * (2 * N * 3264 * 4 + N * N * 4), 2.0 * 3 * B * N * N * 3264),
+        ("edge_logit_kernel", f"edge MLP forward ({N}^2 edges x 100 hidden units, recomputed in the backward)", "valu", N * N * 8 + 2 * N * 100 * 4, 300.0 * N * N),
+        ("edge_bwd_row_kernel", "edge MLP backward, receiver pass", "valu", N * N * 8 + 3 * N * 100 * 4, 600.0 * N * N),
+    ]
 
 
 def main():
-    rows = {}
-    for line in open(sys.argv[1]):
+    import bench
+    ap = argparse.ArgumentParser()
+    ap.add_argument("summary")
+    ap.add_argument("--config", default="STEP_PEMS04", choices=[k for k, v in bench.CONFIGS.items() if not v.get("pretrain")])
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    cfg = bench.CONFIGS[args.config]
+    N, T, B, L = cfg["N"], cfg["T_train"], cfg["B"], cfg["L"]
+    P = L // 12
+    rows, total_ms, ndisp = {}, None, None
+    for line in open(args.summary):
         m = re.match(r"\| (\S+) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
         if m:
-            rows[m.group(1)] = (int(m.group(2)), float(m.group(4)))
-    print("# Per-kernel roofline, config C2 (STEP_PEMS04, B=8), 1x MI355X -- durations: " + sys.argv[1])
+            rows[m.group(1)] = (int(m.group(2)), float(m.group(4)), float(m.group(3)))
+        m = re.match(r"kernel dispatches: (\d+)\s+sum of kernel time: ([\d.]+) ms", line)
+        if m:
+            ndisp, total_ms = int(m.group(1)), float(m.group(2))
+    print(f"# Per-kernel roofline, config {args.config} (N={N}, P={P}, T_train={T}, B={B}), 1x MI355X -- durations: " + args.summary)
     print()
-    print("Algorithmic bytes = the tensors a launch has to read and write once (analytic, f32 unless noted); peak HBM 8 TB/s")
+    print("Algorithmic bytes = the tensors a launch has to read and write once (analytic); peak HBM 8 TB/s")
     print("(6.3 TB/s is what a streaming copy reaches on this part), dense bf16 matrix peak 2.5 PFLOP/s.")
     print()
-    print("| kernel | launches/step | avg us | algorithmic MB | GB/s | % of 8 TB/s | TFLOP/s | bound |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| kernel | launches/step | avg us | ms/step | algorithmic MB | GB/s | % of 8 TB/s | TFLOP/s | % of 2.5 PF | bound |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     steps = None
-    for key, label, bound, nbytes, flop in ROWS:
-        hit = [(k, v) for k, v in rows.items() if key in k]
+    out = []
+    for key, label, bound, nbytes, flop in rows_of(N, T, B, P, L):
+        hit = []
+        for kk in (key if isinstance(key, tuple) else (key,)):
+            hit = [(k, v) for k, v in rows.items() if kk in k]
+            if hit:
+                break
         if not hit:
             continue
-        calls, us = hit[0][1]
+        calls, us, tot = hit[0][1]
         if steps is None:
             steps = calls                                  # the encoder is launched once per step
         gbs = nbytes / us / 1e3 if nbytes else None
         tf = flop / us / 1e6 if flop else None
-        print(f"| {label} | {calls / steps:.0f} | {us:.1f} | {nbytes / MB:.0f} | {gbs:.0f} | {100 * gbs / HBM:.0f} % | "
-              f"{'' if tf is None else f'{tf:.1f}'} | {bound} |")
+        print(f"| {label} | {calls / steps:.0f} | {us:.1f} | {tot / steps:.3f} | {nbytes / MB:.0f} | {gbs:.0f} | {100 * gbs / HBM:.0f} % | "
+              f"{'' if tf is None else f'{tf:.1f}'} | {'' if tf is None else f'{100 * tf / MFMA_BF16:.1f} %'} | {bound} |")
+        out.append({"kernel": hit[0][0][:80], "what": label, "bound": bound, "launches_per_step": calls / steps, "avg_us": us, "ms_per_step": tot / steps,
+                    "algorithmic_bytes_per_launch": nbytes, "algorithmic_flop_per_launch": flop, "GBps": gbs, "frac_of_hbm_peak": gbs / HBM if gbs else None,
+                    "TFLOPps": tf, "frac_of_mfma_peak": tf / MFMA_BF16 if tf else None})
+    if total_ms is not None and steps:
+        print()
+        print(f"Sum of kernel time per step (streams not overlapping): {total_ms / steps:.3f} ms in {ndisp / steps:.0f} dispatches.")
     # measured HBM traffic of the dominant kernel (PMC passes of tools/pmc_enc_ab.sh), next to its algorithmic bytes
-    import json
-    import os
-    pmc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "encoder_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "encoder_pmc.json")
     if os.path.exists(pmc):
-        ent = json.load(open(pmc)).get("STEP_PEMS04:B8")
+        ent = json.load(open(pmc)).get(f"{args.config}:B{B}")
         if ent:
             print()
             print(f"Encoder, measured HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, `profiles/encoder_pmc.json`): "
-                  f"{ent['read_bytes'] / MB:.0f} MB read + {ent['write_bytes'] / MB:.0f} MB written, against 40 MB of input and 158 MB of "
-                  f"bf16 hidden states that have to move.")
+                  f"{ent['read_bytes'] / MB:.0f} MB read + {ent['write_bytes'] / MB:.0f} MB written, against {B * N * L * 4 / MB:.0f} MB of input and "
+                  f"{B * N * P * 96 * 2 / MB:.0f} MB of bf16 hidden states that have to move.")
+    if args.json:
+        db = json.load(open(args.json)) if os.path.exists(args.json) else {}
+        out.sort(key=lambda r: -r["ms_per_step"])
+        db[args.config] = {"source": os.path.relpath(os.path.abspath(args.summary), ROOT), "kernel_ms_per_step": total_ms / steps if total_ms and steps else None,
+                           "dispatches_per_step": ndisp / steps if ndisp and steps else None, "kernels": out}
+        with open(args.json, "w") as f:
+            json.dump(db, f, indent=1)
 
 
 if __name__ == "__main__":
