@@ -179,23 +179,27 @@ def pmc_child(args):
     torch.cuda.synchronize()
 
 
-def cpu_baseline(cfg, data, seed=0):
+def cpu_baseline(cfg, data, seed=0, warm=2, timed=5, two_threads=True):
     """The CPU oracle (restatement of the reference algorithm, kind "port") timed on this host's cores on a bounded sample of
     the same workload: full training steps (forward + step_loss + backward + clip_grad_norm_ + Adam) of ONE window each --
-    two warm-up and five timed steps on all cores (median reported), then one step with two threads, the thread count the
-    reference ships with (step/run.py:10 torch.set_num_threads(2)).  The reference itself cannot run on the GPU box
-    (no /root/reference there); its own CPU timing, taken in the build container, is profiles/r02_cpu_reference_baseline.json."""
+    `warm` warm-up and `timed` timed steps on all cores (median reported), then (headline config) one step with two threads, the thread
+    count the reference ships with (step/run.py:10 torch.set_num_threads(2)).  The reference itself cannot run on the GPU box
+    (no /root/reference there); its own CPU timing, taken in the build container, is profiles/r02_cpu_reference_baseline.json.
+    On graphs of >= 2048 nodes the oracle evaluates the edge MLP in receiver-row blocks (the reference's formulation does not exist
+    there: 2 x 275 GB of one-hot matrices at N = 4096, discrete_graph_learning.py:88-89) -- same arithmetic, restated path."""
     from oracle import step_oracle as O
     torch.manual_seed(seed)
     N, L, Ttr = cfg["N"], cfg["L"], cfg["T_train"]
     model = make_model(cfg, data)
     p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
     for k, v in p.items():
         if v.is_floating_point() and not k.startswith("tsformer.") and "running_" not in k:
             v.requires_grad_(True)
     train = [v for v in p.values() if v.requires_grad]
     opt = torch.optim.Adam(train, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)
     d = torch.from_numpy(data)
+    chunk = 128 if N >= 2048 else None
 
     def one_step(i):
         t = L + 17 + 301 * i
@@ -203,7 +207,7 @@ def cpu_baseline(cfg, data, seed=0):
         u = torch.rand(1, N * N, 2)
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        pred, theta, knn, coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, cfg["k"], 1, training=True)
+        pred, theta, knn, coef = O.step_forward(hist, longh[..., [0]], d[:Ttr, :, 0], p, u, cfg["k"], 1, training=True, edge_row_chunk=chunk)
         loss = O.step_loss(O.rescale(pred, 200.0, 150.0), O.rescale(fut[..., [0]], 200.0, 150.0), theta, knn, coef)
         loss.backward()
         torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 3.0)
@@ -211,16 +215,81 @@ def cpu_baseline(cfg, data, seed=0):
         return time.perf_counter() - t0
     cores = min(os.cpu_count() or 1, 32)          # torch CPU ops stop scaling (and oversubscribe) beyond a few tens of threads
     torch.set_num_threads(cores)
-    one_step(0); one_step(1)
-    ts = sorted(one_step(2 + i) for i in range(5))
-    torch.set_num_threads(2)
-    t2 = one_step(7)
+    for i in range(warm):
+        one_step(i)
+    ts = sorted(one_step(warm + i) for i in range(timed))
+    med = ts[len(ts) // 2]
+    out = {"value": 1.0 / med, "unit": "windows/s", "cores": cores, "kind": "port",
+           "sample": f"full training steps (fwd+loss+bwd+clip+Adam) of 1 window of the same workload, torch CPU fp32 oracle"
+                     + (" (edge MLP in receiver-row blocks: the restated path, the reference cannot build this graph size)" if chunk else "")
+                     + f": {warm} warm-up + {timed} timed on {cores} threads ({ts[0]:.1f} .. {med:.1f} .. {ts[-1]:.1f} s, median reported)"}
+    if two_threads:
+        torch.set_num_threads(2)
+        t2 = one_step(warm + timed)
+        torch.set_num_threads(cores)
+        out["sample"] += f", 1 step on 2 threads ({t2:.1f} s)"
+        out["two_threads"] = {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}
+    return out
+
+
+def cpu_baseline_pretrain(cfg, data, seed=0, warm=1, timed=3):
+    """Config C3's CPU baseline: the oracle's masked pre-training step (tsformer_pretrain + masked MAE on rescaled values + backward +
+    clip 5.0 + Adam, reference step/TSFormer_PEMS-BAY.py:52-76) of ONE window (N sequences of L steps) on this host's cores."""
+    import random
+    from oracle import step_oracle as O
+    from step_amd import TSFormer
+    torch.manual_seed(seed)
+    random.seed(seed)
+    N, L = cfg["N"], cfg["L"]
+    m = TSFormer(**tsformer_args(L, "pre-train"))
+    p = {"tsformer." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    train = [v for v in p.values() if v.requires_grad]
+    opt = torch.optim.Adam(train, lr=0.001, weight_decay=0, eps=1.0e-8, betas=(0.9, 0.95))
+    d = torch.from_numpy(data[:, :, 0])
+    P = L // 12
+
+    def one_step(i):
+        t = L + 31 + 211 * i
+        hist = d[t - L:t][None, :, :, None]                # [1, L, N, 1]
+        idx = list(range(P))
+        random.shuffle(idx)
+        nm = int(P * 0.75)
+        masked, unmasked = sorted(idx[:nm]), sorted(idx[nm:])
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        recon, label = O.tsformer_pretrain(hist, p, unmasked, masked)
+        loss = O.masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([q for q in train if q.grad is not None], 5.0)
+        opt.step()
+        return time.perf_counter() - t0
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    for i in range(warm):
+        one_step(i)
+    ts = sorted(one_step(warm + i) for i in range(timed))
     med = ts[len(ts) // 2]
     return {"value": 1.0 / med, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"full training steps (fwd+loss+bwd+clip+Adam) of 1 window of the same workload, torch CPU fp32 oracle: 2 warm-up + 5 timed "
-                      f"on {cores} threads ({ts[0]:.1f} .. {med:.1f} .. {ts[-1]:.1f} s, median reported), 1 step on 2 threads ({t2:.1f} s)",
-            "two_threads": {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}}
+            "sample": f"masked pre-training steps (fwd+loss+bwd+clip+Adam) of 1 window ({N} sequences x {L} steps), torch CPU fp32 oracle: "
+                      f"{warm} warm-up + {timed} timed on {cores} threads ({ts[0]:.2f} .. {med:.2f} .. {ts[-1]:.2f} s, median reported)"}
+
+
+def static_dominant_kernels(name, top=4):
+    """The config's heaviest kernels by time per step with their roofline fractions, from the committed rocprofv3 table of this code
+    (profiles/kernel_roofline.json, written by tools/roofline_table.py --json from a `--kernel-trace --stats` summary): static evidence,
+    not measured in this run -- the line's own live figures are `roofline` (events around the encoder) and the step time."""
+    path = os.path.join(ROOT, "profiles", "kernel_roofline.json")
+    try:
+        with open(path) as f:
+            ent = json.load(f).get(name)
+        if ent is None:
+            return None
+        ks = [{k: r[k] for k in ("what", "bound", "launches_per_step", "avg_us", "ms_per_step", "GBps", "frac_of_hbm_peak", "TFLOPps", "frac_of_mfma_peak")}
+              for r in ent["kernels"][:top]]
+        return {"static": True, "source": ent["source"], "kernel_ms_per_step_no_overlap": ent["kernel_ms_per_step"],
+                "dispatches_per_step": ent["dispatches_per_step"], "kernels": ks}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def average_grads(model, params, world):
@@ -653,6 +722,8 @@ def main():
                     r = pretrain_run(args, c2, world, rank, dev, 5, 15)
                     others[name] = {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": 15,
                                     "whole_step_frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"], "workload": r["workload"]}
+                    if not args.no_cpu_baseline:
+                        others[name]["cpu_baseline"] = cpu_baseline_pretrain(c2, synth_series(c2["T_all"], c2["N"]))
                 else:
                     ck2 = None
                     if args.pretrain_steps > 0:
@@ -666,7 +737,23 @@ def main():
                                     "whole_step_tflops": fl / (r["ms_per_step"] * 1e-3) / 1e12,
                                     "whole_step_frac_of_mfma_peak": fl / (r["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS,
                                     "workload": f"{name}: N={c2['N']}, L={c2['L']}, batch {c2['B']}/GPU, full train step, natively pre-trained TSFormer"}
+                    efl = encoder_flops(c2, c2["B"])
+                    others[name]["roofline"] = {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": efl / (r["enc_ms"] * 1e-3) / 1e12,
+                                                "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": efl / (r["enc_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS,
+                                                "ms_per_launch": r["enc_ms"], "algorithmic_flop_per_launch": efl,
+                                                "traffic": static_pmc_traffic(name, c2["B"]),
+                                                "note": "events around the encoder on its launch stream inside the timed steps (it shares the GPU with "
+                                                        "the second stream's kernels there)"}
+                    dom = static_dominant_kernels(name)
+                    if dom is not None:
+                        others[name]["dominant_kernels"] = dom
+                    data2 = b2.data
                     b2.close()
+                    if not args.no_cpu_baseline:
+                        # one timed oracle step (plus a warm-up below 2048 nodes): ~10-40 s on 32 threads
+                        big = c2["N"] >= 2048
+                        others[name]["cpu_baseline"] = cpu_baseline(c2, data2, warm=0 if big else 1, timed=1, two_threads=False)
+                    del data2
             except Exception as ex:          # noqa: BLE001 -- a failing extra must not take the headline line with it
                 others[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0:
