@@ -728,8 +728,6 @@ __global__ void adj_ktab_kernel(AdjOffsets o, int N, GemmKSeg* __restrict__ tab)
     tab[s * ADJ_NSEG + j] = g;
 }
 
-#include "gwnet_slice.h"
-
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // ---------------------------------------------------------------------------- buffer carving
@@ -789,7 +787,6 @@ struct Work {
     // xcat / dpre / dh: per-layer copies of what the weight-gradient GEMMs read -- those GEMMs are leaves of the backward and run on
     // the auxiliary stream while the data-gradient chain goes on; dcat: one gcn-buffer gradient per layer (all needed at the end)
     float *xcat[NL], *bsum, *y7, *m7;      // y7 / m7: output and dropout mask of the last layer's (dead) gcn, only for its BatchNorm statistics
-    uint16_t* sfrags;          // [8 layers][SL_FRAGS_PER_LAYER][64 lanes][8] bf16 weight fragments of the slice-resident gcn kernels (gwnet_slice.h)
     float *dcat[NL - 1], *dpre[NL], *dh[NL - 1], *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
     GemmKSeg* ktab;
     float *d_e1, *d_xh, *d_h2, *d_h1;
@@ -808,7 +805,6 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.dbcat = cv.take(NL * 64);
     w.dwskip = cv.take(CS * CS);
     w.acc64 = (double*)cv.take(2L * NL * NCOPY * 64);      // 7 live BatchNorms + the dead bn.7 (only with STEP_GWNET_DEAD_BN7)
-    w.sfrags = (uint16_t*)cv.take((long)NL * SL_FRAGS_PER_LAYER * 64 * 8 / 2);
     for (int i = 0; i < NL; ++i) w.xcat[i] = backward ? cv.take(BN * TOUT[i] * 64) : nullptr;
     w.bsum = cv.take(CS);
     w.y7 = cv.take(BN * TOUT[NL - 1] * C);
@@ -902,39 +898,10 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
             bn.gamma = p->bn_w[i - 1]; bn.beta = p->bn_b[i - 1]; bn.rm = p->bn_rm[i - 1]; bn.rv = p->bn_rv[i - 1];
             bn.stat = S.bnstat[i - 1]; bn.sums = W.acc64 + (long)(i - 1) * NCOPY * 64;
         }
-        const bool has_gcn = !(i == NL - 1 && !(dead_bn7 && training));
-        if (BF16 && has_gcn && slice_path_ok(N)) {
-            // the whole layer as ONE launch, one workgroup per (b, t) slice (gwnet_slice.h)
-            const bool dead = i == NL - 1;
-            SliceFwdArgs a;
-            a.src = i == 0 ? S.x0 : S.y[i - 1]; a.bn = bn;
-            a.B = B; a.N = N; a.Tin = Tin; a.Tout = Tout; a.dil = dil; a.layer = i;
-            a.frags = W.sfrags + (long)i * SL_FRAGS_PER_LAYER * 64 * 8;
-            a.bcat = W.bcat + i * 64; a.mix_bias = p->gconv_b[i]; a.PT16 = S.PT16;
-            a.tf = S.tf[i]; a.sg = S.sg[i]; a.cat = S.cat[i]; a.zlast = S.zlast;
-            a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
-            a.mask = dead ? W.m7 : S.mask[i]; a.y = dead ? W.y7 : S.y[i]; a.sums = W.acc64 + (long)i * NCOPY * 64;
-            const size_t lds = slice_lds_bytes(N, 4, true);
-            const int threads = slice_waves(N) * 64;
-            if (slice_tpw(N) == 1) {
-                (void)hipFuncSetAttribute((const void*)gcn_fwd_slice_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                gcn_fwd_slice_kernel<1><<<B * Tout, threads, lds, st>>>(a);
-            } else {
-                (void)hipFuncSetAttribute((const void*)gcn_fwd_slice_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                gcn_fwd_slice_kernel<2><<<B * Tout, threads, lds, st>>>(a);
-            }
-            STEP_LAUNCH_CHECK("gcn_fwd_slice");
-            if (dead) {
-                const BnFwd b7 = {p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], 1, momentum, S.bnstat[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
-                bn_stats_only_kernel<<<1, 64, 0, st>>>(b7);
-                STEP_LAUNCH_CHECK("bn7_stats");
-            }
-            continue;
-        }
         tcn_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(i == 0 ? S.x0 : S.y[i - 1], bn, npos, Tin, Tout, dil, W.wcat + i * 4096,
                                                                         W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
         STEP_LAUNCH_CHECK("tcn_fwd");
-        if (!has_gcn) break;
+        if (i == NL - 1 && !(dead_bn7 && training)) break;
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, st));      // slots 1,3,5 = P_s z
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, st));      // slots 2,4,6 = P_s (P_s z)
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
@@ -952,7 +919,7 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
     return STEP_OK;
 }
 
-static int pack_weights(const StepGwnetParams* p, const Work& W, int N, hipStream_t st) {
+static int pack_weights(const StepGwnetParams* p, const Work& W, hipStream_t st) {
     GatePtrs gp;
     SkipPtrs sp;
     MixPtrs mp;
@@ -963,12 +930,6 @@ static int pack_weights(const StepGwnetParams* p, const Work& W, int N, hipStrea
     }
     pack_weights_kernel<<<384 + 7 * 28, 256, 0, st>>>(gp, sp, mp, W.wcat, W.wcatT, W.bcat, W.wskip, W.bsum, W.wmixT);
     STEP_LAUNCH_CHECK("pack_weights");
-    if (p->gemm_bf16 && slice_path_ok(N)) {
-        MixPtrs8 m8;
-        for (int i = 0; i < NL; ++i) m8.w[i] = p->gconv_w[i];
-        slice_pack_frags_kernel<<<NL * SL_FRAGS_PER_LAYER, 64, 0, st>>>(W.wcat, m8, W.sfrags);
-        STEP_LAUNCH_CHECK("slice_pack_frags");
-    }
     return STEP_OK;
 }
 
@@ -1024,7 +985,7 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
                                                                                                S.PT16);
         STEP_LAUNCH_CHECK("stacks_to_bf16");
     }
-    STEP_TRY(pack_weights(p, W, N, st));
+    STEP_TRY(pack_weights(p, W, st));
 
     // 8 layers: gated TCN (one kernel), two diffusion hops (the three supports per launch), gcn mix + dropout + residual + BatchNorm
     // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
@@ -1099,24 +1060,6 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
         if (i < NL - 1) {
             // BatchNorm_i backward (sums left by the previous iteration's tcn_bwd) + dropout + mix data gradient
             const BnBwd bn = {p->bn_w[i], S.bnstat[i], grads->bn_w[i], grads->bn_b[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
-            if (BF16 && slice_path_ok(N)) {
-                // BatchNorm backward + dropout + mix data gradient + both adjoint hops as ONE launch, one workgroup per (b, t) slice
-                SliceBwdArgs a;
-                a.dy = dx_next; a.y = S.y[i]; a.bn = bn; a.mask = S.mask[i];
-                a.B = B; a.N = N; a.Tout = Tout;
-                a.frags = W.sfrags + (long)i * SL_FRAGS_PER_LAYER * 64 * 8; a.P16 = S.P16;
-                a.dres = W.dres; a.dh = W.dh[i]; a.dcat = W.dcat[i];
-                const size_t lds = slice_lds_bytes(N, 6, false);
-                const int threads = slice_waves(N) * 64;
-                if (slice_tpw(N) == 1) {
-                    (void)hipFuncSetAttribute((const void*)gcn_bwd_slice_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    gcn_bwd_slice_kernel<1><<<B * Tout, threads, lds, st>>>(a);
-                } else {
-                    (void)hipFuncSetAttribute((const void*)gcn_bwd_slice_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    gcn_bwd_slice_kernel<2><<<B * Tout, threads, lds, st>>>(a);
-                }
-                STEP_LAUNCH_CHECK("gcn_bwd_slice");
-            } else {
             mix_bwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(dx_next, S.y[i], bn, S.mask[i], W.wmixT + i * (C * CAT), npos, W.dres, W.dh[i],
                                                                             W.dcat[i]);
             STEP_LAUNCH_CHECK("mix_bwd");
@@ -1124,7 +1067,6 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
             STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
-            }
             // slots 1..6 of dcat[i] are final here (tcn_bwd only reads dcat).  The LAST adjacency-gradient piece is what the supports' backward
             // waits for after the loop, so it is the smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers
             // 0..1 as one piece after the loop the main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
@@ -1184,7 +1126,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     const int allbf16 = p->gemm_bf16;
     auto split_for = [](long) { return -1; };      // -1: step_gemm picks a split that fills the chip
 
-    STEP_TRY(pack_weights(p, W, N, st));
+    STEP_TRY(pack_weights(p, W, st));
     STEP_TRY(zero(W.dwcat, (long)((float*)W.acc64 - W.dwcat) + 2L * NL * NCOPY * 64, st));       // dwcat, dbcat, dwskip, acc64
     const long NN = (long)N * N;
 
