@@ -31,7 +31,7 @@ import time
 # at a time, and runs 1.6 % faster at PEMS04 / 0.8 % at PEMS07 with TWO queues than with three or four (one queue: no overlap at all,
 # 5.27 ms; profiles/r03_ar_hw_queues_ab.log, r03_as_*).  It has to be in the environment before the runtime initialises, i.e. before
 # torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
-if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv:
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv and "--graph-child" not in sys.argv:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np  # noqa: E402
@@ -156,6 +156,25 @@ def live_pmc_traffic(config, B, ckpt, timeout=150):
     return {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "static": False,
             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) around `bench.py --pmc-child` in this run: "
                       "same checkpoint, same launch size, dropout on; KiB counters, FETCH_SIZE x2 (gfx950)"}
+
+
+def graph_replay_figure(config, B, ckpt, args, steps=30, timeout=240):
+    """The step replayed from one captured hipGraph (step_amd.GraphedTrainStep), measured in a CHILD process: this process pins
+    GPU_MAX_HW_QUEUES=2 for its eager three-stream schedule, and a replay of a graph with three parallel branches needs the runtime's
+    default queue count (with two queues hipGraphLaunch crashes the process, profiles/r04_h_*).  The child runs the eager loop and the
+    replayed loop back to back under the default and prints both."""
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--config", config, "--batch", str(B), "--steps", str(steps), "--warmup", "8",
+           "--no-extras", "--no-cpu-baseline", "--no-pmc", "--matmul", args.matmul, "--pretrain-steps", "0" if ckpt is None else str(args.pretrain_steps)]
+    try:
+        out = subprocess.run(cmd, env=env, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+        for line in reversed(out.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "no output from the graph child"}
+    except Exception as ex:          # noqa: BLE001 -- an optional figure must not take the headline line with it
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def pmc_child(args):
@@ -546,6 +565,32 @@ class StepBench:
                 "what": "same training step, windows gathered on the device from the resident series by forecast origin "
                         "(step_gather_windows, LongHistoryRef), origins uniform over the training split, loader one batch ahead"}
 
+    def graph_figure(self, steps):
+        """the same training step replayed from ONE captured hipGraph (step_amd.GraphedTrainStep): host time per step = one graph launch
+        + the copies of the batch into the graph's static input buffers (inside the timed region)"""
+        from step_amd import GraphedTrainStep
+        m = self.model
+        m.tsformer._events, m.tsformer.fallback_counter = None, None
+        m.cancel_prefetch()
+        gs = GraphedTrainStep(m, self.opt, self.batches[0], scaler=(self.mean, self.std), epoch=1, warmup=3)
+        try:
+            def gstep(i):
+                hist, longh, fut = self.batches[i % len(self.batches)]
+                return gs(hist, longh, fut)
+            dt, per_step, loss = timed_loop(gstep, 5, steps, self.barrier)
+            host = HOST["enqueue_s"] / steps * 1e3
+            same = timed_loop(lambda i: gs(), 3, max(steps // 2, 5), self.barrier)[0] / max(steps // 2, 5) * 1e3
+        finally:
+            gs.close()
+        B = self.cfg["B"]
+        return {"value": B * steps / dt, "unit": "windows/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                "p10": float(np.percentile(per_step, 10)), "p50": float(np.percentile(per_step, 50)), "p90": float(np.percentile(per_step, 90)),
+                "host_enqueue_ms_per_step": host, "ms_per_step_without_input_copies": same, "final_loss": float(loss.detach()),
+                "what": "the same full training step (zero_grad, forward, step_loss, backward, clip + Adam, dropout on) captured once into a "
+                        "hipGraph and replayed: one launch per step; seeds / Adam step count / learning rate / loss coefficient are read from "
+                        "a device-resident state the graph's first node advances; each replay is preceded by the copies of the batch into the "
+                        "graph's static inputs (`ms_per_step_without_input_copies`: replays of the resident batch)"}
+
     def comm_figure(self):
         """data-parallel exchange: the flat-gradient all-reduce alone (isolated) and the part of it the step does not hide"""
         import torch.distributed as dist
@@ -613,12 +658,16 @@ def main():
                     help="validation / test path (SURVEY 8f-4): eval-mode forward + metric under no_grad, no backward / optimizer")
     ap.add_argument("--no-shard", action="store_true", help="--gpus > 1: keep the whole graph learner (and fc.weight) on every rank")
     ap.add_argument("--torch-optim", action="store_true", help="torch clip_grad_norm_ + torch.optim.Adam instead of the fused kernel")
+    ap.add_argument("--graph", action="store_true", help="also measure the step replayed from one captured hipGraph (step_amd.GraphedTrainStep) in a "
+                    "child process with the runtime's default hardware queues (measured slower than the eager three-stream schedule on this "
+                    "stack: 4.72 vs 4.42 ms at PEMS04, profiles/r04_h_graph_replay_*.json)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="--gpus 1 only: create a one-rank process group and issue every collective of the data-parallel path (parameter "
                          "broadcast, chunked async all-reduce, the time-sliced graph learner's small sums) through it, so that RCCL, its "
                          "stream and the event ordering against the step's streams run on a one-GPU box; leaves GPU_MAX_HW_QUEUES at the "
                          "runtime default unless set explicitly")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child is not None:
         return pmc_child(args)
@@ -674,6 +723,15 @@ def main():
     enc_alone_ms = bench.encoder_alone_ms(nxt) if (not args.forward_only and extras) else None
     loader_fig = bench.loader_figure(max(args.steps // 2, 10)) if (not args.forward_only and not args.no_loader_figure and extras) else None
     comm = bench.comm_figure() if (DIST["on"] and not args.forward_only) else None
+    if args.graph_child:
+        # child of graph_replay_figure(): the eager loop above and the replayed loop in ONE process with the runtime's default hardware queues
+        gf = bench.graph_figure(max(args.steps, 10))
+        gf["eager_same_process"] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"]}
+        print(json.dumps(gf), flush=True)
+        return
+    graph_fig = None
+    if not args.forward_only and not DIST["on"] and not args.torch_optim and args.graph:
+        graph_fig = graph_replay_figure(args.config, cfg["B"], ckpt, args)
     # ---- secondary figures of the same config: frozen branch inside forward(); random-init TSFormer
     no_prefetch, random_init = None, None
     short = max(min(args.steps // 3, 40), 5)
@@ -807,6 +865,8 @@ def main():
             out["random_init"] = random_init
         if loader_fig is not None:
             out["device_loader"] = loader_fig
+        if graph_fig is not None:
+            out["graph_replay"] = graph_fig
         if comm is not None:
             out["data_parallel"] = comm
         if others is not None:

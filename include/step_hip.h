@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -363,6 +363,39 @@ int step_loss_scaled_fwd_bwd(const float* pred, const float* real, long n_pred, 
                              float* dpred, float* dtheta, void* stream);
 /* out_a = a * *g, out_b = b * *g with g a device scalar (autograd's incoming gradient of the loss applied to both gradients). */
 int step_scale2(const float* a, long na, const float* b, long nb, const float* g, float* out_a, float* out_b, void* stream);
+
+/* ---------------------------------------------------------------- replayable steps --------
+ * A training step that is captured once into a hipGraph and replayed (step_amd.GraphedTrainStep) cannot take per-step scalars as
+ * launch arguments: they would be frozen into the graph.  What changes from step to step lives in ONE small device struct that
+ * the *_dyn variants of five entry points read at run time (dyn == NULL: exactly the plain entry point):
+ *   seed_xor  -- XORed into the seed argument of the keep-mask pool (step_dropout_pool_fill_dyn), of the Gumbel noise
+ *                (step_dgl_edges_forward_dyn) and of the gcn dropout (step_gwnet_forward_phase_dyn);
+ *   adam_step -- the optimizer step count t of step_adam_clip_dyn (bias corrections 1 - beta^t), lr its learning rate;
+ *   gsl_coef  -- step_loss's coefficient of the graph term (step.py:68-69; it changes with the epoch).
+ * step_dyn_advance (one launch at the head of every replay): seed_xor <- hash(seed_xor), adam_step += 1.  The host writes lr /
+ * gsl_coef with an ordinary copy when the scheduler / the epoch changes them. */
+typedef struct StepDynState {
+    uint64_t seed_xor;
+    int32_t adam_step;
+    float lr;
+    float gsl_coef;
+    float reserved;
+} StepDynState;
+int step_dyn_advance(StepDynState* dyn, void* stream);
+int step_dropout_pool_fill_dyn(uint64_t* pool, long words, float dropout_p, uint64_t seed, const StepDynState* dyn, void* stream);
+int step_dgl_edges_forward_dyn(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
+                               float temperature, float* saved, float* theta_out, float* adj_out, const StepDynState* dyn, void* stream);
+int step_gwnet_forward_phase_dyn(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
+                                 const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
+                                 float* saved, float* work, float* pred, int phase, const StepDynState* dyn, void* stream);
+/* lr and the step count come from dyn (non-NULL) */
+int step_adam_clip_dyn(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, const float* extra_sumsq, float* work, float* out_norm,
+                       const StepDynState* dyn, void* stream);
+/* coef comes from dyn->gsl_coef (non-NULL) */
+int step_loss_scaled_fwd_bwd_dyn(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
+                                 const float* theta, const float* prior, long n_adj, float null_val, double* work, float* loss,
+                                 float* dpred, float* dtheta, const StepDynState* dyn, void* stream);
 
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on

@@ -13,4 +13,7 @@ def __getattr__(name):
     if name in ("LongHistoryRef", "DeviceWindowLoader"):          # device-resident dataset, index-only loader
         from .step_arch import step
         return getattr(step, name)
+    if name == "GraphedTrainStep":          # one captured hipGraph per training step
+        from .graphed import GraphedTrainStep
+        return GraphedTrainStep
     raise AttributeError(name)

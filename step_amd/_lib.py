@@ -47,6 +47,11 @@ class StepGwnetParams(ctypes.Structure):
 _PD = ctypes.POINTER(StepDglParams)
 
 
+class StepDynState(ctypes.Structure):
+    """host mirror of the device-resident per-step scalars of a replayed training step (include/step_hip.h)"""
+    _fields_ = [("seed_xor", ctypes.c_uint64), ("adam_step", ctypes.c_int32), ("lr", _f), ("gsl_coef", _f), ("reserved", _f)]
+
+
 class StepDglShard(ctypes.Structure):
     _fields_ = [("own1", ctypes.c_int), ("count1", ctypes.c_double), ("count2", ctypes.c_double)]
 
@@ -115,12 +120,19 @@ _SIGS = {
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     "step_adam_clip_sharded": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp]),
+    # replayable steps: per-step scalars in a device-resident StepDynState (include/step_hip.h)
+    "step_dyn_advance": (_i, [_vp, _vp]),
+    "step_dropout_pool_fill_dyn": (_i, [_vp, _l, _f, _u64, _vp, _vp]),
+    "step_dgl_edges_forward_dyn": (_i, [_vp, _i, _i, _PD, _vp, _u64, _f, _vp, _vp, _vp, _vp, _vp]),
+    "step_gwnet_forward_phase_dyn": (_i, [_vp, _i, _i, _i, _vp, _vp, _PG, _i, _f, _u64, _f, _vp, _vp, _vp, _i, _vp, _vp]),
+    "step_adam_clip_dyn": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "step_loss_scaled_fwd_bwd_dyn": (_i, [_vp, _vp, _l, _l, _f, _f, _vp, _vp, _l, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
 
 

@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256) void edge_logit_kernel(const float* __restrict
 // theta[b][e] = sigmoid(z[e]);  y0 = sigmoid((z + g0 - g1)/tau), adj = [y0 >= y1] with the diagonal cleared
 __global__ __launch_bounds__(256) void gumbel_sample_kernel(const float* __restrict__ z, const float* __restrict__ u, int B, int N,
                                                             uint32_t seed_lo, uint32_t seed_hi, float inv_tau,
-                                                            float* __restrict__ theta, float* __restrict__ y0, float* __restrict__ adj) {
+                                                            float* __restrict__ theta, float* __restrict__ y0, float* __restrict__ adj,
+                                                            const StepDynState* __restrict__ dyn) {
+    if (dyn) { const uint64_t x = dyn->seed_xor; seed_lo ^= (uint32_t)x; seed_hi ^= (uint32_t)(x >> 32); }      // replayed steps (step_hip.h)
     const long E = (long)N * N;
     const int b = blockIdx.y;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
@@ -1086,6 +1088,11 @@ extern "C" long step_dgl_edges_theta_offset(int N) { return 2L * N * EMB + (long
 // saved layout: sndT [EMB][N] | rcv [N][EMB] | z [N*N] | theta [B][N*N] | y0 [B][N*N]
 extern "C" int step_dgl_edges_forward(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
                                       float temperature, float* saved, float* theta_out, float* adj_out, void* stream) {
+    return step_dgl_edges_forward_dyn(g, N, B, p, u, seed, temperature, saved, theta_out, adj_out, nullptr, stream);
+}
+extern "C" int step_dgl_edges_forward_dyn(const float* g, int N, int B, const StepDglParams* p, const float* u, uint64_t seed,
+                                          float temperature, float* saved, float* theta_out, float* adj_out, const StepDynState* dyn,
+                                          void* stream) {
     STEP_REQUIRE(g && p && saved && adj_out && N > 0 && B > 0 && temperature > 0.f, "dgl_edges_forward: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     float* sndT = saved;
@@ -1108,7 +1115,7 @@ extern "C" int step_dgl_edges_forward(const float* g, int N, int B, const StepDg
     STEP_LAUNCH_CHECK("edge_logit");
     int gx = cdiv((long)N * N, 256);
     if (gx > 4096) gx = 4096;
-    gumbel_sample_kernel<<<dim3(gx, B), 256, 0, st>>>(z, u, B, N, (uint32_t)seed, (uint32_t)(seed >> 32), 1.f / temperature, theta, y0, adj_out);
+    gumbel_sample_kernel<<<dim3(gx, B), 256, 0, st>>>(z, u, B, N, (uint32_t)seed, (uint32_t)(seed >> 32), 1.f / temperature, theta, y0, adj_out, dyn);
     STEP_LAUNCH_CHECK("gumbel_sample");
     if (theta_out && theta_out != theta) {
         if (hipMemcpyAsync(theta_out, theta, (size_t)B * N * N * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {

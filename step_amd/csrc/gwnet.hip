@@ -433,7 +433,9 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ cat, const float* __restrict__ w,
                                                       const float* __restrict__ bias, XIn x, long npos, int Tin, int Tout, int dil,
                                                       float drop_p, uint32_t seed_lo, uint32_t seed_hi, uint32_t layer,
-                                                      float* __restrict__ mask, float* __restrict__ y, double* __restrict__ sums) {
+                                                      float* __restrict__ mask, float* __restrict__ y, double* __restrict__ sums,
+                                                      const StepDynState* __restrict__ dyn) {
+    if (dyn) { const uint64_t sx = dyn->seed_xor; seed_lo ^= (uint32_t)sx; seed_hi ^= (uint32_t)(sx >> 32); }      // replayed steps (step_hip.h)
     __shared__ float red[4][64];
     __shared__ float bsum[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, kg = lane >> 4;
@@ -887,7 +889,7 @@ extern "C" long step_gwnet_saved_offset(int B, int N, int dropout, int item, int
 
 template <bool BF16>
 static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const Work& W, int B, int N, bool training, float drop_p,
-                                uint64_t seed, float momentum, bool dead_bn7, hipStream_t st) {
+                                uint64_t seed, float momentum, bool dead_bn7, const StepDynState* dyn, hipStream_t st) {
     const long BN = (long)B * N;
     for (int i = 0; i < NL; ++i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
@@ -908,7 +910,7 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
         const bool dead = i == NL - 1;              // the reference evaluates gconv[7] / bn[7] and drops the result (model.py:202-213)
         mix_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 64), 256, 0, st>>>(S.cat[i], p->gconv_w[i], p->gconv_b[i], xin, npos, Tin, Tout, dil, drop_p,
                                                                        (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)i, dead ? W.m7 : S.mask[i],
-                                                                       dead ? W.y7 : S.y[i], W.acc64 + (long)i * NCOPY * 64);
+                                                                       dead ? W.y7 : S.y[i], W.acc64 + (long)i * NCOPY * 64, dyn);
         STEP_LAUNCH_CHECK("mix_fwd");
         if (dead) {
             const BnFwd b7 = {p->bn_w[i], p->bn_b[i], p->bn_rm[i], p->bn_rv[i], 1, momentum, S.bnstat[i], (double)npos, W.acc64 + (long)i * NCOPY * 64};
@@ -942,6 +944,12 @@ extern "C" int step_gwnet_forward(const float* hist, int B, int N, int Cin, cons
 extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                                         const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                                         float* saved, float* work, float* pred, int phase, void* stream) {
+    return step_gwnet_forward_phase_dyn(hist, B, N, Cin, hidden_last, adj, p, training, dropout_p, seed, momentum, saved, work, pred, phase, nullptr,
+                                        stream);
+}
+extern "C" int step_gwnet_forward_phase_dyn(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
+                                            const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
+                                            float* saved, float* work, float* pred, int phase, const StepDynState* dyn, void* stream) {
     STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 4, "gwnet_forward: null argument / bad phase");
     const bool do_layers = phase == 0 || phase == 1, do_his = phase == 0 || phase == 2 || phase == 3, do_head = phase == 0 || phase == 2 || phase == 4;
     STEP_REQUIRE(!do_layers || (hist && adj), "gwnet_forward: the layer phase needs hist and adj");
@@ -990,8 +998,8 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
     // 8 layers: gated TCN (one kernel), two diffusion hops (the three supports per launch), gcn mix + dropout + residual + BatchNorm
     // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
     const bool dead_bn7 = (training & 2) != 0;
-    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, st));
-    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, st));
+    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st));
+    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st));
     }
 
     // head (model.py:215-220).  fc_his (phase 3) is the only part that needs the TSFormer's hidden state, and needs nothing else: the

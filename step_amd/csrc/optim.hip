@@ -33,9 +33,15 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
                                                         float wd, float bc1, float bc2_sqrt, float max_norm,
                                                         const float* __restrict__ partial, int npartial, const float* __restrict__ extra_sumsq,
-                                                        float* __restrict__ out_norm) {
+                                                        float* __restrict__ out_norm, const StepDynState* __restrict__ dyn) {
     __shared__ float red[4];
     __shared__ float s_coef;
+    if (dyn) {      // replayed steps (step_hip.h): learning rate and step count live on the device
+        const float t = (float)dyn->adam_step;
+        lr = dyn->lr;
+        bc1 = 1.f - powf(beta1, t);
+        bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+    }
     {   // total gradient norm from the partials (every block recomputes it: 1024 floats, L2-resident)
         float s = 0.f;
         for (int i = threadIdx.x; i < npartial; i += 256) s += partial[i];
@@ -75,9 +81,39 @@ extern "C" int step_adam_clip(float* params, const float* grads, float* exp_avg,
 
 // extra_sumsq (device scalar, may be NULL): sum of squares of gradient elements that live on OTHER ranks (parameter shards), added
 // to this buffer's own sum before the clip coefficient is formed, so that every rank clips with the norm of the whole model
+static int adam_clip_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
+                            float* work, float* out_norm, const StepDynState* dyn, void* stream);
 extern "C" int step_adam_clip_sharded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                                       float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
                                       float* work, float* out_norm, void* stream) {
+    return adam_clip_launch(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, max_norm, extra_sumsq, work, out_norm,
+                            nullptr, stream);
+}
+extern "C" int step_adam_clip_dyn(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float beta1, float beta2,
+                                  float eps, float weight_decay, float max_norm, const float* extra_sumsq, float* work, float* out_norm,
+                                  const StepDynState* dyn, void* stream) {
+    STEP_REQUIRE(dyn, "adam_clip_dyn: null state");
+    return adam_clip_launch(params, grads, exp_avg, exp_avg_sq, n, 0.f, beta1, beta2, eps, weight_decay, 1, max_norm, extra_sumsq, work, out_norm, dyn,
+                            stream);
+}
+// hash step of the replay seed: splitmix64
+__global__ void dyn_advance_kernel(StepDynState* s) {
+    uint64_t z = s->seed_xor + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    s->seed_xor = z ^ (z >> 31);
+    s->adam_step += 1;
+}
+extern "C" int step_dyn_advance(StepDynState* dyn, void* stream) {
+    STEP_REQUIRE(dyn, "dyn_advance: null state");
+    dyn_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dyn);
+    STEP_LAUNCH_CHECK("dyn_advance");
+    return STEP_OK;
+}
+static int adam_clip_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
+                            float* work, float* out_norm, const StepDynState* dyn, void* stream) {
     STEP_REQUIRE(params && grads && exp_avg && exp_avg_sq && work && n > 0 && step >= 1, "adam_clip: bad arguments");
     STEP_REQUIRE((((uintptr_t)grads) & 15) == 0, "adam_clip: gradient buffer must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -88,7 +124,7 @@ extern "C" int step_adam_clip_sharded(float* params, const float* grads, float* 
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     adam_clip_kernel<<<blocks, 256, 0, st>>>(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
-                                             max_norm, work, NB, extra_sumsq, out_norm);
+                                             max_norm, work, NB, extra_sumsq, out_norm, dyn);
     STEP_LAUNCH_CHECK("adam_clip");
     return STEP_OK;
 }
@@ -124,7 +160,9 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
                                                           float scale, float shift,
                                                           const float* __restrict__ theta, const float* __restrict__ prior, long n2,
                                                           float null_val, float coef, const double* __restrict__ acc,
-                                                          float* __restrict__ loss, float* __restrict__ dpred, float* __restrict__ dtheta) {
+                                                          float* __restrict__ loss, float* __restrict__ dpred, float* __restrict__ dtheta,
+                                                          const StepDynState* __restrict__ dyn) {
+    if (dyn) coef = dyn->gsl_coef;      // replayed steps (step_hip.h)
     const double cnt = acc[1];
     const float inv_cnt = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -151,9 +189,23 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ a
 }
 }  // namespace
 
+static int loss_launch(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift, const float* theta,
+                       const float* prior, long n_adj, float null_val, float coef, double* work, float* loss, float* dpred, float* dtheta,
+                       const StepDynState* dyn, void* stream);
 extern "C" int step_loss_scaled_fwd_bwd(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
                                         const float* theta, const float* prior, long n_adj, float null_val, float coef,
                                         double* work /*3 doubles*/, float* loss, float* dpred, float* dtheta, void* stream) {
+    return loss_launch(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, coef, work, loss, dpred, dtheta, nullptr, stream);
+}
+extern "C" int step_loss_scaled_fwd_bwd_dyn(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
+                                            const float* theta, const float* prior, long n_adj, float null_val, double* work, float* loss,
+                                            float* dpred, float* dtheta, const StepDynState* dyn, void* stream) {
+    STEP_REQUIRE(dyn, "step_loss_dyn: null state");
+    return loss_launch(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, 0.f, work, loss, dpred, dtheta, dyn, stream);
+}
+static int loss_launch(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift, const float* theta,
+                       const float* prior, long n_adj, float null_val, float coef, double* work, float* loss, float* dpred, float* dtheta,
+                       const StepDynState* dyn, void* stream) {
     STEP_REQUIRE(pred && real && theta && prior && work && loss && dpred && dtheta && n_pred > 0 && n_adj > 0 && real_stride >= 1,
                  "step_loss: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -167,7 +219,7 @@ extern "C" int step_loss_scaled_fwd_bwd(const float* pred, const float* real, lo
     loss_reduce_kernel<<<rblocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, work);
     STEP_LAUNCH_CHECK("loss_reduce");
     loss_finish_kernel<<<blocks, 256, 0, st>>>(pred, real, n_pred, real_stride, scale, shift, theta, prior, n_adj, null_val, coef, work, loss,
-                                               dpred, dtheta);
+                                               dpred, dtheta, dyn);
     STEP_LAUNCH_CHECK("loss_finish");
     return STEP_OK;
 }

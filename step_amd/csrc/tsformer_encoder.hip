@@ -806,12 +806,19 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
 template <int MAXW, bool DROP, bool PARK, bool F16, int TG>
 int launch_enc_tg(const EncArgs& a, hipStream_t st) {
     size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (size_t)a.nkt * parked_frags<MAXW, PARK>() * TSF_FRAG;
-    // per launch, not once per process: the attribute is per device and setting it is cheap
-    hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-        step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
-        return STEP_ERR_HIP;
+    // once per device and instantiation (the attribute is per device): not on every launch, so that a launch inside a stream capture
+    // (step_amd.GraphedTrainStep, after its eager warm-up steps) is a plain kernel node
+    static bool raised[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!raised[dev & 15]) {
+        hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+            return STEP_ERR_HIP;
+        }
+        raised[dev & 15] = true;
     }
     const int grid = (TSF_PERSIST > 0 && a.S > TSF_PERSIST) ? TSF_PERSIST : a.S;
     tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, a.nkt * 64, lds, st>>>(a);
@@ -836,7 +843,8 @@ int launch_enc(const EncArgs& a, hipStream_t st) {
 // Dropout pool: word w = 64 Bernoulli(keep) bits, bit l <- Philox4x32-10(counter (w, l / 4), key seed) word l % 4 >= drop * 2^32.
 // One thread per Philox call (4 bits), 16 threads per word; the nibbles are OR-combined with four xor-shuffles.
 __global__ __launch_bounds__(256) void dropout_pool_kernel(unsigned long long* __restrict__ pool, long words, uint32_t thresh,
-                                                           uint32_t k0, uint32_t k1) {
+                                                           uint32_t k0, uint32_t k1, const StepDynState* __restrict__ dyn) {
+    if (dyn) { const uint64_t x = dyn->seed_xor; k0 ^= (uint32_t)x; k1 ^= (uint32_t)(x >> 32); }       // replayed steps: the key moves on the device
     const long id = (long)blockIdx.x * 256 + threadIdx.x;
     const long w = id >> 4;
     const int q = (int)(id & 15);
@@ -857,12 +865,15 @@ __global__ __launch_bounds__(256) void dropout_pool_kernel(unsigned long long* _
 }  // namespace
 
 extern "C" int step_dropout_pool_fill(uint64_t* pool, long words, float dropout_p, uint64_t seed, void* stream) {
+    return step_dropout_pool_fill_dyn(pool, words, dropout_p, seed, nullptr, stream);
+}
+extern "C" int step_dropout_pool_fill_dyn(uint64_t* pool, long words, float dropout_p, uint64_t seed, const StepDynState* dyn, void* stream) {
     STEP_REQUIRE(pool, "dropout_pool_fill: null pool");
     STEP_REQUIRE(words >= 16 && (words & (words - 1)) == 0, "dropout_pool_fill: %ld words is not a power of two >= 16", words);
     STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_pool_fill: bad dropout %f", dropout_p);
     const uint32_t thresh = (uint32_t)((double)dropout_p * 4294967296.0);
     dropout_pool_kernel<<<cdiv(words, 16), 256, 0, (hipStream_t)stream>>>((unsigned long long*)pool, words, thresh, (uint32_t)seed,
-                                                                         (uint32_t)(seed >> 32));
+                                                                         (uint32_t)(seed >> 32), dyn);
     STEP_LAUNCH_CHECK("step_dropout_pool_fill");
     return STEP_OK;
 }

@@ -29,6 +29,7 @@ class FusedAdamClip(torch.optim.Optimizer):
         self.step_count = 0
         self.work = torch.empty(int(_lib.lib().step_adam_work_floats()), device=self.flat.device)
         self.grad_norm = torch.zeros(1, device=self.flat.device)
+        self.dyn = None                     # device StepDynState while a GraphedTrainStep drives this optimizer
         model._backward_count = 0
 
     def zero_grad(self, set_to_none=True):
@@ -58,6 +59,14 @@ class FusedAdamClip(torch.optim.Optimizer):
             # the fc weight slices of the other ranks belong to the model's gradient norm: the sum of their squared norms came back
             # in the layout's spare slot with the gradient all-reduce (step.py backward) -- no collective of its own
             extra = self.model._other_slices_sumsq
+        if self.dyn is not None:
+            # replayed (graph-captured) step: the step count and the learning rate are read from the device state (step_amd/graphed.py
+            # advances the count at the head of every replay and copies the scheduler's rate when it changes)
+            _lib.call("step_adam_clip_dyn", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                      self.flat.numel(), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]), float(pg["weight_decay"]),
+                      float(self.max_norm or 0.0), _lib.ptr(extra), _lib.ptr(self.work), _lib.ptr(self.grad_norm), _lib.ptr(self.dyn),
+                      _lib.stream())
+            return
         _lib.call("step_adam_clip_sharded", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                   self.flat.numel(), float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
                   float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(extra), _lib.ptr(self.work),

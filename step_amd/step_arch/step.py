@@ -132,11 +132,11 @@ class _StepFunction(torch.autograd.Function):
                            L.ptr(gsaved), L.ptr(gwork), L.ptr(sums), L.ptr(g), ctypes.byref(sstruct), phase, sst)
                     if phase in exchange:
                         model._sum_over_ranks(exchange[phase])
-            L.call("step_dgl_edges_forward", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
-                   TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), sst)
-            L.call("step_gwnet_forward_phase", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct),
+            L.call("step_dgl_edges_forward_dyn", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
+                   TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), L.ptr(model._dyn), sst)
+            L.call("step_gwnet_forward_phase_dyn", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct),
                    int(training) | (2 if (training and model.track_dead_bn7) else 0),
-                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, sst)
+                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, L.ptr(model._dyn), sst)
             if training:
                 with torch.no_grad():
                     # the BatchNorm step counters: one multi-tensor launch instead of ten scalar ones, on this (the second) stream -- on the
@@ -330,6 +330,7 @@ class STEP(nn.Module):
         self.track_dead_bn7 = False
         self._noise_override = None         # tests: explicit uniform noise [B, N*N, 2]
         self._seed_ctr = 0
+        self._dyn = None                    # device StepDynState of a replayed (graph-captured) step (step_amd/graphed.py); None: eager
         self._process_group = None
         self._min_world = 1                 # collectives are issued for groups larger than this (0: also for a single rank)
         self._layout = None

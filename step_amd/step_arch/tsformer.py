@@ -394,6 +394,7 @@ class TSFormer(nn.Module):
         # layer) reads its 10 912 words (PEMS04) at a hashed WORD offset, so two of the 12 280 chunks of a launch coincide with
         # probability 2^-18 per pair (tests/test_encoder_dropout_pool.py counts them)
         self.dropout_pool_words = 1 << 18
+        self._dyn = None                    # device StepDynState of a replayed (graph-captured) step: the pool's Philox key moves with it (step_amd/graphed.py)
         self._drop_pool = None
         self._pool_override = None          # tests: int64 cuda tensor of keep-mask words used instead of the Philox fill
         self.encoder_debug_flags = 0        # tests: _lib.ENC_ALWAYS_RESHIFT
@@ -436,7 +437,7 @@ class TSFormer(nn.Module):
             words *= 2
         if self._drop_pool is None or self._drop_pool.numel() != words + 16 or self._drop_pool.device != device:
             self._drop_pool = torch.empty(words + 16, dtype=torch.int64, device=device)      # + the wrap-around copy of the first 16
-        _lib.call("step_dropout_pool_fill", _lib.ptr(self._drop_pool), words, float(drop), int(seed), _lib.stream())
+        _lib.call("step_dropout_pool_fill_dyn", _lib.ptr(self._drop_pool), words, float(drop), int(seed), _lib.ptr(self._dyn), _lib.stream())
         return self._drop_pool, words
 
     # ------------------------------------------------------------------ device entry points

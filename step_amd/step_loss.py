@@ -56,8 +56,13 @@ class _NativeStepLoss(torch.autograd.Function):
         dp, dt = torch.empty_like(p), torch.empty_like(t)
         work = torch.empty(3, device=p.device, dtype=torch.float64)
         assert r.is_cuda and r.dtype == torch.float32
-        _lib.call("step_loss_scaled_fwd_bwd", _lib.ptr(p), ctypes.c_void_p(r.data_ptr()), p.numel(), rs, float(scale), float(shift), _lib.ptr(t), _lib.ptr(a),
-                  t.numel(), float(null_val), float(coef), _lib.ptr(work), _lib.ptr(loss), _lib.ptr(dp), _lib.ptr(dt), _lib.stream())
+        if torch.is_tensor(coef):
+            # replayed (graph-captured) step: `coef` is the device StepDynState whose gsl_coef field the kernel reads (step_amd/graphed.py)
+            _lib.call("step_loss_scaled_fwd_bwd_dyn", _lib.ptr(p), ctypes.c_void_p(r.data_ptr()), p.numel(), rs, float(scale), float(shift), _lib.ptr(t),
+                      _lib.ptr(a), t.numel(), float(null_val), _lib.ptr(work), _lib.ptr(loss), _lib.ptr(dp), _lib.ptr(dt), _lib.ptr(coef), _lib.stream())
+        else:
+            _lib.call("step_loss_scaled_fwd_bwd", _lib.ptr(p), ctypes.c_void_p(r.data_ptr()), p.numel(), rs, float(scale), float(shift), _lib.ptr(t),
+                      _lib.ptr(a), t.numel(), float(null_val), float(coef), _lib.ptr(work), _lib.ptr(loss), _lib.ptr(dp), _lib.ptr(dt), _lib.stream())
         ctx.save_for_backward(dp, dt)
         ctx.shapes = (prediction.shape, theta.shape)
         return loss
