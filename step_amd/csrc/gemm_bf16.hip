@@ -1021,6 +1021,11 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
         return STEP_OK;
     };
     if (fast && fused) return big ? launch_fast_fused<128, 128>(g, fa, amode, bmode, st) : launch_fast_fused<64, 64>(g, fa, amode, bmode, st);
+    // both operands k-contiguous bf16 on a large graph (the diffusion hops with their transposed source copy): 128 x 128 tiles when they fill
+    // the chip -- the support is then re-read by 3 column tiles instead of 6 (STEP_GEMM_HOP128=0: the 128 x 64 rule below, A/B measurements)
+    static const bool hop128 = []() { const char* e = getenv("STEP_GEMM_HOP128"); return !e || atoi(e) != 0; }();
+    if (hop128 && fast && !big && amode == KC_BF16 && bmode == KC_BF16 && g.M >= 2048 && g.N >= 256 && tiles128 >= 256)
+        return finish(launch_fast<128, 128>(g, fa, amode, bmode, st));
     static const int tall_m = []() { const char* e = getenv("STEP_GEMM_TALL_M"); return e ? atoi(e) : 1024; }();      // (A/B knob)
     if (fast && !big && bmode != MC_BF16 && g.M >= tall_m && g.N > 64) {
         // tall products with a short n axis (the diffusion hops of large graphs: 4096 x 32 T x 4096): 128 x 64 tiles -- three workgroups per

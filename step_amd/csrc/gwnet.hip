@@ -149,6 +149,31 @@ __global__ void stacks_to_bf16_kernel(const float* __restrict__ P, const float* 
     f2 t = {a, b};
     *(uint32_t*)(dst + row * N8 + j) = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, b2));
 }
+// Hop operand of large graphs: 32-channel slots of the gcn buffer as bf16, transposed to [source][b][column = t * 32 + c][node] with the
+// node axis contiguous (pitch N8, zero padded) -- the k-contiguous B operand of the hop product.  Read in place as f32 [node][t][224]
+// the staged GEMM re-reads and re-converts the slot once per 128-row tile of the support (32 times at 4096 nodes: 1.2 GB through L2
+// per launch, profiles/r03_j_C5_*); this copy is 3 MB per source and is read with plain 16-byte loads.
+// grid (node tiles of 64, T, nsrc * B), 256 threads; source i reads slot slot0 + sstep * i.
+__global__ __launch_bounds__(256) void slots_to_bf16T_kernel(const float* __restrict__ cat, int slot0, int sstep, int B, int N, int T, int N8,
+                                                             uint16_t* __restrict__ XT) {
+    __shared__ float tile[64][33];
+    const int v0 = blockIdx.x * 64, t = blockIdx.y, src = blockIdx.z / B, b = blockIdx.z % B;
+    const int slot = slot0 + sstep * src;
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    for (int i = r; i < 64; i += 8) {
+        const int v = v0 + i;
+        tile[i][c] = v < N ? cat[(((long)b * N + v) * T + t) * CAT + slot * C + c] : 0.f;
+    }
+    __syncthreads();
+    // thread -> (channel = threadIdx / 8, 8 consecutive nodes): one 16-byte store
+    const int cc = threadIdx.x >> 3, g8 = (threadIdx.x & 7) * 8;
+    if (v0 + g8 < N8) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = tile[g8 + j][cc];
+        *(bf16x8*)(XT + (((long)blockIdx.z * T + t) * C + cc) * N8 + v0 + g8) = pack8(v8);
+    }
+}
 // out[e] = sum_b x[b][e]
 __global__ void sum_batches_kernel(const float* __restrict__ x, long n, int B, float* __restrict__ out) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -745,6 +770,12 @@ struct Carver {
 };
 
 static inline int n8(int N) { return (N + 7) & ~7; }
+// graphs from this many nodes on feed the diffusion hops a transposed bf16 copy of their source slots (see slots_to_bf16T_kernel);
+// STEP_HOP_XT_MIN_N overrides the threshold (A/B measurements: a huge value = always the in-place f32 operand)
+static inline bool hop_transposed_operand(int N) {
+    static const int min_n = []() { const char* e = getenv("STEP_HOP_XT_MIN_N"); return e ? atoi(e) : 1024; }();
+    return N >= min_n;
+}
 
 struct Saved {
     float *x0, *cat[NL], *tf[NL], *sg[NL], *y[NL], *mask[NL], *bnstat[NL], *zlast;     // x0: start conv output; layer i >= 1 reads BN(y[i-1])
@@ -789,6 +820,7 @@ struct Work {
     // xcat / dpre / dh: per-layer copies of what the weight-gradient GEMMs read -- those GEMMs are leaves of the backward and run on
     // the auxiliary stream while the data-gradient chain goes on; dcat: one gcn-buffer gradient per layer (all needed at the end)
     float *xcat[NL], *bsum, *y7, *m7;      // y7 / m7: output and dropout mask of the last layer's (dead) gcn, only for its BatchNorm statistics
+    uint16_t* xT;              // [3][B][12 * 32][N8] bf16: transposed hop operand of large graphs (slots_to_bf16T_kernel)
     float *dcat[NL - 1], *dpre[NL], *dh[NL - 1], *dres, *dxa, *dxb, *dskip, *dPstk, *dPa, *dM, *rf, *rb;
     GemmKSeg* ktab;
     float *d_e1, *d_xh, *d_h2, *d_h1;
@@ -807,6 +839,7 @@ Work carve_work(float* base, int B, int N, bool backward) {
     w.dbcat = cv.take(NL * 64);
     w.dwskip = cv.take(CS * CS);
     w.acc64 = (double*)cv.take(2L * NL * NCOPY * 64);      // 7 live BatchNorms + the dead bn.7 (only with STEP_GWNET_DEAD_BN7)
+    w.xT = hop_transposed_operand(N) ? (uint16_t*)cv.take(3L * B * 12 * C * n8(N) / 2) : nullptr;
     for (int i = 0; i < NL; ++i) w.xcat[i] = backward ? cv.take(BN * TOUT[i] * 64) : nullptr;
     w.bsum = cv.take(CS);
     w.y7 = cv.take(BN * TOUT[NL - 1] * C);
@@ -848,8 +881,21 @@ int zero(float* p, long n, hipStream_t st) {
 // Forward hop  Out_s[b][w][n] = sum_v P_s[b][v][w] X_s[b][v][n]  reading slot src0 + sstep*s, writing dst0 + 2*s.
 // bf16 mode: A(m=w, k=v) = PT16[w][v] (k contiguous, bf16) -- no transposition on the way into LDS.
 int nconv_fwd3(const float* Pstk, const uint16_t* PT16, float* cat, int src0, int sstep, int dst0, int B, int N, int T, int bf16,
-               hipStream_t st) {
+               uint16_t* xT, hipStream_t st) {
     StepGemm g = gemm_desc(N, T * C, N, Pstk, 1, N, cat + src0 * C, (long)T * CAT, 1, cat + dst0 * C, (long)T * CAT);
+    if (bf16 && xT) {
+        // B(k = v, n = column) = xT[source][b][column][v]: k contiguous bf16, one source for all three supports (sstep == 0) or one each
+        const int nsrc = sstep == 0 ? 1 : 3;
+        slots_to_bf16T_kernel<<<dim3(cdiv(N, 64), T, nsrc * B), 256, 0, st>>>(cat, src0, sstep, B, N, T, n8(N), xT);
+        STEP_LAUNCH_CHECK("slots_to_bf16T");
+        g.batch = 3 * B; g.batch0 = B;
+        g.A = PT16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N);
+        g.B = xT; g.b_bf16 = 1; g.sbk = 1; g.sbn = n8(N); g.sbb = (long)T * C * n8(N); g.sbb1 = nsrc == 1 ? 0 : (long)B * T * C * n8(N);
+        g.scb = (long)N * T * CAT; g.scb1 = 2L * C;
+        g.c_nblk = C; g.c_nstride = CAT;
+        g.compute_bf16 = 1;
+        return step_gemm_launch(g, st);
+    }
     g.batch = 3 * B; g.batch0 = B;
     g.sab = (long)N * N; g.sab1 = (long)B * N * N;
     if (bf16) { g.A = PT16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N); }
@@ -862,8 +908,21 @@ int nconv_fwd3(const float* Pstk, const uint16_t* PT16, float* cat, int src0, in
 // Adjoint hop  dDst_s[b][v][n] += sum_w P_s[b][v][w] dSrc_s[b][w][n]  (reads the transposed stack: A(m=v,k=w) = PT[w][v]).
 // dstep == 0: the three supports accumulate into the same slot -> atomics.
 int nconv_bwd_data3(const float* PTstk, const uint16_t* P16, float* dcat, int src0, int dst0, int dstep, int B, int N, int T, int bf16,
-                    hipStream_t st) {
+                    uint16_t* xT, hipStream_t st) {
     StepGemm g = gemm_desc(N, T * C, N, PTstk, 1, N, dcat + src0 * C, (long)T * CAT, 1, dcat + dst0 * C, (long)T * CAT);
+    if (bf16 && xT) {
+        // the three sources are the slots src0, src0 + 2, src0 + 4 of the gradient buffer
+        slots_to_bf16T_kernel<<<dim3(cdiv(N, 64), T, 3 * B), 256, 0, st>>>(dcat, src0, 2, B, N, T, n8(N), xT);
+        STEP_LAUNCH_CHECK("slots_to_bf16T");
+        g.batch = 3 * B; g.batch0 = B;
+        g.A = P16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N);
+        g.B = xT; g.b_bf16 = 1; g.sbk = 1; g.sbn = n8(N); g.sbb = (long)T * C * n8(N); g.sbb1 = (long)B * T * C * n8(N);
+        g.scb = (long)N * T * CAT; g.scb1 = (long)dstep * C;
+        g.c_nblk = C; g.c_nstride = CAT;
+        g.accumulate = dstep == 0 ? 2 : 1;
+        g.compute_bf16 = 1;
+        return step_gemm_launch(g, st);
+    }
     g.batch = 3 * B; g.batch0 = B;
     g.sab = (long)N * N; g.sab1 = (long)B * N * N;
     if (bf16) { g.A = P16; g.a_bf16 = 1; g.sam = n8(N); g.sak = 1; g.sab = (long)N * n8(N); g.sab1 = (long)B * N * n8(N); }
@@ -904,8 +963,8 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
                                                                         W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
         STEP_LAUNCH_CHECK("tcn_fwd");
         if (i == NL - 1 && !(dead_bn7 && training)) break;
-        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, st));      // slots 1,3,5 = P_s z
-        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, st));      // slots 2,4,6 = P_s (P_s z)
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, W.xT, st));      // slots 1,3,5 = P_s z
+        STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, W.xT, st));      // slots 2,4,6 = P_s (P_s z)
         const XIn xin = {i == 0 ? S.x0 : S.y[i - 1], i == 0 ? nullptr : S.bnstat[i - 1]};
         const bool dead = i == NL - 1;              // the reference evaluates gconv[7] / bn[7] and drops the result (model.py:202-213)
         mix_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 64), 256, 0, st>>>(S.cat[i], p->gconv_w[i], p->gconv_b[i], xin, npos, Tin, Tout, dil, drop_p,
@@ -1073,8 +1132,8 @@ static int gwnet_layers_backward(const StepGwnetParams* p, const StepGwnetParams
             STEP_LAUNCH_CHECK("mix_bwd");
             // diffusion hops, the three supports per launch: slots (1,2) <- P_f, (3,4) <- P_b, (5,6) <- P_a
             // (the adjacency gradients x (x) d_hop of all layers are contracted in one launch after the loop: every dcat[i] is kept)
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, st));          // d_x1 += P (d_x2)
-            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, st));          // d_z  += sum_s P_s (d_x1_s)
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 2, 1, 2, B, N, Tout, BF16, W.xT, st));          // d_x1 += P (d_x2)
+            STEP_TRY(nconv_bwd_data3(S.PTstk, S.P16, W.dcat[i], 1, 0, 0, B, N, Tout, BF16, W.xT, st));          // d_z  += sum_s P_s (d_x1_s)
             // slots 1..6 of dcat[i] are final here (tcn_bwd only reads dcat).  The LAST adjacency-gradient piece is what the supports' backward
             // waits for after the loop, so it is the smallest possible -- layer 0 alone -- and is queued before layer 0's tcn_bwd (with layers
             // 0..1 as one piece after the loop the main stream waited 111 us for it at PEMS04, profiles/r03_ac_C2_step_timeline.md)
