@@ -980,6 +980,9 @@ static int dgl_global_backward_impl(const float* series_nt, int N, int T, const 
             bn2_fused_coef_kernel<<<1, 64, 0, st>>>(dots, st2, p->bn2_w, count2, grads->bn2_w, grads->bn2_b, coef);
             STEP_LAUNCH_CHECK("bn2_fused_coef");
             // dz2 = BatchNorm2 backward of dgpre @ fc_w, masked by conv2's ReLU: the scale rides in wp, the rest in the epilogue; bf16 rows out
+            // (round 4: a column-strip kernel over all rows -- wp's slice as register-resident fragments, the gradient as pre-packed
+            //  fragments, 1.6 instead of 4.7 B of operand traffic per output element -- was measured and is NOT faster than this tiled GEMM:
+            //  16.38 vs 16.33 ms at 4096 nodes, 5.99 vs 5.92 at PEMS07, profiles/r04_l_fc_dgrad_strips_ab.log)
             StepGemm gm = gemm_desc(N, (int)K, EMB, dgpre, EMB, 1, wp, K, 1, d_a2, K);
             gm.b_bf16 = 1;
             gm.compute_bf16 = 1;

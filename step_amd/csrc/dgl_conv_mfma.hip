@@ -448,17 +448,28 @@ __global__ __launch_bounds__(256) void conv1_fwd_cl_kernel(const float* __restri
                                                            float* __restrict__ partial, int T, int stat_limit) {
     __shared__ float ws[KW][C1_];
     __shared__ float red[4][2 * C1_];
+    __shared__ __attribute__((aligned(16))) float xs[1024 + 16];
     const int tid = threadIdx.x, n = blockIdx.y, T1 = T - (KW - 1);
     if (tid < KW * C1_) ws[tid / C1_][tid % C1_] = w[(tid % C1_) * KW + tid / C1_];
+    // the workgroup's 1024 + 9 series values through LDS: coalesced dword loads (a series row of odd length has no 16-byte alignment),
+    // then four aligned 16-byte LDS reads per thread -- instead of 13 stride-16-byte global loads per thread (22 % of the HBM rate)
+    {
+        const int tb = blockIdx.x * 1024;
+        const float* xr = x + (long)n * T + tb;
+        for (int i = tid; i < 1024 + 16; i += 256) xs[i] = tb + i < T ? xr[i] : 0.f;
+    }
     __syncthreads();
     const int t0 = (blockIdx.x * 256 + tid) * 4;
     float s1[C1_], s2[C1_];
 #pragma unroll
     for (int c = 0; c < C1_; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     if (t0 < T1) {
-        float xv[4 + KW - 1];
+        float xv[16];
 #pragma unroll
-        for (int q = 0; q < 4 + KW - 1; ++q) xv[q] = t0 + q < T ? x[(long)n * T + t0 + q] : 0.f;
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 v4 = *(const float4*)(xs + 4 * tid + 4 * q4);
+            xv[4 * q4] = v4.x; xv[4 * q4 + 1] = v4.y; xv[4 * q4 + 2] = v4.z; xv[4 * q4 + 3] = v4.w;
+        }
         float acc[4][C1_];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -802,6 +813,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_cl_kernel(const uint4* __rest
     }
     if (tid < C1) out[C1 * KW + tid] = redb[0][tid] + redb[1][tid] + redb[2][tid] + redb[3][tid];
 }
+
 
 }  // namespace
 
