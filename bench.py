@@ -31,7 +31,9 @@ import time
 # at a time, and runs 1.6 % faster at PEMS04 / 0.8 % at PEMS07 with TWO queues than with three or four (one queue: no overlap at all,
 # 5.27 ms; profiles/r03_ar_hw_queues_ab.log, r03_as_*).  It has to be in the environment before the runtime initialises, i.e. before
 # torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
-if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv and "--graph-child" not in sys.argv:
+# Only when bench.py IS the program: a process that imports it as a module (the tests do, for the configuration table) keeps its own
+# runtime settings -- a captured-graph replay (step_amd.GraphedTrainStep) crashes inside hipGraphLaunch with two hardware queues.
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv and "--graph-child" not in sys.argv:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np  # noqa: E402

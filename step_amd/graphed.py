@@ -23,6 +23,7 @@ Restrictions: fixed batch shape; single process (the gradient collectives of ``e
 ``FusedAdamClip`` as the optimizer; the warm-up iterations before the capture are real optimizer steps on the example batch.
 """
 import ctypes
+import os
 
 import torch
 
@@ -40,6 +41,13 @@ class GraphedTrainStep:
         hist, long_hist, fut = example_batch
         if not hist.is_cuda:
             raise RuntimeError("step_amd runs only on an AMD GPU: libstep_hip has no CPU fallback")
+        queues = os.environ.get("GPU_MAX_HW_QUEUES")
+        if queues is not None and queues.strip().isdigit() and int(queues) < 4:
+            # ROCm 7.2: hipGraphLaunch of this graph (parallel branches: main / side / aux stream) crashes when the runtime was initialised
+            # with fewer hardware queues than its default of four (1, 2, 3: segmentation fault; 4, 8, unset: fine --
+            # profiles/r04_n_graph_replay_hw_queues.log) -- refuse instead
+            raise RuntimeError(f"GraphedTrainStep needs the HIP runtime's default hardware queues (GPU_MAX_HW_QUEUES={queues} is set): "
+                               "a replay of the captured graph crashes inside hipGraphLaunch with fewer than four")
         self.model, self.opt = model, optimizer
         self.mean, self.std = float(scaler[0]), float(scaler[1])
         self.null_val = float(null_val)

@@ -333,14 +333,16 @@ def test_loss_target_stride_detection():
 
 
 def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
-    """bench.py puts GPU_MAX_HW_QUEUES=2 into the environment before torch (the HIP runtime) is imported -- for single-process runs, unless
-    the caller set it; multi-process runs (WORLD_SIZE > 1: the collective library has its own stream) keep the runtime's default."""
+    """bench.py puts GPU_MAX_HW_QUEUES=2 into the environment before torch (the HIP runtime) is imported -- for single-process runs of the
+    program itself, unless the caller set it; multi-process runs (WORLD_SIZE > 1: the collective library has its own stream) keep the runtime's default."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, sys; sys.argv = ['bench.py']; import bench; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    code = ("import os, sys, runpy\nsys.argv = ['bench.py', '--help']\ntry:\n    runpy.run_path('bench.py', run_name='__main__')\n"
+            "except SystemExit:\n    pass\nprint(os.environ.get('GPU_MAX_HW_QUEUES'))")
+    as_module = "import os, sys; sys.argv = ['bench.py']; import bench; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
 
-    def run(extra):
+    def run(extra, code=code):
         env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE")}
         env.update(extra)
         out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
@@ -350,3 +352,4 @@ def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
     assert run({"WORLD_SIZE": "1"}) == "2"
     assert run({"WORLD_SIZE": "8"}) == "None"
     assert run({"GPU_MAX_HW_QUEUES": "4"}) == "4"
+    assert run({}, as_module) == "None"                                    # imported as a module (the tests): the process's settings stay
