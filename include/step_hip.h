@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer); 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -283,6 +283,28 @@ int step_pt_ffn_hidden_fwd(const float* x, const float* w1, const float* b1, lon
                            uint16_t* hidden, void* stream);
 int step_pt_ffn_hidden_bwd(const float* dy, const float* w2, const uint16_t* hidden, long R, float p, uint16_t* dhidden, void* stream);
 int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void* stream);      /* out[c] += sum_r x[r][c] */
+/* Fused feed-forward block of a pre-training layer (bf16 operands, f32 accumulate; csrc/pretrain_fused.hip): replaces, for
+ * nn.TransformerEncoderLayer's linear1 -> ReLU -> dropout -> linear2 (reference transformer_layers.py:7-21 under tsformer.py:71-160),
+ * step_pt_ffn_hidden_fwd + the linear2 step_gemm in the forward and two weight-gradient GEMMs, step_pt_ffn_hidden_bwd,
+ * step_pt_colsum_bf16 and the input-gradient GEMM in the backward.  The [R, 384] hidden layer is never stored: the backward recomputes it.
+ *   step_pt_ffn_pack          w1 [384, 96], b1 [384], w2 [96, 384], b2 [96] (f32) -> operand fragments (step_pt_ffn_pack_bytes() bytes, 16-byte
+ *                             aligned); call it whenever the weights changed (once per training step)
+ *   step_pt_ffn_fused_fwd     f2 [R, 96] = w2 . dropout(relu(w1 . h1 + b1)) + b2
+ *   step_pt_ffn_fused_bwd_data     dh1 [R, 96] += ((df2 . w2) * relu' * keep / (1 - p)) . w1
+ *   step_pt_ffn_fused_bwd_weights  dw1 [384, 96] += dhid^T h1, db1 [384] += column sums of dhid, dw2 [96, 384] += df2^T hid;
+ *                             ws: step_pt_ffn_wgrad_ws_floats(R) floats of scratch
+ * Dropout (p > 0): keep decisions are bits of the per-step pool written by step_dropout_pool_fill (pool_words a power of two >= 512, followed by
+ * the 16-word wrap copy); rows 32 k .. 32 k + 31 of call site `site` own 192 consecutive words at a hashed offset, the same in all three calls. */
+long step_pt_ffn_pack_bytes(void);
+int step_pt_ffn_wgrad_workgroups(long R);
+long step_pt_ffn_wgrad_ws_floats(long R);
+int step_pt_ffn_pack(const float* w1, const float* b1, const float* w2, const float* b2, void* pack, void* stream);
+int step_pt_ffn_fused_fwd(const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words, uint64_t seed, uint32_t site,
+                          float* f2, void* stream);
+int step_pt_ffn_fused_bwd_data(const float* df2, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words,
+                               uint64_t seed, uint32_t site, float* dh1, void* stream);
+int step_pt_ffn_fused_bwd_weights(const float* df2, const float* h1, long R, const void* pack, const float* b1, float p, const uint64_t* pool,
+                                  long pool_words, uint64_t seed, uint32_t site, float* ws, float* dw1, float* db1, float* dw2, void* stream);
 /* d = dropout(d) * [relu_of > 0] in one pass: the backward of relu -> dropout (same mask stream as step_pt_dropout at `site`) */
 int step_pt_dropout_relu_mask(float* d, const float* relu_of, long n, float p, uint64_t seed, uint32_t site, void* stream);
 int step_pt_add_dropout(const float* a, const float* b, float* out, long n, float p, uint64_t seed, uint32_t site, void* stream);

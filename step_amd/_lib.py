@@ -95,6 +95,13 @@ _SIGS = {
     "step_pt_ffn_hidden_fwd": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp]),
     "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),
     "step_pt_colsum_bf16": (_i, [_vp, _l, _i, _vp, _vp]),
+    "step_pt_ffn_pack_bytes": (_l, []),
+    "step_pt_ffn_wgrad_workgroups": (_i, [_l]),
+    "step_pt_ffn_wgrad_ws_floats": (_l, [_l]),
+    "step_pt_ffn_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "step_pt_ffn_fused_fwd": (_i, [_vp, _l, _vp, _f, _vp, _l, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_ffn_fused_bwd_data": (_i, [_vp, _vp, _l, _vp, _f, _vp, _l, _u64, ctypes.c_uint32, _vp, _vp]),
+    "step_pt_ffn_fused_bwd_weights": (_i, [_vp, _vp, _l, _vp, _vp, _f, _vp, _l, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_add_layernorm_fwd": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_layernorm_bwd_dropout": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
     "step_pt_dropout_relu_mask": (_i, [_vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp]),
@@ -132,7 +139,7 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
 
 

@@ -1,0 +1,662 @@
+// Fused feed-forward block of the TSFormer pre-training step (reference: the two linear layers, ReLU and dropout of
+// nn.TransformerEncoderLayer inside step/step_arch/tsformer/transformer_layers.py:7-21, trained by tsformer.py:71-160), bf16 mode.
+//
+// The layer-by-layer path (pretrain.hip + step_gemm) stores the [R, 384] hidden layer and its gradient as bf16 tensors
+// (R = sequences x tokens = 873 600 rows in the decoder layer of config C3: 671 MB each) and walks them eight times per layer.
+// Here the hidden layer never leaves registers, in the forward AND in the backward (which recomputes it):
+//
+//   ffn_fwd_kernel       f2        = W2 . drop(relu(W1 . h1 + b1)) + b2                     reads h1, writes f2
+//   ffn_bwd_data_kernel  dh1      += W1^T . [ (W2^T . df2) * relu' * keep ]                 reads h1, df2, read-modify-writes dh1
+//   ffn_bwd_w2_kernel    dW2[o,j]  = sum over rows of df2[row,o] * hid[row,j]               reads h1, df2
+//   ffn_bwd_w1_kernel    dW1[j,i]  = sum over rows of dhid[row,j] * h1[row,i], db1 = column sums of dhid     reads h1, df2
+//
+// The first two keep activations TRANSPOSED like the forecasting-mode encoder (tsformer_encoder.hip): token = lane & 31, the 96
+// features of a token in three accumulator tiles, weights as the A operand streamed through an LDS ring of stage blocks
+// (global_load_lds, two chunks of 32 hidden units per block), and every accumulator tile is the next product's B operand after a
+// plain f32 -> bf16 pack (k-slot map F(s, h, j) of tsformer_layout.h).
+// The two weight-gradient kernels contract over ROWS, so there a wave owns a chunk of 32 hidden units for the whole launch (its
+// slices of W1 / W2 as B operands in registers, its 96 x 32 gradient tile in accumulators) and all twelve waves of the workgroup
+// walk the same row tiles, whose operand fragments -- rows as the non-contracted index ("X") and rows as the contracted index
+// ("Y") -- are staged in LDS once per tile.  hid / dhid come out of the matrix cores with the hidden unit as the lane, which is
+// already the operand layout of the products that follow.  Per-workgroup partial gradients go to a workspace; ffn_reduce_kernel
+// adds them into the gradient buffers.
+//
+// Dropout of the hidden units: keep decisions are bits of the per-step Bernoulli pool (step_dropout_pool_fill, the forecasting
+// encoder's scheme, tsformer_device.h): the 32-row tile `tile32` of call site `site` owns 12 x 16 consecutive 64-bit words at a
+// hashed offset; word c * 16 + i, bit 32 h + r  <->  row 32 tile32 + r, hidden unit 32 c + (i & 3) + 8 (i >> 2) + 4 h.
+// Forward and backward-data read them as lane masks (scalar loads); the weight-gradient kernels, where the lane is the hidden
+// unit, load the one word that holds their unit and test the row's bit.
+#include "common.h"
+#include "step_internal.h"
+#include "tsformer_device.h"
+
+#ifndef FF_ABLATE
+#define FF_ABLATE 0       // timing experiments only (WRONG results): 1 no matrix-core chains in the row kernels, 2 no global loads of the row tiles, 4 no stores,
+                          // 8 no global loads in the weight-gradient kernels' staging, 16 no matrix-core work there
+#endif
+
+namespace {
+
+typedef bf16x8 op8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int FF_FRAG = 1024;
+constexpr int FF_BLOCK_F = 25 * FF_FRAG;            // forward stage block: 2 x (6 W1 + 6 W2 fragments) + 1 KB of f32 vectors
+constexpr int FF_BLOCK_B = 37 * FF_FRAG;            // backward-data stage block: 2 x (6 W1 + 6 W2^T + 6 W1^T fragments) + 1 KB
+constexpr int FF_OFF_B = 6 * FF_BLOCK_F;
+constexpr int FF_PACK_BYTES = 6 * FF_BLOCK_F + 6 * FF_BLOCK_B;
+
+__device__ __forceinline__ int chain_f(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+__device__ __forceinline__ int row16(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+__device__ __forceinline__ op8 relu_bf16(op8 v) {
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(op8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
+__device__ __forceinline__ op8 mfrag(const char* base, int frag, int lane) { return *(const op8*)(base + frag * FF_FRAG + lane * 16); }
+__device__ __forceinline__ f32x16 mma(op8 a, op8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ op8 pack_lo_hi(const f32x16& v, int s) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = v[8 * s + j];
+    return pack8(t);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weight fragments
+// A-operand fragment: lane (h, r), slot j.  Forward block jb, chunk c = 2 jb + cc, fragments 12 cc + ...:
+//     0..5   W1 rows 32 c + r, k-step ks: W1[32 c + r][32 (ks >> 1) + F(ks & 1, h, j)]
+//     6..11  W2 tile t, k-step s:         W2[32 t + r][32 c + F(s, h, j)]
+// backward block jb, fragments 18 cc + ...:
+//     0..5   the same W1 fragments
+//     6..11  W2^T rows = hidden units:    W2[32 (ks >> 1) + F(ks & 1, h, j)][32 c + r]
+//     12..17 W1^T tile t, k-step s:       W1[32 c + F(s, h, j)][32 t + r]
+// f32 tail of every block: [0..63] b1 of both chunks in accumulator-register order [cc][h][16]; forward blocks also [64..159] b2 [h][48].
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, char* __restrict__ pack) {
+    constexpr int NF_F = 6 * 24, NF_B = 6 * 36;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < (NF_F + NF_B) * 64) {
+        const int frag = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+        float v[8];
+        char* dst;
+        int q, c;
+        bool bwd = frag >= NF_F;
+        if (!bwd) {
+            const int jb = frag / 24, f = frag % 24;
+            c = 2 * jb + f / 12;
+            q = f % 12;
+            dst = pack + (long)jb * FF_BLOCK_F + f * FF_FRAG + lane * 16;
+        } else {
+            const int fb = frag - NF_F, jb = fb / 36, f = fb % 36;
+            c = 2 * jb + f / 18;
+            q = f % 18;
+            dst = pack + FF_OFF_B + (long)jb * FF_BLOCK_B + f * FF_FRAG + lane * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (q < 6) v[j] = w1[(32 * c + r) * 96 + 32 * (q >> 1) + chain_f(q & 1, h, j)];
+            else if (!bwd) v[j] = w2[(32 * ((q - 6) >> 1) + r) * 384 + 32 * c + chain_f((q - 6) & 1, h, j)];
+            else if (q < 12) v[j] = w2[(32 * ((q - 6) >> 1) + chain_f((q - 6) & 1, h, j)) * 384 + 32 * c + r];
+            else v[j] = w1[(32 * c + chain_f((q - 12) & 1, h, j)) * 96 + 32 * ((q - 12) >> 1) + r];
+        }
+        *(op8*)dst = pack8(v);
+        return;
+    }
+    const int t = gid - (NF_F + NF_B) * 64;          // tails: 12 blocks x 256 floats
+    if (t < 12 * 256) {
+        const int blk = t >> 8, i = t & 255;
+        const bool bwd = blk >= 6;
+        const int jb = bwd ? blk - 6 : blk;
+        float* dst = (float*)(pack + (bwd ? FF_OFF_B + (long)jb * FF_BLOCK_B + 36 * FF_FRAG : (long)jb * FF_BLOCK_F + 24 * FF_FRAG));
+        float v = 0.f;
+        if (i < 64) {
+            const int cc = i >> 5, h = (i >> 4) & 1, e = i & 15;
+            v = b1[32 * (2 * jb + cc) + row16(e, h)];
+        } else if (i < 160 && !bwd) {
+            const int k = i - 64, h = k / 48, tt = (k % 48) >> 4, e = k & 15;
+            v = b2[32 * tt + row16(e, h)];
+        }
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- shared pieces
+struct FfnArgs {
+    const float* h1;                 // [R, 96] input of the block (LayerNorm1 output)
+    const float* df2;                // [R, 96] gradient of the block's output (backward kernels)
+    float* out;                      // forward: f2 [R, 96]; backward-data: dh1 [R, 96], accumulated in place
+    long R;
+    const char* pack;
+    const float* b1;                 // [384] (weight-gradient kernels: bias by lane)
+    float inv_keep;                  // 1 / (1 - p), 1 when dropout is off
+    const unsigned long long* pool;  // keep-mask pool (NULL: no dropout)
+    uint32_t pool_mask;
+    uint32_t seed, site;
+    float* ws;                       // weight-gradient kernels: per-workgroup partial results
+};
+
+__device__ __forceinline__ uint32_t ffn_mask_base(uint32_t seed, uint32_t site, long tile32, uint32_t pool_mask) {
+    return mix32(seed + (uint32_t)tile32 * 0x9E3779B1u + (site + 1u) * 0x632BE5ABu) & pool_mask;
+}
+
+// rows [row] of a [R, 96] f32 tensor into the transposed accumulator layout: a[t][4 q + i] = x[row][32 t + 8 q + 4 h + i]
+__device__ __forceinline__ void load_rows_T(const float* __restrict__ x, long row, bool ok, int h, f32x16 (&a)[3]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && !(FF_ABLATE & 2)) v = *(const float4*)(x + row * 96 + 32 * t + 8 * q + 4 * h);
+            a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w;
+        }
+}
+__device__ __forceinline__ void store_rows_T(float* __restrict__ y, long row, bool ok, int h, const f32x16 (&a)[3]) {
+    if (!ok || (FF_ABLATE & 4)) return;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(y + row * 96 + 32 * t + 8 * q + 4 * h) = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+}
+__device__ __forceinline__ void pack_rows_T(const f32x16 (&a)[3], op8 (&b)[6]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { b[2 * t] = pack_lo_hi(a[t], 0); b[2 * t + 1] = pack_lo_hi(a[t], 1); }
+}
+
+// Row tiles move between HBM and the transposed register layout through wave-private LDS, so that every global access is a full
+// 128-byte line (a lane reading its own row's 16 bytes touches 32 lines per instruction: measured 2.4x the time of the kernel's
+// matrix work, profiles/r04_p_ffn_ablations.log):
+//   in : the tile's 32 x 96 floats are one contiguous 12 KB run: 12 coalesced float4 loads -> bf16 -> [32 rows][24 chunks of 8 bytes],
+//        chunk c of row r at position c ^ ((r >> 1) & 7) (conflict-free for the 16 lanes of a ds_read_b64 pass); an operand fragment
+//        (k-step f = 2 b + s, lane (r, h)) is chunks 4 f + h and 4 f + h + 2 of row r
+//   out: one 32-feature block at a time, [32 rows][8 chunks of 16 bytes] f32, chunk position c ^ (r & 7); read back as 8 lanes per
+//        128-byte line of a row (plain store, or read-modify-write for the accumulated input gradient)
+constexpr int STG_IN = 32 * 192, STG_OUT = 32 * 128, STG_WAVE = STG_IN + STG_OUT;
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }      // LDS executes a wave's accesses in order; this pins the program order
+
+__device__ __forceinline__ void tile_in(const float* __restrict__ x, long row0, long R, char* stg, int lane) {
+    const float* src = x + row0 * 96;
+    const long left = R - row0;
+    const int nvalid = (int)(left >= 32 ? 32 : (left > 0 ? left : 0)) * 96;
+    float4 v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int flat = k * 256 + lane * 4;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flat < nvalid && !(FF_ABLATE & 2)) v[k] = *(const float4*)(src + flat);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int flat = k * 256 + lane * 4, r = flat / 96, c = (flat - r * 96) >> 2;
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[k].x, v[k].y);
+        pk[1] = pack_bf16x2(v[k].z, v[k].w);
+        *(u32x2*)(stg + r * 192 + 8 * (c ^ ((r >> 1) & 7))) = pk;
+    }
+    lds_order();
+}
+__device__ __forceinline__ void tile_frags(const char* stg, int lane, op8 (&b)[6]) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+    const char* row = stg + r * 192;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const u32x2 lo = *(const u32x2*)(row + 8 * ((4 * f + h) ^ sw)), hi = *(const u32x2*)(row + 8 * ((4 * f + h + 2) ^ sw));
+        u32x4 w;
+        w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+        b[f] = __builtin_bit_cast(op8, w);
+    }
+    lds_order();
+}
+template <bool RMW>
+__device__ __forceinline__ void tile_out(float* __restrict__ y, long row0, long R, char* ost, int lane, const f32x16 (&acc)[3]) {
+    if (FF_ABLATE & 4) return;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(ost + r * 128 + 16 * ((2 * q + h) ^ (r & 7))) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        lds_order();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int id = n * 64 + lane, rr = id >> 3, cq = id & 7;
+            float4 v = *(const float4*)(ost + rr * 128 + 16 * (cq ^ (rr & 7)));
+            if (row0 + rr < R) {
+                float* g = y + (row0 + rr) * 96 + 32 * t + 4 * cq;
+                if constexpr (RMW) {
+                    const float4 o = *(const float4*)g;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *(float4*)g = v;
+            }
+        }
+        lds_order();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward / backward-data
+// One workgroup = NW waves = NW tiles of 32 rows per pass; persistent over passes.  BWD = false: forward, BWD = true: backward-data.
+template <int NW, bool BWD, bool DROP>
+__global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int BLOCK = BWD ? FF_BLOCK_B : FF_BLOCK_F;
+    constexpr int NPIECE = BLOCK / FF_FRAG;
+    constexpr int TAILOFF = (NPIECE - 1) * FF_FRAG;
+    constexpr int CF = BWD ? 18 : 12;                   // fragments per chunk
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    const long npass = (A.R + 32 * NW - 1) / (32 * NW);
+    if ((long)blockIdx.x >= npass) return;
+    const int mine = (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1;
+    const int nstage = mine * 6;
+    const char* W = A.pack + (BWD ? FF_OFF_B : 0);
+    const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(smem));
+    const mask_ptr pool = (mask_ptr)(uintptr_t)A.pool;
+    char* stg = smem + 2 * BLOCK + wave * STG_WAVE;     // this wave's staging area (tile_in / tile_out)
+
+    auto issue_fill = [&](int g) {                      // stage g reads block g mod 6 into ring slot g mod 2
+        const char* src = W + (long)(g % 6) * BLOCK + lane * 16;
+        const uint32_t dst = ring_addr + (uint32_t)(g & 1) * BLOCK;
+        for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * FF_FRAG, dst + (uint32_t)pc * FF_FRAG);
+    };
+    int issued = 1;
+    auto stage_begin = [&](int g) -> const char* {      // see tsformer_encoder.hip: my pieces landed, everybody's did, slot of g - 1 is free
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int upto = g + 1 < nstage ? g + 1 : nstage - 1;
+        for (; issued <= upto; ++issued) issue_fill(issued);
+        return smem + (g & 1) * BLOCK;
+    };
+    issue_fill(0);
+
+    int g = 0;
+#pragma unroll 1
+    for (long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        const long tile32 = pass * NW + wave;
+        op8 xb[6], db[6];
+        f32x16 acc[3];
+        tile_in(A.h1, tile32 * 32, A.R, stg, lane);
+        tile_frags(stg, lane, xb);
+        if constexpr (BWD) {
+            tile_in(A.df2, tile32 * 32, A.R, stg, lane);
+            tile_frags(stg, lane, db);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const uint32_t mbase = DROP ? ffn_mask_base(A.seed, A.site, tile32, A.pool_mask) : 0u;
+        const char* blk = nullptr;
+#pragma unroll 1
+        for (int jb = 0; jb < ((FF_ABLATE & 1) ? 1 : 6); ++jb, g += ((FF_ABLATE & 1) ? 6 : 1)) {
+            blk = stage_begin(g);
+            const float* tail = (const float*)(blk + TAILOFF);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                op8 wu[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wu[ks] = mfrag(blk, cc * CF + ks, lane);
+                f32x16 hh;
+                const float* b1 = tail + (cc * 2 + h) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hh[i] = b1[i];
+                unsigned long long mw[16];
+                if constexpr (DROP) {
+                    const mask_ptr mp = pool + ((mbase + (uint32_t)(jb * 2 + cc) * 16u) & A.pool_mask);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mw[i] = mp[i];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) hh = mma(wu[ks], xb[ks], hh);
+                if constexpr (!BWD) {
+                    op8 wd[6];
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) wd[f] = mfrag(blk, cc * CF + 6 + f, lane);
+                    if constexpr (DROP) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[i]) ? hh[i] : 0.f;
+                    }
+                    const op8 hb0 = relu_bf16(pack_lo_hi(hh, 0)), hb1 = relu_bf16(pack_lo_hi(hh, 1));
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        acc[t] = mma(wd[2 * t], hb0, acc[t]);
+                        acc[t] = mma(wd[2 * t + 1], hb1, acc[t]);
+                    }
+                } else {
+                    op8 wt[6];
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) wt[ks] = mfrag(blk, cc * CF + 6 + ks, lane);
+                    f32x16 dd;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dd[i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) dd = mma(wt[ks], db[ks], dd);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        bool open = hh[i] > 0.f;
+                        if constexpr (DROP) open = open && __builtin_amdgcn_inverse_ballot_w64(mw[i]);
+                        dd[i] = open ? dd[i] * A.inv_keep : 0.f;
+                    }
+                    const op8 d0 = pack_lo_hi(dd, 0), d1 = pack_lo_hi(dd, 1);
+                    op8 wc[6];
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) wc[f] = mfrag(blk, cc * CF + 12 + f, lane);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        acc[t] = mma(wc[2 * t], d0, acc[t]);
+                        acc[t] = mma(wc[2 * t + 1], d1, acc[t]);
+                    }
+                }
+            }
+        }
+        if constexpr (!BWD) {
+            const float* b2 = (const float*)(blk + TAILOFF) + 64 + h * 48;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(acc[t][i], A.inv_keep, b2[t * 16 + i]);
+        }
+        tile_out<BWD>(A.out, tile32 * 32, A.R, stg + STG_IN, lane, acc);          // backward-data: added onto the residual branch's gradient already in dh1
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weight gradients
+// Twelve waves, wave = chunk of 32 hidden units.  Per 32-row tile the workgroup stages operand fragments in LDS (bf16):
+//   X(h1), X(df2): 6 fragments each, lane = row, slots = features in chain order (A operand of hid / dhid)
+//   Y(v), 6 fragments [t][s]: lane = feature 32 t + r, slots = rows F(s, h, j) (rows as the contracted index)
+// W2 kernel: X(h1), Y(df2);   W1 kernel: X(h1), X(df2), Y(h1).
+constexpr int FW_WAVES = 12;
+constexpr int FW_TILES = 2;                       // 32-row tiles per stage
+
+template <bool W1K>
+struct FwLayout {
+    static constexpr int FRAGS = W1K ? 18 : 12;   // per 32-row tile
+    static constexpr int STAGE = FW_TILES * FRAGS * FF_FRAG;
+    static constexpr int JOBS = W1K ? 5 : 4;      // staging jobs per tile: X jobs (one tensor each), Y jobs (two fragments... see below)
+};
+
+// stage one 32-row tile's fragments into `dst`; job ids: W2 kernel {0: X(h1) -> frags 0..5, 1..3: Y(df2) tile t = job - 1 -> frags 6 + 2 t ..};
+// W1 kernel {0: X(h1) -> 0..5, 1: X(df2) -> 6..11, 2..4: Y(h1) tile t = job - 2 -> frags 12 + 2 t ..}
+template <bool W1K>
+__device__ __forceinline__ void fw_stage_job(const FfnArgs& A, int job, long row0, char* dst, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    const int nx = W1K ? 2 : 1;
+    if (job < nx) {
+        const float* src = job == 0 ? A.h1 : A.df2;
+        const long row = row0 + r;
+        const bool ok = row < A.R;
+        // one 32-feature block at a time (not unrolled): the gradient accumulators and the weight slices stay in registers meanwhile
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t) {
+            f32x16 a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && !(FF_ABLATE & 8)) v = *(const float4*)(src + row * 96 + 32 * t + 8 * q + 4 * h);
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+            *(op8*)(dst + (job * 6 + 2 * t) * FF_FRAG + lane * 16) = pack_lo_hi(a, 0);
+            *(op8*)(dst + (job * 6 + 2 * t + 1) * FF_FRAG + lane * 16) = pack_lo_hi(a, 1);
+        }
+    } else {
+        const int t = job - nx;
+        const float* src = W1K ? A.h1 : A.df2;
+        const int fbase = (W1K ? 12 : 6) + 2 * t;
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long row = row0 + chain_f(s, h, j);
+                v[j] = row < A.R && !(FF_ABLATE & 8) ? src[row * 96 + 32 * t + r] : 0.f;
+            }
+            *(op8*)(dst + (fbase + s) * FF_FRAG + lane * 16) = pack8(v);
+        }
+    }
+}
+
+template <bool W1K, bool DROP>
+__global__ __launch_bounds__(FW_WAVES * 64) void ffn_wgrad_kernel(FfnArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef FwLayout<W1K> LY;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // = chunk of 32 hidden units
+    const int u = lane & 31, h = lane >> 5;
+    const long ntile = (A.R + 31) / 32;
+    const long nstage_all = (ntile + FW_TILES - 1) / FW_TILES;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float dbias = 0.f;
+    // this wave's slices of the weights as B operands (lane = hidden unit), from the backward stage blocks of the pack
+    op8 w1a[6], w2t[6];
+    {
+        const char* blk = A.pack + FF_OFF_B + (long)(wave >> 1) * FF_BLOCK_B + (wave & 1) * 18 * FF_FRAG;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            w1a[ks] = mfrag(blk, ks, lane);
+            if constexpr (W1K) w2t[ks] = mfrag(blk, 6 + ks, lane);
+        }
+    }
+    const float bias = A.b1[32 * wave + u];
+    // the pool word of this lane's hidden unit inside a chunk's 16 words, and which half of it holds the row bits
+    const uint32_t widx = (uint32_t)((u & 3) + 4 * (u >> 3));
+    const int hp = (u >> 2) & 1;
+
+    auto stage_fill = [&](long st, char* buf) {
+        for (int jb = wave; jb < FW_TILES * LY::JOBS; jb += FW_WAVES) {
+            const int tl = jb / LY::JOBS, job = jb % LY::JOBS;
+            fw_stage_job<W1K>(A, job, (st * FW_TILES + tl) * 32, buf + tl * LY::FRAGS * FF_FRAG, lane);
+        }
+    };
+    if ((long)blockIdx.x < nstage_all) stage_fill(blockIdx.x, smem);
+    __syncthreads();
+    int par = 0;
+#pragma unroll 1
+    for (long st = blockIdx.x; st < nstage_all; st += gridDim.x, par ^= 1) {
+        const long nxt = st + gridDim.x;
+        if (nxt < nstage_all) stage_fill(nxt, smem + (par ^ 1) * LY::STAGE);
+        const char* buf = smem + par * LY::STAGE;
+#pragma unroll 1
+        for (int tl = 0; tl < FW_TILES; ++tl) {
+            const long tile32 = st * FW_TILES + tl;
+            if (tile32 >= ntile || ((FF_ABLATE & 16) && tile32 > 0)) break;
+            const char* fr = buf + tl * LY::FRAGS * FF_FRAG;
+            f32x16 hh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hh[i] = bias;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) hh = mma(mfrag(fr, ks, lane), w1a[ks], hh);          // hid[row, unit]: lane = unit, registers = rows
+            unsigned long long word = ~0ull;
+            if constexpr (DROP) {
+                const uint32_t mbase = ffn_mask_base(A.seed, A.site, tile32, A.pool_mask);
+                word = A.pool[(mbase + (uint32_t)wave * 16u + widx) & A.pool_mask] >> (32 * hp);
+            }
+            const uint32_t bits = (uint32_t)word >> (4 * h);                                  // bit (i & 3) + 8 (i >> 2): the row of register i
+            if constexpr (!W1K) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool open = hh[i] > 0.f && (bits & (1u << ((i & 3) + 8 * (i >> 2))));
+                    hh[i] = open ? hh[i] : 0.f;
+                }
+                const op8 hb0 = pack_lo_hi(hh, 0), hb1 = pack_lo_hi(hh, 1);                    // B operand: k = rows (chain order), n = unit
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = mma(mfrag(fr, 6 + 2 * t, lane), hb0, acc[t]);                      // dW2[o, unit] += df2[rows, o]^T hid[rows, unit]
+                    acc[t] = mma(mfrag(fr, 7 + 2 * t, lane), hb1, acc[t]);
+                }
+            } else {
+                f32x16 dd;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dd[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) dd = mma(mfrag(fr, 6 + ks, lane), w2t[ks], dd);   // (df2 . W2)[row, unit]
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool open = hh[i] > 0.f && (bits & (1u << ((i & 3) + 8 * (i >> 2))));
+                    dd[i] = open ? dd[i] : 0.f;
+                    dbias += dd[i];
+                }
+                const op8 da0 = pack_lo_hi(dd, 0), da1 = pack_lo_hi(dd, 1);                    // A operand: m = unit, k = rows (chain order)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = mma(da0, mfrag(fr, 12 + 2 * t, lane), acc[t]);                     // dW1[unit, i] += dhid[rows, unit]^T h1[rows, i]
+                    acc[t] = mma(da1, mfrag(fr, 13 + 2 * t, lane), acc[t]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // partial results of this workgroup (the dropout survivor scale is applied by the reduction)
+    float* ws = A.ws + (long)blockIdx.x * (W1K ? 384 * 96 + 384 : 96 * 384);
+    if constexpr (!W1K) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ws[(32 * t + row16(i, h)) * 384 + 32 * wave + u] = acc[t][i];      // dW2[o][unit]
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ws[(32 * wave + row16(i, h)) * 96 + 32 * t + u] = acc[t][i];       // dW1[unit][i]
+        const float other = __shfl_xor(dbias, 32, 64);
+        if (h == 0) ws[384 * 96 + 32 * wave + u] = dbias + other;
+    }
+}
+
+// out[i] += scale * sum over the workgroups' partial results; blockIdx.y takes every gridDim.y-th partial (f32 atomics: at most 8 per element)
+__global__ __launch_bounds__(256) void ffn_reduce_kernel(const float* __restrict__ ws, int parts, long n, long stride, float scale, float* __restrict__ out0,
+                                                          long n0, float* __restrict__ out1) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f;
+    int p = blockIdx.y;
+    for (; p + (int)gridDim.y < parts; p += 2 * gridDim.y) { s0 += ws[(long)p * stride + i]; s1 += ws[(long)(p + gridDim.y) * stride + i]; }
+    if (p < parts) s0 += ws[(long)p * stride + i];
+    atomicAdd(i < n0 ? out0 + i : out1 + (i - n0), scale * (s0 + s1));
+}
+
+int check_common(const char* who, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words) {
+    STEP_REQUIRE(h1 && pack, "%s: null input", who);
+    STEP_REQUIRE(R > 0 && R < (1L << 36), "%s: bad row count %ld", who, R);
+    STEP_REQUIRE(p >= 0.f && p < 1.f, "%s: bad dropout %f", who, p);
+    if (p > 0.f) {
+        STEP_REQUIRE(pool, "%s: dropout needs a keep-mask pool (step_dropout_pool_fill)", who);
+        STEP_REQUIRE(pool_words >= 512 && (pool_words & (pool_words - 1)) == 0 && pool_words <= (1L << 31),
+                     "%s: pool of %ld words is not a power of two in [512, 2^31]", who, pool_words);
+    }
+    return STEP_OK;
+}
+
+FfnArgs make_args(const float* h1, const float* df2, float* out, long R, const void* pack, const float* b1, float p, const uint64_t* pool,
+                  long pool_words, uint64_t seed, uint32_t site, float* ws) {
+    FfnArgs a;
+    a.h1 = h1; a.df2 = df2; a.out = out; a.R = R; a.pack = (const char*)pack; a.b1 = b1;
+    a.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    a.pool = p > 0.f ? (const unsigned long long*)pool : nullptr;
+    a.pool_mask = p > 0.f ? (uint32_t)(pool_words - 1) : 0u;
+    a.seed = (uint32_t)(seed ^ (seed >> 32)); a.site = site; a.ws = ws;
+    return a;
+}
+
+constexpr int FR_WAVES = 8;
+
+template <typename K>
+int raise_lds(K kernel, int bytes, bool& done) {
+    if (!done) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            step_set_error("pretrain_fused: cannot raise the dynamic LDS limit to %d bytes", bytes);
+            return STEP_ERR_HIP;
+        }
+        done = true;
+    }
+    return STEP_OK;
+}
+
+template <bool BWD>
+int launch_rows(const FfnArgs& a, hipStream_t st) {
+    static bool raised[2] = {false, false};
+    const int lds = 2 * (BWD ? FF_BLOCK_B : FF_BLOCK_F) + FR_WAVES * STG_WAVE;
+    const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
+    const int grid = (int)(npass < 512 ? npass : 512);
+    if (a.pool) {
+        STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, BWD, true>, lds, raised[1]));
+        ffn_rows_kernel<FR_WAVES, BWD, true><<<grid, FR_WAVES * 64, lds, st>>>(a);
+    } else {
+        STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, BWD, false>, lds, raised[0]));
+        ffn_rows_kernel<FR_WAVES, BWD, false><<<grid, FR_WAVES * 64, lds, st>>>(a);
+    }
+    return STEP_OK;
+}
+
+template <bool W1K>
+int launch_wgrad(const FfnArgs& a, int grid, hipStream_t st) {
+    static bool raised[2] = {false, false};
+    const int lds = 2 * FwLayout<W1K>::STAGE;
+    if (a.pool) {
+        STEP_TRY(raise_lds(ffn_wgrad_kernel<W1K, true>, lds, raised[1]));
+        ffn_wgrad_kernel<W1K, true><<<grid, FW_WAVES * 64, lds, st>>>(a);
+    } else {
+        STEP_TRY(raise_lds(ffn_wgrad_kernel<W1K, false>, lds, raised[0]));
+        ffn_wgrad_kernel<W1K, false><<<grid, FW_WAVES * 64, lds, st>>>(a);
+    }
+    return STEP_OK;
+}
+
+}  // namespace
+
+extern "C" long step_pt_ffn_pack_bytes(void) { return FF_PACK_BYTES; }
+
+extern "C" int step_pt_ffn_wgrad_workgroups(long R) {
+    const long nstage = ((R + 31) / 32 + FW_TILES - 1) / FW_TILES;
+    return (int)(nstage < 256 ? nstage : 256);
+}
+extern "C" long step_pt_ffn_wgrad_ws_floats(long R) { return (long)step_pt_ffn_wgrad_workgroups(R) * (96 * 384 + 384 * 96 + 384); }
+
+extern "C" int step_pt_ffn_pack(const float* w1, const float* b1, const float* w2, const float* b2, void* pack, void* stream) {
+    STEP_REQUIRE(w1 && b1 && w2 && b2 && pack, "pt_ffn_pack: null argument");
+    STEP_REQUIRE(((uintptr_t)pack & 15) == 0, "pt_ffn_pack: the fragment buffer must be 16-byte aligned");
+    const int threads = (6 * 24 + 6 * 36) * 64 + 12 * 256;
+    ffn_pack_kernel<<<cdiv(threads, 256), 256, 0, (hipStream_t)stream>>>(w1, b1, w2, b2, (char*)pack);
+    STEP_LAUNCH_CHECK("step_pt_ffn_pack");
+    return STEP_OK;
+}
+
+extern "C" int step_pt_ffn_fused_fwd(const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words, uint64_t seed,
+                                     uint32_t site, float* f2, void* stream) {
+    STEP_TRY(check_common("pt_ffn_fused_fwd", h1, R, pack, p, pool, pool_words));
+    STEP_REQUIRE(f2, "pt_ffn_fused_fwd: null output");
+    STEP_TRY(launch_rows<false>(make_args(h1, nullptr, f2, R, pack, nullptr, p, pool, pool_words, seed, site, nullptr), (hipStream_t)stream));
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_fwd");
+    return STEP_OK;
+}
+
+extern "C" int step_pt_ffn_fused_bwd_data(const float* df2, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words,
+                                          uint64_t seed, uint32_t site, float* dh1, void* stream) {
+    STEP_TRY(check_common("pt_ffn_fused_bwd_data", h1, R, pack, p, pool, pool_words));
+    STEP_REQUIRE(df2 && dh1, "pt_ffn_fused_bwd_data: null argument");
+    STEP_TRY(launch_rows<true>(make_args(h1, df2, dh1, R, pack, nullptr, p, pool, pool_words, seed, site, nullptr), (hipStream_t)stream));
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_bwd_data");
+    return STEP_OK;
+}
+
+extern "C" int step_pt_ffn_fused_bwd_weights(const float* df2, const float* h1, long R, const void* pack, const float* b1, float p, const uint64_t* pool,
+                                             long pool_words, uint64_t seed, uint32_t site, float* ws, float* dw1, float* db1, float* dw2, void* stream) {
+    STEP_TRY(check_common("pt_ffn_fused_bwd_weights", h1, R, pack, p, pool, pool_words));
+    STEP_REQUIRE(df2 && b1 && ws && dw1 && db1 && dw2, "pt_ffn_fused_bwd_weights: null argument");
+    const hipStream_t st = (hipStream_t)stream;
+    const int grid = step_pt_ffn_wgrad_workgroups(R);
+    float* ws2 = ws;
+    float* ws1 = ws + (long)grid * 96 * 384;
+    STEP_TRY(launch_wgrad<false>(make_args(h1, df2, nullptr, R, pack, b1, p, pool, pool_words, seed, site, ws2), grid, st));
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_bwd_weights (W2)");
+    STEP_TRY(launch_wgrad<true>(make_args(h1, df2, nullptr, R, pack, b1, p, pool, pool_words, seed, site, ws1), grid, st));
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_bwd_weights (W1)");
+    const float ks = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    ffn_reduce_kernel<<<dim3(cdiv(96 * 384, 256), 8), 256, 0, st>>>(ws2, grid, 96 * 384, 96 * 384, ks, dw2, 96 * 384, nullptr);
+    ffn_reduce_kernel<<<dim3(cdiv(384 * 96 + 384, 256), 8), 256, 0, st>>>(ws1, grid, 384 * 96 + 384, 384 * 96 + 384, ks, dw1, 384 * 96, db1);
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_bwd_weights (reduce)");
+    return STEP_OK;
+}

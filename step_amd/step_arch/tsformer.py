@@ -7,6 +7,7 @@ checkpoints load unchanged.  The sub-modules below only *hold* parameters; arith
 ``libstep_hip`` (``step_tsformer_encode``).  There is no PyTorch fallback: CPU tensors raise.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -110,6 +111,20 @@ def _splitk_ws(dev):
     return t
 
 
+_FFN_WS = {}
+PT_POOL_WORDS = 1 << 18        # keep-mask pool of the fused feed-forward blocks (2 MB: resident in every XCD's L2, like the forecasting encoder's; refilled
+                               # every step; a 32-row tile reads 192 words of it at a hashed offset)
+
+
+def _ffn_ws(dev, R):
+    """scratch of step_pt_ffn_fused_bwd_weights: the per-workgroup partial gradients (at most 256 x 74 112 floats = 76 MB)"""
+    n = _lib.lib().step_pt_ffn_wgrad_ws_floats(int(R))
+    t = _FFN_WS.get(dev)
+    if t is None or t.numel() < n:
+        t = _FFN_WS[dev] = torch.empty(n, device=dev, dtype=torch.float32)
+    return t
+
+
 def _linear_fwd(x, w, b, relu=False):
     """y[R,N] = x[R,K] @ w[N,K]^T + b   (step_gemm: exact-f32 matrix cores, or bf16 operands in the bf16 mode)."""
     R, K = x.shape
@@ -147,6 +162,14 @@ class _PretrainFunction(torch.autograd.Function):
         p = model.dropout_p if model.training else 0.0
         seed = model._next_seed()
         saved = {"seed": seed, "p": p}
+        fz = None
+        if _BF16 and model.fused_ffn:
+            # feed-forward blocks without a stored hidden layer (csrc/pretrain_fused.hip): operand fragments of this step's weights per layer,
+            # and the step's keep-mask pool
+            fz = {"packs": model._ffn_packs(series.device), "pool": None, "words": 0}
+            if p > 0:
+                fz["pool"], fz["words"] = model._pt_pool(series.device, p, seed)
+        saved["fz"] = fz
         pos = P_["positional_encoding.position_embedding"]
         # patch embedding + positional embedding (+dropout), gather the unmasked tokens, scale by sqrt(d)
         patches = series.view(S * P, 12)
@@ -159,7 +182,7 @@ class _PretrainFunction(torch.autograd.Function):
         del e0
         layers = []
         for l in range(model.encoder_depth):
-            x, sv = _PretrainFunction._layer_fwd(x, S, Pu, P_, f"encoder.transformer_encoder.layers.{l}.", p, seed, 16 * l)
+            x, sv = _PretrainFunction._layer_fwd(x, S, Pu, P_, f"encoder.transformer_encoder.layers.{l}.", p, seed, 16 * l, fz)
             layers.append(sv)
         y = _empty(S * Pu, 96, like=series)
         st_enc = _empty(S * Pu, 2, like=series)
@@ -171,7 +194,7 @@ class _PretrainFunction(torch.autograd.Function):
         dec_layers = []
         d = d0
         for l in range(model.decoder_depth):
-            d, sv = _PretrainFunction._layer_fwd(d, S, P, P_, f"decoder.transformer_encoder.layers.{l}.", p, seed, 16 * (8 + l))
+            d, sv = _PretrainFunction._layer_fwd(d, S, P, P_, f"decoder.transformer_encoder.layers.{l}.", p, seed, 16 * (8 + l), fz)
             dec_layers.append(sv)
         d2 = _empty(S * P, 96, like=series)
         st_dec = _empty(S * P, 2, like=series)
@@ -185,7 +208,7 @@ class _PretrainFunction(torch.autograd.Function):
         return r.view(S, P, 12)
 
     @staticmethod
-    def _layer_fwd(x, S, T, P_, pre, p, seed, site):
+    def _layer_fwd(x, S, T, P_, pre, p, seed, site, fz=None):
         L = _lib
         st = L.stream()
         R = S * T
@@ -211,7 +234,15 @@ class _PretrainFunction(torch.autograd.Function):
         h1pre, h1, st1 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
         L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]),
                L.ptr(h1pre), L.ptr(h1), L.ptr(st1), st)
-        if _BF16:
+        f2 = None
+        if fz is not None:
+            pk = fz["packs"][pre]
+            L.call("step_pt_ffn_pack", L.ptr(P_[pre + "linear1.weight"]), L.ptr(P_[pre + "linear1.bias"]), L.ptr(P_[pre + "linear2.weight"]),
+                   L.ptr(P_[pre + "linear2.bias"]), L.ptr(pk), st)
+            f1 = f1d = None
+            f2 = _empty(R, 96, like=x)
+            L.call("step_pt_ffn_fused_fwd", L.ptr(h1), R, L.ptr(pk), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2, L.ptr(f2), st)
+        elif _BF16:
             # ReLU and dropout in the epilogue of the first linear layer, the hidden layer stored once, as bf16 (the f32 path writes
             # relu(.) and its dropped copy: 2 x 1.3 GB per decoder layer at config C3); same Philox stream as step_pt_dropout
             f1 = None
@@ -224,12 +255,13 @@ class _PretrainFunction(torch.autograd.Function):
             if p > 0:
                 f1d = _empty(R, 384, like=x)
                 L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
-        f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
+        if f2 is None:
+            f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
         h2pre, h2, st2 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
         L.call("step_pt_add_layernorm_fwd", L.ptr(h1), L.ptr(f2), R, p, seed, site + 3, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]),
                L.ptr(h2pre), L.ptr(h2), L.ptr(st2), st)
         return h2, dict(x=x, qkv=qkv, a=a, stats=stats, keepbits=kb, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
-                        site=site, T=T)
+                        site=site, T=T, fz=fz)
 
     @staticmethod
     def _layer_bwd(dh2, sv, S, P_, G, p, seed):
@@ -247,7 +279,17 @@ class _PretrainFunction(torch.autograd.Function):
         if df2 is None:
             df2 = dh2pre
         dh1 = dh2pre if p > 0 else dh2pre.clone()          # residual branch of H2pre = H1 + dropout(F2)
-        if _BF16:
+        if sv["fz"] is not None:
+            # fused feed-forward block: the hidden layer and its gradient are recomputed inside the kernels (db2 = colsum(df2) came out of the
+            # LayerNorm backward above)
+            fz = sv["fz"]
+            pk = fz["packs"][pre]
+            L.call("step_pt_ffn_fused_bwd_data", L.ptr(df2), L.ptr(sv["h1"]), R, L.ptr(pk), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2,
+                   L.ptr(dh1), st)
+            L.call("step_pt_ffn_fused_bwd_weights", L.ptr(df2), L.ptr(sv["h1"]), R, L.ptr(pk), L.ptr(P_[pre + "linear1.bias"]), p, L.ptr(fz["pool"]),
+                   fz["words"], seed, site + 2, L.ptr(_ffn_ws(dh2.device, R)), L.ptr(G[pre + "linear1.weight"]), L.ptr(G[pre + "linear1.bias"]),
+                   L.ptr(G[pre + "linear2.weight"]), st)
+        elif _BF16:
             # bf16 hidden layer (see _layer_fwd): its gradient is masked in the GEMM epilogue and stored as bf16 as well
             hid = sv["f1d"]
             w1, w2 = P_[pre + "linear1.weight"], P_[pre + "linear2.weight"]
@@ -378,6 +420,11 @@ class TSFormer(nn.Module):
         nn.init.trunc_normal_(self.mask_token, std=.02)
         self._pt_names = [n for n, _ in self.named_parameters()]
         self._seed_ctr2 = 0
+        # bf16 mode of the pre-training step: feed-forward blocks through csrc/pretrain_fused.hip (no stored hidden layer; the backward
+        # recomputes it).  STEP_PT_FUSED_FFN=0 keeps the layer-by-layer kernels (A/B measurements)
+        self.fused_ffn = os.environ.get("STEP_PT_FUSED_FFN", "1") != "0"
+        self._ffn_pack_bufs = None
+        self._pt_pool_buf = None
         self._packed = None
         self._packed_key = None
         self._plist = None
@@ -502,6 +549,22 @@ class TSFormer(nn.Module):
             off += (p.numel() + 3) & ~3
         self._flat_grad = flat
         return flat, G
+
+    def _ffn_packs(self, device):
+        """per-layer operand-fragment buffers of the fused feed-forward blocks (rewritten by step_pt_ffn_pack every step)"""
+        if self._ffn_pack_bufs is None or next(iter(self._ffn_pack_bufs.values())).device != device:
+            n = _lib.lib().step_pt_ffn_pack_bytes()
+            keys = [f"encoder.transformer_encoder.layers.{l}." for l in range(self.encoder_depth)] + \
+                   [f"decoder.transformer_encoder.layers.{l}." for l in range(self.decoder_depth)]
+            self._ffn_pack_bufs = {k: torch.empty(n, dtype=torch.uint8, device=device) for k in keys}
+        return self._ffn_pack_bufs
+
+    def _pt_pool(self, device, p, seed):
+        """this step's keep-mask pool of the fused feed-forward blocks: (int64 tensor, words)"""
+        if self._pt_pool_buf is None or self._pt_pool_buf.device != device:
+            self._pt_pool_buf = torch.empty(PT_POOL_WORDS + 16, dtype=torch.int64, device=device)
+        _lib.call("step_dropout_pool_fill", _lib.ptr(self._pt_pool_buf), PT_POOL_WORDS, float(p), int(seed) ^ 0x5EED_F00D, _lib.stream())
+        return self._pt_pool_buf, PT_POOL_WORDS
 
     def _next_seed(self):
         self._seed_ctr2 += 1

@@ -381,3 +381,57 @@ def test_weight_gradient_contraction_split_k_workspace(N, K):
     L.gemm(a, b, c, 96, N, K, 1, 96, N, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=ws)
     torch.cuda.synchronize()
     assert rel_l2(c.cpu().double(), 2 * want) < 2e-5
+
+
+@pytest.mark.parametrize("R,p", [(256 * 3 + 77, 0.0), (256 * 3 + 77, 0.1), (256 * 600 + 45, 0.1)])
+def test_fused_feed_forward_block_matches_reference(R, p):
+    """step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (csrc/pretrain_fused.hip: the hidden layer never stored, recomputed by the backward)
+    against float64 matrix algebra: f2 = W2 . keep(relu(W1 . h1 + b1)) / (1 - p) + b2, its input gradient added onto dh1 and the three
+    parameter gradients added onto their buffers.  The keep decisions are rebuilt on the host from the device pool's words
+    (tests/ffn_fused_host.py); the large case makes every workgroup loop over several row tiles.  bf16 operands: 6e-3."""
+    from step_amd import _lib as L
+    from tests import ffn_fused_host as FH
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(R, 96, generator=gen).cuda()
+    w1 = (torch.randn(384, 96, generator=gen) * 0.15).cuda()
+    b1 = (torch.randn(384, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(96, 384, generator=gen) * 0.1).cuda()
+    b2 = (torch.randn(96, generator=gen) * 0.1).cuda()
+    df2 = torch.randn(R, 96, generator=gen).cuda()
+    dh1_in = torch.randn(R, 96, generator=gen).cuda()
+    seed, site, st = 0x0BAD_5EED_1234, 34, L.stream()
+    words = 1 << 14
+    pool = torch.zeros(words + 16, dtype=torch.int64, device="cuda")
+    keep = torch.ones(R, 384, dtype=torch.bool)
+    if p > 0:
+        L.call("step_dropout_pool_fill", L.ptr(pool), words, p, 0x77AA_0001, st)
+        torch.cuda.synchronize()
+        keep = torch.from_numpy(FH.keep_matrix(pool[:words].cpu().numpy().view(np.uint64), seed, site, R))
+        assert abs(float(keep.float().mean()) - (1 - p)) < 5e-3
+    pack = torch.empty(L.lib().step_pt_ffn_pack_bytes(), dtype=torch.uint8, device="cuda")
+    L.call("step_pt_ffn_pack", L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(pack), st)
+    f2 = torch.empty(R, 96, device="cuda")
+    L.call("step_pt_ffn_fused_fwd", L.ptr(x), R, L.ptr(pack), p, L.ptr(pool), words, seed, site, L.ptr(f2), st)
+    dh1 = dh1_in.clone()
+    L.call("step_pt_ffn_fused_bwd_data", L.ptr(df2), L.ptr(x), R, L.ptr(pack), p, L.ptr(pool), words, seed, site, L.ptr(dh1), st)
+    ws = torch.empty(L.lib().step_pt_ffn_wgrad_ws_floats(R), device="cuda")
+    g0 = [torch.randn(384, 96, generator=gen).cuda(), torch.randn(384, generator=gen).cuda(), torch.randn(96, 384, generator=gen).cuda()]
+    dw1, db1, dw2 = [t.clone() for t in g0]
+    L.call("step_pt_ffn_fused_bwd_weights", L.ptr(df2), L.ptr(x), R, L.ptr(pack), L.ptr(b1), p, L.ptr(pool), words, seed, site, L.ptr(ws),
+           L.ptr(dw1), L.ptr(db1), L.ptr(dw2), st)
+    torch.cuda.synchronize()
+    kd = keep.cuda().double() / (1 - p)
+    pre = x.double() @ w1.double().T + b1.double()
+    # which hidden units are open is decided on the operands the kernels see (bf16-rounded h1 and W1, exact products): at the ReLU edge
+    # (|pre| below the operand rounding, 1e-3 of the units) the float64 sign differs, and a flipped unit moves d hid by its full size
+    pre_seen = x.bfloat16().double() @ w1.bfloat16().double().T + b1.double()
+    flipped = float(((pre > 0) != (pre_seen > 0)).float().mean())
+    hid = torch.relu(pre) * kd
+    want_f2 = hid @ w2.double().T + b2.double()
+    dhid = (df2.double() @ w2.double()) * (pre_seen > 0) * kd
+    want = {"f2": want_f2, "dh1": dh1_in.double() + dhid @ w1.double(), "dw1": g0[0].double() + dhid.T @ x.double(),
+            "db1": g0[1].double() + dhid.sum(0), "dw2": g0[2].double() + df2.double().T @ hid}
+    got = {"f2": f2, "dh1": dh1, "dw1": dw1, "db1": db1, "dw2": dw2}
+    errs = {k: rel_l2(got[k].double().cpu(), want[k].cpu()) for k in want}
+    print(f"fused feed-forward block R={R} p={p}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()), f"(units whose sign the operand rounding flips: {flipped:.1e})")
+    assert max(errs.values()) < 6e-3
