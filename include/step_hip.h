@@ -296,7 +296,7 @@ int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void
  * Dropout (p > 0): keep decisions are bits of the per-step pool written by step_dropout_pool_fill (pool_words a power of two >= 512, followed by
  * the 16-word wrap copy); rows 32 k .. 32 k + 31 of call site `site` own 192 consecutive words at a hashed offset, the same in all three calls. */
 long step_pt_ffn_pack_bytes(void);
-int step_pt_ffn_wgrad_workgroups(long R);
+long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);
 int step_pt_ffn_pack(const float* w1, const float* b1, const float* w2, const float* b2, void* pack, void* stream);
 int step_pt_ffn_fused_fwd(const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words, uint64_t seed, uint32_t site,

@@ -96,7 +96,7 @@ _SIGS = {
     "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),
     "step_pt_colsum_bf16": (_i, [_vp, _l, _i, _vp, _vp]),
     "step_pt_ffn_pack_bytes": (_l, []),
-    "step_pt_ffn_wgrad_workgroups": (_i, [_l]),
+    "step_pt_ffn_wgrad_workgroups": (_l, [_l]),
     "step_pt_ffn_wgrad_ws_floats": (_l, [_l]),
     "step_pt_ffn_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_ffn_fused_fwd": (_i, [_vp, _l, _vp, _f, _vp, _l, _u64, ctypes.c_uint32, _vp, _vp]),

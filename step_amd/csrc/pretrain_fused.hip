@@ -609,9 +609,9 @@ int launch_wgrad(const FfnArgs& a, int grid, hipStream_t st) {
 
 extern "C" long step_pt_ffn_pack_bytes(void) { return FF_PACK_BYTES; }
 
-extern "C" int step_pt_ffn_wgrad_workgroups(long R) {
+extern "C" long step_pt_ffn_wgrad_workgroups(long R) {
     const long nstage = ((R + 31) / 32 + FW_TILES - 1) / FW_TILES;
-    return (int)(nstage < 256 ? nstage : 256);
+    return nstage < 256 ? nstage : 256;
 }
 extern "C" long step_pt_ffn_wgrad_ws_floats(long R) { return (long)step_pt_ffn_wgrad_workgroups(R) * (96 * 384 + 384 * 96 + 384); }
 
@@ -647,7 +647,7 @@ extern "C" int step_pt_ffn_fused_bwd_weights(const float* df2, const float* h1, 
     STEP_TRY(check_common("pt_ffn_fused_bwd_weights", h1, R, pack, p, pool, pool_words));
     STEP_REQUIRE(df2 && b1 && ws && dw1 && db1 && dw2, "pt_ffn_fused_bwd_weights: null argument");
     const hipStream_t st = (hipStream_t)stream;
-    const int grid = step_pt_ffn_wgrad_workgroups(R);
+    const int grid = (int)step_pt_ffn_wgrad_workgroups(R);
     float* ws2 = ws;
     float* ws1 = ws + (long)grid * 96 * 384;
     STEP_TRY(launch_wgrad<false>(make_args(h1, df2, nullptr, R, pack, b1, p, pool, pool_words, seed, site, ws2), grid, st));
