@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer); 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words); 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -345,9 +345,12 @@ int step_pt_attention_bwd(const float* qkv, const float* out, const float* dout,
  * module uses when matmul_precision == "bf16" (the producing / consuming GEMMs write / read bf16: step_pt_linear_bf16out, step_gemm
  * with a_bf16 / b_bf16).  T <= 352 (the backward holds seven operand copies and the keep bits in LDS: 139 KB at 352 tokens).
  * keepbits (nullable): [S][4][T][ceil(T/32)] words -- the forward stores the keep decisions of every (query, key tile), a backward
- * given the same buffer reads them instead of regenerating the Philox stream. */
+ * given the same buffer reads them instead of regenerating the Philox stream.
+ * pool (nullable; needs keepbits): the forward takes the keep word of every (query, key tile) from the step's Bernoulli pool
+ * (step_dropout_pool_fill; pool_words a power of two >= 4096; a (sequence, head) reads T * ceil(T/32) consecutive 32-bit words at a
+ * hashed offset) instead of running Philox -- 0.73 -> 0.4 ms at config C3's decoder layer. */
 int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats,
-                               uint32_t* keepbits, void* stream);
+                               uint32_t* keepbits, const uint64_t* pool, long pool_words, void* stream);
 int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* stats, long S, int T, float p,
                                uint64_t seed, uint32_t site, uint16_t* dqkv, const uint32_t* keepbits, void* stream);
 /* out[r][n] = bf16(sum_k x[r][k] w(k, n) + bias[n]), x f32 [R][K] rows (16-byte aligned, K % 4 == 0), w(k, n) at w + k * swk + n * swn

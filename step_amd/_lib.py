@@ -116,7 +116,7 @@ _SIGS = {
     "step_pt_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_attention_fwd": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
     "step_pt_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
-    "step_pt_attention_fwd_bf16": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "step_pt_attention_fwd_bf16": (_i, [_vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _l, _vp]),
     "step_pt_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
     "step_pt_linear_bf16out": (_i, [_vp, _vp, _l, _l, _vp, _l, _i, _i, _vp, _vp]),
     "step_pt_relu_mask": (_i, [_vp, _vp, _l, _vp]),

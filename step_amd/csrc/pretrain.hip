@@ -64,12 +64,15 @@ __global__ void add_dropout_kernel(const float* __restrict__ a, const float* __r
         for (long i = k * 4; i < n; ++i) out[i] = a[i] + (p > 0.f ? b[i] * keep_scale(lo, hi, site, i, p) : b[i]);
     }
 }
-// x[s][p][:] += vec[idx ? idx[p] : p][:]
-__global__ void add_rows_kernel(float* __restrict__ x, long S, int P, const float* __restrict__ vec, const int* __restrict__ idx) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= S * P * D) return;
-    int f = i % D, p = (i / D) % P;
-    x[i] += vec[(long)(idx ? idx[p] : p) * D + f];
+// x[s][p][:] += vec[idx ? idx[p] : p][:]        (one thread = 4 consecutive features; n4 = S * P * 24 < 2^32)
+__global__ void add_rows_kernel(float* __restrict__ x, uint32_t n4, int P, const float* __restrict__ vec, const int* __restrict__ idx) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t f4 = i % 24u, p = (i / 24u) % (uint32_t)P;
+    const float4 v = ((const float4*)vec)[(uint32_t)(idx ? idx[p] : (int)p) * 24u + f4];
+    float4 a = ((float4*)x)[i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    ((float4*)x)[i] = a;
 }
 // dvec[idx ? idx[p] : p][f] += sum_s dx[s][p][f]        one block per token position p
 __global__ __launch_bounds__(384) void sum_over_seq_kernel(const float* __restrict__ dx, long S, int P, int p_off, int p_cnt, int ldp,
@@ -105,35 +108,41 @@ __global__ void token_scatter_kernel(const float* __restrict__ ddst, long S, int
 }
 // decoder input (tsformer.py:120-127 + transformer_layers.py:15): out[s][t] = sqrt(96) * (t < Pu ? z[s][t]
 //                                                                   : dropout(mask_token + pos[midx[t-Pu]]))
+// One thread = 4 consecutive features = one Philox call of the step_pt_dropout stream (element index of `out`); n4 = S * P * 24 < 2^32.
 __global__ void dec_input_kernel(const float* __restrict__ z, const float* __restrict__ mask_token, const float* __restrict__ pos,
-                                 const int* __restrict__ midx, long S, int P, int Pu, float scale, float p, uint32_t lo, uint32_t hi,
+                                 const int* __restrict__ midx, uint32_t n4, int P, int Pu, float scale, float p, uint32_t lo, uint32_t hi,
                                  uint32_t site, float* __restrict__ out) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= S * P * D) return;
-    int f = i % D, t = (i / D) % P;
-    long s = i / ((long)D * P);
-    float v;
-    if (t < Pu) {
-        v = z[(s * Pu + t) * D + f];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t f4 = i % 24u, st = i / 24u, t = st % (uint32_t)P, s = st / (uint32_t)P;
+    float4 v;
+    if (t < (uint32_t)Pu) {
+        v = ((const float4*)z)[(s * (uint32_t)Pu + t) * 24u + f4];
     } else {
-        v = mask_token[f] + pos[(long)midx[t - Pu] * D + f];
-        if (p > 0.f) v *= keep_scale(lo, hi, site, i, p);
+        const float4 a = ((const float4*)mask_token)[f4], b = ((const float4*)pos)[(uint32_t)midx[t - Pu] * 24u + f4];
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) keep_scale4(lo, hi, site, (long)i, p, m);
+        v = make_float4((a.x + b.x) * m[0], (a.y + b.y) * m[1], (a.z + b.z) * m[2], (a.w + b.w) * m[3]);
     }
-    out[i] = v * scale;
+    ((float4*)out)[i] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
 }
 // backward: dz[s][t] = scale * dout[s][t] (t < Pu);  dm[s][j] = scale * mask * dout[s][Pu + j]   (dm: [S][Pm][96] scratch)
-__global__ void dec_input_bwd_kernel(const float* __restrict__ dout, long S, int P, int Pu, float scale, float p, uint32_t lo, uint32_t hi,
+__global__ void dec_input_bwd_kernel(const float* __restrict__ dout, uint32_t n4, int P, int Pu, float scale, float p, uint32_t lo, uint32_t hi,
                                      uint32_t site, float* __restrict__ dz, float* __restrict__ dm) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= S * P * D) return;
-    int f = i % D, t = (i / D) % P;
-    long s = i / ((long)D * P);
-    float g = dout[i] * scale;
-    if (t < Pu) {
-        dz[(s * Pu + t) * D + f] = g;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    const uint32_t f4 = i % 24u, st = i / 24u, t = st % (uint32_t)P, s = st / (uint32_t)P;
+    float4 g = ((const float4*)dout)[i];
+    g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+    if (t < (uint32_t)Pu) {
+        ((float4*)dz)[(s * (uint32_t)Pu + t) * 24u + f4] = g;
     } else {
-        if (p > 0.f) g *= keep_scale(lo, hi, site, i, p);
-        dm[(s * (P - Pu) + (t - Pu)) * D + f] = g;
+        if (p > 0.f) {
+            float m[4];
+            keep_scale4(lo, hi, site, (long)i, p, m);
+            g.x *= m[0]; g.y *= m[1]; g.z *= m[2]; g.w *= m[3];
+        }
+        ((float4*)dm)[(s * (uint32_t)(P - Pu) + (t - (uint32_t)Pu)) * 24u + f4] = g;
     }
 }
 
@@ -433,6 +442,10 @@ __device__ __forceinline__ void ma_keep16(uint32_t lo, uint32_t hi, uint32_t sit
         for (int f = 0; f < 8; ++f) m[8 * b + f] = ((r[f >> 1] >> (16 * (f & 1))) & 0xffffu) >= thr ? ks : 0.f;
     }
 }
+__device__ __forceinline__ uint32_t ma_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ int ma_key(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }     // accumulator register -> row of the tile
 
 // Activations in HBM are bf16 (qkv [S][T][288], out / d out [S][T][96], d qkv [S][T][288]: the GEMM epilogues write them and the
@@ -475,7 +488,7 @@ __device__ __forceinline__ uint16_t ma_half(const uint4& v, int c) {      // ele
 // forward: out [S][T][96], stats [S][H][T][2] = (row max, row sum) like attn_kernel
 __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __restrict__ qkv, int T, int Tp, float p, uint32_t lo, uint32_t hi,
                                                             uint32_t site, uint16_t* __restrict__ out, float* __restrict__ stats,
-                                                            uint32_t* __restrict__ keepbits) {
+                                                            uint32_t* __restrict__ keepbits, const uint32_t* __restrict__ pool32, uint32_t pmask32) {
     extern __shared__ __attribute__((aligned(16))) uint16_t ml[];
     const int TPt = ma_tpitch(Tp);
     uint16_t* Qs = ml;                       // [Tp][MA_RP]  q (the 1/sqrt(24) of the scores is applied to the f32 products)
@@ -501,6 +514,9 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __re
     __syncthreads();
     const int q = wave * 32 + col, nkt = Tp / 32;
     const long srow = (s * H + hd) * (long)T;
+    // pool32 != NULL: the keep decisions of (query, key tile) are one 32-bit word of the step's Bernoulli pool (step_dropout_pool_fill) --
+    // this (sequence, head) reads T * nkt consecutive words at a hashed offset -- instead of two Philox calls per lane and tile
+    const uint32_t pbase = ma_mix32(lo + unit * 0x9E3779B1u + (site + 1u) * 0x632BE5ABu);
     bf16x8 bq[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) bq[st] = ma_row8(Qs + q * MA_RP + 16 * st + 8 * h);
@@ -527,6 +543,8 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __re
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     for (int kt = 0; kt < nkt; ++kt) {
+        uint32_t pword = 0u;                 // requested before the score products: its latency hides behind them and the exponentials
+        if (p > 0.f && pool32 && q < T) pword = pool32[(pbase + (uint32_t)(q * nkt + kt)) & pmask32];
         f32x16 acc;
         scores(kt, acc);
         float pv[16];
@@ -534,7 +552,12 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __re
         for (int e = 0; e < 16; ++e) { pv[e] = __expf((acc[e] - mx) * scale); l += pv[e]; }
         if (p > 0.f) {
             uint32_t word = 0u;
-            if (q < T) {
+            if (q < T && pool32) {
+                word = pword;
+                const uint32_t wh = word >> (4 * h);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[e] = (wh & (1u << ((e & 3) + 8 * (e >> 2)))) ? pv[e] * ks : 0.f;
+            } else if (q < T) {
                 float m[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) m[e] = ks;
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(704) void attn_mfma_fwd_kernel(const uint16_t* __re
                 for (int e = 0; e < 16; ++e) { pv[e] *= m[e]; if (m[e] > 0.f) word |= 1u << ma_key(e, h); }
             }
             // the keep decisions of (query, key tile) as one word: the backward reads them instead of re-running Philox
-            word |= __shfl_xor(word, 32, 64);
+            if (!pool32) word |= __shfl_xor(word, 32, 64);
             if (keepbits && h == 0 && q < T) keepbits[(srow + q) * nkt + kt] = word;
         }
 #pragma unroll
@@ -585,10 +608,10 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
     uint16_t* KT = QT + DH * TPt;
     uint16_t* OT = KT + DH * TPt;
     uint16_t* ZT = OT + DH * TPt;             // [TPt] zeros: the padded head dimensions 24 .. 31 of all three
-    float* smx = (float*)(ZT + TPt);          // [Tp] row max, 1 / row sum, delta
-    float* sinv = smx + Tp;
-    float* sdl = sinv + Tp;
-    uint32_t* bits = (uint32_t*)(sdl + Tp);   // [Tp][nt] keep bits of (query, key tile)
+    float* smx = (float*)(ZT + TPt);          // [Tp] exponent offset of a query row: P = exp2(score * scale * log2(e) + smx) (rows >= T: -1e30)
+    float* sinv = smx + Tp;                   // (unused slot kept for the layout of ma_bwd_lds)
+    float* sdl = sinv + Tp;                   // [Tp] delta
+    uint32_t* bits = (uint32_t*)(sdl + Tp);   // [nt][Tp] keep bits of (key tile, query): four consecutive queries are one 16-byte read
     const unsigned unit = ma_unit(blockIdx.x, gridDim.x);
     const long s = unit / H;
     const int hd = unit % H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
         }
     }
     if (keepbits && p > 0.f)                 // the forward's keep decisions of this (sequence, head): one contiguous run of T nt words
-        for (int i = tid; i < Tp * nt; i += blockDim.x) bits[i] = i < T * nt ? keepbits[srow * nt + i] : 0u;
+        for (int i = tid; i < Tp * nt; i += blockDim.x) bits[(i % nt) * Tp + i / nt] = i < T * nt ? keepbits[srow * nt + i] : 0u;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int e = tid + it * blockDim.x, t = e >> 2, d8 = e & 3;
@@ -635,14 +658,16 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
     for (int i = tid; i < Tp; i += blockDim.x) {
         float2 st2 = make_float2(0.f, 1.f);
         if (i < T) st2 = *(const float2*)(stats + (srow + i) * 2);
-        smx[i] = i < T ? st2.x * (1.f / scale) : 0.f; sinv[i] = i < T ? 1.f / st2.y : 0.f;       // row max in the unscaled-score domain
+        // stats = (row max of the scaled scores, row sum): P = exp(s * scale - max) / sum = exp2(s * scale * log2(e) + smx)
+        smx[i] = i < T ? -st2.x * 1.4426950408889634f - __log2f(st2.y) : -1e30f;
     }
     __syncthreads();
     const float ks = p > 0.f ? 1.f / (1.f - p) : 1.f;
     f32x16 dq_keep;
     {   // ---- phase A: this wave's 32 queries against every key tile (keys in registers, query = lane)
         const int q = wave * 32 + col;
-        const float mq = smx[q], iq = sinv[q], dq_ = sdl[q];
+        const float mq = smx[q], dq_ = sdl[q];
+        const float sl2 = scale * 1.4426950408889634f;
         bf16x8 bq[2], bo[2];
 #pragma unroll
         for (int st = 0; st < 2; ++st) { bq[st] = mb_row8(Qs, q, st, h); bo[st] = mb_row8(Os, q, st, h); }
@@ -661,7 +686,7 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
             float mk[16];
             uint32_t word = 0u;
             if (keepbits && p > 0.f) {               // the forward's keep decisions
-                word = q < T ? bits[q * nt + kt] : 0u;
+                word = q < T ? bits[kt * Tp + q] : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -674,12 +699,12 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
                 for (int e = 0; e < 16; ++e) if (mk[e] > 0.f) word |= 1u << ma_key(e, h);
                 word |= __shfl_xor(word, 32, 64);
             }
-            if (h == 0 && !(keepbits && p > 0.f)) bits[q * nt + kt] = word;
+            if (h == 0 && !(keepbits && p > 0.f)) bits[kt * Tp + q] = word;
             float ds[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const bool kok = kt * 32 + ma_key(e, h) < T;
-                const float pij = kok ? __expf((sc[e] - mq) * scale) * iq : 0.f;
+                const float pij = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], sl2, mq)) : 0.f;
                 ds[e] = pij * (dp[e] * mk[e] - dq_);
             }
 #pragma unroll
@@ -707,13 +732,23 @@ __global__ __launch_bounds__(704) void attn_mfma_bwd_kernel(const uint16_t* __re
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mb_row8(Os, qt * 32 + col, st, h), bv[st], dp, 0, 0, 0);
             }
             float pm[16], ds[16];
+            const float sl2 = scale * 1.4426950408889634f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qi = qt * 32 + ma_key(e, h);
-                const float mkv = (bits[qi * nt + wave] >> col) & 1u ? ks : 0.f;
-                const float pij = kj < T ? __expf((sc[e] - smx[qi]) * scale) * sinv[qi] : 0.f;      // rows qi >= T: sinv = 0
-                pm[e] = pij * mkv;
-                ds[e] = pij * (dp[e] * mkv - sdl[qi]);
+            for (int g = 0; g < 4; ++g) {
+                // queries qt * 32 + 8 g + 4 h + (0..3) are accumulator registers 4 g .. 4 g + 3: their statistics and keep words are 16-byte reads
+                const int q0 = qt * 32 + 8 * g + 4 * h;
+                const float4 eq = *(const float4*)(smx + q0), dl4 = *(const float4*)(sdl + q0);
+                const uint4 bw = *(const uint4*)(bits + wave * Tp + q0);
+                const float eqv[4] = {eq.x, eq.y, eq.z, eq.w}, dlv[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+                const uint32_t bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * g + j;
+                    const float mkv = (bwv[j] >> col) & 1u ? ks : 0.f;
+                    const float pij = kj < T ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], sl2, eqv[j])) : 0.f;      // rows qi >= T: exp2(-1e30) = 0
+                    pm[e] = pij * mkv;
+                    ds[e] = pij * (dp[e] * mkv - dlv[j]);
+                }
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -801,7 +836,8 @@ extern "C" int step_pt_add_dropout(const float* a, const float* b, float* out, l
 }
 extern "C" int step_pt_add_rows(float* x, long S, int P, const float* vec, const int* idx, void* stream) {
     STEP_REQUIRE(x && vec && S > 0 && P > 0, "pt_add_rows: bad arguments");
-    add_rows_kernel<<<g1(S * P * D), 256, 0, (hipStream_t)stream>>>(x, S, P, vec, idx);
+    STEP_REQUIRE(S * P * 24 < (1L << 32), "pt_add_rows: %ld x %d tokens exceed the 32-bit index range", S, P);
+    add_rows_kernel<<<g1(S * P * 24), 256, 0, (hipStream_t)stream>>>(x, (uint32_t)(S * P * 24), P, vec, idx);
     STEP_LAUNCH_CHECK("pt_add_rows");
     return STEP_OK;
 }
@@ -829,7 +865,8 @@ extern "C" int step_pt_token_scatter(const float* ddst, long S, int P, const int
 extern "C" int step_pt_dec_input(const float* z, const float* mask_token, const float* pos, const int* midx, long S, int P, int Pu,
                                  float p, uint64_t seed, uint32_t site, float* out, void* stream) {
     STEP_REQUIRE(z && mask_token && pos && midx && out && S > 0 && P > Pu && Pu > 0, "pt_dec_input: bad arguments");
-    dec_input_kernel<<<g1(S * P * D), 256, 0, (hipStream_t)stream>>>(z, mask_token, pos, midx, S, P, Pu, 9.797958971132712f, p,
+    STEP_REQUIRE(S * P * 24 < (1L << 32), "pt_dec_input: %ld x %d tokens exceed the 32-bit index range", S, P);
+    dec_input_kernel<<<g1(S * P * 24), 256, 0, (hipStream_t)stream>>>(z, mask_token, pos, midx, (uint32_t)(S * P * 24), P, Pu, 9.797958971132712f, p,
                                                                      SEED_LO(seed), SEED_HI(seed), site, out);
     STEP_LAUNCH_CHECK("pt_dec_input");
     return STEP_OK;
@@ -837,7 +874,8 @@ extern "C" int step_pt_dec_input(const float* z, const float* mask_token, const 
 extern "C" int step_pt_dec_input_bwd(const float* dout, long S, int P, int Pu, float p, uint64_t seed, uint32_t site, float* dz,
                                      float* dm, void* stream) {
     STEP_REQUIRE(dout && dz && dm && S > 0 && P > Pu && Pu > 0, "pt_dec_input_bwd: bad arguments");
-    dec_input_bwd_kernel<<<g1(S * P * D), 256, 0, (hipStream_t)stream>>>(dout, S, P, Pu, 9.797958971132712f, p, SEED_LO(seed),
+    STEP_REQUIRE(S * P * 24 < (1L << 32), "pt_dec_input_bwd: %ld x %d tokens exceed the 32-bit index range", S, P);
+    dec_input_bwd_kernel<<<g1(S * P * 24), 256, 0, (hipStream_t)stream>>>(dout, (uint32_t)(S * P * 24), P, Pu, 9.797958971132712f, p, SEED_LO(seed),
                                                                          SEED_HI(seed), site, dz, dm);
     STEP_LAUNCH_CHECK("pt_dec_input_bwd");
     return STEP_OK;
@@ -917,16 +955,23 @@ static size_t ma_fwd_lds(int Tp) {      // operands, re-used by the f32 staging 
 }
 static size_t ma_bwd_lds(int Tp) { return (size_t)(4 * Tp * MB_RP + (3 * DH + 1) * (Tp + 8)) * 2 + (size_t)(3 * Tp + Tp * (Tp / 32)) * 4; }
 extern "C" int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats,
-                                          uint32_t* keepbits, void* stream) {
+                                          uint32_t* keepbits, const uint64_t* pool, long pool_words, void* stream) {
     STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 352 && p >= 0.f && p < 1.f && ((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0,
                  "pt_attention_fwd_bf16: bad arguments (T=%d; at most 352 tokens, 16-byte aligned bf16 tensors)", T);
+    if (pool && p > 0.f) {
+        STEP_REQUIRE(keepbits, "pt_attention_fwd_bf16: pool-drawn keep decisions reach the backward through `keepbits` only");
+        STEP_REQUIRE(pool_words >= 4096 && (pool_words & (pool_words - 1)) == 0 && pool_words <= (1L << 30),
+                     "pt_attention_fwd_bf16: pool of %ld words is not a power of two in [4096, 2^30]", pool_words);
+    }
     const int Tp = (T + 31) & ~31;
     if (hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         step_set_error("pt_attention_fwd_bf16: cannot raise the dynamic LDS limit");
         return STEP_ERR_HIP;
     }
     attn_mfma_fwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_fwd_lds(Tp), (hipStream_t)stream>>>(qkv, T, Tp, p, SEED_LO(seed), SEED_HI(seed),
-                                                                                                    site, out, stats, keepbits);
+                                                                                                    site, out, stats, keepbits,
+                                                                                                    pool && p > 0.f ? (const uint32_t*)pool : nullptr,
+                                                                                                    pool && p > 0.f ? (uint32_t)(2 * pool_words - 1) : 0u);
     STEP_LAUNCH_CHECK("pt_attention_fwd_bf16");
     return STEP_OK;
 }

@@ -174,17 +174,19 @@ __device__ __forceinline__ void pack_rows_T(const f32x16 (&a)[3], op8 (&b)[6]) {
 constexpr int STG_IN = 32 * 192, STG_OUT = 32 * 128, STG_WAVE = STG_IN + STG_OUT;
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }      // LDS executes a wave's accesses in order; this pins the program order
 
-__device__ __forceinline__ void tile_in(const float* __restrict__ x, long row0, long R, char* stg, int lane) {
+// tile_load only issues the 12 loads (the next pass's tile is requested before the current pass's matrix work and converted after it)
+__device__ __forceinline__ void tile_load(const float* __restrict__ x, long row0, long R, int lane, float4 (&v)[12]) {
     const float* src = x + row0 * 96;
     const long left = R - row0;
     const int nvalid = (int)(left >= 32 ? 32 : (left > 0 ? left : 0)) * 96;
-    float4 v[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const int flat = k * 256 + lane * 4;
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (flat < nvalid && !(FF_ABLATE & 2)) v[k] = *(const float4*)(src + flat);
     }
+}
+__device__ __forceinline__ void tile_put(const float4 (&v)[12], char* stg, int lane) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
         const int flat = k * 256 + lane * 4, r = flat / 96, c = (flat - r * 96) >> 2;
@@ -270,22 +272,42 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
     issue_fill(0);
 
     int g = 0;
+    float4 nx[12];                                      // the next pass's h1 tile, in flight while the current pass computes
+    tile_load(A.h1, ((long)blockIdx.x * NW + wave) * 32, A.R, lane, nx);
 #pragma unroll 1
     for (long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
         const long tile32 = pass * NW + wave;
         op8 xb[6], db[6];
         f32x16 acc[3];
-        tile_in(A.h1, tile32 * 32, A.R, stg, lane);
+        tile_put(nx, stg, lane);
         tile_frags(stg, lane, xb);
         if constexpr (BWD) {
-            tile_in(A.df2, tile32 * 32, A.R, stg, lane);
+            float4 dv[12];
+            tile_load(A.df2, tile32 * 32, A.R, lane, dv);
+            tile_put(dv, stg, lane);
             tile_frags(stg, lane, db);
         }
+        if (pass + gridDim.x < npass) tile_load(A.h1, ((pass + gridDim.x) * NW + wave) * 32, A.R, lane, nx);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
         const uint32_t mbase = DROP ? ffn_mask_base(A.seed, A.site, tile32, A.pool_mask) : 0u;
+        // keep-mask words of a stage's two chunks (scalar loads).  They are requested at the END of the previous stage: LDS reads and scalar
+        // loads share one wait counter, so a request next to its use is waited for by the first fragment read behind it (0.07 ms of a
+        // 0.28 ms forward); behind the last matrix instructions of a stage it completes under the barrier.
+        unsigned long long mw[2][16];
+        auto load_masks = [&](int jb_) {
+            if constexpr (DROP) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const mask_ptr mp = pool + ((mbase + (uint32_t)(jb_ * 2 + cc) * 16u) & A.pool_mask);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mw[cc][i] = mp[i];
+                }
+            }
+        };
+        load_masks(0);
         const char* blk = nullptr;
 #pragma unroll 1
         for (int jb = 0; jb < ((FF_ABLATE & 1) ? 1 : 6); ++jb, g += ((FF_ABLATE & 1) ? 6 : 1)) {
@@ -300,12 +322,6 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
                 const float* b1 = tail + (cc * 2 + h) * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[i] = b1[i];
-                unsigned long long mw[16];
-                if constexpr (DROP) {
-                    const mask_ptr mp = pool + ((mbase + (uint32_t)(jb * 2 + cc) * 16u) & A.pool_mask);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mw[i] = mp[i];
-                }
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) hh = mma(wu[ks], xb[ks], hh);
                 if constexpr (!BWD) {
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
                     for (int f = 0; f < 6; ++f) wd[f] = mfrag(blk, cc * CF + 6 + f, lane);
                     if constexpr (DROP) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[i]) ? hh[i] : 0.f;
+                        for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[cc][i]) ? hh[i] : 0.f;
                     }
                     const op8 hb0 = relu_bf16(pack_lo_hi(hh, 0)), hb1 = relu_bf16(pack_lo_hi(hh, 1));
 #pragma unroll
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         bool open = hh[i] > 0.f;
-                        if constexpr (DROP) open = open && __builtin_amdgcn_inverse_ballot_w64(mw[i]);
+                        if constexpr (DROP) open = open && __builtin_amdgcn_inverse_ballot_w64(mw[cc][i]);
                         dd[i] = open ? dd[i] * A.inv_keep : 0.f;
                     }
                     const op8 d0 = pack_lo_hi(dd, 0), d1 = pack_lo_hi(dd, 1);
@@ -348,6 +364,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
                     }
                 }
             }
+            if (jb < 5) load_masks(jb + 1);
         }
         if constexpr (!BWD) {
             const float* b2 = (const float*)(blk + TAILOFF) + 64 + h * 48;

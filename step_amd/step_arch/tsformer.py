@@ -224,7 +224,9 @@ class _PretrainFunction(torch.autograd.Function):
                    R, 288, 96, L.ptr(qkv), st)
             a = torch.empty(R, 96, device=x.device, dtype=torch.bfloat16)
             kb = torch.empty(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device=x.device) if p > 0 else None
-            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), L.ptr(kb), st)
+            # (with the fused path's pool the keep words come from it: no Philox in the kernel; the backward reads `kb` either way)
+            pool, words = (fz["pool"], fz["words"]) if fz is not None else (None, 0)
+            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), L.ptr(kb), L.ptr(pool), words, st)
         else:
             qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
             a = _empty(R, 96, like=x)

@@ -128,7 +128,7 @@ def test_matrix_core_attention_matches_f32_attention(T, p):
         dqkv = torch.zeros(S, T, 288, device="cuda", dtype=dt)
         if tag:
             kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda") if T != 77 else None      # (T = 77: the backward regenerates the masks)
-            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_fwd" + tag, L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), None, 0, st)
             L.call("step_pt_attention_bwd" + tag, L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
         else:
             L.call("step_pt_attention_fwd" + tag, L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
@@ -171,7 +171,7 @@ def test_attention_kernels_match_fp64_reference_with_their_own_masks(T):
         stats = torch.empty(S * 4 * T, 2, device="cuda")
         dqkv = torch.zeros(S, T, 288, device="cuda", dtype=dt)
         if tag:
-            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+            L.call("step_pt_attention_fwd_bf16", L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), None, 0, st)
             L.call("step_pt_attention_bwd_bf16", L.ptr(qkv_t), L.ptr(out), L.ptr(dout_t), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
         else:
             L.call("step_pt_attention_fwd", L.ptr(qkv_t), S, T, p, seed, site, L.ptr(out), L.ptr(stats), st)
@@ -435,3 +435,46 @@ def test_fused_feed_forward_block_matches_reference(R, p):
     errs = {k: rel_l2(got[k].double().cpu(), want[k].cpu()) for k in want}
     print(f"fused feed-forward block R={R} p={p}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()), f"(units whose sign the operand rounding flips: {flipped:.1e})")
     assert max(errs.values()) < 6e-3
+
+
+@pytest.mark.parametrize("T", [42, 168])
+def test_matrix_core_attention_with_pool_drawn_keep_words(T):
+    """step_pt_attention_fwd_bf16 with a keep-mask pool (what the pre-training step passes in the bf16 mode): the keep word of every
+    (query, key tile) is the pool's 32-bit word at the (sequence, head)'s hashed offset -- rebuilt here on the host --, it reaches the
+    backward through `keepbits`, and forward / backward match the float64 oracle that replays those bits (1.5e-2 / 2.5e-2 as above)."""
+    from step_amd import _lib as L
+    from tests import ffn_fused_host as FH
+    S, p = 5, 0.1
+    gen = torch.Generator().manual_seed(300 + T)
+    qkv = (torch.randn(S, T, 288, generator=gen) * 1.5).bfloat16().cuda()
+    dout = torch.randn(S, T, 96, generator=gen).bfloat16().cuda()
+    seed, site, st = 0x0BAD_5EED_4321, 16, L.stream()
+    nkt = (T + 31) // 32
+    words = 1 << 12
+    pool = torch.zeros(words + 16, dtype=torch.int64, device="cuda")
+    L.call("step_dropout_pool_fill", L.ptr(pool), words, p, 0x1234_0001, st)
+    kb = torch.zeros(S * 4 * T * nkt, dtype=torch.int32, device="cuda")
+    out = torch.empty(S, T, 96, device="cuda", dtype=torch.bfloat16)
+    stats = torch.empty(S * 4 * T, 2, device="cuda")
+    dqkv = torch.zeros(S, T, 288, device="cuda", dtype=torch.bfloat16)
+    L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, seed, site, L.ptr(out), L.ptr(stats), L.ptr(kb), L.ptr(pool), words, st)
+    L.call("step_pt_attention_bwd_bf16", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, seed, site, L.ptr(dqkv), L.ptr(kb), st)
+    torch.cuda.synchronize()
+    got = kb.cpu().numpy().view(np.uint32).reshape(S * 4, T * nkt)
+    p32 = pool[:words].cpu().numpy().view(np.uint32)                     # the pool as 32-bit words (little endian: low half first)
+    lo = seed & 0xFFFFFFFF
+    for unit in range(S * 4):
+        base = FH.mix32(lo + unit * 0x9E3779B1 + (site + 1) * 0x632BE5AB)
+        want = p32[(base + np.arange(T * nkt)) & (2 * words - 1)]
+        assert np.array_equal(got[unit], want), unit
+    bits = ((got.reshape(S, 4, T, nkt)[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(S, 4, T, nkt * 32)[..., :T]
+    keep = torch.from_numpy(bits.astype(np.float64))
+    assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    x = qkv.float().cpu().double().requires_grad_(True)
+    q, k, v = [t.reshape(S, T, 4, 24).transpose(1, 2) for t in x.split(96, dim=-1)]
+    att = torch.softmax(q @ k.transpose(-1, -2) / 24 ** 0.5, dim=-1) * keep / (1 - p)
+    want = (att @ v).transpose(1, 2).reshape(S, T, 96)
+    want.backward(dout.float().cpu().double())
+    eo, eg = rel_l2(out.float().cpu().double(), want.detach()), rel_l2(dqkv.float().cpu().double(), x.grad)
+    print(f"T={T} matrix-core attention with pool-drawn keep words vs float64 oracle: out {eo:.2e}, dqkv {eg:.2e}")
+    assert eo < 1.5e-2 and eg < 2.5e-2

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from step_amd import _lib as L  # noqa: E402
 
 
+POOL = os.environ.get("ATTN_POOL", "1") != "0"       # keep words of the forward from the Bernoulli pool (what the pre-training step does)
+
+
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 5200
     tag = os.environ.get("STEP_HIP_LIB", "default")
@@ -21,9 +24,11 @@ def main():
         dqkv = torch.zeros(S, T, 288, device="cuda", dtype=torch.bfloat16)
         kb = torch.zeros(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device="cuda")
         st = L.stream()
+        pool = torch.zeros((1 << 18) + 16, dtype=torch.int64, device="cuda")
+        L.call("step_dropout_pool_fill", L.ptr(pool), 1 << 18, 0.1, 77, st)
         for p in (0.1, 0.0):
             def fwd():
-                L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, 1234, 7, L.ptr(out), L.ptr(stats), L.ptr(kb), st)
+                L.call("step_pt_attention_fwd_bf16", L.ptr(qkv), S, T, p, 1234, 7, L.ptr(out), L.ptr(stats), L.ptr(kb), L.ptr(pool) if POOL else None, 1 << 18, st)
 
             def bwd():
                 L.call("step_pt_attention_bwd_bf16", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(stats), S, T, p, 1234, 7, L.ptr(dqkv), L.ptr(kb), st)
