@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words); 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -295,6 +295,15 @@ int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void
  *                             ws: step_pt_ffn_wgrad_ws_floats(R) floats of scratch
  * Dropout (p > 0): keep decisions are bits of the per-step pool written by step_dropout_pool_fill (pool_words a power of two >= 512, followed by
  * the 16-word wrap copy); rows 32 k .. 32 k + 31 of call site `site` own 192 consecutive words at a hashed offset, the same in all three calls. */
+/* The four thin products around the attention of a pre-training layer as row kernels with LDS-resident weights (csrc/pretrain_fused.hip):
+ * y[R, 96 nog] (accumulate ? += : =) x[R, 96 nkc] . M^T + bias, nkc * nog <= 3, M(out, in) = w[out * swo + in * swi] packed once per step
+ * by step_pt_rows_linear_pack (bias nullable; step_pt_rows_linear_pack_bytes(nkc, nog) bytes, 16-byte aligned).  Forms:
+ *   (nkc 1, nog 3 | 1, x f32, y bf16)  qkv = x . Wi^T + bi,  da = do . Wo          (what step_pt_linear_bf16out computes)
+ *   (1, 1, x bf16, y f32)              o = a . Wo^T + bo
+ *   (3, 1, x bf16, y f32, accumulate)  dx += dqkv . Wi */
+long step_pt_rows_linear_pack_bytes(int nkc, int nog);
+int step_pt_rows_linear_pack(const float* w, long swo, long swi, int nkc, int nog, const float* bias, void* pack, void* stream);
+int step_pt_rows_linear(const void* x, int x_bf16, long R, const void* pack, int nkc, int nog, void* y, int y_bf16, int accumulate, void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

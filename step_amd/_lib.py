@@ -95,6 +95,9 @@ _SIGS = {
     "step_pt_ffn_hidden_fwd": (_i, [_vp, _vp, _vp, _l, _f, _u64, ctypes.c_uint32, _vp, _vp]),
     "step_pt_ffn_hidden_bwd": (_i, [_vp, _vp, _vp, _l, _f, _vp, _vp]),
     "step_pt_colsum_bf16": (_i, [_vp, _l, _i, _vp, _vp]),
+    "step_pt_rows_linear_pack_bytes": (_l, [_i, _i]),
+    "step_pt_rows_linear_pack": (_i, [_vp, _l, _l, _i, _i, _vp, _vp, _vp]),
+    "step_pt_rows_linear": (_i, [_vp, _i, _l, _vp, _i, _i, _vp, _i, _i, _vp]),
     "step_pt_ffn_pack_bytes": (_l, []),
     "step_pt_ffn_wgrad_workgroups": (_l, [_l]),
     "step_pt_ffn_wgrad_ws_floats": (_l, [_l]),

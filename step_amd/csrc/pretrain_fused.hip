@@ -555,6 +555,144 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(const float* __restrict
     atomicAdd(i < n0 ? out0 + i : out1 + (i - n0), scale * (s0 + s1));
 }
 
+// ---------------------------------------------------------------------------------------------------------------- projections of the attention block
+// y[R, 96 NOG] (= | +=) x[R, 96 NKC] . M^T + bias with NKC * NOG <= 3: the four thin products around the attention of a layer --
+//   qkv  = x . Wi^T + bi        (f32 in, bf16 out, NOG = 3)        o    = a . Wo^T + bo   (bf16 in, f32 out)
+//   da   = do . Wo              (f32 in, bf16 out)                 dx  += dqkv . Wi       (bf16 in, NKC = 3, f32 read-modify-write)
+// Same transposed layout and tile staging as the feed-forward row kernels, but the whole operand-fragment set of M (at most 54 KB)
+// stays in LDS for the launch: after the first barrier a wave never waits for another one, so the eight waves of a workgroup drift
+// apart and one wave's loads and stores run under the others' matrix work.  The step_gemm path these replace moves the same bytes at
+// 1.5-2.3 TB/s (K = 96: one k step per tile, nothing to pipeline).
+struct LinArgs {
+    const void* x; void* y; long R; int ldx, ldy;        // leading dimensions in elements
+    const char* pack;                                     // NOG * 3 * NKC * 6 fragments, then bias [NOG][2][48] f32 (zeros when there is none)
+};
+// M(out, in) = w[out * swo + in * swi]; fragment ((og * 3 + t) * NKC + kc) * 6 + ks: lane (h, r), slot j -> M(96 og + 32 t + r, 96 kc + 32 (ks >> 1) + F(ks & 1, h, j))
+__global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__ w, long swo, long swi, int NKC, int NOG, const float* __restrict__ bias,
+                                                        char* __restrict__ pack) {
+    const int nfrag = NOG * 3 * NKC * 6, gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid < nfrag * 64) {
+        const int frag = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
+        const int ks = frag % 6, kc = (frag / 6) % NKC, ot = frag / (6 * NKC);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w[(long)(32 * ot + r) * swo + (long)(96 * kc + 32 * (ks >> 1) + chain_f(ks & 1, h, j)) * swi];
+        *(op8*)(pack + (long)frag * FF_FRAG + lane * 16) = pack8(v);
+        return;
+    }
+    const int i = gid - nfrag * 64;
+    if (i < NOG * 96) {
+        const int og = i / 96, k = i % 96, h = k / 48, t = (k % 48) >> 4, e = k & 15;
+        ((float*)(pack + (long)nfrag * FF_FRAG))[i] = bias ? bias[96 * og + 32 * t + row16(e, h)] : 0.f;
+    }
+}
+
+// a 32 x 96 block of a bf16 tensor (leading dimension ld elements, first column col0) -> the swizzled bf16 tile of tile_put
+__device__ __forceinline__ void tile_load_bf16(const uint16_t* __restrict__ x, long row0, long R, int ld, int col0, int lane, uint4 (&v)[6]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = k * 64 + lane, r = idx / 12, c16 = idx - r * 12;
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + r < R) v[k] = *(const uint4*)(x + (row0 + r) * ld + col0 + c16 * 8);
+    }
+}
+__device__ __forceinline__ void tile_put_bf16(const uint4 (&v)[6], char* stg, int lane) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = k * 64 + lane, r = idx / 12, c16 = idx - r * 12, sw = (r >> 1) & 7;
+        // 8-byte chunks 2 c16 and 2 c16 + 1 land at positions p and p ^ 1 of one aligned 16-byte slot: one write, halves swapped when sw is odd
+        const uint4 o = (sw & 1) ? make_uint4(v[k].z, v[k].w, v[k].x, v[k].y) : v[k];
+        *(uint4*)(stg + r * 192 + 8 * (((2 * c16) ^ sw) & ~1)) = o;
+    }
+    lds_order();
+}
+// three accumulator tiles (96 features of 32 rows) -> bf16 rows y[row][col0 ..] through the swizzled tile
+__device__ __forceinline__ void tile_out_bf16(uint16_t* __restrict__ y, long row0, long R, int ld, int col0, char* stg, int lane, const f32x16 (&acc)[3]) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(acc[t][4 * q], acc[t][4 * q + 1]);
+            pk[1] = pack_bf16x2(acc[t][4 * q + 2], acc[t][4 * q + 3]);
+            *(u32x2*)(stg + r * 192 + 8 * ((8 * t + 2 * q + h) ^ sw)) = pk;
+        }
+    lds_order();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = k * 64 + lane, rr = idx / 12, c16 = idx - rr * 12, s2 = (rr >> 1) & 7;
+        const uint4 v = *(const uint4*)(stg + rr * 192 + 8 * (((2 * c16) ^ s2) & ~1));
+        const uint4 o = (s2 & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;
+        if (row0 + rr < R) *(uint4*)(y + (row0 + rr) * ld + col0 + c16 * 8) = o;
+    }
+    lds_order();
+}
+
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM>
+__global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NW = 8, NFRAG = NOG * 3 * NKC * 6, WBYTES = NFRAG * FF_FRAG + NOG * 96 * 4;
+    static_assert(NKC * NOG <= 3 && !(IN_BF16 && NKC == 1 && false), "fragment set must fit the LDS");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    for (int i = threadIdx.x; i < WBYTES / 16; i += NW * 64) ((uint4*)smem)[i] = ((const uint4*)A.pack)[i];
+    __syncthreads();
+    const float* bias = (const float*)(smem + NFRAG * FF_FRAG);
+    char* stg = smem + ((WBYTES + 1023) & ~1023) + wave * STG_WAVE;
+    const long ntile = (A.R + 31) / 32;
+#pragma unroll 1
+    for (long tile = (long)blockIdx.x * NW + wave; tile < ntile; tile += (long)gridDim.x * NW) {
+        const long row0 = tile * 32;
+        if constexpr (NKC == 1) {
+            op8 xb[6];
+            if constexpr (IN_BF16) {
+                uint4 v[6];
+                tile_load_bf16((const uint16_t*)A.x, row0, A.R, A.ldx, 0, lane, v);
+                tile_put_bf16(v, stg, lane);
+            } else {
+                float4 v[12];
+                tile_load((const float*)A.x, row0, A.R, lane, v);
+                tile_put(v, stg, lane);
+            }
+            tile_frags(stg, lane, xb);
+#pragma unroll 1
+            for (int og = 0; og < NOG; ++og) {
+                f32x16 acc[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] = bias[og * 96 + h * 48 + t * 16 + i];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) acc[t] = mma(mfrag(smem, (og * 3 + t) * 6 + ks, lane), xb[ks], acc[t]);
+                if constexpr (OUT_BF16) tile_out_bf16((uint16_t*)A.y, row0, A.R, A.ldy, og * 96, stg, lane, acc);
+                else tile_out<ACCUM>((float*)A.y + og * 96, row0, A.R, stg + STG_IN, lane, acc);
+            }
+        } else {
+            static_assert(NKC == 1 || (IN_BF16 && NOG == 1 && !OUT_BF16), "the K = 288 form reads bf16 and writes f32");
+            f32x16 acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = bias[h * 48 + t * 16 + i];
+#pragma unroll 1
+            for (int kc = 0; kc < NKC; ++kc) {
+                op8 xb[6];
+                uint4 v[6];
+                tile_load_bf16((const uint16_t*)A.x, row0, A.R, A.ldx, kc * 96, lane, v);
+                tile_put_bf16(v, stg, lane);
+                tile_frags(stg, lane, xb);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) acc[t] = mma(mfrag(smem, (t * NKC + kc) * 6 + ks, lane), xb[ks], acc[t]);
+            }
+            tile_out<ACCUM>((float*)A.y, row0, A.R, stg + STG_IN, lane, acc);
+        }
+    }
+}
+
 int check_common(const char* who, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words) {
     STEP_REQUIRE(h1 && pack, "%s: null input", who);
     STEP_REQUIRE(R > 0 && R < (1L << 36), "%s: bad row count %ld", who, R);
@@ -675,5 +813,50 @@ extern "C" int step_pt_ffn_fused_bwd_weights(const float* df2, const float* h1, 
     ffn_reduce_kernel<<<dim3(cdiv(96 * 384, 256), 8), 256, 0, st>>>(ws2, grid, 96 * 384, 96 * 384, ks, dw2, 96 * 384, nullptr);
     ffn_reduce_kernel<<<dim3(cdiv(384 * 96 + 384, 256), 8), 256, 0, st>>>(ws1, grid, 384 * 96 + 384, 384 * 96 + 384, ks, dw1, 384 * 96, db1);
     STEP_LAUNCH_CHECK("step_pt_ffn_fused_bwd_weights (reduce)");
+    return STEP_OK;
+}
+
+extern "C" long step_pt_rows_linear_pack_bytes(int nkc, int nog) { return (long)nog * 3 * nkc * 6 * FF_FRAG + (long)nog * 96 * 4; }
+
+extern "C" int step_pt_rows_linear_pack(const float* w, long swo, long swi, int nkc, int nog, const float* bias, void* pack, void* stream) {
+    STEP_REQUIRE(w && pack && nkc >= 1 && nog >= 1 && nkc * nog <= 3, "pt_rows_linear_pack: bad arguments (blocks of 96: %d in x %d out)", nkc, nog);
+    STEP_REQUIRE(((uintptr_t)pack & 15) == 0, "pt_rows_linear_pack: the fragment buffer must be 16-byte aligned");
+    const int threads = nog * 3 * nkc * 6 * 64 + nog * 96;
+    lin_pack_kernel<<<cdiv(threads, 256), 256, 0, (hipStream_t)stream>>>(w, swo, swi, nkc, nog, bias, (char*)pack);
+    STEP_LAUNCH_CHECK("step_pt_rows_linear_pack");
+    return STEP_OK;
+}
+
+namespace {
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM>
+int launch_lin(const LinArgs& a, hipStream_t st) {
+    static bool raised = false;
+    const int wbytes = NOG * 3 * NKC * 6 * FF_FRAG + NOG * 96 * 4;
+    const int lds = ((wbytes + 1023) & ~1023) + 8 * STG_WAVE;
+    STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM>, lds, raised));
+    const long ntile = (a.R + 31) / 32, nwg = (ntile + 7) / 8;
+    rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM><<<(int)(nwg < 256 ? nwg : 256), 512, lds, st>>>(a);
+    return STEP_OK;
+}
+}  // namespace
+
+// y[R, 96 nog] (accumulate ? += : =) x[R, 96 nkc] . M^T + bias, M and bias as packed by step_pt_rows_linear_pack.  Supported forms:
+// (nkc 1, nog 1 | 3, x f32, y bf16), (1, 1, x bf16, y f32), (3, 1, x bf16, y f32, accumulate 0 | 1)
+extern "C" int step_pt_rows_linear(const void* x, int x_bf16, long R, const void* pack, int nkc, int nog, void* y, int y_bf16, int accumulate,
+                                   void* stream) {
+    STEP_REQUIRE(x && pack && y && R > 0 && R < (1L << 36), "pt_rows_linear: bad arguments");
+    STEP_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)pack) & 15) == 0, "pt_rows_linear: 16-byte aligned tensors expected");
+    LinArgs a;
+    a.x = x; a.y = y; a.R = R; a.ldx = 96 * nkc; a.ldy = 96 * nog; a.pack = (const char*)pack;
+    const hipStream_t st = (hipStream_t)stream;
+    int rc = -1;
+    if (nkc == 1 && nog == 3 && !x_bf16 && y_bf16 && !accumulate) rc = launch_lin<1, 3, false, true, false>(a, st);
+    else if (nkc == 1 && nog == 1 && !x_bf16 && y_bf16 && !accumulate) rc = launch_lin<1, 1, false, true, false>(a, st);
+    else if (nkc == 1 && nog == 1 && x_bf16 && !y_bf16 && !accumulate) rc = launch_lin<1, 1, true, false, false>(a, st);
+    else if (nkc == 3 && nog == 1 && x_bf16 && !y_bf16) rc = accumulate ? launch_lin<3, 1, true, false, true>(a, st) : launch_lin<3, 1, true, false, false>(a, st);
+    STEP_REQUIRE(rc != -1, "pt_rows_linear: unsupported form (%d x 96 %s in, %d x 96 %s out, accumulate %d)", nkc, x_bf16 ? "bf16" : "f32", nog,
+                 y_bf16 ? "bf16" : "f32", accumulate);
+    STEP_TRY(rc);
+    STEP_LAUNCH_CHECK("step_pt_rows_linear");
     return STEP_OK;
 }

@@ -166,7 +166,8 @@ class _PretrainFunction(torch.autograd.Function):
         if _BF16 and model.fused_ffn:
             # feed-forward blocks without a stored hidden layer (csrc/pretrain_fused.hip): operand fragments of this step's weights per layer,
             # and the step's keep-mask pool
-            fz = {"packs": model._ffn_packs(series.device), "pool": None, "words": 0}
+            fz = {"packs": model._ffn_packs(series.device), "pool": None, "words": 0,
+                  "proj": model._proj_packs(series.device) if model.fused_proj else None}
             if p > 0:
                 fz["pool"], fz["words"] = model._pt_pool(series.device, p, seed)
         saved["fz"] = fz
@@ -220,8 +221,17 @@ class _PretrainFunction(torch.autograd.Function):
             # kernels -- would round it to), the attention output likewise (read by the out-projection and its weight gradient as a
             # matrix-core operand); the keep decisions of the probability dropout are handed to the backward as bit masks
             qkv = torch.empty(R, 288, device=x.device, dtype=torch.bfloat16)
-            L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(P_[pre + "self_attn.in_proj_weight"]), 1, 96, L.ptr(P_[pre + "self_attn.in_proj_bias"]),
-                   R, 288, 96, L.ptr(qkv), st)
+            pj = fz["proj"][pre] if fz is not None and fz["proj"] is not None else None
+            if pj is not None:
+                wi, wo = P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.out_proj.weight"]
+                L.call("step_pt_rows_linear_pack", L.ptr(wi), 96, 1, 1, 3, L.ptr(P_[pre + "self_attn.in_proj_bias"]), L.ptr(pj[0]), st)
+                L.call("step_pt_rows_linear_pack", L.ptr(wo), 96, 1, 1, 1, L.ptr(P_[pre + "self_attn.out_proj.bias"]), L.ptr(pj[1]), st)
+                L.call("step_pt_rows_linear_pack", L.ptr(wo), 1, 96, 1, 1, None, L.ptr(pj[2]), st)
+                L.call("step_pt_rows_linear_pack", L.ptr(wi), 1, 96, 3, 1, None, L.ptr(pj[3]), st)
+                L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(pj[0]), 1, 3, L.ptr(qkv), 1, 0, st)
+            else:
+                L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(P_[pre + "self_attn.in_proj_weight"]), 1, 96, L.ptr(P_[pre + "self_attn.in_proj_bias"]),
+                       R, 288, 96, L.ptr(qkv), st)
             a = torch.empty(R, 96, device=x.device, dtype=torch.bfloat16)
             kb = torch.empty(S * 4 * T * ((T + 31) // 32), dtype=torch.int32, device=x.device) if p > 0 else None
             # (with the fused path's pool the keep words come from it: no Philox in the kernel; the backward reads `kb` either way)
@@ -231,7 +241,11 @@ class _PretrainFunction(torch.autograd.Function):
             qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
             a = _empty(R, 96, like=x)
             L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
-        o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
+        if mc and pj is not None:
+            o = _empty(R, 96, like=x)
+            L.call("step_pt_rows_linear", L.ptr(a), 1, R, L.ptr(pj[1]), 1, 1, L.ptr(o), 0, 0, st)
+        else:
+            o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
         # residual add (+ dropout of the branch) and LayerNorm in one pass
         h1pre, h1, st1 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
         L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]),
@@ -323,14 +337,21 @@ class _PretrainFunction(torch.autograd.Function):
             # dWo[j, i] += sum_r do[r, j] a[r, i]  (dbo = colsum(do) came out of the LayerNorm backward above)
             _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
-            L.call("step_pt_linear_bf16out", L.ptr(do), L.ptr(wo), 96, 1, None, R, 96, 96, L.ptr(da), st)          # da = do @ Wo
+            pj = sv["fz"]["proj"][pre] if sv["fz"] is not None and sv["fz"]["proj"] is not None else None
+            if pj is not None:
+                L.call("step_pt_rows_linear", L.ptr(do), 0, R, L.ptr(pj[2]), 1, 1, L.ptr(da), 1, 0, st)                 # da = do @ Wo
+            else:
+                L.call("step_pt_linear_bf16out", L.ptr(do), L.ptr(wo), 96, 1, None, R, 96, 96, L.ptr(da), st)          # da = do @ Wo
             dqkv = torch.empty(R, 288, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
                    L.ptr(sv["keepbits"]), st)
             # dWi[j, i] += sum_r dqkv[r, j] x[r, i], computed as its transpose (A = x with i contiguous, B = dqkv with j contiguous)
             _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
             L.call("step_pt_colsum_bf16", L.ptr(dqkv), R, 288, L.ptr(G[pre + "self_attn.in_proj_bias"]), st)
-            _lib.gemm(dqkv, wi, dx, R, 96, 288, 288, 1, 96, 1, 96, accumulate=1, compute_bf16=True)                   # dx += dqkv @ Wi
+            if pj is not None:
+                L.call("step_pt_rows_linear", L.ptr(dqkv), 1, R, L.ptr(pj[3]), 3, 1, L.ptr(dx), 0, 1, st)               # dx += dqkv @ Wi
+            else:
+                _lib.gemm(dqkv, wi, dx, R, 96, 288, 288, 1, 96, 1, 96, accumulate=1, compute_bf16=True)                   # dx += dqkv @ Wi
             return dx
         da = _empty(R, 96, like=dh2)
         _linear_bwd(do, sv["a"], P_[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.weight"],
@@ -426,6 +447,8 @@ class TSFormer(nn.Module):
         # recomputes it).  STEP_PT_FUSED_FFN=0 keeps the layer-by-layer kernels (A/B measurements)
         self.fused_ffn = os.environ.get("STEP_PT_FUSED_FFN", "1") != "0"
         self._ffn_pack_bufs = None
+        self.fused_proj = os.environ.get("STEP_PT_FUSED_PROJ", "1") != "0"       # qkv / out-projection and their data gradients as row kernels
+        self._proj_pack_bufs = None
         self._pt_pool_buf = None
         self._packed = None
         self._packed_key = None
@@ -560,6 +583,16 @@ class TSFormer(nn.Module):
                    [f"decoder.transformer_encoder.layers.{l}." for l in range(self.decoder_depth)]
             self._ffn_pack_bufs = {k: torch.empty(n, dtype=torch.uint8, device=device) for k in keys}
         return self._ffn_pack_bufs
+
+    def _proj_packs(self, device):
+        """per-layer operand fragments of the attention block's projections: (qkv, out-projection, d a = d o . Wo, d x += d qkv . Wi)"""
+        if self._proj_pack_bufs is None or next(iter(self._proj_pack_bufs.values()))[0].device != device:
+            nb = _lib.lib().step_pt_rows_linear_pack_bytes
+            keys = [f"encoder.transformer_encoder.layers.{l}." for l in range(self.encoder_depth)] + \
+                   [f"decoder.transformer_encoder.layers.{l}." for l in range(self.decoder_depth)]
+            self._proj_pack_bufs = {k: tuple(torch.empty(nb(kc, og), dtype=torch.uint8, device=device) for kc, og in ((1, 3), (1, 1), (1, 1), (3, 1)))
+                                    for k in keys}
+        return self._proj_pack_bufs
 
     def _pt_pool(self, device, p, seed):
         """this step's keep-mask pool of the fused feed-forward blocks: (int64 tensor, words)"""

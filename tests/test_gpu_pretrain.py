@@ -478,3 +478,43 @@ def test_matrix_core_attention_with_pool_drawn_keep_words(T):
     eo, eg = rel_l2(out.float().cpu().double(), want.detach()), rel_l2(dqkv.float().cpu().double(), x.grad)
     print(f"T={T} matrix-core attention with pool-drawn keep words vs float64 oracle: out {eo:.2e}, dqkv {eg:.2e}")
     assert eo < 1.5e-2 and eg < 2.5e-2
+
+
+@pytest.mark.parametrize("R", [256 * 2 + 45, 256 * 300 + 77])
+def test_row_kernels_of_the_attention_projections(R):
+    """step_pt_rows_linear (csrc/pretrain_fused.hip: LDS-resident weights, no workgroup barrier after the first) in its four forms -- qkv = x Wi^T + bi
+    (f32 -> bf16), o = a Wo^T + bo (bf16 -> f32), da = do Wo (f32 -> bf16), dx += dqkv Wi (bf16 -> f32, accumulated) -- against float64
+    products of the same inputs.  bf16 operands (and bf16 results where stored so): 6e-3."""
+    from step_amd import _lib as L
+    gen = torch.Generator().manual_seed(31)
+    wi = (torch.randn(288, 96, generator=gen) * 0.15).cuda()
+    bi = (torch.randn(288, generator=gen) * 0.1).cuda()
+    wo = (torch.randn(96, 96, generator=gen) * 0.15).cuda()
+    bo = (torch.randn(96, generator=gen) * 0.1).cuda()
+    x = torch.randn(R, 96, generator=gen).cuda()
+    a = torch.randn(R, 96, generator=gen).bfloat16().cuda()
+    do = torch.randn(R, 96, generator=gen).cuda()
+    dqkv = torch.randn(R, 288, generator=gen).bfloat16().cuda()
+    dx0 = torch.randn(R, 96, generator=gen).cuda()
+    st = L.stream()
+    nb = L.lib().step_pt_rows_linear_pack_bytes
+    packs = [torch.empty(nb(kc, og), dtype=torch.uint8, device="cuda") for kc, og in ((1, 3), (1, 1), (1, 1), (3, 1))]
+    L.call("step_pt_rows_linear_pack", L.ptr(wi), 96, 1, 1, 3, L.ptr(bi), L.ptr(packs[0]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wo), 96, 1, 1, 1, L.ptr(bo), L.ptr(packs[1]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wo), 1, 96, 1, 1, None, L.ptr(packs[2]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wi), 1, 96, 3, 1, None, L.ptr(packs[3]), st)
+    qkv = torch.empty(R, 288, device="cuda", dtype=torch.bfloat16)
+    o = torch.empty(R, 96, device="cuda")
+    da = torch.empty(R, 96, device="cuda", dtype=torch.bfloat16)
+    dx = dx0.clone()
+    L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(packs[0]), 1, 3, L.ptr(qkv), 1, 0, st)
+    L.call("step_pt_rows_linear", L.ptr(a), 1, R, L.ptr(packs[1]), 1, 1, L.ptr(o), 0, 0, st)
+    L.call("step_pt_rows_linear", L.ptr(do), 0, R, L.ptr(packs[2]), 1, 1, L.ptr(da), 1, 0, st)
+    L.call("step_pt_rows_linear", L.ptr(dqkv), 1, R, L.ptr(packs[3]), 3, 1, L.ptr(dx), 0, 1, st)
+    torch.cuda.synchronize()
+    want = {"qkv": x.double() @ wi.double().T + bi.double(), "o": a.double() @ wo.double().T + bo.double(), "da": do.double() @ wo.double(),
+            "dx": dx0.double() + dqkv.double() @ wi.double()}
+    got = {"qkv": qkv, "o": o, "da": da, "dx": dx}
+    errs = {k: rel_l2(got[k].double().cpu(), want[k].cpu()) for k in want}
+    print(f"row kernels of the attention projections R={R}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < 6e-3

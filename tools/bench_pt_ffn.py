@@ -49,6 +49,21 @@ def main():
             gb_f, gb_d = R * 96 * 4 * 2 / 1e3, R * 96 * 4 * 4 / 1e3
             print(f"{tag} R={R} p={p}: forward {t_f:.0f} us ({gb_f / t_f:.0f} GB/s), backward-data {t_d:.0f} us ({gb_d / t_d:.0f} GB/s), "
                   f"backward-weights (W2 + W1 + 2 reductions) {t_w:.0f} us", flush=True)
+        nb = L.lib().step_pt_rows_linear_pack_bytes
+        wi = (torch.randn(288, 96, generator=gen) * 0.15).cuda()
+        packs = [torch.empty(nb(kc, og), dtype=torch.uint8, device="cuda") for kc, og in ((1, 3), (1, 1), (3, 1))]
+        L.call("step_pt_rows_linear_pack", L.ptr(wi), 96, 1, 1, 3, None, L.ptr(packs[0]), st)
+        L.call("step_pt_rows_linear_pack", L.ptr(w1), 96, 1, 1, 1, None, L.ptr(packs[1]), st)
+        L.call("step_pt_rows_linear_pack", L.ptr(wi), 1, 96, 3, 1, None, L.ptr(packs[2]), st)
+        qkv = torch.empty(R, 288, device="cuda", dtype=torch.bfloat16)
+        ab = torch.randn(R, 96, device="cuda").bfloat16()
+        t_q = timed(lambda: L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(packs[0]), 1, 3, L.ptr(qkv), 1, 0, st))
+        t_q0 = timed(lambda: L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(wi), 1, 96, None, R, 288, 96, L.ptr(qkv), st))
+        t_o = timed(lambda: L.call("step_pt_rows_linear", L.ptr(ab), 1, R, L.ptr(packs[1]), 1, 1, L.ptr(out), 0, 0, st))
+        t_a = timed(lambda: L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(packs[1]), 1, 1, L.ptr(ab), 1, 0, st))
+        t_x = timed(lambda: L.call("step_pt_rows_linear", L.ptr(qkv), 1, R, L.ptr(packs[2]), 3, 1, L.ptr(out), 0, 1, st))
+        print(f"{tag} R={R} projections: qkv {t_q:.0f} us ({R * (384 + 576) / 1e3 / t_q:.0f} GB/s; step_pt_linear_bf16out {t_q0:.0f} us), out-projection {t_o:.0f} us, "
+              f"da {t_a:.0f} us, dx += {t_x:.0f} us ({R * (576 + 768) / 1e3 / t_x:.0f} GB/s)", flush=True)
         t_p = timed(lambda: L.call("step_pt_ffn_pack", L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(pack), st))
         print(f"{tag} pack {t_p:.1f} us", flush=True)
 
