@@ -304,6 +304,10 @@ int step_pt_colsum_bf16(const uint16_t* x, long rows, int cols, float* out, void
 long step_pt_rows_linear_pack_bytes(int nkc, int nog);
 int step_pt_rows_linear_pack(const float* w, long swo, long swi, int nkc, int nog, const float* bias, void* pack, void* stream);
 int step_pt_rows_linear(const void* x, int x_bf16, long R, const void* pack, int nkc, int nog, void* y, int y_bf16, int accumulate, void* stream);
+/* every fragment buffer of one layer in one launch: what step_pt_ffn_pack and the four step_pt_rows_linear_pack calls of a layer write
+ * (qkv: (1, 3) of Wi with bi; o: (1, 1) of Wo with bo; da: (1, 1) of Wo transposed; dx: (3, 1) of Wi transposed) */
+int step_pt_layer_pack(const float* wi, const float* bi, const float* wo, const float* bo, const float* w1, const float* b1, const float* w2,
+                       const float* b2, void* ffn, void* qkv, void* o, void* da, void* dx, void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

@@ -6,6 +6,7 @@
 // This first version is position-wise VALU code plus f32-MFMA GEMMs (not fused like the forecasting-mode
 // encoder); it exists so that config C3 runs natively with parity against the oracle.
 #include "common.h"
+#include <stdlib.h>
 #include "step_internal.h"
 
 namespace {
@@ -903,8 +904,17 @@ extern "C" int step_pt_layernorm_bwd_dropout(const float* dy, const float* x, lo
     STEP_REQUIRE(dy && x && g && stats && dx && dgamma && dbeta && R > 0 && p >= 0.f && p < 1.f, "pt_layernorm_bwd_dropout: bad arguments");
     STEP_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_dropped | (uintptr_t)g) & 15) == 0,
                  "pt_layernorm_bwd_dropout: 16-byte aligned buffers");
+    // every block ends with 3 x 96 atomic adds onto the same 288 addresses: the cap trades that serial tail against rows in flight
+    // (STEP_LN_BWD_BLOCKS: A/B measurements, profiles/r04_u_layernorm_backward_blocks.log)
+    // measured at config C3's sizes: 873 600 rows 293 / 272 / 289 us with 1024 / 2048 / 4096 blocks, 218 400 rows 85 / 102 / 125 us
+    static long cap = -1;
+    if (cap < 0) {
+        const char* e = getenv("STEP_LN_BWD_BLOCKS");
+        cap = e && atol(e) > 0 ? atol(e) : 0;
+    }
     long blocks = (R + 7) / 8;
-    if (blocks > 4096) blocks = 4096;
+    const long want = cap > 0 ? cap : (R / 256 < 1024 ? 1024 : (R / 256 > 2048 ? 2048 : R / 256));
+    if (blocks > want) blocks = want;
     ln_bwd_drop_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(dy, x, R, g, stats, dx, dx_dropped, p, SEED_LO(seed), SEED_HI(seed), site,
                                                                          dgamma, dbeta, out_colsum);
     STEP_LAUNCH_CHECK("pt_layernorm_bwd_dropout");

@@ -71,10 +71,10 @@ __device__ __forceinline__ op8 pack_lo_hi(const f32x16& v, int s) {
 //     6..11  W2^T rows = hidden units:    W2[32 (ks >> 1) + F(ks & 1, h, j)][32 c + r]
 //     12..17 W1^T tile t, k-step s:       W1[32 c + F(s, h, j)][32 t + r]
 // f32 tail of every block: [0..63] b1 of both chunks in accumulator-register order [cc][h][16]; forward blocks also [64..159] b2 [h][48].
-__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, char* __restrict__ pack) {
+constexpr int FFN_PACK_THREADS = (6 * 24 + 6 * 36) * 64 + 12 * 256;
+__device__ __forceinline__ void ffn_pack_body(int gid, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                              const float* __restrict__ b2, char* __restrict__ pack) {
     constexpr int NF_F = 6 * 24, NF_B = 6 * 36;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid < (NF_F + NF_B) * 64) {
         const int frag = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
         float v[8];
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
         }
         dst[i] = v;
     }
+}
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, char* __restrict__ pack) {
+    ffn_pack_body(blockIdx.x * 256 + threadIdx.x, w1, b1, w2, b2, pack);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- shared pieces
@@ -568,9 +572,9 @@ struct LinArgs {
     const char* pack;                                     // NOG * 3 * NKC * 6 fragments, then bias [NOG][2][48] f32 (zeros when there is none)
 };
 // M(out, in) = w[out * swo + in * swi]; fragment ((og * 3 + t) * NKC + kc) * 6 + ks: lane (h, r), slot j -> M(96 og + 32 t + r, 96 kc + 32 (ks >> 1) + F(ks & 1, h, j))
-__global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__ w, long swo, long swi, int NKC, int NOG, const float* __restrict__ bias,
-                                                        char* __restrict__ pack) {
-    const int nfrag = NOG * 3 * NKC * 6, gid = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void lin_pack_body(int gid, const float* __restrict__ w, long swo, long swi, int NKC, int NOG, const float* __restrict__ bias,
+                                              char* __restrict__ pack) {
+    const int nfrag = NOG * 3 * NKC * 6;
     if (gid < nfrag * 64) {
         const int frag = gid >> 6, lane = gid & 63, r = lane & 31, h = lane >> 5;
         const int ks = frag % 6, kc = (frag / 6) % NKC, ot = frag / (6 * NKC);
@@ -585,6 +589,26 @@ __global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__
         const int og = i / 96, k = i % 96, h = k / 48, t = (k % 48) >> 4, e = k & 15;
         ((float*)(pack + (long)nfrag * FF_FRAG))[i] = bias ? bias[96 * og + 32 * t + row16(e, h)] : 0.f;
     }
+}
+__global__ __launch_bounds__(256) void lin_pack_kernel(const float* __restrict__ w, long swo, long swi, int NKC, int NOG, const float* __restrict__ bias,
+                                                        char* __restrict__ pack) {
+    lin_pack_body(blockIdx.x * 256 + threadIdx.x, w, swo, swi, NKC, NOG, bias, pack);
+}
+// every fragment buffer of one layer in one launch: the feed-forward pack and the four projections (qkv, out-projection, d a, d x)
+struct LayerPackArgs {
+    const float *wi, *bi, *wo, *bo, *w1, *b1, *w2, *b2;
+    char *ffn, *qkv, *o, *da, *dx;
+};
+constexpr int lin_pack_threads(int nkc, int nog) { return nog * 3 * nkc * 6 * 64 + nog * 96; }
+constexpr int LP_B0 = (FFN_PACK_THREADS + 255) / 256, LP_B1 = LP_B0 + (lin_pack_threads(1, 3) + 255) / 256, LP_B2 = LP_B1 + (lin_pack_threads(1, 1) + 255) / 256,
+              LP_B3 = LP_B2 + (lin_pack_threads(1, 1) + 255) / 256, LP_B4 = LP_B3 + (lin_pack_threads(3, 1) + 255) / 256;
+__global__ __launch_bounds__(256) void layer_pack_kernel(LayerPackArgs A) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b < LP_B0) ffn_pack_body(b * 256 + t, A.w1, A.b1, A.w2, A.b2, A.ffn);
+    else if (b < LP_B1) lin_pack_body((b - LP_B0) * 256 + t, A.wi, 96, 1, 1, 3, A.bi, A.qkv);
+    else if (b < LP_B2) lin_pack_body((b - LP_B1) * 256 + t, A.wo, 96, 1, 1, 1, A.bo, A.o);
+    else if (b < LP_B3) lin_pack_body((b - LP_B2) * 256 + t, A.wo, 1, 96, 1, 1, nullptr, A.da);
+    else lin_pack_body((b - LP_B3) * 256 + t, A.wi, 1, 96, 3, 1, nullptr, A.dx);
 }
 
 // a 32 x 96 block of a bf16 tensor (leading dimension ld elements, first column col0) -> the swizzled bf16 tile of tile_put
@@ -773,8 +797,7 @@ extern "C" long step_pt_ffn_wgrad_ws_floats(long R) { return (long)step_pt_ffn_w
 extern "C" int step_pt_ffn_pack(const float* w1, const float* b1, const float* w2, const float* b2, void* pack, void* stream) {
     STEP_REQUIRE(w1 && b1 && w2 && b2 && pack, "pt_ffn_pack: null argument");
     STEP_REQUIRE(((uintptr_t)pack & 15) == 0, "pt_ffn_pack: the fragment buffer must be 16-byte aligned");
-    const int threads = (6 * 24 + 6 * 36) * 64 + 12 * 256;
-    ffn_pack_kernel<<<cdiv(threads, 256), 256, 0, (hipStream_t)stream>>>(w1, b1, w2, b2, (char*)pack);
+    ffn_pack_kernel<<<cdiv(FFN_PACK_THREADS, 256), 256, 0, (hipStream_t)stream>>>(w1, b1, w2, b2, (char*)pack);
     STEP_LAUNCH_CHECK("step_pt_ffn_pack");
     return STEP_OK;
 }
@@ -858,5 +881,17 @@ extern "C" int step_pt_rows_linear(const void* x, int x_bf16, long R, const void
                  y_bf16 ? "bf16" : "f32", accumulate);
     STEP_TRY(rc);
     STEP_LAUNCH_CHECK("step_pt_rows_linear");
+    return STEP_OK;
+}
+
+// all fragment buffers of one transformer layer in one launch (what five step_pt_ffn_pack / step_pt_rows_linear_pack calls write):
+// ffn (step_pt_ffn_pack_bytes), qkv (1, 3), o (1, 1), da (1, 1: Wo transposed), dx (3, 1: Wi transposed)
+extern "C" int step_pt_layer_pack(const float* wi, const float* bi, const float* wo, const float* bo, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, void* ffn, void* qkv, void* o, void* da, void* dx, void* stream) {
+    STEP_REQUIRE(wi && bi && wo && bo && w1 && b1 && w2 && b2 && ffn && qkv && o && da && dx, "pt_layer_pack: null argument");
+    STEP_REQUIRE((((uintptr_t)ffn | (uintptr_t)qkv | (uintptr_t)o | (uintptr_t)da | (uintptr_t)dx) & 15) == 0, "pt_layer_pack: 16-byte aligned buffers");
+    LayerPackArgs a = {wi, bi, wo, bo, w1, b1, w2, b2, (char*)ffn, (char*)qkv, (char*)o, (char*)da, (char*)dx};
+    layer_pack_kernel<<<LP_B4, 256, 0, (hipStream_t)stream>>>(a);
+    STEP_LAUNCH_CHECK("step_pt_layer_pack");
     return STEP_OK;
 }

@@ -223,11 +223,11 @@ class _PretrainFunction(torch.autograd.Function):
             qkv = torch.empty(R, 288, device=x.device, dtype=torch.bfloat16)
             pj = fz["proj"][pre] if fz is not None and fz["proj"] is not None else None
             if pj is not None:
-                wi, wo = P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.out_proj.weight"]
-                L.call("step_pt_rows_linear_pack", L.ptr(wi), 96, 1, 1, 3, L.ptr(P_[pre + "self_attn.in_proj_bias"]), L.ptr(pj[0]), st)
-                L.call("step_pt_rows_linear_pack", L.ptr(wo), 96, 1, 1, 1, L.ptr(P_[pre + "self_attn.out_proj.bias"]), L.ptr(pj[1]), st)
-                L.call("step_pt_rows_linear_pack", L.ptr(wo), 1, 96, 1, 1, None, L.ptr(pj[2]), st)
-                L.call("step_pt_rows_linear_pack", L.ptr(wi), 1, 96, 3, 1, None, L.ptr(pj[3]), st)
+                # this step's weights of the layer as operand fragments: the four projections and the feed-forward block, one launch
+                L.call("step_pt_layer_pack", L.ptr(P_[pre + "self_attn.in_proj_weight"]), L.ptr(P_[pre + "self_attn.in_proj_bias"]),
+                       L.ptr(P_[pre + "self_attn.out_proj.weight"]), L.ptr(P_[pre + "self_attn.out_proj.bias"]), L.ptr(P_[pre + "linear1.weight"]),
+                       L.ptr(P_[pre + "linear1.bias"]), L.ptr(P_[pre + "linear2.weight"]), L.ptr(P_[pre + "linear2.bias"]), L.ptr(fz["packs"][pre]),
+                       L.ptr(pj[0]), L.ptr(pj[1]), L.ptr(pj[2]), L.ptr(pj[3]), st)
                 L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(pj[0]), 1, 3, L.ptr(qkv), 1, 0, st)
             else:
                 L.call("step_pt_linear_bf16out", L.ptr(x), L.ptr(P_[pre + "self_attn.in_proj_weight"]), 1, 96, L.ptr(P_[pre + "self_attn.in_proj_bias"]),
@@ -253,8 +253,9 @@ class _PretrainFunction(torch.autograd.Function):
         f2 = None
         if fz is not None:
             pk = fz["packs"][pre]
-            L.call("step_pt_ffn_pack", L.ptr(P_[pre + "linear1.weight"]), L.ptr(P_[pre + "linear1.bias"]), L.ptr(P_[pre + "linear2.weight"]),
-                   L.ptr(P_[pre + "linear2.bias"]), L.ptr(pk), st)
+            if not (mc and pj is not None):          # (otherwise written by step_pt_layer_pack above)
+                L.call("step_pt_ffn_pack", L.ptr(P_[pre + "linear1.weight"]), L.ptr(P_[pre + "linear1.bias"]), L.ptr(P_[pre + "linear2.weight"]),
+                       L.ptr(P_[pre + "linear2.bias"]), L.ptr(pk), st)
             f1 = f1d = None
             f2 = _empty(R, 96, like=x)
             L.call("step_pt_ffn_fused_fwd", L.ptr(h1), R, L.ptr(pk), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2, L.ptr(f2), st)

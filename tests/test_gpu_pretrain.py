@@ -518,3 +518,27 @@ def test_row_kernels_of_the_attention_projections(R):
     errs = {k: rel_l2(got[k].double().cpu(), want[k].cpu()) for k in want}
     print(f"row kernels of the attention projections R={R}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     assert max(errs.values()) < 6e-3
+
+
+def test_layer_pack_matches_the_separate_packs():
+    """step_pt_layer_pack (all fragment buffers of a layer, one launch) writes exactly what step_pt_ffn_pack and the four
+    step_pt_rows_linear_pack calls write."""
+    from step_amd import _lib as L
+    gen = torch.Generator().manual_seed(77)
+    r = lambda *sh: torch.randn(*sh, generator=gen).cuda()
+    wi, bi, wo, bo, w1, b1, w2, b2 = r(288, 96), r(288), r(96, 96), r(96), r(384, 96), r(384), r(96, 384), r(96)
+    st = L.stream()
+    nb = L.lib().step_pt_rows_linear_pack_bytes
+    sizes = [L.lib().step_pt_ffn_pack_bytes(), nb(1, 3), nb(1, 1), nb(1, 1), nb(3, 1)]
+    one = [torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda") for n in sizes]
+    sep = [torch.full((n,), 0xAB, dtype=torch.uint8, device="cuda") for n in sizes]
+    L.call("step_pt_layer_pack", L.ptr(wi), L.ptr(bi), L.ptr(wo), L.ptr(bo), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), *[L.ptr(t) for t in one], st)
+    L.call("step_pt_ffn_pack", L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(sep[0]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wi), 96, 1, 1, 3, L.ptr(bi), L.ptr(sep[1]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wo), 96, 1, 1, 1, L.ptr(bo), L.ptr(sep[2]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wo), 1, 96, 1, 1, None, L.ptr(sep[3]), st)
+    L.call("step_pt_rows_linear_pack", L.ptr(wi), 1, 96, 3, 1, None, L.ptr(sep[4]), st)
+    torch.cuda.synchronize()
+    for a, b in zip(one, sep):
+        assert torch.equal(a, b)
+        assert int((a == 0xAB).sum()) < a.numel() // 8          # (written: the fill pattern is gone)

@@ -51,16 +51,46 @@ def rows_of(N, T, B, P, L):
     ]
 
 
+def rows_of_pretrain(N, B, P, Pu=None):
+    """Config C3 (TSFormer pre-training, bf16 mode): per-launch AVERAGES over the step's launches of a kernel (4 encoder layers of
+    S * Pu rows + 1 decoder layer of S * P rows; the LayerNorm kernels also run once for each final norm)."""
+    S = B * N
+    Pu = Pu or P // 4
+    Re, Rd = S * Pu, S * P
+    lay = (4 * Re + Rd) / 5.0                                   # rows of an average layer launch
+    ln = (2 * (4 * Re + Rd) + Re + Rd) / 12.0                   # rows of an average LayerNorm launch
+    att = lambda k: (4 * S * 4 * Pu * Pu + S * 4 * P * P) / 5.0 * 2.0 * 24 * k      # k products of T x T x 24 per (sequence, head)
+    f32, b16 = 96 * 4, 96 * 2
+    return [
+        ("attn_mfma_bwd_kernel", "attention backward on the matrix cores (dQ, dK, dV; scores recomputed in both orientations)", "valu/lds",
+         lay * (2 * 3 * b16 + 2 * b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(5)),
+        ("ln_bwd_drop_kernel", "LayerNorm backward + dropout of the continuing gradient + parameter / bias gradient sums", "hbm", ln * 4 * f32 * (10.0 / 12) + ln * 3 * f32 * (2.0 / 12), None),
+        ("add_ln_fwd_kernel", "residual add + dropout + LayerNorm forward", "hbm", ln * 4 * f32 * (10.0 / 12) + ln * 2 * f32 * (2.0 / 12), None),
+        ("gemm_fast_kernelILi128ELi128ELi2ELi3ELb0", "weight gradients of the out-projection and of the qkv projection (split-K GEMMs, K = rows)", "hbm", lay * (f32 + b16 + f32 + 3 * b16) / 2, lay * 2.0 * 96 * (96 + 288) / 2),
+        ("ffn_rows_kernelILi8ELb1", "fused feed-forward, input gradient (hidden layer recomputed; reads h1, d f2, read-modify-writes d h1)", "hbm", lay * 4 * f32, lay * 3 * 2.0 * 96 * 384),
+        ("attn_mfma_fwd_kernel", "attention forward on the matrix cores", "valu/lds", lay * (3 * b16 + b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(2)),
+        ("ffn_wgrad_kernelILb1", "fused feed-forward, d W1 and d b1 (hidden layer and its gradient recomputed)", "lds", lay * 2 * f32, lay * 3 * 2.0 * 96 * 384),
+        ("ffn_rows_kernelILi8ELb0", "fused feed-forward, forward (hidden layer in registers)", "hbm", lay * 2 * f32, lay * 2 * 2.0 * 96 * 384),
+        ("rows_linear_kernelILi3ELi1ELb1ELb0ELb1", "d x += d qkv . Wi (row kernel, LDS-resident weights)", "hbm", lay * (3 * b16 + 2 * f32), lay * 2.0 * 96 * 288),
+        ("ffn_wgrad_kernelILb0", "fused feed-forward, d W2 (hidden layer recomputed)", "lds", lay * 2 * f32, lay * 2 * 2.0 * 96 * 384),
+        ("rows_linear_kernelILi1ELi3ELb0ELb1ELb0", "qkv = x . Wi^T + bi (row kernel, LDS-resident weights)", "hbm", lay * (f32 + 3 * b16), lay * 2.0 * 96 * 288),
+        ("colsum_bf16_kernel", "bias gradient of the qkv projection (column sums of d qkv)", "hbm", lay * 3 * b16, None),
+        ("rows_linear_kernelILi1ELi1ELb1ELb0ELb0", "o = a . Wo^T + bo (row kernel)", "hbm", lay * (b16 + f32), lay * 2.0 * 96 * 96),
+        ("rows_linear_kernelILi1ELi1ELb0ELb1ELb0", "d a = d o . Wo (row kernel)", "hbm", lay * (f32 + b16), lay * 2.0 * 96 * 96),
+    ]
+
+
 def main():
     import bench
     ap = argparse.ArgumentParser()
     ap.add_argument("summary")
-    ap.add_argument("--config", default="STEP_PEMS04", choices=[k for k, v in bench.CONFIGS.items() if not v.get("pretrain")])
+    ap.add_argument("--config", default="STEP_PEMS04", choices=list(bench.CONFIGS))
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     N, T, B, L = cfg["N"], cfg["T_train"], cfg["B"], cfg["L"]
     P = L // 12
+    pre = bool(cfg.get("pretrain"))
     rows, total_ms, ndisp = {}, None, None
     for line in open(args.summary):
         m = re.match(r"\| (\S+) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
@@ -78,7 +108,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|---|---|")
     steps = None
     out = []
-    for key, label, bound, nbytes, flop in rows_of(N, T, B, P, L):
+    for key, label, bound, nbytes, flop in (rows_of_pretrain(N, B, P) if pre else rows_of(N, T, B, P, L)):
         hit = []
         for kk in (key if isinstance(key, tuple) else (key,)):
             hit = [(k, v) for k, v in rows.items() if kk in k]
@@ -88,7 +118,7 @@ def main():
             continue
         calls, us, tot = hit[0][1]
         if steps is None:
-            steps = calls                                  # the encoder is launched once per step
+            steps = calls // 5 if pre else calls           # the encoder is launched once per step (pre-training: the attention backward five times)
         gbs = nbytes / us / 1e3 if nbytes else None
         tf = flop / us / 1e6 if flop else None
         print(f"| {label} | {calls / steps:.0f} | {us:.1f} | {tot / steps:.3f} | {nbytes / MB:.0f} | {gbs:.0f} | {100 * gbs / HBM:.0f} % | "
