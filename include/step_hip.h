@@ -308,6 +308,12 @@ int step_pt_rows_linear(const void* x, int x_bf16, long R, const void* pack, int
  * (qkv: (1, 3) of Wi with bi; o: (1, 1) of Wo with bo; da: (1, 1) of Wo transposed; dx: (3, 1) of Wi transposed) */
 int step_pt_layer_pack(const float* wi, const float* bi, const float* wo, const float* bo, const float* w1, const float* b1, const float* w2,
                        const float* b2, void* ffn, void* qkv, void* o, void* da, void* dx, void* stream);
+/* the weight gradients of a layer's two projections and the qkv bias gradient in one pass over the four row tensors:
+ * dwi [288, 96] += dqkv^T x, dbi [288] += column sums of dqkv, dwo [96, 96] += dov^T a   (x, dov f32 [R, 96]; dqkv bf16 [R, 288]; a bf16 [R, 96];
+ * ws: step_pt_proj_wgrad_ws_floats(R) floats of scratch) */
+long step_pt_proj_wgrad_ws_floats(long R);
+int step_pt_proj_wgrad(const float* x, const uint16_t* dqkv, const float* dov, const uint16_t* a, long R, float* ws, float* dwi, float* dbi, float* dwo,
+                       void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

@@ -99,6 +99,8 @@ _SIGS = {
     "step_pt_rows_linear_pack": (_i, [_vp, _l, _l, _i, _i, _vp, _vp, _vp]),
     "step_pt_rows_linear": (_i, [_vp, _i, _l, _vp, _i, _i, _vp, _i, _i, _vp]),
     "step_pt_layer_pack": (_i, [_vp] * 14),
+    "step_pt_proj_wgrad_ws_floats": (_l, [_l]),
+    "step_pt_proj_wgrad": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_ffn_pack_bytes": (_l, []),
     "step_pt_ffn_wgrad_workgroups": (_l, [_l]),
     "step_pt_ffn_wgrad_ws_floats": (_l, [_l]),

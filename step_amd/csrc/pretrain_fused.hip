@@ -717,6 +717,114 @@ __global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- weight gradients of the projections
+// d Wi[j, i] = sum_r d qkv[r, j] x[r, i] (288 x 96), d bi[j] = sum_r d qkv[r, j], d Wo[j, i] = sum_r d o[r, j] a[r, i] (96 x 96) in ONE pass over
+// the four row tensors (the split-K GEMMs they replace read them at 2.9 TB/s, and the bias gradient was a fifth pass over d qkv).
+// Twelve waves: waves 0..8 own a block of 32 rows j of d Wi (three accumulator tiles + the bias sum), waves 9..11 a block of d Wo.  A 32-row
+// tile of all four tensors (48 KB: each a contiguous run) is copied to LDS as it is -- 16-byte coalesced loads, requested one tile
+// ahead -- and every wave gathers its operand fragments from the raw rows: both operands of these products contract over ROWS, i.e. lane
+// = column, slots = rows F(s, h, j), which in a row-major tile is 32 consecutive elements per read (conflict-free).
+constexpr int PW_DQ = 32 * 288 * 2, PW_X = 32 * 96 * 4, PW_DO = 32 * 96 * 4, PW_A = 32 * 96 * 2, PW_TILE = PW_DQ + PW_X + PW_DO + PW_A;     // 49152
+constexpr int PW_WS = 288 * 96 + 288 + 96 * 96;
+struct ProjWgradArgs { const float* x; const uint16_t* dqkv; const float* dov; const uint16_t* a; long R; float* ws; };
+
+__global__ __launch_bounds__(FW_WAVES * 64) void proj_wgrad_kernel(ProjWgradArgs A) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 31, h = lane >> 5;
+    const long ntile = (A.R + 31) / 32;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float bsum = 0.f;
+    // piece p (1 KB) of a tile's 48: which tensor, where
+    auto piece_load = [&](long tile, int p) -> uint4 {
+        const char* src; long off, lim;
+        if (p < 18) { src = (const char*)A.dqkv; off = tile * PW_DQ + p * 1024; lim = A.R * 576; }
+        else if (p < 30) { src = (const char*)A.x; off = tile * PW_X + (p - 18) * 1024; lim = A.R * 384; }
+        else if (p < 42) { src = (const char*)A.dov; off = tile * PW_DO + (p - 30) * 1024; lim = A.R * 384; }
+        else { src = (const char*)A.a; off = tile * PW_A + (p - 42) * 1024; lim = A.R * 192; }
+        off += lane * 16;
+        return off < lim ? *(const uint4*)(src + off) : make_uint4(0u, 0u, 0u, 0u);          // (row sizes are multiples of 16 bytes: a piece never straddles the end)
+    };
+    uint4 nx[4];
+    auto tile_request = [&](long tile) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nx[k] = piece_load(tile, wave + 12 * k);
+    };
+    auto tile_commit = [&](char* buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(uint4*)(buf + (wave + 12 * k) * 1024 + lane * 16) = nx[k];
+    };
+    if ((long)blockIdx.x < ntile) { tile_request(blockIdx.x); tile_commit(smem); }
+    __syncthreads();
+    int par = 0;
+#pragma unroll 1
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x, par ^= 1) {
+        const long nxt = tile + gridDim.x;
+        if (nxt < ntile) tile_request(nxt);
+        const char* buf = smem + par * PW_TILE;
+        const uint16_t* dq = (const uint16_t*)buf;
+        const float* xx = (const float*)(buf + PW_DQ);
+        const float* dd = (const float*)(buf + PW_DQ + PW_X);
+        const uint16_t* aa = (const uint16_t*)(buf + PW_DQ + PW_X + PW_DO);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            op8 af;
+            if (wave < 9) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t lo = dq[chain_f(s, h, j) * 288 + 32 * wave + c], hi = dq[chain_f(s, h, j + 1) * 288 + 32 * wave + c];
+                    w[j >> 1] = lo | (hi << 16);
+                    bsum += __uint_as_float(lo << 16) + __uint_as_float(hi << 16);
+                }
+                u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+                af = __builtin_bit_cast(op8, v);
+            } else {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = dd[chain_f(s, h, j) * 96 + 32 * (wave - 9) + c];
+                af = pack8(v);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                op8 bf;
+                if (wave < 9) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = xx[chain_f(s, h, j) * 96 + 32 * t + c];
+                    bf = pack8(v);
+                } else {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) w[j >> 1] = (uint32_t)aa[chain_f(s, h, j) * 96 + 32 * t + c] | ((uint32_t)aa[chain_f(s, h, j + 1) * 96 + 32 * t + c] << 16);
+                    u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+                    bf = __builtin_bit_cast(op8, v);
+                }
+                acc[t] = mma(af, bf, acc[t]);
+            }
+        }
+        if (nxt < ntile) tile_commit(smem + (par ^ 1) * PW_TILE);
+        __syncthreads();
+    }
+    float* ws = A.ws + (long)blockIdx.x * PW_WS;
+    if (wave < 9) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ws[(32 * wave + row16(i, h)) * 96 + 32 * t + c] = acc[t][i];
+        const float other = __shfl_xor(bsum, 32, 64);
+        if (h == 0) ws[288 * 96 + 32 * wave + c] = bsum + other;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ws[288 * 96 + 288 + (32 * (wave - 9) + row16(i, h)) * 96 + 32 * t + c] = acc[t][i];
+    }
+}
+
 int check_common(const char* who, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words) {
     STEP_REQUIRE(h1 && pack, "%s: null input", who);
     STEP_REQUIRE(R > 0 && R < (1L << 36), "%s: bad row count %ld", who, R);
@@ -893,5 +1001,28 @@ extern "C" int step_pt_layer_pack(const float* wi, const float* bi, const float*
     LayerPackArgs a = {wi, bi, wo, bo, w1, b1, w2, b2, (char*)ffn, (char*)qkv, (char*)o, (char*)da, (char*)dx};
     layer_pack_kernel<<<LP_B4, 256, 0, (hipStream_t)stream>>>(a);
     STEP_LAUNCH_CHECK("step_pt_layer_pack");
+    return STEP_OK;
+}
+
+extern "C" long step_pt_proj_wgrad_ws_floats(long R) {
+    const long ntile = (R + 31) / 32;
+    return (ntile < 256 ? ntile : 256) * PW_WS;
+}
+// d Wi [288, 96] += d qkv^T x, d bi [288] += column sums of d qkv, d Wo [96, 96] += d o^T a; x, d o f32 [R, 96], d qkv bf16 [R, 288], a bf16 [R, 96]
+extern "C" int step_pt_proj_wgrad(const float* x, const uint16_t* dqkv, const float* dov, const uint16_t* a, long R, float* ws, float* dwi, float* dbi,
+                                  float* dwo, void* stream) {
+    STEP_REQUIRE(x && dqkv && dov && a && ws && dwi && dbi && dwo && R > 0 && R < (1L << 36), "pt_proj_wgrad: bad arguments");
+    STEP_REQUIRE((((uintptr_t)x | (uintptr_t)dqkv | (uintptr_t)dov | (uintptr_t)a) & 15) == 0, "pt_proj_wgrad: 16-byte aligned tensors expected");
+    static bool raised = false;
+    STEP_TRY(raise_lds(proj_wgrad_kernel, 2 * PW_TILE, raised));
+    const hipStream_t st = (hipStream_t)stream;
+    const long ntile = (R + 31) / 32;
+    const int grid = (int)(ntile < 256 ? ntile : 256);
+    ProjWgradArgs pa = {x, dqkv, dov, a, R, ws};
+    proj_wgrad_kernel<<<grid, FW_WAVES * 64, 2 * PW_TILE, st>>>(pa);
+    STEP_LAUNCH_CHECK("step_pt_proj_wgrad");
+    ffn_reduce_kernel<<<dim3(cdiv(288 * 96 + 288, 256), 8), 256, 0, st>>>(ws, grid, 288 * 96 + 288, PW_WS, 1.f, dwi, 288 * 96, dbi);
+    ffn_reduce_kernel<<<dim3(cdiv(96 * 96, 256), 8), 256, 0, st>>>(ws + 288 * 96 + 288, grid, 96 * 96, PW_WS, 1.f, dwo, 96 * 96, nullptr);
+    STEP_LAUNCH_CHECK("step_pt_proj_wgrad (reduce)");
     return STEP_OK;
 }

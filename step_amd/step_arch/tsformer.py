@@ -117,8 +117,8 @@ PT_POOL_WORDS = 1 << 18        # keep-mask pool of the fused feed-forward blocks
 
 
 def _ffn_ws(dev, R):
-    """scratch of step_pt_ffn_fused_bwd_weights: the per-workgroup partial gradients (at most 256 x 74 112 floats = 76 MB)"""
-    n = _lib.lib().step_pt_ffn_wgrad_ws_floats(int(R))
+    """scratch of step_pt_ffn_fused_bwd_weights / step_pt_proj_wgrad: the per-workgroup partial gradients (at most 256 x 74 112 floats = 76 MB)"""
+    n = max(_lib.lib().step_pt_ffn_wgrad_ws_floats(int(R)), _lib.lib().step_pt_proj_wgrad_ws_floats(int(R)))
     t = _FFN_WS.get(dev)
     if t is None or t.numel() < n:
         t = _FFN_WS[dev] = torch.empty(n, device=dev, dtype=torch.float32)
@@ -335,10 +335,11 @@ class _PretrainFunction(torch.autograd.Function):
         if sv["qkv"].dtype == torch.bfloat16:
             # bf16 activations (see _layer_fwd): the gradients that are only read as matrix-core operands are stored as bf16 too
             wo, wi = P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.in_proj_weight"]
-            # dWo[j, i] += sum_r do[r, j] a[r, i]  (dbo = colsum(do) came out of the LayerNorm backward above)
-            _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
-            da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
             pj = sv["fz"]["proj"][pre] if sv["fz"] is not None and sv["fz"]["proj"] is not None else None
+            if pj is None:
+                # dWo[j, i] += sum_r do[r, j] a[r, i]  (dbo = colsum(do) came out of the LayerNorm backward above)
+                _lib.gemm(do, sv["a"], G[pre + "self_attn.out_proj.weight"], 96, 96, R, 1, 96, 96, 1, 96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
+            da = torch.empty(R, 96, device=dh2.device, dtype=torch.bfloat16)
             if pj is not None:
                 L.call("step_pt_rows_linear", L.ptr(do), 0, R, L.ptr(pj[2]), 1, 1, L.ptr(da), 1, 0, st)                 # da = do @ Wo
             else:
@@ -346,9 +347,14 @@ class _PretrainFunction(torch.autograd.Function):
             dqkv = torch.empty(R, 288, device=dh2.device, dtype=torch.bfloat16)
             L.call("step_pt_attention_bwd_bf16", L.ptr(sv["qkv"]), L.ptr(sv["a"]), L.ptr(da), L.ptr(sv["stats"]), S, T, p, seed, site, L.ptr(dqkv),
                    L.ptr(sv["keepbits"]), st)
-            # dWi[j, i] += sum_r dqkv[r, j] x[r, i], computed as its transpose (A = x with i contiguous, B = dqkv with j contiguous)
-            _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
-            L.call("step_pt_colsum_bf16", L.ptr(dqkv), R, 288, L.ptr(G[pre + "self_attn.in_proj_bias"]), st)
+            if pj is not None:
+                # dWi += dqkv^T x, dbi += colsum(dqkv), dWo += do^T a: one pass over the four row tensors
+                L.call("step_pt_proj_wgrad", L.ptr(sv["x"]), L.ptr(dqkv), L.ptr(do), L.ptr(sv["a"]), R, L.ptr(_ffn_ws(dh2.device, R)),
+                       L.ptr(G[pre + "self_attn.in_proj_weight"]), L.ptr(G[pre + "self_attn.in_proj_bias"]), L.ptr(G[pre + "self_attn.out_proj.weight"]), st)
+            else:
+                # dWi[j, i] += sum_r dqkv[r, j] x[r, i], computed as its transpose (A = x with i contiguous, B = dqkv with j contiguous)
+                _lib.gemm(sv["x"], dqkv, G[pre + "self_attn.in_proj_weight"], 96, 288, R, 1, 96, 288, 1, 1, scn=96, accumulate=2, splitk=-1, compute_bf16=True, splitk_ws=_splitk_ws(dh2.device))
+                L.call("step_pt_colsum_bf16", L.ptr(dqkv), R, 288, L.ptr(G[pre + "self_attn.in_proj_bias"]), st)
             if pj is not None:
                 L.call("step_pt_rows_linear", L.ptr(dqkv), 1, R, L.ptr(pj[3]), 3, 1, L.ptr(dx), 0, 1, st)               # dx += dqkv @ Wi
             else:

@@ -62,6 +62,10 @@ def main():
         t_o = timed(lambda: L.call("step_pt_rows_linear", L.ptr(ab), 1, R, L.ptr(packs[1]), 1, 1, L.ptr(out), 0, 0, st))
         t_a = timed(lambda: L.call("step_pt_rows_linear", L.ptr(x), 0, R, L.ptr(packs[1]), 1, 1, L.ptr(ab), 1, 0, st))
         t_x = timed(lambda: L.call("step_pt_rows_linear", L.ptr(qkv), 1, R, L.ptr(packs[2]), 3, 1, L.ptr(out), 0, 1, st))
+        wsp = torch.empty(L.lib().step_pt_proj_wgrad_ws_floats(R), device="cuda")
+        gwi, gbi, gwo = torch.zeros(288, 96, device="cuda"), torch.zeros(288, device="cuda"), torch.zeros(96, 96, device="cuda")
+        t_g = timed(lambda: L.call("step_pt_proj_wgrad", L.ptr(x), L.ptr(qkv), L.ptr(df2), L.ptr(ab), R, L.ptr(wsp), L.ptr(gwi), L.ptr(gbi), L.ptr(gwo), st))
+        print(f"{tag} R={R} projection weight gradients (dWi, dbi, dWo + 2 reductions): {t_g:.0f} us ({R * (576 + 384 + 384 + 192) / 1e3 / t_g:.0f} GB/s)", flush=True)
         print(f"{tag} R={R} projections: qkv {t_q:.0f} us ({R * (384 + 576) / 1e3 / t_q:.0f} GB/s; step_pt_linear_bf16out {t_q0:.0f} us), out-projection {t_o:.0f} us, "
               f"da {t_a:.0f} us, dx += {t_x:.0f} us ({R * (576 + 768) / 1e3 / t_x:.0f} GB/s)", flush=True)
         t_p = timed(lambda: L.call("step_pt_ffn_pack", L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(pack), st))
