@@ -314,6 +314,14 @@ int step_pt_layer_pack(const float* wi, const float* bi, const float* wo, const 
 long step_pt_proj_wgrad_ws_floats(long R);
 int step_pt_proj_wgrad(const float* x, const uint16_t* dqkv, const float* dov, const uint16_t* a, long R, float* ws, float* dwi, float* dbi, float* dwo,
                        void* stream);
+/* The forward row kernels with step_pt_add_layernorm_fwd as their output stage (same Philox stream, same results to f32 summation order): the
+ * branch's [R, 96] tile never reaches HBM.
+ *   step_pt_ffn_fused_fwd_ln   pre (nullable) = h1 + dropout(feed-forward(h1)) at site_out, y = LayerNorm(pre), stats [R, 2] = (mean, rstd)
+ *   step_pt_rows_linear_ln     pre = res + dropout(x . M^T + bias), x bf16 [R, 96], pack of form (1, 1): the attention's out-projection */
+int step_pt_ffn_fused_fwd_ln(const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words, uint64_t seed, uint32_t site_hidden,
+                             uint32_t site_out, const float* gamma, const float* beta, float* pre, float* y, float* stats, void* stream);
+int step_pt_rows_linear_ln(const uint16_t* x, long R, const void* pack, const float* res, float p, uint64_t seed, uint32_t site, const float* gamma,
+                           const float* beta, float* pre, float* y, float* stats, void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------- shared pieces
+struct LnEpi {
+    const float* res; float* pre; float* y; float* stats; const float* gamma; const float* beta;
+    float p; uint32_t lo, hi, site;
+};
 struct FfnArgs {
     const float* h1;                 // [R, 96] input of the block (LayerNorm1 output)
     const float* df2;                // [R, 96] gradient of the block's output (backward kernels)
@@ -137,6 +141,7 @@ struct FfnArgs {
     uint32_t pool_mask;
     uint32_t seed, site;
     float* ws;                       // weight-gradient kernels: per-workgroup partial results
+    LnEpi ln;                        // forward with LN = true: the output stage (residual add + dropout + LayerNorm 2)
 };
 
 __device__ __forceinline__ uint32_t ffn_mask_base(uint32_t seed, uint32_t site, long tile32, uint32_t pool_mask) {
@@ -240,9 +245,75 @@ __device__ __forceinline__ void tile_out(float* __restrict__ y, long row0, long 
     }
 }
 
+// Residual add + dropout + LayerNorm as the output stage of a row kernel (what step_pt_add_layernorm_fwd does in a pass of its own, with
+// the same Philox stream: one call per 4 consecutive elements of the [R, 96] tensor): pre = res + dropout(branch), y = LayerNorm(pre),
+// stats = (mean, rstd).  It runs in the row-major domain of tile_out: a lane holds 4 consecutive features of 4 rows per 32-feature block,
+// the 8 lanes of a row are adjacent, so the row statistics are three xor-shuffles; the branch's 32 x 96 tile never reaches HBM.
+__device__ __forceinline__ float sum8(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ void tile_out_ln(const LnEpi& E, long row0, long R, char* ost, int lane, const f32x16 (&acc)[3]) {
+    const int r = lane & 31, h = lane >> 5, cq = lane & 7;
+    const float ks = E.p > 0.f ? 1.f / (1.f - E.p) : 1.f;
+    float4 val[4][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4*)(ost + r * 128 + 16 * ((2 * q + h) ^ (r & 7))) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        lds_order();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int rr = n * 8 + (lane >> 3);
+            const float4 v = *(const float4*)(ost + rr * 128 + 16 * (cq ^ (rr & 7)));
+            const long row = row0 + rr, k = row * 24 + 8 * t + cq;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            float m[4] = {1.f, 1.f, 1.f, 1.f};
+            if (row < R) {
+                a = ((const float4*)E.res)[k];
+                if (E.p > 0.f) {
+                    uint32_t rnd[4];
+                    philox4x32((uint32_t)k, (uint32_t)(k >> 32), E.site, 0xD20Fu, E.lo, E.hi, rnd);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = u32_to_unit(rnd[j]) >= E.p ? ks : 0.f;
+                }
+            }
+            val[n][t] = make_float4(a.x + v.x * m[0], a.y + v.y * m[1], a.z + v.z * m[2], a.w + v.w * m[3]);
+        }
+        lds_order();
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const long row = row0 + n * 8 + (lane >> 3);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) s += (val[n][t].x + val[n][t].y) + (val[n][t].z + val[n][t].w);
+        const float mean = sum8(s) * (1.f / 96.f);
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float dx = val[n][t].x - mean, dy = val[n][t].y - mean, dz = val[n][t].z - mean, dw = val[n][t].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = rsqrtf(sum8(q) * (1.f / 96.f) + 1e-5f);
+        if (row < R) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const long k = row * 24 + 8 * t + cq;
+                const float4 g4 = ((const float4*)E.gamma)[8 * t + cq], b4 = ((const float4*)E.beta)[8 * t + cq], v = val[n][t];
+                if (E.pre) ((float4*)E.pre)[k] = v;
+                ((float4*)E.y)[k] = make_float4((v.x - mean) * rstd * g4.x + b4.x, (v.y - mean) * rstd * g4.y + b4.y, (v.z - mean) * rstd * g4.z + b4.z,
+                                               (v.w - mean) * rstd * g4.w + b4.w);
+            }
+            if (cq == 0) { E.stats[row * 2] = mean; E.stats[row * 2 + 1] = rstd; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward / backward-data
 // One workgroup = NW waves = NW tiles of 32 rows per pass; persistent over passes.  BWD = false: forward, BWD = true: backward-data.
-template <int NW, bool BWD, bool DROP>
+template <int NW, bool BWD, bool DROP, bool LN = false>
 __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int BLOCK = BWD ? FF_BLOCK_B : FF_BLOCK_F;
@@ -377,7 +448,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(acc[t][i], A.inv_keep, b2[t * 16 + i]);
         }
-        tile_out<BWD>(A.out, tile32 * 32, A.R, stg + STG_IN, lane, acc);          // backward-data: added onto the residual branch's gradient already in dh1
+        if constexpr (LN) tile_out_ln(A.ln, tile32 * 32, A.R, stg + STG_IN, lane, acc);
+        else tile_out<BWD>(A.out, tile32 * 32, A.R, stg + STG_IN, lane, acc);     // backward-data: added onto the residual branch's gradient already in dh1
     }
 }
 
@@ -570,6 +642,7 @@ __global__ __launch_bounds__(256) void ffn_reduce_kernel(const float* __restrict
 struct LinArgs {
     const void* x; void* y; long R; int ldx, ldy;        // leading dimensions in elements
     const char* pack;                                     // NOG * 3 * NKC * 6 fragments, then bias [NOG][2][48] f32 (zeros when there is none)
+    LnEpi ln;                                             // LN = true: residual add + dropout + LayerNorm as the output stage
 };
 // M(out, in) = w[out * swo + in * swi]; fragment ((og * 3 + t) * NKC + kc) * 6 + ks: lane (h, r), slot j -> M(96 og + 32 t + r, 96 kc + 32 (ks >> 1) + F(ks & 1, h, j))
 __device__ __forceinline__ void lin_pack_body(int gid, const float* __restrict__ w, long swo, long swi, int NKC, int NOG, const float* __restrict__ bias,
@@ -653,7 +726,7 @@ __device__ __forceinline__ void tile_out_bf16(uint16_t* __restrict__ y, long row
     lds_order();
 }
 
-template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM>
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
 __global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int NW = 8, NFRAG = NOG * 3 * NKC * 6, WBYTES = NFRAG * FF_FRAG + NOG * 96 * 4;
@@ -690,7 +763,8 @@ __global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) acc[t] = mma(mfrag(smem, (og * 3 + t) * 6 + ks, lane), xb[ks], acc[t]);
-                if constexpr (OUT_BF16) tile_out_bf16((uint16_t*)A.y, row0, A.R, A.ldy, og * 96, stg, lane, acc);
+                if constexpr (LN) tile_out_ln(A.ln, row0, A.R, stg + STG_IN, lane, acc);
+                else if constexpr (OUT_BF16) tile_out_bf16((uint16_t*)A.y, row0, A.R, A.ldy, og * 96, stg, lane, acc);
                 else tile_out<ACCUM>((float*)A.y + og * 96, row0, A.R, stg + STG_IN, lane, acc);
             }
         } else {
@@ -862,6 +936,21 @@ int raise_lds(K kernel, int bytes, bool& done) {
     return STEP_OK;
 }
 
+int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
+    static bool raised[2] = {false, false};
+    const int lds = 2 * FF_BLOCK_F + FR_WAVES * STG_WAVE;
+    const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
+    const int grid = (int)(npass < 512 ? npass : 512);
+    if (a.pool) {
+        STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, false, true, true>, lds, raised[1]));
+        ffn_rows_kernel<FR_WAVES, false, true, true><<<grid, FR_WAVES * 64, lds, st>>>(a);
+    } else {
+        STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, false, false, true>, lds, raised[0]));
+        ffn_rows_kernel<FR_WAVES, false, false, true><<<grid, FR_WAVES * 64, lds, st>>>(a);
+    }
+    return STEP_OK;
+}
+
 template <bool BWD>
 int launch_rows(const FfnArgs& a, hipStream_t st) {
     static bool raised[2] = {false, false};
@@ -959,14 +1048,14 @@ extern "C" int step_pt_rows_linear_pack(const float* w, long swo, long swi, int 
 }
 
 namespace {
-template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM>
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
 int launch_lin(const LinArgs& a, hipStream_t st) {
     static bool raised = false;
     const int wbytes = NOG * 3 * NKC * 6 * FF_FRAG + NOG * 96 * 4;
     const int lds = ((wbytes + 1023) & ~1023) + 8 * STG_WAVE;
-    STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM>, lds, raised));
+    STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN>, lds, raised));
     const long ntile = (a.R + 31) / 32, nwg = (ntile + 7) / 8;
-    rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM><<<(int)(nwg < 256 ? nwg : 256), 512, lds, st>>>(a);
+    rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN><<<(int)(nwg < 256 ? nwg : 256), 512, lds, st>>>(a);
     return STEP_OK;
 }
 }  // namespace
@@ -1024,5 +1113,43 @@ extern "C" int step_pt_proj_wgrad(const float* x, const uint16_t* dqkv, const fl
     ffn_reduce_kernel<<<dim3(cdiv(288 * 96 + 288, 256), 8), 256, 0, st>>>(ws, grid, 288 * 96 + 288, PW_WS, 1.f, dwi, 288 * 96, dbi);
     ffn_reduce_kernel<<<dim3(cdiv(96 * 96, 256), 8), 256, 0, st>>>(ws + 288 * 96 + 288, grid, 96 * 96, PW_WS, 1.f, dwo, 96 * 96, nullptr);
     STEP_LAUNCH_CHECK("step_pt_proj_wgrad (reduce)");
+    return STEP_OK;
+}
+
+namespace {
+int make_ln(LnEpi& e, const char* who, const float* res, float* pre, float* y, float* stats, const float* gamma, const float* beta, float p, uint64_t seed,
+            uint32_t site) {
+    STEP_REQUIRE(res && y && stats && gamma && beta, "%s: null LayerNorm argument", who);
+    STEP_REQUIRE((((uintptr_t)res | (uintptr_t)pre | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                 "%s: 16-byte aligned row tensors expected", who);
+    e.res = res; e.pre = pre; e.y = y; e.stats = stats; e.gamma = gamma; e.beta = beta; e.p = p; e.lo = (uint32_t)seed; e.hi = (uint32_t)(seed >> 32); e.site = site;
+    return STEP_OK;
+}
+}  // namespace
+
+// step_pt_ffn_fused_fwd followed by step_pt_add_layernorm_fwd(h1, f2, ..., site_out) without the f2 round trip through HBM:
+// pre [R, 96] (nullable) = h1 + dropout(f2), y = LayerNorm(pre) * gamma + beta, stats [R, 2] = (mean, rstd)
+extern "C" int step_pt_ffn_fused_fwd_ln(const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words, uint64_t seed,
+                                        uint32_t site_hidden, uint32_t site_out, const float* gamma, const float* beta, float* pre, float* y, float* stats,
+                                        void* stream) {
+    STEP_TRY(check_common("pt_ffn_fused_fwd_ln", h1, R, pack, p, pool, pool_words));
+    FfnArgs a = make_args(h1, nullptr, nullptr, R, pack, nullptr, p, pool, pool_words, seed, site_hidden, nullptr);
+    STEP_TRY(make_ln(a.ln, "pt_ffn_fused_fwd_ln", h1, pre, y, stats, gamma, beta, p, seed, site_out));
+    STEP_TRY(launch_rows_ln(a, (hipStream_t)stream));
+    STEP_LAUNCH_CHECK("step_pt_ffn_fused_fwd_ln");
+    return STEP_OK;
+}
+
+// step_pt_rows_linear (bf16 in, one block of 96, f32 out) followed by step_pt_add_layernorm_fwd(res, o, ..., site): the out-projection of the attention
+// with its residual add, dropout and LayerNorm as the output stage
+extern "C" int step_pt_rows_linear_ln(const uint16_t* x, long R, const void* pack, const float* res, float p, uint64_t seed, uint32_t site, const float* gamma,
+                                      const float* beta, float* pre, float* y, float* stats, void* stream) {
+    STEP_REQUIRE(x && pack && R > 0 && R < (1L << 36) && p >= 0.f && p < 1.f, "pt_rows_linear_ln: bad arguments");
+    STEP_REQUIRE((((uintptr_t)x | (uintptr_t)pack) & 15) == 0, "pt_rows_linear_ln: 16-byte aligned tensors expected");
+    LinArgs a;
+    a.x = x; a.y = nullptr; a.R = R; a.ldx = 96; a.ldy = 96; a.pack = (const char*)pack;
+    STEP_TRY(make_ln(a.ln, "pt_rows_linear_ln", res, pre, y, stats, gamma, beta, p, seed, site));
+    STEP_TRY((launch_lin<1, 1, true, false, false, true>(a, (hipStream_t)stream)));
+    STEP_LAUNCH_CHECK("step_pt_rows_linear_ln");
     return STEP_OK;
 }

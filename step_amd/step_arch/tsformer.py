@@ -167,7 +167,7 @@ class _PretrainFunction(torch.autograd.Function):
             # feed-forward blocks without a stored hidden layer (csrc/pretrain_fused.hip): operand fragments of this step's weights per layer,
             # and the step's keep-mask pool
             fz = {"packs": model._ffn_packs(series.device), "pool": None, "words": 0,
-                  "proj": model._proj_packs(series.device) if model.fused_proj else None}
+                  "proj": model._proj_packs(series.device) if model.fused_proj else None, "ln": model.fused_proj and model.fused_ln}
             if p > 0:
                 fz["pool"], fz["words"] = model._pt_pool(series.device, p, seed)
         saved["fz"] = fz
@@ -241,15 +241,21 @@ class _PretrainFunction(torch.autograd.Function):
             qkv = _linear_fwd(x, P_[pre + "self_attn.in_proj_weight"], P_[pre + "self_attn.in_proj_bias"])
             a = _empty(R, 96, like=x)
             L.call("step_pt_attention_fwd", L.ptr(qkv), S, T, p, seed, site, L.ptr(a), L.ptr(stats), st)
-        if mc and pj is not None:
-            o = _empty(R, 96, like=x)
-            L.call("step_pt_rows_linear", L.ptr(a), 1, R, L.ptr(pj[1]), 1, 1, L.ptr(o), 0, 0, st)
-        else:
-            o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
-        # residual add (+ dropout of the branch) and LayerNorm in one pass
         h1pre, h1, st1 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
-        L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]),
-               L.ptr(h1pre), L.ptr(h1), L.ptr(st1), st)
+        fuse_ln = mc and pj is not None and fz["ln"]
+        if fuse_ln:
+            # out-projection with the residual add, dropout and LayerNorm 1 as its output stage
+            L.call("step_pt_rows_linear_ln", L.ptr(a), R, L.ptr(pj[1]), L.ptr(x), p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]),
+                   L.ptr(P_[pre + "norm1.bias"]), L.ptr(h1pre), L.ptr(h1), L.ptr(st1), st)
+        else:
+            if mc and pj is not None:
+                o = _empty(R, 96, like=x)
+                L.call("step_pt_rows_linear", L.ptr(a), 1, R, L.ptr(pj[1]), 1, 1, L.ptr(o), 0, 0, st)
+            else:
+                o = _linear_fwd(a, P_[pre + "self_attn.out_proj.weight"], P_[pre + "self_attn.out_proj.bias"])
+            # residual add (+ dropout of the branch) and LayerNorm in one pass
+            L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, site + 1, L.ptr(P_[pre + "norm1.weight"]), L.ptr(P_[pre + "norm1.bias"]),
+                   L.ptr(h1pre), L.ptr(h1), L.ptr(st1), st)
         f2 = None
         if fz is not None:
             pk = fz["packs"][pre]
@@ -257,8 +263,9 @@ class _PretrainFunction(torch.autograd.Function):
                 L.call("step_pt_ffn_pack", L.ptr(P_[pre + "linear1.weight"]), L.ptr(P_[pre + "linear1.bias"]), L.ptr(P_[pre + "linear2.weight"]),
                        L.ptr(P_[pre + "linear2.bias"]), L.ptr(pk), st)
             f1 = f1d = None
-            f2 = _empty(R, 96, like=x)
-            L.call("step_pt_ffn_fused_fwd", L.ptr(h1), R, L.ptr(pk), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2, L.ptr(f2), st)
+            if not fuse_ln:
+                f2 = _empty(R, 96, like=x)
+                L.call("step_pt_ffn_fused_fwd", L.ptr(h1), R, L.ptr(pk), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2, L.ptr(f2), st)
         elif _BF16:
             # ReLU and dropout in the epilogue of the first linear layer, the hidden layer stored once, as bf16 (the f32 path writes
             # relu(.) and its dropped copy: 2 x 1.3 GB per decoder layer at config C3); same Philox stream as step_pt_dropout
@@ -272,11 +279,16 @@ class _PretrainFunction(torch.autograd.Function):
             if p > 0:
                 f1d = _empty(R, 384, like=x)
                 L.call("step_pt_dropout", L.ptr(f1), L.ptr(f1d), f1.numel(), p, seed, site + 2, st)
-        if f2 is None:
-            f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
         h2pre, h2, st2 = _empty(R, 96, like=x), _empty(R, 96, like=x), _empty(R, 2, like=x)
-        L.call("step_pt_add_layernorm_fwd", L.ptr(h1), L.ptr(f2), R, p, seed, site + 3, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]),
-               L.ptr(h2pre), L.ptr(h2), L.ptr(st2), st)
+        if fuse_ln:
+            # feed-forward block with the residual add, dropout and LayerNorm 2 as its output stage
+            L.call("step_pt_ffn_fused_fwd_ln", L.ptr(h1), R, L.ptr(fz["packs"][pre]), p, L.ptr(fz["pool"]), fz["words"], seed, site + 2, site + 3,
+                   L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]), L.ptr(h2pre), L.ptr(h2), L.ptr(st2), st)
+        else:
+            if f2 is None:
+                f2 = _linear_fwd(f1d, P_[pre + "linear2.weight"], P_[pre + "linear2.bias"])
+            L.call("step_pt_add_layernorm_fwd", L.ptr(h1), L.ptr(f2), R, p, seed, site + 3, L.ptr(P_[pre + "norm2.weight"]), L.ptr(P_[pre + "norm2.bias"]),
+                   L.ptr(h2pre), L.ptr(h2), L.ptr(st2), st)
         return h2, dict(x=x, qkv=qkv, a=a, stats=stats, keepbits=kb, h1pre=h1pre, st1=st1, h1=h1, f1=f1, f1d=f1d, h2pre=h2pre, st2=st2, pre=pre,
                         site=site, T=T, fz=fz)
 
@@ -455,6 +467,7 @@ class TSFormer(nn.Module):
         self.fused_ffn = os.environ.get("STEP_PT_FUSED_FFN", "1") != "0"
         self._ffn_pack_bufs = None
         self.fused_proj = os.environ.get("STEP_PT_FUSED_PROJ", "1") != "0"       # qkv / out-projection and their data gradients as row kernels
+        self.fused_ln = os.environ.get("STEP_PT_FUSED_LN", "1") != "0"           # residual add + dropout + LayerNorm as the output stage of the forward row kernels
         self._proj_pack_bufs = None
         self._pt_pool_buf = None
         self._packed = None

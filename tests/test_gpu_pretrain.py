@@ -564,3 +564,46 @@ def test_projection_weight_gradients_in_one_pass(R):
     errs = [rel_l2(g.double().cpu(), w.cpu()) for g, w in zip((dwi, dbi, dwo), want)]
     print(f"projection weight gradients R={R}: dWi {errs[0]:.2e}, dbi {errs[1]:.2e}, dWo {errs[2]:.2e}")
     assert errs[0] < 6e-3 and errs[1] < 1e-5 and errs[2] < 6e-3
+
+
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_forward_row_kernels_with_layernorm_output_stage(p):
+    """step_pt_rows_linear_ln / step_pt_ffn_fused_fwd_ln against the two-kernel sequences they replace (row kernel, then
+    step_pt_add_layernorm_fwd with the same seed and site): the pre-LayerNorm sum must be IDENTICAL (same branch arithmetic, same Philox
+    stream), LayerNorm output and statistics equal to f32 summation order; R not a multiple of 32."""
+    from step_amd import _lib as L
+    R = 256 * 9 + 21
+    gen = torch.Generator().manual_seed(55)
+    r = lambda *sh: torch.randn(*sh, generator=gen).cuda()
+    x, a = r(R, 96), r(R, 96).bfloat16()
+    wo, bo, w1, b1, w2, b2 = r(96, 96) * 0.15, r(96) * 0.1, r(384, 96) * 0.15, r(384) * 0.1, r(96, 384) * 0.1, r(96) * 0.1
+    g, beta = 1 + 0.1 * r(96), 0.1 * r(96)
+    seed, st = 0x1111_2222_3333, L.stream()
+    words = 1 << 12
+    pool = torch.zeros(words + 16, dtype=torch.int64, device="cuda")
+    if p > 0:
+        L.call("step_dropout_pool_fill", L.ptr(pool), words, p, 99, st)
+    e = lambda *sh: torch.empty(*sh, device="cuda")
+    # out-projection + LayerNorm 1
+    pk = torch.empty(L.lib().step_pt_rows_linear_pack_bytes(1, 1), dtype=torch.uint8, device="cuda")
+    L.call("step_pt_rows_linear_pack", L.ptr(wo), 96, 1, 1, 1, L.ptr(bo), L.ptr(pk), st)
+    o, pre0, y0, st0 = e(R, 96), e(R, 96), e(R, 96), e(R, 2)
+    L.call("step_pt_rows_linear", L.ptr(a), 1, R, L.ptr(pk), 1, 1, L.ptr(o), 0, 0, st)
+    L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(o), R, p, seed, 17, L.ptr(g), L.ptr(beta), L.ptr(pre0), L.ptr(y0), L.ptr(st0), st)
+    pre1, y1, st1 = e(R, 96), e(R, 96), e(R, 2)
+    L.call("step_pt_rows_linear_ln", L.ptr(a), R, L.ptr(pk), L.ptr(x), p, seed, 17, L.ptr(g), L.ptr(beta), L.ptr(pre1), L.ptr(y1), L.ptr(st1), st)
+    # feed-forward + LayerNorm 2
+    fp = torch.empty(L.lib().step_pt_ffn_pack_bytes(), dtype=torch.uint8, device="cuda")
+    L.call("step_pt_ffn_pack", L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(fp), st)
+    f2, pre2, y2, st2 = e(R, 96), e(R, 96), e(R, 96), e(R, 2)
+    L.call("step_pt_ffn_fused_fwd", L.ptr(x), R, L.ptr(fp), p, L.ptr(pool), words, seed, 18, L.ptr(f2), st)
+    L.call("step_pt_add_layernorm_fwd", L.ptr(x), L.ptr(f2), R, p, seed, 19, L.ptr(g), L.ptr(beta), L.ptr(pre2), L.ptr(y2), L.ptr(st2), st)
+    pre3, y3, st3 = e(R, 96), e(R, 96), e(R, 2)
+    L.call("step_pt_ffn_fused_fwd_ln", L.ptr(x), R, L.ptr(fp), p, L.ptr(pool), words, seed, 18, 19, L.ptr(g), L.ptr(beta), L.ptr(pre3), L.ptr(y3), L.ptr(st3), st)
+    torch.cuda.synchronize()
+    assert torch.equal(pre0, pre1) and torch.equal(pre2, pre3)
+    if p > 0:
+        assert 0.05 < float((pre1 == x).float().mean()) < 0.15          # (a dropped element leaves the residual value)
+    errs = {"y1": rel_l2(y1.cpu(), y0.cpu()), "stats1": rel_l2(st1.cpu(), st0.cpu()), "y2": rel_l2(y3.cpu(), y2.cpu()), "stats2": rel_l2(st3.cpu(), st2.cpu())}
+    print(f"row kernels with the LayerNorm output stage p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 2e-6
