@@ -313,6 +313,20 @@ def static_dominant_kernels(name, top=4):
         return None
 
 
+def static_roofline(name):
+    """`roofline` object of a config's heaviest kernel from the committed per-kernel table (static: durations are the rocprofv3 averages of
+    the run named in `source`, bytes / FLOPs analytic); None without a table."""
+    dom = static_dominant_kernels(name, top=1)
+    if not dom or not dom["kernels"]:
+        return None
+    k = dom["kernels"][0]
+    mf = k.get("TFLOPps") is not None and k["bound"] not in ("hbm", "hbm/L2")
+    return {"kernel": k["what"], "bound": "mfma" if mf else "hbm", "kernel_class": k["bound"],
+            "achieved": k["TFLOPps"] if mf else k["GBps"], "peak": PEAK_TFLOPS if mf else 8000.0, "unit": "TFLOP/s" if mf else "GB/s",
+            "frac": k["frac_of_mfma_peak"] if mf else k["frac_of_hbm_peak"], "ms_per_launch": k["avg_us"] / 1e3,
+            "launches_per_step": k["launches_per_step"], "traffic": None, "static": True, "source": dom["source"]}
+
+
 def average_grads(model, params, world):
     """Data-parallel exchange step of the pre-training bench (the job DistributedDataParallel does for easytorch in the reference):
     the native backward leaves every gradient in ONE flat buffer (TSFormer._flat_grad) that autograd adopts as the parameters'
@@ -324,11 +338,11 @@ def average_grads(model, params, world):
     flat = model._flat_grad
     lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
     grads = [p.grad for p in params if p.grad is not None]
+    dist.all_reduce(flat)               # (the flat buffer is also what step_amd.optim.FusedAdamClip consumes)
+    flat.mul_(1.0 / world)
     if all(lo <= g.data_ptr() < hi for g in grads):
-        dist.all_reduce(flat)
-        flat.mul_(1.0 / world)
         return
-    buf = torch.cat([g.reshape(-1) for g in grads])
+    buf = torch.cat([g.reshape(-1) for g in grads])          # autograd cloned: average the clones too (what torch.optim reads)
     dist.all_reduce(buf)
     buf.mul_(1.0 / world)
     off = 0
@@ -384,7 +398,15 @@ def pretrain_run(args, cfg, world, rank, dev, warmup, steps):
     model.train()
     model.matmul_precision = args.matmul
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=0.001, weight_decay=0, eps=1.0e-8, betas=(0.9, 0.95))
+    if args.torch_optim:
+        opt = torch.optim.Adam(params, lr=0.001, weight_decay=0, eps=1.0e-8, betas=(0.9, 0.95))      # step/TSFormer_PEMS-BAY.py:60-66
+    else:
+        # same update rule and the runner's clip (5.0) as one fused pass over the flat parameter / gradient buffers; the loss below is the
+        # same masked MAE on the rescaled values, value and gradient from two launches (the reference's runner makes ~60 element-wise ones)
+        from step_amd.optim import FusedAdamClip
+        from step_amd.step_loss import masked_mae_native
+        model.flatten_parameters()
+        opt = FusedAdamClip(model, lr=0.001, weight_decay=0.0, eps=1.0e-8, betas=(0.9, 0.95), max_norm=5.0)
     dser = torch.from_numpy(data[:, :, :1]).to(dev)
     rng = np.random.default_rng(99 + rank)
     batches = []
@@ -395,10 +417,14 @@ def pretrain_run(args, cfg, world, rank, dev, warmup, steps):
     def step(i):
         opt.zero_grad(set_to_none=True)
         recon, label = model(history_data=batches[i % len(batches)], future_data=None, batch_seen=i, epoch=1)
-        loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+        if args.torch_optim:
+            loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+        else:
+            loss = masked_mae_native(recon.transpose(1, 2), label.transpose(1, 2), 0.0, rescale=(200.0, 150.0))
         loss.backward()
         average_grads(model, params, world)
-        torch.nn.utils.clip_grad_norm_(params, max_norm=5.0)
+        if args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=5.0)
         opt.step()
         return loss
 
@@ -709,7 +735,8 @@ def main():
                               "dtype": "bf16 operands, f32 accumulate" if args.matmul == "bf16" else "f32", "data": "synthetic",
                               "config": {"workload": r["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
                                          "final_loss": r["final_loss"]},
-                              "whole_step": {"tflops": r["whole_step_tflops"], "frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"]}}), flush=True)
+                              "whole_step": {"tflops": r["whole_step_tflops"], "frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"]},
+                              "roofline": static_roofline(args.config), "dominant_kernels": static_dominant_kernels(args.config)}), flush=True)
         if DIST["on"]:
             torch.distributed.destroy_process_group()
         return
@@ -782,6 +809,10 @@ def main():
                     r = pretrain_run(args, c2, world, rank, dev, 5, 15)
                     others[name] = {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": 15,
                                     "whole_step_frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"], "workload": r["workload"]}
+                    others[name]["roofline"] = static_roofline(name)
+                    dom = static_dominant_kernels(name)
+                    if dom is not None:
+                        others[name]["dominant_kernels"] = dom
                     if not args.no_cpu_baseline:
                         others[name]["cpu_baseline"] = cpu_baseline_pretrain(c2, synth_series(c2["T_all"], c2["N"]))
                 else:

@@ -1,4 +1,5 @@
-"""Fused clip_grad_norm_ + Adam for the native STEP module (one pass over flat buffers, libstep_hip).
+"""Fused clip_grad_norm_ + Adam for the native STEP module -- and for `TSFormer(mode="pre-train")` after `flatten_parameters()` -- (one pass over flat
+buffers, libstep_hip).
 
 Drop-in for the pair of torch calls the reference's training loop makes through easytorch
 (``CFG.TRAIN.CLIP_GRAD_PARAM`` + ``CFG.TRAIN.OPTIM``, reference ``step/STEP_PEMS04.py:90-106``): same update
@@ -54,7 +55,7 @@ class FusedAdamClip(torch.optim.Optimizer):
         pg = self.param_groups[0]
         self.step_count += 1
         extra = None
-        sh = self.model.discrete_graph_learning._shard
+        sh = getattr(getattr(self.model, "discrete_graph_learning", None), "_shard", None)      # (a TSFormer in pre-training mode has no graph learner)
         if sh is not None and self.max_norm:
             # the fc weight slices of the other ranks belong to the model's gradient norm: the sum of their squared norms came back
             # in the layout's spare slot with the gradient all-reduce (step.py backward) -- no collective of its own

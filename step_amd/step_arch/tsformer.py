@@ -426,6 +426,7 @@ class _PretrainFunction(torch.autograd.Function):
         patches = sv["series"].view(S * P, 12)
         _linear_bwd(de, patches, None, G["patch_embedding.input_embedding.weight"].view(96, 12), G["patch_embedding.input_embedding.bias"])
         ctx.saved = None
+        model._backward_count += 1
         return (None, None, None, None) + tuple(G[n] for n in model._pt_names)
 
 
@@ -466,6 +467,9 @@ class TSFormer(nn.Module):
         # recomputes it).  STEP_PT_FUSED_FFN=0 keeps the layer-by-layer kernels (A/B measurements)
         self.fused_ffn = os.environ.get("STEP_PT_FUSED_FFN", "1") != "0"
         self._ffn_pack_bufs = None
+        self._flat_param = None             # flatten_parameters(): all parameters as views into one buffer (FusedAdamClip)
+        self._flat_grad = None
+        self._backward_count = 0            # native backwards since zero_grad() (FusedAdamClip consumes exactly one)
         self.fused_proj = os.environ.get("STEP_PT_FUSED_PROJ", "1") != "0"       # qkv / out-projection and their data gradients as row kernels
         self.fused_ln = os.environ.get("STEP_PT_FUSED_LN", "1") != "0"           # residual add + dropout + LayerNorm as the output stage of the forward row kernels
         self._proj_pack_bufs = None
@@ -583,6 +587,29 @@ class TSFormer(nn.Module):
     def _pt_params(self):
         d = dict(self.named_parameters())
         return [d[n] for n in self._pt_names]
+
+    def flatten_parameters(self):
+        """Re-home every parameter as a view into ONE flat f32 buffer with the layout of the native backward's gradient buffer
+        (`_pt_grad_buffers`: parameters in `_pt_names` order, each starting at a multiple of 4 floats), so that clip + Adam are one
+        fused pass over (parameters, gradients, moments) -- `step_amd.optim.FusedAdamClip(tsformer, ...)`.  Values and `state_dict` are
+        unchanged; call it after `.to(device)` and before building the optimizer."""
+        prm = self._pt_params()
+        total = sum((p.numel() + 3) & ~3 for p in prm)
+        flat = torch.zeros(total, device=prm[0].device, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in prm:
+                v = flat[off:off + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                off += (p.numel() + 3) & ~3
+        self._flat_param = flat
+        self._plist = None
+        return flat
+
+    def zero_grad(self, set_to_none=True):
+        self._backward_count = 0
+        super().zero_grad(set_to_none=set_to_none)
 
     def _pt_grad_buffers(self):
         prm = self._pt_params()

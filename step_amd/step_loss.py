@@ -97,3 +97,18 @@ def step_loss(prediction, real_value, theta, priori_adj, gsl_coefficient, null_v
     loss_graph = torch.nn.functional.binary_cross_entropy(t, y)
     loss_pred = masked_mae(prediction, real_value, null_val)
     return loss_pred + loss_graph * gsl_coefficient
+
+
+_DUMMY = {}
+
+
+def masked_mae_native(preds, labels, null_val=0.0, rescale=None):
+    """``masked_mae(preds * std + mean, labels * std + mean, null_val)`` (basicts/metrics/mae.py:5-28 behind the runner's inverse scaling,
+    base_tsf_runner.py:240-250) with value and gradient from the two launches of ``step_loss_native`` -- the TSFormer pre-training loss
+    (step/TSFormer_*.py: ``CFG.TRAIN.LOSS = masked_mae``).  Element order does not matter to a mean: pass the tensors in whatever
+    contiguous layout they have (the pre-training module's outputs are transposed views of contiguous tensors: ``recon.transpose(1, 2)``)."""
+    dev = preds.device
+    d = _DUMMY.get(dev)
+    if d is None:      # the graph term of step_loss with coefficient 0: one edge with theta = prior = 1/2
+        d = _DUMMY[dev] = (torch.full((1, 1, 1), 0.5, device=dev), torch.full((1, 1, 1), 0.5, device=dev))
+    return step_loss_native(preds, labels, d[0], d[1], 0.0, null_val=null_val, rescale=rescale)

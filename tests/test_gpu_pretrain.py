@@ -607,3 +607,49 @@ def test_forward_row_kernels_with_layernorm_output_stage(p):
     errs = {"y1": rel_l2(y1.cpu(), y0.cpu()), "stats1": rel_l2(st1.cpu(), st0.cpu()), "y2": rel_l2(y3.cpu(), y2.cpu()), "stats2": rel_l2(st3.cpu(), st2.cpu())}
     print(f"row kernels with the LayerNorm output stage p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
     assert max(errs.values()) < 2e-6
+
+
+def test_pretrain_fused_optimizer_and_native_loss_match_the_torch_loop():
+    """The caller-side pieces of the pre-training loop in their native form -- `masked_mae_native` on the rescaled values and
+    `TSFormer.flatten_parameters()` + `FusedAdamClip(max_norm=5)` -- against the reference loop's torch calls (`masked_mae`,
+    `clip_grad_norm_`, `torch.optim.Adam`, step/TSFormer_PEMS-BAY.py:52-76): three steps from the same weights, dropout off; loss values
+    equal, parameters equal to f32 rounding of the two update orders; `state_dict` keys and shapes unchanged by the flattening."""
+    from step_amd.optim import FusedAdamClip
+    from step_amd.step_loss import masked_mae, masked_mae_native
+    g = load_golden("tsformer_pretrain_tiny")
+    x = g["in.x"].cuda()
+    um, mk = g["in.unmasked"].tolist(), g["in.masked"].tolist()
+    models = []
+    for fused in (False, True):
+        m = _model(g, x.shape[1])
+        m.train()
+        m.dropout_p = 0.0
+        m.mask.forward = lambda: (um, mk)
+        keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        if fused:
+            m.flatten_parameters()
+            assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == keys
+            opt = FusedAdamClip(m, lr=1e-3, weight_decay=0.0, eps=1e-8, betas=(0.9, 0.95), max_norm=5.0)
+        else:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0, eps=1e-8, betas=(0.9, 0.95))
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            recon, label = m(history_data=x, future_data=None, batch_seen=0, epoch=1)
+            if fused:
+                loss = masked_mae_native(recon.transpose(1, 2), label.transpose(1, 2), 0.0, rescale=(200.0, 150.0))
+            else:
+                loss = masked_mae(recon * 150.0 + 200.0, label * 150.0 + 200.0, 0.0)
+            loss.backward()
+            if not fused:
+                torch.nn.utils.clip_grad_norm_(list(m.parameters()), max_norm=5.0)
+            opt.step()
+            losses.append(float(loss))
+        models.append((m, losses))
+    torch.cuda.synchronize()
+    (m0, l0), (m1, l1) = models
+    assert l1 == pytest.approx(l0, rel=2e-5)
+    assert l0[2] < l0[0]
+    worst = max(rel_l2(p1.detach().cpu(), p0.detach().cpu()) for (_, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()))
+    print("pre-training loop, fused optimizer + native loss vs torch: losses", l1, "worst parameter rel-L2", worst)
+    assert worst < 2e-5

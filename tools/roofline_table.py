@@ -65,17 +65,16 @@ def rows_of_pretrain(N, B, P, Pu=None):
         ("attn_mfma_bwd_kernel", "attention backward on the matrix cores (dQ, dK, dV; scores recomputed in both orientations)", "valu/lds",
          lay * (2 * 3 * b16 + 2 * b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(5)),
         ("ln_bwd_drop_kernel", "LayerNorm backward + dropout of the continuing gradient + parameter / bias gradient sums", "hbm", ln * 4 * f32 * (10.0 / 12) + ln * 3 * f32 * (2.0 / 12), None),
-        ("add_ln_fwd_kernel", "residual add + dropout + LayerNorm forward", "hbm", ln * 4 * f32 * (10.0 / 12) + ln * 2 * f32 * (2.0 / 12), None),
-        ("gemm_fast_kernelILi128ELi128ELi2ELi3ELb0", "weight gradients of the out-projection and of the qkv projection (split-K GEMMs, K = rows)", "hbm", lay * (f32 + b16 + f32 + 3 * b16) / 2, lay * 2.0 * 96 * (96 + 288) / 2),
+        ("add_ln_fwd_kernel", "LayerNorm forward of the two final norms (the layers' residual + dropout + LayerNorm steps are output stages of row kernels)", "hbm", (Re + Rd) / 2.0 * 2 * f32, None),
         ("ffn_rows_kernelILi8ELb1", "fused feed-forward, input gradient (hidden layer recomputed; reads h1, d f2, read-modify-writes d h1)", "hbm", lay * 4 * f32, lay * 3 * 2.0 * 96 * 384),
         ("attn_mfma_fwd_kernel", "attention forward on the matrix cores", "valu/lds", lay * (3 * b16 + b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(2)),
         ("ffn_wgrad_kernelILb1", "fused feed-forward, d W1 and d b1 (hidden layer and its gradient recomputed)", "lds", lay * 2 * f32, lay * 3 * 2.0 * 96 * 384),
-        ("ffn_rows_kernelILi8ELb0", "fused feed-forward, forward (hidden layer in registers)", "hbm", lay * 2 * f32, lay * 2 * 2.0 * 96 * 384),
+        ("ffn_rows_kernelILi8ELb0", "fused feed-forward, forward (hidden layer in registers) + residual + dropout + LayerNorm 2 as its output stage", "hbm", lay * 3 * f32, lay * 2 * 2.0 * 96 * 384),
         ("rows_linear_kernelILi3ELi1ELb1ELb0ELb1", "d x += d qkv . Wi (row kernel, LDS-resident weights)", "hbm", lay * (3 * b16 + 2 * f32), lay * 2.0 * 96 * 288),
         ("ffn_wgrad_kernelILb0", "fused feed-forward, d W2 (hidden layer recomputed)", "lds", lay * 2 * f32, lay * 2 * 2.0 * 96 * 384),
         ("rows_linear_kernelILi1ELi3ELb0ELb1ELb0", "qkv = x . Wi^T + bi (row kernel, LDS-resident weights)", "hbm", lay * (f32 + 3 * b16), lay * 2.0 * 96 * 288),
-        ("colsum_bf16_kernel", "bias gradient of the qkv projection (column sums of d qkv)", "hbm", lay * 3 * b16, None),
-        ("rows_linear_kernelILi1ELi1ELb1ELb0ELb0", "o = a . Wo^T + bo (row kernel)", "hbm", lay * (b16 + f32), lay * 2.0 * 96 * 96),
+        ("rows_linear_kernelILi1ELi1ELb1ELb0ELb0", "o = a . Wo^T + bo (row kernel) + residual + dropout + LayerNorm 1 as its output stage", "hbm", lay * (b16 + 3 * f32), lay * 2.0 * 96 * 96),
+        ("proj_wgrad_kernel", "d Wi, d bi, d Wo in one pass over x, d qkv, d o, a", "lds", lay * (f32 + 3 * b16 + f32 + b16), lay * 2.0 * 96 * (288 + 96)),
         ("rows_linear_kernelILi1ELi1ELb0ELb1ELb0", "d a = d o . Wo (row kernel)", "hbm", lay * (f32 + b16), lay * 2.0 * 96 * 96),
     ]
 
