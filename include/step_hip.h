@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear, step_pt_proj_wgrad, step_pt_embed_unmasked_*; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -322,6 +322,13 @@ int step_pt_ffn_fused_fwd_ln(const float* h1, long R, const void* pack, float p,
                              uint32_t site_out, const float* gamma, const float* beta, float* pre, float* y, float* stats, void* stream);
 int step_pt_rows_linear_ln(const uint16_t* x, long R, const void* pack, const float* res, float p, uint64_t seed, uint32_t site, const float* gamma,
                            const float* beta, float* pre, float* y, float* stats, void* stream);
+/* Encoder input of the pre-training step for the unmasked tokens only (tsformer.py:88-104; the masked tokens' embeddings are dead):
+ * x [S, Pu, 96] = sqrt(96) * dropout(w . patch(s, um[t]) + b + pos[um[t]]), w [96, 12] the patch embedding, um [Pu] int32 on the device;
+ * the backward turns d x into the three parameter gradients (accumulated): dpos [*, 96] rows um[t], dw [96, 12], db [96]. */
+int step_pt_embed_unmasked_fwd(const float* series, const int* um, const float* w, const float* b, const float* pos, long S, int L, int Pu, float p,
+                               uint64_t seed, uint32_t site, float* x, void* stream);
+int step_pt_embed_unmasked_bwd(const float* dx, const float* series, const int* um, long S, int L, int Pu, float p, uint64_t seed, uint32_t site,
+                               float* dpos, float* dw, float* db, void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

@@ -899,6 +899,94 @@ __global__ __launch_bounds__(FW_WAVES * 64) void proj_wgrad_kernel(ProjWgradArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- patch embedding of the unmasked tokens
+// Encoder input of the pre-training step (tsformer.py:88-104: patch embedding -> positional encoding (+ dropout) -> keep the unmasked
+// tokens -> * sqrt(d), transformer_layers.py:15).  The masked tokens' embeddings are dead -- the decoder puts mask_token + position there --
+// so only the Pu = P / 4 unmasked tokens are computed: x[s][t] = sqrt(96) * dropout(W_pe . patch(s, um[t]) + b_pe + pos[um[t]]), and the backward
+// produces the three parameter gradients from d x alone.  (The layer-by-layer path embeds all P tokens, adds / drops / gathers in four passes over
+// [S, P, 96] and scatters back into a zeroed [S, P, 96] in the backward: 0.9 ms per step at config C3.)
+// One thread = 4 consecutive features of one token = one Philox call of the step_pt_dropout stream over the [S, Pu, 96] tensor.
+__device__ __forceinline__ void embed_keep4(uint32_t lo, uint32_t hi, uint32_t site, long i4, float p, float* m) {
+    uint32_t r[4];
+    philox4x32((uint32_t)i4, (uint32_t)(i4 >> 32), site, 0xD20Fu, lo, hi, r);
+    const float ks = 1.f / (1.f - p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = u32_to_unit(r[j]) >= p ? ks : 0.f;
+}
+__global__ __launch_bounds__(256) void embed_unmasked_fwd_kernel(const float* __restrict__ series, const int* __restrict__ um, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, const float* __restrict__ pos, long S, int L, int Pu,
+                                                                  float scale, float p, uint32_t lo, uint32_t hi, uint32_t site, float* __restrict__ x) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= S * Pu * 24) return;
+    const int f4 = (int)(i4 % 24);
+    const long st = i4 / 24;
+    const int t = (int)(st % Pu);
+    const long s = st / Pu;
+    const int tok = um[t];
+    const float4* pp = (const float4*)(series + s * L + (long)tok * 12);
+    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    const float pv[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    const float4 b4 = ((const float4*)b)[f4], e4 = ((const float4*)pos)[(long)tok * 24 + f4];
+    float v[4] = {b4.x + e4.x, b4.y + e4.y, b4.z + e4.z, b4.w + e4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4* wr = (const float4*)(w + (4 * f4 + j) * 12);
+        const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2];
+        const float wv[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a = __builtin_fmaf(wv[k], pv[k], a);
+        v[j] += a;
+    }
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p > 0.f) embed_keep4(lo, hi, site, i4, p, m);
+    ((float4*)x)[i4] = make_float4(v[0] * m[0] * scale, v[1] * m[1] * scale, v[2] * m[2] * scale, v[3] * m[3] * scale);
+}
+// block (t, c): token position t, sequences c, c + gridDim.y, ...; thread = (4 features f4, one of 16 sequence lanes)
+__global__ __launch_bounds__(384) void embed_unmasked_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ series, const int* __restrict__ um,
+                                                                  long S, int L, int Pu, float scale, float p, uint32_t lo, uint32_t hi, uint32_t site,
+                                                                  float* __restrict__ dpos, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[24 * 52];
+    const int t = blockIdx.x, f4 = threadIdx.x % 24, part = threadIdx.x / 24;
+    const int tok = um[t];
+    for (int i = threadIdx.x; i < 24 * 52; i += 384) red[i] = 0.f;
+    __syncthreads();
+    float aw[4][12], ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) aw[j][k] = 0.f;
+    for (long s = (long)blockIdx.y * 16 + part; s < S; s += (long)gridDim.y * 16) {
+        const long i4 = (s * Pu + t) * 24 + f4;
+        const float4 g4 = ((const float4*)dx)[i4];
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) embed_keep4(lo, hi, site, i4, p, m);
+        const float g[4] = {g4.x * m[0] * scale, g4.y * m[1] * scale, g4.z * m[2] * scale, g4.w * m[3] * scale};
+        const float4* pp = (const float4*)(series + s * L + (long)tok * 12);
+        const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+        const float pv[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ab[j] += g[j];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) aw[j][k] = __builtin_fmaf(g[j], pv[k], aw[j][k]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        atomicAdd(&red[f4 * 52 + j * 13 + 12], ab[j]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) atomicAdd(&red[f4 * 52 + j * 13 + k], aw[j][k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 24 * 52; i += 384) {
+        const int f = (i / 52) * 4 + (i % 52) / 13, k = i % 13;
+        const float v = red[i];
+        if (k < 12) atomicAdd(&dw[f * 12 + k], v);
+        else { atomicAdd(&db[f], v); atomicAdd(&dpos[(long)tok * 96 + f], v); }
+    }
+}
+
 int check_common(const char* who, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words) {
     STEP_REQUIRE(h1 && pack, "%s: null input", who);
     STEP_REQUIRE(R > 0 && R < (1L << 36), "%s: bad row count %ld", who, R);
@@ -1151,5 +1239,29 @@ extern "C" int step_pt_rows_linear_ln(const uint16_t* x, long R, const void* pac
     STEP_TRY(make_ln(a.ln, "pt_rows_linear_ln", res, pre, y, stats, gamma, beta, p, seed, site));
     STEP_TRY((launch_lin<1, 1, true, false, false, true>(a, (hipStream_t)stream)));
     STEP_LAUNCH_CHECK("step_pt_rows_linear_ln");
+    return STEP_OK;
+}
+
+// x [S, Pu, 96] = sqrt(96) * dropout(patch embedding + positional embedding) of the unmasked tokens um [Pu] (int32, device) of series [S, L] (L a multiple of 12)
+extern "C" int step_pt_embed_unmasked_fwd(const float* series, const int* um, const float* w, const float* b, const float* pos, long S, int L, int Pu, float p,
+                                          uint64_t seed, uint32_t site, float* x, void* stream) {
+    STEP_REQUIRE(series && um && w && b && pos && x && S > 0 && L > 0 && L % 12 == 0 && Pu > 0 && Pu <= L / 12 && p >= 0.f && p < 1.f,
+                 "pt_embed_unmasked_fwd: bad arguments");
+    STEP_REQUIRE((((uintptr_t)series | (uintptr_t)w | (uintptr_t)b | (uintptr_t)pos | (uintptr_t)x) & 15) == 0, "pt_embed_unmasked_fwd: 16-byte aligned tensors expected");
+    embed_unmasked_fwd_kernel<<<cdiv(S * Pu * 24, 256), 256, 0, (hipStream_t)stream>>>(series, um, w, b, pos, S, L, Pu, 9.797958971132712f, p, (uint32_t)seed,
+                                                                                      (uint32_t)(seed >> 32), site, x);
+    STEP_LAUNCH_CHECK("step_pt_embed_unmasked_fwd");
+    return STEP_OK;
+}
+// from d x [S, Pu, 96]: dpos[um[t]] += sum_s g, dw [96, 12] += sum g patch^T, db [96] += sum g with g = sqrt(96) * keep * d x (same seed / site as the forward)
+extern "C" int step_pt_embed_unmasked_bwd(const float* dx, const float* series, const int* um, long S, int L, int Pu, float p, uint64_t seed, uint32_t site,
+                                          float* dpos, float* dw, float* db, void* stream) {
+    STEP_REQUIRE(dx && series && um && dpos && dw && db && S > 0 && L > 0 && L % 12 == 0 && Pu > 0 && Pu <= L / 12 && p >= 0.f && p < 1.f,
+                 "pt_embed_unmasked_bwd: bad arguments");
+    STEP_REQUIRE((((uintptr_t)series | (uintptr_t)dx) & 15) == 0, "pt_embed_unmasked_bwd: 16-byte aligned tensors expected");
+    const int ny = (int)(S >= 16 * 16 ? 16 : (S + 15) / 16);
+    embed_unmasked_bwd_kernel<<<dim3(Pu, ny), 384, 0, (hipStream_t)stream>>>(dx, series, um, S, L, Pu, 9.797958971132712f, p, (uint32_t)seed, (uint32_t)(seed >> 32),
+                                                                            site, dpos, dw, db);
+    STEP_LAUNCH_CHECK("step_pt_embed_unmasked_bwd");
     return STEP_OK;
 }

@@ -173,14 +173,20 @@ class _PretrainFunction(torch.autograd.Function):
         saved["fz"] = fz
         pos = P_["positional_encoding.position_embedding"]
         # patch embedding + positional embedding (+dropout), gather the unmasked tokens, scale by sqrt(d)
-        patches = series.view(S * P, 12)
-        e0 = _linear_fwd(patches, P_["patch_embedding.input_embedding.weight"].view(96, 12), P_["patch_embedding.input_embedding.bias"])
-        L.call("step_pt_add_rows", L.ptr(e0), S, P, L.ptr(pos), None, st)
-        if p > 0:
-            L.call("step_pt_dropout", L.ptr(e0), L.ptr(e0), e0.numel(), p, seed, 100, st)
         x = _empty(S * Pu, 96, like=series)
-        L.call("step_pt_token_gather", L.ptr(e0), S, P, L.ptr(um), Pu, SQRT_D, L.ptr(x), st)
-        del e0
+        saved["embed_unmasked"] = model.fused_embed
+        if model.fused_embed:
+            # only the unmasked tokens are embedded (the others' embeddings are dead: the decoder puts mask_token + position there)
+            L.call("step_pt_embed_unmasked_fwd", L.ptr(series), L.ptr(um), L.ptr(P_["patch_embedding.input_embedding.weight"]),
+                   L.ptr(P_["patch_embedding.input_embedding.bias"]), L.ptr(pos), S, Lh, Pu, p, seed, 100, L.ptr(x), st)
+        else:
+            patches = series.view(S * P, 12)
+            e0 = _linear_fwd(patches, P_["patch_embedding.input_embedding.weight"].view(96, 12), P_["patch_embedding.input_embedding.bias"])
+            L.call("step_pt_add_rows", L.ptr(e0), S, P, L.ptr(pos), None, st)
+            if p > 0:
+                L.call("step_pt_dropout", L.ptr(e0), L.ptr(e0), e0.numel(), p, seed, 100, st)
+            L.call("step_pt_token_gather", L.ptr(e0), S, P, L.ptr(um), Pu, SQRT_D, L.ptr(x), st)
+            del e0
         layers = []
         for l in range(model.encoder_depth):
             x, sv = _PretrainFunction._layer_fwd(x, S, Pu, P_, f"encoder.transformer_encoder.layers.{l}.", p, seed, 16 * l, fz)
@@ -417,6 +423,13 @@ class _PretrainFunction(torch.autograd.Function):
                None, 0.0, 0, 0, L.ptr(G["encoder_norm.weight"]), L.ptr(G["encoder_norm.bias"]), None, st)
         for lsv in reversed(sv["layers"]):
             dx = _PretrainFunction._layer_bwd(dx, lsv, S, P_, G, p, seed)
+        if sv["embed_unmasked"]:
+            L.call("step_pt_embed_unmasked_bwd", L.ptr(dx), L.ptr(sv["series"]), L.ptr(sv["um"]), S, P * 12, Pu, p, seed, 100,
+                   L.ptr(G["positional_encoding.position_embedding"]), L.ptr(G["patch_embedding.input_embedding.weight"]),
+                   L.ptr(G["patch_embedding.input_embedding.bias"]), st)
+            ctx.saved = None
+            model._backward_count += 1
+            return (None, None, None, None) + tuple(G[n] for n in model._pt_names)
         # scatter back to all token positions (zeros at masked ones), dropout, positional and patch embedding
         de = torch.zeros(S * P, 96, device=dev)
         L.call("step_pt_token_scatter", L.ptr(dx), S, P, L.ptr(sv["um"]), Pu, SQRT_D, L.ptr(de), st)
@@ -470,6 +483,7 @@ class TSFormer(nn.Module):
         self._flat_param = None             # flatten_parameters(): all parameters as views into one buffer (FusedAdamClip)
         self._flat_grad = None
         self._backward_count = 0            # native backwards since zero_grad() (FusedAdamClip consumes exactly one)
+        self.fused_embed = os.environ.get("STEP_PT_FUSED_EMBED", "1") != "0"     # patch + positional embedding of the unmasked tokens only (both precisions)
         self.fused_proj = os.environ.get("STEP_PT_FUSED_PROJ", "1") != "0"       # qkv / out-projection and their data gradients as row kernels
         self.fused_ln = os.environ.get("STEP_PT_FUSED_LN", "1") != "0"           # residual add + dropout + LayerNorm as the output stage of the forward row kernels
         self._proj_pack_bufs = None
