@@ -27,6 +27,7 @@
 // Forward and backward-data read them as lane masks (scalar loads); the weight-gradient kernels, where the lane is the hidden
 // unit, load the one word that holds their unit and test the row's bit.
 #include "common.h"
+#include <stdlib.h>
 #include "step_internal.h"
 #include "tsformer_device.h"
 
@@ -313,7 +314,12 @@ __device__ __forceinline__ void tile_out_ln(const LnEpi& E, long row0, long R, c
 
 // ---------------------------------------------------------------------------------------------------------------- forward / backward-data
 // One workgroup = NW waves = NW tiles of 32 rows per pass; persistent over passes.  BWD = false: forward, BWD = true: backward-data.
-template <int NW, bool BWD, bool DROP, bool LN = false>
+// FLAGS (experiment, STEP_FFN_RING_FLAGS=1): the weight ring without workgroup barriers.  Every wave is producer (of its DMA pieces) and
+// consumer of every stage block; instead of s_barrier it (a) adds its piece count to the slot's `arrived` counter once its pieces have
+// landed and waits until the counter shows all 25 / 37 pieces of the block it is about to read, (b) adds 1 to the slot's `done` counter when
+// it has read a block, and refills a slot only when all NW waves are done with the block that was in it.  With NSLOT = 3 the waves may
+// drift up to two stages apart, so one wave's tile loads and stores run under the others' matrix work.
+template <int NW, bool BWD, bool DROP, bool LN = false, int NSLOT = 2, bool FLAGS = false>
 __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int BLOCK = BWD ? FF_BLOCK_B : FF_BLOCK_F;
@@ -330,19 +336,44 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
     const char* W = A.pack + (BWD ? FF_OFF_B : 0);
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(smem));
     const mask_ptr pool = (mask_ptr)(uintptr_t)A.pool;
-    char* stg = smem + 2 * BLOCK + wave * STG_WAVE;     // this wave's staging area (tile_in / tile_out)
+    uint32_t* flag = (uint32_t*)(smem + NSLOT * BLOCK);                      // FLAGS: arrived[NSLOT], done[NSLOT]
+    char* stg = smem + NSLOT * BLOCK + (FLAGS ? 64 : 0) + wave * STG_WAVE;    // this wave's staging area (tile_in / tile_out)
+    if constexpr (FLAGS) {
+        if (threadIdx.x < 2 * NSLOT) flag[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const uint32_t my_pieces = (uint32_t)((NPIECE - wave + NW - 1) / NW);
 
-    auto issue_fill = [&](int g) {                      // stage g reads block g mod 6 into ring slot g mod 2
+    auto issue_fill = [&](int g) {                      // stage g reads block g mod 6 into ring slot g mod NSLOT
+        if constexpr (FLAGS) {                          // ... once every wave has read the block that was there
+            const uint32_t need = (uint32_t)NW * (uint32_t)(g / NSLOT);
+            while (__atomic_load_n(&flag[NSLOT + g % NSLOT], __ATOMIC_RELAXED) < need) __builtin_amdgcn_s_sleep(1);
+        }
         const char* src = W + (long)(g % 6) * BLOCK + lane * 16;
-        const uint32_t dst = ring_addr + (uint32_t)(g & 1) * BLOCK;
+        const uint32_t dst = ring_addr + (uint32_t)(g % NSLOT) * BLOCK;
         for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * FF_FRAG, dst + (uint32_t)pc * FF_FRAG);
     };
-    int issued = 1;
+    int issued = 1, signaled = 0;
     auto stage_begin = [&](int g) -> const char* {      // see tsformer_encoder.hip: my pieces landed, everybody's did, slot of g - 1 is free
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int upto = g + 1 < nstage ? g + 1 : nstage - 1;
+        if constexpr (FLAGS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my pieces of every block requested so far have landed
+            for (; signaled < issued; ++signaled)
+                if (lane == 0) atomicAdd(&flag[signaled % NSLOT], my_pieces);
+            const uint32_t want = (uint32_t)NPIECE * (uint32_t)(g / NSLOT + 1);
+            while (__atomic_load_n(&flag[g % NSLOT], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const int upto = g + NSLOT - 1 < nstage ? g + NSLOT - 1 : nstage - 1;
         for (; issued <= upto; ++issued) issue_fill(issued);
-        return smem + (g & 1) * BLOCK;
+        return smem + (g % NSLOT) * BLOCK;
+    };
+    auto stage_end = [&](int g) {                       // FLAGS: this wave has read block g
+        if constexpr (FLAGS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&flag[NSLOT + g % NSLOT], 1u);
+        }
     };
     issue_fill(0);
 
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
                     }
                 }
             }
-            if (jb < 5) load_masks(jb + 1);
+            if (jb < 5) { load_masks(jb + 1); stage_end(g); }
         }
         if constexpr (!BWD) {
             const float* b2 = (const float*)(blk + TAILOFF) + 64 + h * 48;
@@ -448,6 +479,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(acc[t][i], A.inv_keep, b2[t * 16 + i]);
         }
+        stage_end(g - 1);                               // (the last block of the pass: b2 rides in its tail)
         if constexpr (LN) tile_out_ln(A.ln, tile32 * 32, A.R, stg + STG_IN, lane, acc);
         else tile_out<BWD>(A.out, tile32 * 32, A.R, stg + STG_IN, lane, acc);     // backward-data: added onto the residual branch's gradient already in dh1
     }
@@ -1024,11 +1056,27 @@ int raise_lds(K kernel, int bytes, bool& done) {
     return STEP_OK;
 }
 
+bool ring_flags() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("STEP_FFN_RING_FLAGS"); on = e && e[0] == '1'; }
+    return on == 1;
+}
 int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
-    static bool raised[2] = {false, false};
-    const int lds = 2 * FF_BLOCK_F + FR_WAVES * STG_WAVE;
+    static bool raised[4] = {false, false, false, false};
     const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
     const int grid = (int)(npass < 512 ? npass : 512);
+    if (ring_flags()) {
+        const int lds3 = 3 * FF_BLOCK_F + 64 + FR_WAVES * STG_WAVE;
+        if (a.pool) {
+            STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, false, true, true, 3, true>, lds3, raised[3]));
+            ffn_rows_kernel<FR_WAVES, false, true, true, 3, true><<<grid, FR_WAVES * 64, lds3, st>>>(a);
+        } else {
+            STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, false, false, true, 3, true>, lds3, raised[2]));
+            ffn_rows_kernel<FR_WAVES, false, false, true, 3, true><<<grid, FR_WAVES * 64, lds3, st>>>(a);
+        }
+        return STEP_OK;
+    }
+    const int lds = 2 * FF_BLOCK_F + FR_WAVES * STG_WAVE;
     if (a.pool) {
         STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, false, true, true>, lds, raised[1]));
         ffn_rows_kernel<FR_WAVES, false, true, true><<<grid, FR_WAVES * 64, lds, st>>>(a);
@@ -1041,10 +1089,22 @@ int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
 
 template <bool BWD>
 int launch_rows(const FfnArgs& a, hipStream_t st) {
-    static bool raised[2] = {false, false};
+    static bool raised[4] = {false, false, false, false};
     const int lds = 2 * (BWD ? FF_BLOCK_B : FF_BLOCK_F) + FR_WAVES * STG_WAVE;
     const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
     const int grid = (int)(npass < 512 ? npass : 512);
+    if (ring_flags()) {                                 // forward: three slots; backward-data (37 KB blocks): two slots, waves at most one stage apart
+        constexpr int NS = BWD ? 2 : 3;
+        const int ldsf = NS * (BWD ? FF_BLOCK_B : FF_BLOCK_F) + 64 + FR_WAVES * STG_WAVE;
+        if (a.pool) {
+            STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, BWD, true, false, NS, true>, ldsf, raised[3]));
+            ffn_rows_kernel<FR_WAVES, BWD, true, false, NS, true><<<grid, FR_WAVES * 64, ldsf, st>>>(a);
+        } else {
+            STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, BWD, false, false, NS, true>, ldsf, raised[2]));
+            ffn_rows_kernel<FR_WAVES, BWD, false, false, NS, true><<<grid, FR_WAVES * 64, ldsf, st>>>(a);
+        }
+        return STEP_OK;
+    }
     if (a.pool) {
         STEP_TRY(raise_lds(ffn_rows_kernel<FR_WAVES, BWD, true>, lds, raised[1]));
         ffn_rows_kernel<FR_WAVES, BWD, true><<<grid, FR_WAVES * 64, lds, st>>>(a);
