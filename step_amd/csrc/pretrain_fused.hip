@@ -33,7 +33,8 @@
 
 #ifndef FF_ABLATE
 #define FF_ABLATE 0       // timing experiments only (WRONG results): 1 no matrix-core chains in the row kernels, 2 no global loads of the row tiles, 4 no stores,
-                          // 8 no global loads in the weight-gradient kernels' staging, 16 no matrix-core work there
+                          // 8 no global loads in the weight-gradient kernels' staging, 16 no matrix-core work there,
+                          // 32 no weight-fragment DMA in the row kernels (the ring keeps whatever it holds)
 #endif
 
 namespace {
@@ -351,7 +352,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
         }
         const char* src = W + (long)(g % 6) * BLOCK + lane * 16;
         const uint32_t dst = ring_addr + (uint32_t)(g % NSLOT) * BLOCK;
-        for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * FF_FRAG, dst + (uint32_t)pc * FF_FRAG);
+        if (!(FF_ABLATE & 32))
+            for (int pc = wave; pc < NPIECE; pc += NW) dma_1k(src + pc * FF_FRAG, dst + (uint32_t)pc * FF_FRAG);
     };
     int issued = 1, signaled = 0;
     auto stage_begin = [&](int g) -> const char* {      // see tsformer_encoder.hip: my pieces landed, everybody's did, slot of g - 1 is free
