@@ -1046,15 +1046,24 @@ FfnArgs make_args(const float* h1, const float* df2, float* out, long R, const v
 
 constexpr int FR_WAVES = 8;
 
+// the dynamic-LDS limit of a kernel is a per-device attribute: raised once per (kernel, device), not on every launch (a launch inside a stream
+// capture then stays a plain kernel node).  `done` is the caller's fast path for device 0.
 template <typename K>
 int raise_lds(K kernel, int bytes, bool& done) {
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-            step_set_error("pretrain_fused: cannot raise the dynamic LDS limit to %d bytes", bytes);
-            return STEP_ERR_HIP;
-        }
-        done = true;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev == 0 && done) return STEP_OK;
+    static const void* seen[128];
+    static int seen_dev[128], nseen = 0;
+    const void* kp = (const void*)kernel;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == kp && seen_dev[i] == dev) return STEP_OK;
+    if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        step_set_error("pretrain_fused: cannot raise the dynamic LDS limit to %d bytes", bytes);
+        return STEP_ERR_HIP;
     }
+    if (nseen < 128) { seen[nseen] = kp; seen_dev[nseen] = dev; ++nseen; }
+    if (dev == 0) done = true;
     return STEP_OK;
 }
 
