@@ -329,6 +329,10 @@ int step_pt_embed_unmasked_fwd(const float* series, const int* um, const float* 
                                uint64_t seed, uint32_t site, float* x, void* stream);
 int step_pt_embed_unmasked_bwd(const float* dx, const float* series, const int* um, long S, int L, int Pu, float p, uint64_t seed, uint32_t site,
                                float* dpos, float* dw, float* db, void* stream);
+/* step_pt_dec_input_bwd + step_pt_sum_over_seq(midx) + step_colsum in one pass over dout [S, P, 96] (no [S, P - Pu, 96] scratch):
+ * dz [S, Pu, 96] = sqrt(96) * dout rows t < Pu; dpos [*, 96] rows midx[j] += and dmask [96] += the dropped, scaled rows Pu + j summed over s. */
+int step_pt_dec_input_bwd_sums(const float* dout, long S, int P, int Pu, float p, uint64_t seed, uint32_t site, const int* midx, float* dz, float* dpos,
+                               float* dmask, void* stream);
 long step_pt_ffn_pack_bytes(void);
 long step_pt_ffn_wgrad_workgroups(long R);
 long step_pt_ffn_wgrad_ws_floats(long R);

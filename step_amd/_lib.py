@@ -105,6 +105,7 @@ _SIGS = {
     "step_pt_rows_linear_ln": (_i, [_vp, _l, _vp, _vp, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_embed_unmasked_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _u64, ctypes.c_uint32, _vp, _vp]),
     "step_pt_embed_unmasked_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "step_pt_dec_input_bwd_sums": (_i, [_vp, _l, _i, _i, _f, _u64, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
     "step_pt_ffn_pack_bytes": (_l, []),
     "step_pt_ffn_wgrad_workgroups": (_l, [_l]),
     "step_pt_ffn_wgrad_ws_floats": (_l, [_l]),

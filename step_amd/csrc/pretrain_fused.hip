@@ -1021,6 +1021,43 @@ __global__ __launch_bounds__(384) void embed_unmasked_bwd_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- decoder input, backward
+// d z[s][t] = sqrt(96) * d out[s][t] (t < Pu), and for the masked positions j the two parameter gradients straight from d out:
+// d pos[midx[j]] += sum_s g, d mask_token += sum_{s, j} g with g = sqrt(96) * keep * d out[s][Pu + j] (the keep decisions of step_pt_dec_input:
+// one Philox call per 4 consecutive elements of the [S, P, 96] tensor).  The [S, Pm, 96] scratch tensor of step_pt_dec_input_bwd and the two
+// reduction passes over it (step_pt_sum_over_seq, step_colsum) are gone.  Block (t, c): token position t, sequences c, c + gridDim.y, ...
+__global__ __launch_bounds__(384) void dec_input_bwd_sums_kernel(const float* __restrict__ dout, long S, int P, int Pu, float scale, float p, uint32_t lo,
+                                                                  uint32_t hi, uint32_t site, const int* __restrict__ midx, float* __restrict__ dz,
+                                                                  float* __restrict__ dpos, float* __restrict__ dmask) {
+    __shared__ float red[96];
+    const int t = blockIdx.x, f4 = threadIdx.x % 24, part = threadIdx.x / 24;
+    if (t < Pu) {
+        for (long s = (long)blockIdx.y * 16 + part; s < S; s += (long)gridDim.y * 16) {
+            const float4 g = ((const float4*)dout)[(s * P + t) * 24 + f4];
+            ((float4*)dz)[(s * Pu + t) * 24 + f4] = make_float4(g.x * scale, g.y * scale, g.z * scale, g.w * scale);
+        }
+        return;
+    }
+    if (threadIdx.x < 96) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long s = (long)blockIdx.y * 16 + part; s < S; s += (long)gridDim.y * 16) {
+        const long i4 = (s * P + t) * 24 + f4;
+        const float4 g = ((const float4*)dout)[i4];
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p > 0.f) embed_keep4(lo, hi, site, i4, p, m);
+        a[0] += g.x * m[0]; a[1] += g.y * m[1]; a[2] += g.z * m[2]; a[3] += g.w * m[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(&red[4 * f4 + j], a[j] * scale);
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const float v = red[threadIdx.x];
+        atomicAdd(&dpos[(long)midx[t - Pu] * 96 + threadIdx.x], v);
+        atomicAdd(&dmask[threadIdx.x], v);
+    }
+}
+
 int check_common(const char* who, const float* h1, long R, const void* pack, float p, const uint64_t* pool, long pool_words) {
     STEP_REQUIRE(h1 && pack, "%s: null input", who);
     STEP_REQUIRE(R > 0 && R < (1L << 36), "%s: bad row count %ld", who, R);
@@ -1334,5 +1371,18 @@ extern "C" int step_pt_embed_unmasked_bwd(const float* dx, const float* series, 
     embed_unmasked_bwd_kernel<<<dim3(Pu, ny), 384, 0, (hipStream_t)stream>>>(dx, series, um, S, L, Pu, 9.797958971132712f, p, (uint32_t)seed, (uint32_t)(seed >> 32),
                                                                             site, dpos, dw, db);
     STEP_LAUNCH_CHECK("step_pt_embed_unmasked_bwd");
+    return STEP_OK;
+}
+
+// step_pt_dec_input_bwd + step_pt_sum_over_seq(midx) + step_colsum in one pass over d out [S, P, 96]: dz [S, Pu, 96] written,
+// dpos [*, 96] rows midx[j] and dmask [96] accumulated
+extern "C" int step_pt_dec_input_bwd_sums(const float* dout, long S, int P, int Pu, float p, uint64_t seed, uint32_t site, const int* midx, float* dz,
+                                          float* dpos, float* dmask, void* stream) {
+    STEP_REQUIRE(dout && midx && dz && dpos && dmask && S > 0 && P > Pu && Pu > 0 && p >= 0.f && p < 1.f, "pt_dec_input_bwd_sums: bad arguments");
+    STEP_REQUIRE((((uintptr_t)dout | (uintptr_t)dz) & 15) == 0, "pt_dec_input_bwd_sums: 16-byte aligned tensors expected");
+    const int ny = (int)(S >= 16 * 16 ? 16 : (S + 15) / 16);
+    dec_input_bwd_sums_kernel<<<dim3(P, ny), 384, 0, (hipStream_t)stream>>>(dout, S, P, Pu, 9.797958971132712f, p, (uint32_t)seed, (uint32_t)(seed >> 32), site,
+                                                                           midx, dz, dpos, dmask);
+    STEP_LAUNCH_CHECK("step_pt_dec_input_bwd_sums");
     return STEP_OK;
 }

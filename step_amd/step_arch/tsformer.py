@@ -411,10 +411,15 @@ class _PretrainFunction(torch.autograd.Function):
             dd = _PretrainFunction._layer_bwd(dd, lsv, S, P_, G, p, seed)
         # decoder input: split into d z and the mask-token / positional part
         dz = _empty(S * Pu, 96, like=dr)
-        dm = _empty(S * Pm, 96, like=dr)
-        L.call("step_pt_dec_input_bwd", L.ptr(dd), S, P, Pu, p, seed, 101, L.ptr(dz), L.ptr(dm), st)
-        L.call("step_pt_sum_over_seq", L.ptr(dm), S, Pm, 0, Pm, L.ptr(sv["mk"]), L.ptr(G["positional_encoding.position_embedding"]), st)
-        L.call("step_colsum", L.ptr(dm), S * Pm, 96, 96, L.ptr(G["mask_token"]), st)
+        if model.fused_embed:
+            # d z and the positional / mask-token gradients of the masked positions in one pass over d d (no [S, Pm, 96] scratch)
+            L.call("step_pt_dec_input_bwd_sums", L.ptr(dd), S, P, Pu, p, seed, 101, L.ptr(sv["mk"]), L.ptr(dz),
+                   L.ptr(G["positional_encoding.position_embedding"]), L.ptr(G["mask_token"]), st)
+        else:
+            dm = _empty(S * Pm, 96, like=dr)
+            L.call("step_pt_dec_input_bwd", L.ptr(dd), S, P, Pu, p, seed, 101, L.ptr(dz), L.ptr(dm), st)
+            L.call("step_pt_sum_over_seq", L.ptr(dm), S, Pm, 0, Pm, L.ptr(sv["mk"]), L.ptr(G["positional_encoding.position_embedding"]), st)
+            L.call("step_colsum", L.ptr(dm), S * Pm, 96, 96, L.ptr(G["mask_token"]), st)
         # enc_2_dec_emb, encoder norm, encoder layers
         dy = _empty(S * Pu, 96, like=dr)
         _linear_bwd(dz, sv["y"], P_["enc_2_dec_emb.weight"], G["enc_2_dec_emb.weight"], G["enc_2_dec_emb.bias"], dy)

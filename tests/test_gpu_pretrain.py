@@ -689,3 +689,55 @@ def test_unmasked_token_embedding_matches_the_all_token_path():
     assert worst[0] < 1e-4
     for n in ("patch_embedding.input_embedding.weight", "patch_embedding.input_embedding.bias", "positional_encoding.position_embedding"):
         assert rel_l2(res[0][1][n], res[1][1][n]) < 1e-4, n
+
+
+@pytest.mark.parametrize("p", [0.5, 0.0])
+def test_embedding_and_decoder_input_backward_use_the_forward_masks(p):
+    """step_pt_embed_unmasked_{fwd,bwd} and step_pt_dec_input / step_pt_dec_input_bwd_sums with dropout ON: the keep decisions the forward
+    used are read off its output (ratio to the p = 0 output), and the backward kernels' parameter gradients must equal torch autograd of
+    the same expression with exactly those masks -- a backward that regenerated other decisions would be off by tens of per cent at p = 0.5."""
+    from step_amd import _lib as L
+    S, Lh, P, Pu = 37, 12 * 24, 24, 6
+    Pm = P - Pu
+    gen = torch.Generator().manual_seed(9)
+    r = lambda *sh: torch.randn(*sh, generator=gen).cuda()
+    series, w, b, pos = r(S, Lh), r(96, 12) * 0.3, r(96) * 0.1, r(40, 96) * 0.5
+    perm = torch.randperm(P, generator=gen)
+    um, mk = perm[:Pu].int().cuda(), perm[Pu:].int().cuda()
+    seed, st = 0x5151_0000_7777, L.stream()
+    x0, xp = torch.empty(S, Pu, 96, device="cuda"), torch.empty(S, Pu, 96, device="cuda")
+    L.call("step_pt_embed_unmasked_fwd", L.ptr(series), L.ptr(um), L.ptr(w), L.ptr(b), L.ptr(pos), S, Lh, Pu, 0.0, seed, 100, L.ptr(x0), st)
+    L.call("step_pt_embed_unmasked_fwd", L.ptr(series), L.ptr(um), L.ptr(w), L.ptr(b), L.ptr(pos), S, Lh, Pu, p, seed, 100, L.ptr(xp), st)
+    torch.cuda.synchronize()
+    mask = torch.where(x0.abs() > 1e-6, xp / x0, torch.ones_like(x0))                 # 0 or 1 / (1 - p)
+    ks = 1.0 / (1.0 - p)
+    assert bool(((mask.abs() < 1e-4) | ((mask - ks).abs() < 1e-3)).all())
+    if p > 0:
+        assert abs(float((mask > 0).float().mean()) - (1 - p)) < 0.02
+    wq, bq, posq = [t.clone().double().requires_grad_(True) for t in (w, b, pos)]
+    patches = series.view(S, P, 12)[:, um.long(), :].double()
+    want_x = (patches @ wq.T + bq + posq[um.long()]) * mask.double() * 96 ** 0.5
+    assert rel_l2(xp.double().cpu(), want_x.detach().cpu()) < 1e-5
+    dx = r(S, Pu, 96)
+    want_x.backward(dx.double())
+    dpos, dw, db = torch.zeros(40, 96, device="cuda"), torch.zeros(96, 12, device="cuda"), torch.zeros(96, device="cuda")
+    L.call("step_pt_embed_unmasked_bwd", L.ptr(dx), L.ptr(series), L.ptr(um), S, Lh, Pu, p, seed, 100, L.ptr(dpos), L.ptr(dw), L.ptr(db), st)
+    # decoder input
+    z, mtok = r(S, Pu, 96), r(96) * 0.1
+    d0, dp = torch.empty(S, P, 96, device="cuda"), torch.empty(S, P, 96, device="cuda")
+    L.call("step_pt_dec_input", L.ptr(z), L.ptr(mtok), L.ptr(pos), L.ptr(mk), S, P, Pu, 0.0, seed, 101, L.ptr(d0), st)
+    L.call("step_pt_dec_input", L.ptr(z), L.ptr(mtok), L.ptr(pos), L.ptr(mk), S, P, Pu, p, seed, 101, L.ptr(dp), st)
+    torch.cuda.synchronize()
+    m2 = torch.where(d0[:, Pu:].abs() > 1e-6, dp[:, Pu:] / d0[:, Pu:], torch.ones_like(d0[:, Pu:]))
+    assert torch.equal(d0[:, :Pu], dp[:, :Pu])
+    dout = r(S, P, 96)
+    dz, dpos2, dmask = torch.empty(S, Pu, 96, device="cuda"), torch.zeros(40, 96, device="cuda"), torch.zeros(96, device="cuda")
+    L.call("step_pt_dec_input_bwd_sums", L.ptr(dout), S, P, Pu, p, seed, 101, L.ptr(mk), L.ptr(dz), L.ptr(dpos2), L.ptr(dmask), st)
+    torch.cuda.synchronize()
+    gm = (dout[:, Pu:].double() * m2.double() * 96 ** 0.5).sum(0)                       # [Pm, 96]
+    want_dpos2 = torch.zeros(40, 96, dtype=torch.float64, device="cuda").index_add_(0, mk.long(), gm)
+    errs = {"dw": rel_l2(dw.double().cpu(), wq.grad.cpu()), "db": rel_l2(db.double().cpu(), bq.grad.cpu()), "dpos": rel_l2(dpos.double().cpu(), posq.grad.cpu()),
+            "dz": rel_l2(dz.double().cpu(), (dout[:, :Pu].double() * 96 ** 0.5).cpu()), "dpos (decoder)": rel_l2(dpos2.double().cpu(), want_dpos2.cpu()),
+            "dmask_token": rel_l2(dmask.double().cpu(), gm.sum(0).cpu())}
+    print(f"embedding / decoder-input backward with the forward's masks p={p}:", {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-5
