@@ -1,14 +1,22 @@
-// Fused feed-forward block of the TSFormer pre-training step (reference: the two linear layers, ReLU and dropout of
-// nn.TransformerEncoderLayer inside step/step_arch/tsformer/transformer_layers.py:7-21, trained by tsformer.py:71-160), bf16 mode.
+// Row kernels of the TSFormer pre-training step (reference: nn.TransformerEncoderLayer inside step/step_arch/tsformer/transformer_layers.py:7-21,
+// trained by tsformer.py:71-160), bf16 mode: everything of a layer that acts on one token at a time, as kernels that stream [R, 96] row
+// tensors once.  In this file, in order:
+//   the fused feed-forward block        ffn_pack / ffn_rows (forward, backward-data) / ffn_wgrad / ffn_reduce        (described below)
+//   tile staging helpers                row tiles <-> transposed register layout through wave-private swizzled LDS, and
+//                                       residual add + dropout + LayerNorm as an output stage (tile_out_ln)
+//   the projections of the attention    rows_linear (qkv, out-projection, d a, d x +=; weights resident in LDS), proj_wgrad (d Wi, d bi, d Wo in one pass)
+//   the ends of the network             embed_unmasked_fwd / _bwd (patch + positional embedding of the unmasked tokens), dec_input_bwd_sums
+//   layer_pack                          one launch that writes all operand-fragment buffers of a layer
+// The attention itself, the LayerNorm backward and the f32 path are in pretrain.hip.
 //
-// The layer-by-layer path (pretrain.hip + step_gemm) stores the [R, 384] hidden layer and its gradient as bf16 tensors
+// Fused feed-forward block.  The layer-by-layer path (pretrain.hip + step_gemm) stores the [R, 384] hidden layer and its gradient as bf16 tensors
 // (R = sequences x tokens = 873 600 rows in the decoder layer of config C3: 671 MB each) and walks them eight times per layer.
 // Here the hidden layer never leaves registers, in the forward AND in the backward (which recomputes it):
 //
-//   ffn_fwd_kernel       f2        = W2 . drop(relu(W1 . h1 + b1)) + b2                     reads h1, writes f2
-//   ffn_bwd_data_kernel  dh1      += W1^T . [ (W2^T . df2) * relu' * keep ]                 reads h1, df2, read-modify-writes dh1
-//   ffn_bwd_w2_kernel    dW2[o,j]  = sum over rows of df2[row,o] * hid[row,j]               reads h1, df2
-//   ffn_bwd_w1_kernel    dW1[j,i]  = sum over rows of dhid[row,j] * h1[row,i], db1 = column sums of dhid     reads h1, df2
+//   ffn_rows_kernel<BWD = false>   f2   = W2 . drop(relu(W1 . h1 + b1)) + b2 (+ residual, dropout, LayerNorm 2)    reads h1, writes f2 (or pre / y / stats)
+//   ffn_rows_kernel<BWD = true>    dh1 += W1^T . [ (W2^T . df2) * relu' * keep ]                               reads h1, df2, read-modify-writes dh1
+//   ffn_wgrad_kernel<W1K = false>  dW2[o,j] = sum over rows of df2[row,o] * hid[row,j]                          reads h1, df2
+//   ffn_wgrad_kernel<W1K = true>   dW1[j,i] = sum over rows of dhid[row,j] * h1[row,i], db1 = column sums of dhid   reads h1, df2
 //
 // The first two keep activations TRANSPOSED like the forecasting-mode encoder (tsformer_encoder.hip): token = lane & 31, the 96
 // features of a token in three accumulator tiles, weights as the A operand streamed through an LDS ring of stage blocks
