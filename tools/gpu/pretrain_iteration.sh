@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, call r: pool-drawn keep words in the matrix-core attention forward, vectorised decoder-input kernels, keep-mask words of the
-# fused feed-forward kernels requested a stage ahead: tests, micro-benchmarks, C3 bench + kernel table
+# one iteration on the pre-training step (config C3): its GPU tests, the micro-benchmarks of its kernels, the bench line and the kernel table
+# usage (through gpurun): bash tools/gpu/pretrain_iteration.sh <tag>  ->  gpurun_out/<tag>_*
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
 t=${1:-r04r}
