@@ -329,7 +329,7 @@ __device__ __forceinline__ void tile_out_ln(const LnEpi& E, long row0, long R, c
 // it has read a block, and refills a slot only when all NW waves are done with the block that was in it.  With NSLOT = 3 the waves may
 // drift up to two stages apart, so one wave's tile loads and stores run under the others' matrix work.
 template <int NW, bool BWD, bool DROP, bool LN = false, int NSLOT = 2, bool FLAGS = false>
-__global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 2 : 1)) void ffn_rows_kernel(FfnArgs A) {      // (four-wave variant: two waves per SIMD = two workgroups per unit)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int BLOCK = BWD ? FF_BLOCK_B : FF_BLOCK_F;
     constexpr int NPIECE = BLOCK / FF_FRAG;
@@ -346,7 +346,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
     const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(LDS_ADDR(smem));
     const mask_ptr pool = (mask_ptr)(uintptr_t)A.pool;
     uint32_t* flag = (uint32_t*)(smem + NSLOT * BLOCK);                      // FLAGS: arrived[NSLOT], done[NSLOT]
-    char* stg = smem + NSLOT * BLOCK + (FLAGS ? 64 : 0) + wave * STG_WAVE;    // this wave's staging area (tile_in / tile_out)
+    // this wave's staging area (tile_in / tile_out).  Four-wave workgroups (STEP_FFN_FWD_WAVES=4: two workgroups per compute unit) stage their
+    // output over the input tile, which is dead once its fragments are in registers: 74 KB of LDS per workgroup instead of 90
+    constexpr int WSTRIDE = NW == 4 ? STG_IN : STG_WAVE, OUT_OFF = NW == 4 ? 0 : STG_IN;
+    char* stg = smem + NSLOT * BLOCK + (FLAGS ? 64 : 0) + wave * WSTRIDE;
     if constexpr (FLAGS) {
         if (threadIdx.x < 2 * NSLOT) flag[threadIdx.x] = 0u;
         __syncthreads();
@@ -490,8 +493,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_rows_kernel(FfnArgs A) {
                 for (int i = 0; i < 16; ++i) acc[t][i] = __builtin_fmaf(acc[t][i], A.inv_keep, b2[t * 16 + i]);
         }
         stage_end(g - 1);                               // (the last block of the pass: b2 rides in its tail)
-        if constexpr (LN) tile_out_ln(A.ln, tile32 * 32, A.R, stg + STG_IN, lane, acc);
-        else tile_out<BWD>(A.out, tile32 * 32, A.R, stg + STG_IN, lane, acc);     // backward-data: added onto the residual branch's gradient already in dh1
+        if constexpr (LN) tile_out_ln(A.ln, tile32 * 32, A.R, stg + OUT_OFF, lane, acc);
+        else tile_out<BWD>(A.out, tile32 * 32, A.R, stg + OUT_OFF, lane, acc);     // backward-data: added onto the residual branch's gradient already in dh1
     }
 }
 
@@ -1117,8 +1120,29 @@ bool ring_flags() {
     if (on < 0) { const char* e = getenv("STEP_FFN_RING_FLAGS"); on = e && e[0] == '1'; }
     return on == 1;
 }
+int fwd_waves() {
+    static int n = 0;
+    if (n == 0) { const char* e = getenv("STEP_FFN_FWD_WAVES"); n = e && atoi(e) == 4 ? 4 : 8; }
+    return n;
+}
+template <bool LN>
+int launch_rows_fwd4(const FfnArgs& a, hipStream_t st) {       // four waves per workgroup, two workgroups per compute unit (A/B variant)
+    static bool raised[2] = {false, false};
+    const int lds = 2 * FF_BLOCK_F + 4 * STG_IN;
+    const long npass = (a.R + 127) / 128;
+    const int grid = (int)(npass < 512 ? npass : 512);
+    if (a.pool) {
+        STEP_TRY(raise_lds(ffn_rows_kernel<4, false, true, LN>, lds, raised[1]));
+        ffn_rows_kernel<4, false, true, LN><<<grid, 256, lds, st>>>(a);
+    } else {
+        STEP_TRY(raise_lds(ffn_rows_kernel<4, false, false, LN>, lds, raised[0]));
+        ffn_rows_kernel<4, false, false, LN><<<grid, 256, lds, st>>>(a);
+    }
+    return STEP_OK;
+}
 int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
     static bool raised[4] = {false, false, false, false};
+    if (fwd_waves() == 4) return launch_rows_fwd4<true>(a, st);
     const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
     const int grid = (int)(npass < 512 ? npass : 512);
     if (ring_flags()) {
@@ -1146,6 +1170,9 @@ int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
 template <bool BWD>
 int launch_rows(const FfnArgs& a, hipStream_t st) {
     static bool raised[4] = {false, false, false, false};
+    if constexpr (!BWD) {
+        if (fwd_waves() == 4) return launch_rows_fwd4<false>(a, st);
+    }
     const int lds = 2 * (BWD ? FF_BLOCK_B : FF_BLOCK_F) + FR_WAVES * STG_WAVE;
     const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
     const int grid = (int)(npass < 512 ? npass : 512);
