@@ -857,32 +857,43 @@ __global__ __launch_bounds__(FW_WAVES * 64) void proj_wgrad_kernel(ProjWgradArgs
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float bsum = 0.f;
-    // piece p (1 KB) of a tile's 48: which tensor, where
-    auto piece_load = [&](long tile, int p) -> uint4 {
-        const char* src; long off, lim;
-        if (p < 18) { src = (const char*)A.dqkv; off = tile * PW_DQ + p * 1024; lim = A.R * 576; }
-        else if (p < 30) { src = (const char*)A.x; off = tile * PW_X + (p - 18) * 1024; lim = A.R * 384; }
-        else if (p < 42) { src = (const char*)A.dov; off = tile * PW_DO + (p - 30) * 1024; lim = A.R * 384; }
-        else { src = (const char*)A.a; off = tile * PW_A + (p - 42) * 1024; lim = A.R * 192; }
-        off += lane * 16;
-        return off < lim ? *(const uint4*)(src + off) : make_uint4(0u, 0u, 0u, 0u);          // (row sizes are multiples of 16 bytes: a piece never straddles the end)
-    };
-    uint4 nx[4];
-    auto tile_request = [&](long tile) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) nx[k] = piece_load(tile, wave + 12 * k);
-    };
-    auto tile_commit = [&](char* buf) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *(uint4*)(buf + (wave + 12 * k) * 1024 + lane * 16) = nx[k];
-    };
-    if ((long)blockIdx.x < ntile) { tile_request(blockIdx.x); tile_commit(smem); }
+    // piece p (1 KB) of a tile's 48: dqkv 0..17, x 18..29, d o 30..41, a 42..47; this wave moves pieces wave, wave + 12, wave + 24, wave + 36, i.e. one
+    // of each of the ranges [0, 12) dqkv, [12, 24) dqkv | x, [24, 36) x | d o, [36, 48) d o | a
+    const int pc0 = wave, pc1 = wave + 12, pc2 = wave + 24, pc3 = wave + 36;
+    const char *ps0 = (const char*)A.dqkv, *ps1 = pc1 < 18 ? (const char*)A.dqkv : (const char*)A.x, *ps2 = pc2 < 30 ? (const char*)A.x : (const char*)A.dov,
+               *ps3 = pc3 < 42 ? (const char*)A.dov : (const char*)A.a;
+    const long po0 = (long)pc0 * 1024 + lane * 16, po1 = (long)(pc1 < 18 ? pc1 : pc1 - 18) * 1024 + lane * 16,
+               po2 = (long)(pc2 < 30 ? pc2 - 18 : pc2 - 30) * 1024 + lane * 16, po3 = (long)(pc3 < 42 ? pc3 - 30 : pc3 - 42) * 1024 + lane * 16;
+    const long pl0 = A.R * 576, pl1 = pc1 < 18 ? A.R * 576 : A.R * 384, pl2 = A.R * 384, pl3 = pc3 < 42 ? A.R * 384 : A.R * 192;
+    const long ts0 = PW_DQ, ts1 = pc1 < 18 ? PW_DQ : PW_X, ts2 = pc2 < 30 ? PW_X : PW_DO, ts3 = pc3 < 42 ? PW_DO : PW_A;
+    uint4 nx0, nx1, nx2, nx3;
+#define PW_REQUEST(tile_)                                                                                                              \
+    do {                                                                                                                               \
+        const long o0 = (tile_) * ts0 + po0, o1 = (tile_) * ts1 + po1, o2 = (tile_) * ts2 + po2, o3 = (tile_) * ts3 + po3;             \
+        const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);          /* (row sizes are multiples of 16 bytes: a piece never straddles the end) */ \
+        /* (out-of-range lanes read the tensor's first 16 bytes and are zeroed afterwards: a select between the address and a zero */  \
+        /*  constant becomes a flat load from a scratch copy of the constant) */                                                        \
+        nx0 = *(const uint4*)(ps0 + (o0 < pl0 ? o0 : 0)); nx1 = *(const uint4*)(ps1 + (o1 < pl1 ? o1 : 0));                           \
+        nx2 = *(const uint4*)(ps2 + (o2 < pl2 ? o2 : 0)); nx3 = *(const uint4*)(ps3 + (o3 < pl3 ? o3 : 0));                           \
+        if (!(o0 < pl0)) nx0 = z4;                                                                                                     \
+        if (!(o1 < pl1)) nx1 = z4;                                                                                                     \
+        if (!(o2 < pl2)) nx2 = z4;                                                                                                     \
+        if (!(o3 < pl3)) nx3 = z4;                                                                                                     \
+    } while (0)
+#define PW_COMMIT(buf_)                                                                                                                \
+    do {                                                                                                                               \
+        *(uint4*)((buf_) + pc0 * 1024 + lane * 16) = nx0;                                                                              \
+        *(uint4*)((buf_) + pc1 * 1024 + lane * 16) = nx1;                                                                              \
+        *(uint4*)((buf_) + pc2 * 1024 + lane * 16) = nx2;                                                                              \
+        *(uint4*)((buf_) + pc3 * 1024 + lane * 16) = nx3;                                                                              \
+    } while (0)
+    if ((long)blockIdx.x < ntile) { PW_REQUEST((long)blockIdx.x); PW_COMMIT(smem); }
     __syncthreads();
     int par = 0;
 #pragma unroll 1
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x, par ^= 1) {
         const long nxt = tile + gridDim.x;
-        if (nxt < ntile) tile_request(nxt);
+        if (nxt < ntile) PW_REQUEST(nxt);
         const char* buf = smem + par * PW_TILE;
         const uint16_t* dq = (const uint16_t*)buf;
         const float* xx = (const float*)(buf + PW_DQ);
@@ -892,40 +903,38 @@ __global__ __launch_bounds__(FW_WAVES * 64) void proj_wgrad_kernel(ProjWgradArgs
         for (int s = 0; s < 2; ++s) {
             op8 af;
             if (wave < 9) {
-                uint32_t w[4];
+                u32x4 v;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const uint32_t lo = dq[chain_f(s, h, j) * 288 + 32 * wave + c], hi = dq[chain_f(s, h, j + 1) * 288 + 32 * wave + c];
-                    w[j >> 1] = lo | (hi << 16);
+                    v[j >> 1] = lo | (hi << 16);
                     bsum += __uint_as_float(lo << 16) + __uint_as_float(hi << 16);
                 }
-                u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
                 af = __builtin_bit_cast(op8, v);
             } else {
-                float v[8];
+                f32x8 v;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = dd[chain_f(s, h, j) * 96 + 32 * (wave - 9) + c];
-                af = pack8(v);
+                af = __builtin_convertvector(v, op8);
             }
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 op8 bf;
                 if (wave < 9) {
-                    float v[8];
+                    f32x8 v;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = xx[chain_f(s, h, j) * 96 + 32 * t + c];
-                    bf = pack8(v);
+                    bf = __builtin_convertvector(v, op8);
                 } else {
-                    uint32_t w[4];
+                    u32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) w[j >> 1] = (uint32_t)aa[chain_f(s, h, j) * 96 + 32 * t + c] | ((uint32_t)aa[chain_f(s, h, j + 1) * 96 + 32 * t + c] << 16);
-                    u32x4 v; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+                    for (int j = 0; j < 8; j += 2) v[j >> 1] = (uint32_t)aa[chain_f(s, h, j) * 96 + 32 * t + c] | ((uint32_t)aa[chain_f(s, h, j + 1) * 96 + 32 * t + c] << 16);
                     bf = __builtin_bit_cast(op8, v);
                 }
                 acc[t] = mma(af, bf, acc[t]);
             }
         }
-        if (nxt < ntile) tile_commit(smem + (par ^ 1) * PW_TILE);
+        if (nxt < ntile) PW_COMMIT(smem + (par ^ 1) * PW_TILE);
         __syncthreads();
     }
     float* ws = A.ws + (long)blockIdx.x * PW_WS;
