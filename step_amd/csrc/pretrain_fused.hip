@@ -158,30 +158,6 @@ __device__ __forceinline__ uint32_t ffn_mask_base(uint32_t seed, uint32_t site, 
     return mix32(seed + (uint32_t)tile32 * 0x9E3779B1u + (site + 1u) * 0x632BE5ABu) & pool_mask;
 }
 
-// rows [row] of a [R, 96] f32 tensor into the transposed accumulator layout: a[t][4 q + i] = x[row][32 t + 8 q + 4 h + i]
-__device__ __forceinline__ void load_rows_T(const float* __restrict__ x, long row, bool ok, int h, f32x16 (&a)[3]) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && !(FF_ABLATE & 2)) v = *(const float4*)(x + row * 96 + 32 * t + 8 * q + 4 * h);
-            a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w;
-        }
-}
-__device__ __forceinline__ void store_rows_T(float* __restrict__ y, long row, bool ok, int h, const f32x16 (&a)[3]) {
-    if (!ok || (FF_ABLATE & 4)) return;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *(float4*)(y + row * 96 + 32 * t + 8 * q + 4 * h) = make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-}
-__device__ __forceinline__ void pack_rows_T(const f32x16 (&a)[3], op8 (&b)[6]) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t) { b[2 * t] = pack_lo_hi(a[t], 0); b[2 * t + 1] = pack_lo_hi(a[t], 1); }
-}
-
 // Row tiles move between HBM and the transposed register layout through wave-private LDS, so that every global access is a full
 // 128-byte line (a lane reading its own row's 16 bytes touches 32 lines per instruction: measured 2.4x the time of the kernel's
 // matrix work, profiles/r04_p_ffn_ablations.log):

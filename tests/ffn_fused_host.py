@@ -88,7 +88,8 @@ def pack(w1, w2):
 
 
 def rows_T(x, row0):
-    """load_rows_T: [3][64, 16]: a[t][lane, 4 q + i] = x[row0 + r, 32 t + 8 q + 4 h + i]"""
+    """a 32-row tile in the transposed register layout (what tile_put + tile_frags deliver, before the bf16 pack): [3][64, 16],
+    a[t][lane, 4 q + i] = x[row0 + r, 32 t + 8 q + 4 h + i]"""
     R = x.shape[0]
     a = np.zeros((3, 64, 16))
     for t in range(3):
@@ -100,7 +101,7 @@ def rows_T(x, row0):
 
 
 def pack_T(a):
-    """pack_rows_T: six operand fragments, b[2 t + s][lane, j] = a[t][lane, 8 s + j]"""
+    """the six operand fragments of a tile (tile_frags): b[2 t + s][lane, j] = a[t][lane, 8 s + j]"""
     return [a[t][:, 8 * s:8 * s + 8] for t in range(3) for s in range(2)]
 
 
