@@ -353,3 +353,29 @@ def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
     assert run({"WORLD_SIZE": "8"}) == "None"
     assert run({"GPU_MAX_HW_QUEUES": "4"}) == "4"
     assert run({}, as_module) == "None"                                    # imported as a module (the tests): the process's settings stay
+
+
+def test_tsformer_flatten_parameters_keeps_the_state_dict_and_shares_one_buffer():
+    """TSFormer.flatten_parameters() (host logic, no device needed): every parameter becomes a view into ONE f32 buffer laid out like the
+    native backward's flat gradient buffer (parameters in `_pt_names` order, each at a multiple of 4 floats), values, `state_dict` keys and
+    shapes unchanged, and `zero_grad()` rewinds the backward counter the fused optimizer checks."""
+    import torch
+    from step_amd import TSFormer
+    torch.manual_seed(0)
+    m = TSFormer(12, 1, 96, 4, 4, 0.1, 24, 0.75, 4, 1, mode="pre-train")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = m.flatten_parameters()
+    after = m.state_dict()
+    assert list(after) == list(before)
+    assert all(torch.equal(after[k], before[k]) and after[k].shape == before[k].shape for k in before)
+    off = 0
+    for p in m._pt_params():
+        assert p.data.data_ptr() == flat.data_ptr() + 4 * off and off % 4 == 0
+        off += (p.numel() + 3) & ~3
+    assert off == flat.numel()
+    with torch.no_grad():
+        flat.mul_(2.0)                                    # the buffer IS the parameters
+    assert all(torch.equal(m.state_dict()[k], 2.0 * before[k]) for k in before)
+    m._backward_count = 3
+    m.zero_grad()
+    assert m._backward_count == 0
