@@ -1261,7 +1261,7 @@ extern "C" int step_gwnet_backward(const float* hist, int B, int N, int Cin, con
     if (allbf16) STEP_TRY(gwnet_layers_backward<true>(p, grads, S, W, B, N, &dx0, st, lane, leaves, &adj_done));
     else STEP_TRY(gwnet_layers_backward<false>(p, grads, S, W, B, N, &dx0, st, lane, leaves, &adj_done));
     // the adjacency gradients are complete from here on (the event behind the last piece; leaves queued on that stream after it -- layer
-    // 0's gate gradient -- no longer hold the main stream back: 100 us at PEMS07, profiles/r03_ai_C4_step_timeline.md)
+    // 0's gate gradient -- no longer hold the main stream back: 100 us at PEMS07, profiles/r03_aj_C4_step_timeline.md)
     STEP_TRY(lane.wait_done(adj_done));
     // ---------------------------------------------------------------- supports
     // What the caller's next kernels wait for is dadj alone: the random-walk normalisations' backward stays on the main stream.  The

@@ -35,6 +35,7 @@
 // Forward and backward-data read them as lane masks (scalar loads); the weight-gradient kernels, where the lane is the hidden
 // unit, load the one word that holds their unit and test the row's bit.
 #include "common.h"
+#include <mutex>
 #include <stdlib.h>
 #include "step_internal.h"
 #include "tsformer_device.h"
@@ -1085,7 +1086,10 @@ template <typename K>
 int raise_lds(K kernel, int bytes, bool& done) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev == 0 && done) return STEP_OK;
+    if (dev == 0 && __atomic_load_n(&done, __ATOMIC_ACQUIRE)) return STEP_OK;
+    // first launches may come from two host threads at once (the autograd worker and the main thread): the list below is shared
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     static const void* seen[128];
     static int seen_dev[128], nseen = 0;
     const void* kp = (const void*)kernel;
@@ -1096,7 +1100,7 @@ int raise_lds(K kernel, int bytes, bool& done) {
         return STEP_ERR_HIP;
     }
     if (nseen < 128) { seen[nseen] = kp; seen_dev[nseen] = dev; ++nseen; }
-    if (dev == 0) done = true;
+    if (dev == 0) __atomic_store_n(&done, true, __ATOMIC_RELEASE);
     return STEP_OK;
 }
 

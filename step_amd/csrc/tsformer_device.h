@@ -235,6 +235,7 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
 // lds_dst is wave-uniform; lane i's 16 bytes land at lds_dst + 16 i.
 __device__ __forceinline__ void dma_1k(const char* gsrc_lane, uint32_t lds_dst) {
     uint32_t keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);      // provably scalar for the "s" operand (the compiler has been seen to hand over a vector register)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc_lane), "s"(lds_dst)

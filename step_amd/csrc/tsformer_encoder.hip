@@ -49,7 +49,7 @@ namespace {
 #define TSF_BIAS 60.0f
 #ifndef TSF_ABLATE
 #define TSF_ABLATE 0        // timing experiments only (WRONG results): 1 no exp2, 2 no attention keep-masks, 4 no re-shift check, 16 no denominator adds,
-                            // 32 no key-tile loop at all, 64 one FFN stage instead of six, 128 no LayerNorm arithmetic
+                            // 32 no key-tile loop at all, 64 one FFN stage instead of six, 128 no LayerNorm arithmetic, 256 no matrix products in the fast key-tile loop
 #endif
 #ifndef TSF_FAST_ATTN
 #define TSF_FAST_ATTN 1     // 0: always the re-shifting loop (A/B builds)
@@ -93,11 +93,50 @@ constexpr int parked_frags() { return PARK ? 6 : ((MAXW == 12 || MAXW == 8) && T
 #ifndef TSF_RELU_PACKED
 #define TSF_RELU_PACKED 1   // 0: f32 clamp before the pack (A/B builds)
 #endif
+// ---- round 5: what profiles/r05_a_encoder_phase_table.md (s_memtime stamps per wave and phase) and profiles/r05_b_simd_probe.log (what one
+// SIMD does with this instruction mix) say, turned into defaults.  A SIMD arbitrates its waves by priority, then AGE; one wave alone issues a
+// vector instruction every ~7.5 cycles (three together one every ~3), and a matrix product costs every other wave of the SIMD ~16 cycles of
+// vector issue.  Left alone, the first-dispatched wave of a SIMD runs each phase almost unimpeded and then waits at the barrier (49 % of its
+// time) while the last-dispatched one finishes ALONE at the single-wave rate: key-tile loop 5.6k / 9k / 12.7k cycles for the three waves.
+#ifndef TSF_FFN_PIPE
+#define TSF_FFN_PIPE 1      // 1: the feed-forward chunks request their weight fragments one matrix-product group AHEAD, pinned with scheduling fences
+#endif                      // (left to itself the compiler sinks every fragment read to one or two products in front of its use).  0: the round-4 loop
+#ifndef TSF_QKV_PIPE
+#define TSF_QKV_PIPE 3      // Q / K / V projections: 0 the compiler's order; 1 fences around the rolling three-fragment batches; 2 two six-fragment
+#endif                      // buffers (spills); 3 a ring of six fragment registers refilled one at a time + the out-projection's fragments requested early
+#ifndef TSF_PROGRESS_PRIO
+#define TSF_PROGRESS_PRIO 1 // 1: a wave's issue priority FALLS as it advances through a phase (key-tile loop: by key-tile pair; feed-forward: by chunk):
+#endif                      // a wave that is ahead yields to the ones behind it (key-tile loop 7.5k .. 11.9k instead of 5.6k .. 12.7k).  2 / 3 / 4:
+                            // per-step schemes, measured slower (profiles/r05_d_*).  0: off
+#ifndef TSF_FILL_OLD
+#define TSF_FILL_OLD 1      // 1: the weight ring's DMA pieces are requested by waves 0..3 only (see issue_fill)
+#endif
+#ifndef TSF_ATTN_IL
+#define TSF_ATTN_IL 0       // 1: the fast key-tile step issues its four matrix products interleaved with the vector work (see fast_step)
+#endif
+#ifndef TSF_TIMING
+#define TSF_TIMING 0        // 1: s_memtime stamps at the phase boundaries of sampled workgroups (tools/enc_ab.cpp dumps them, tools/enc_phase_table.py reads them)
+#endif
+#if TSF_TIMING
+#define TSF_NSTAMP 40       // stamps per layer and wave
+__device__ unsigned long long* g_tsf_timing = nullptr;      // [sampled workgroup][wave 16][layer 4][TSF_NSTAMP]
+#define TSF_STAMP(idx) do { if (tbuf && layer < 4) { const unsigned long long t_ = __builtin_readcyclecounter(); if (fresh_lane_id() == 0) tbuf[layer * TSF_NSTAMP + (idx)] = t_; } } while (0)
+#else
+#define TSF_STAMP(idx) do { } while (0)
+#endif
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 template <bool F16>
 __device__ __forceinline__ typename Opnd<F16>::v8 relu_packed(typename Opnd<F16>::v8 v) {
     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return __builtin_bit_cast(typename Opnd<F16>::v8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
+
+// level 0..3 -> s_setprio (an immediate operand: the wave-uniform level is branched on)
+__device__ __forceinline__ void prio_level(int lvl) {
+    if (lvl >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 }
 
 struct Yes { static constexpr bool value = true; };
@@ -154,6 +193,14 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     auto issue_fill = [&](int g) {            // stage block g -> ring slot g mod NSLOT, pieces spread over the waves
         const char* src = W + TSF_LAYER0 + (long)g * TSF_BLOCK + lane * 16;
         const uint32_t dst = ring_addr + (uint32_t)(g & (NSLOT - 1)) * TSF_BLOCK;
+        if (TSF_FILL_OLD) {
+            // only the four first-dispatched waves (one per SIMD) request the pieces: they are the ones that reach every barrier early and wait
+            // there (49 % of their time, profiles/r05_a_encoder_phase_table.md), while a piece costs the last-arriving wave 100+ cycles of the
+            // workgroup's critical path behind every stage boundary
+            if (wave < 4)
+                for (int pc = wave; pc < 25; pc += 4) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
+            return;
+        }
         for (int pc = wave; pc < 25; pc += nkt) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
     };
     // Stage boundary: my DMA pieces of every block requested so far have landed (vmcnt), everybody's have (barrier), and
@@ -167,7 +214,11 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         return slot_of(g);
     };
 
-    if (TSF_STATIC_PRIO && wave * 2 >= nkt) __builtin_amdgcn_s_setprio(1);
+    if (TSF_STATIC_PRIO == 1 && wave * 2 >= nkt) __builtin_amdgcn_s_setprio(1);
+    if (TSF_STATIC_PRIO == 2) {               // (A/B builds) the later a wave was dispatched onto its SIMD, the higher its priority: reverses the age order
+        if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
     bool first_block_requested = false;       // (persistent launch) block 0 of this sequence was requested during the previous one
 #if TSF_PERSIST
 #pragma unroll 1
@@ -230,6 +281,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     }
 
     // ------------------------------------------------------------------ encoder layers
+#if TSF_TIMING
+    unsigned long long* tbuf = (g_tsf_timing && (seq & 63) == 7) ? g_tsf_timing + ((long)(seq >> 6) * 16 + wave) * (4 * TSF_NSTAMP) : nullptr;
+#endif
     int g = 0;                                  // global stage index (10 per layer)
     int slow_units = 0;                         // (wave-uniform) heads of this wave that ran the re-shifting softmax loop
 #pragma unroll 1
@@ -240,6 +294,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
 
         // the first head's stage is opened outside the loop so that the f32 residual stream xT is
         // dead (folded into acc / xb) while the head loop runs
+        TSF_STAMP(0);
         const char* blk = stage_begin(g, 1);
         const float* tail = (const float*)(blk + TSF_TAIL);
         {
@@ -262,6 +317,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 blk = stage_begin(g, PAIR && hd == TSF_HEADS - 1 ? 2 : 1);      // the last head also requests the second ffn block
                 tail = (const float*)(blk + TSF_TAIL);
             }
+            TSF_STAMP(1 + 5 * hd);
             if constexpr (NPARK > 0) {
 #pragma unroll
                 for (int f = 6 - NPARK; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f - (6 - NPARK), lane);
@@ -270,6 +326,92 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // 4-register buffer through read -> wait -> MFMA, one exposed LDS latency per MFMA.
             TSF_PRIO_CHAIN(1);
             op8 qb[2];
+#if TSF_QKV_PIPE == 3
+            {
+                // a ring of six fragment registers refilled one at a time: fragment i + 6 is requested right behind product i (static indices, the
+                // scheduling fences pin each read there), so every product finds its fragment requested six products = ~190 cycles earlier
+                op8 wr[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) wr[k] = lfrag<F16>(blk, k, lane);
+                f32x16 q, kk, vv;
+                const float* bq = tail + h * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
+                const float bv = tail[32 + c];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { kk[i] = 0.f; vv[i] = bv; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    if (i < 6) q = mfma16<F16>(wr[i % 6], xb[i], q);
+                    else if (i < 12) kk = mfma16<F16>(wr[i % 6], xb[i - 6], kk);
+                    else vv = mfma16<F16>(xb[i - 12], wr[i % 6], vv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i + 6 < 18) {
+                        wr[i % 6] = lfrag<F16>(blk, i + 6, lane);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (i == 8) {
+                        qb[0] = pack_half<F16>(q, 0);
+                        qb[1] = pack_half<F16>(q, 1);
+                        if (h == 0) { qb[1][5] = (ope)0.0f; qb[1][6] = (ope)(-30000.0f); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (i == 14) {
+                        if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                        *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                        *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
+            }
+#elif TSF_QKV_PIPE == 2
+            {
+                // six-fragment buffers, each requested a whole chain ahead and pinned there: A = Wq, then Wv; B = Wk
+                op8 wA[6], wB[6];
+                auto load6 = [&](op8 (&w)[6], int f0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) w[k] = lfrag<F16>(blk, f0 + k, lane);
+                };
+                load6(wA, 0);
+                f32x16 q;
+                const float* bq = tail + h * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
+                const float bv = tail[32 + c];
+                __builtin_amdgcn_sched_barrier(0);
+                q = mfma16<F16>(wA[0], xb[0], q);
+                __builtin_amdgcn_sched_barrier(0);
+                load6(wB, 6);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 1; k < 6; ++k) q = mfma16<F16>(wA[k], xb[k], q);
+                __builtin_amdgcn_sched_barrier(0);
+                load6(wA, 12);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 kk;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kk[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) kk = mfma16<F16>(wB[k], xb[k], kk);
+                qb[0] = pack_half<F16>(q, 0);
+                qb[1] = pack_half<F16>(q, 1);
+                if (h == 0) { qb[1][5] = (ope)0.0f; qb[1][6] = (ope)(-30000.0f); }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 vv;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vv[i] = bv;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) vv = mfma16<F16>(xb[k], wA[k], vv);
+                if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
+            }
+#else
             {
                 // the 18 weight fragments are written as two rolling 3-fragment buffers (reads of the batch after the next issued
                 // behind each batch's MFMAs); the order is a hint -- pinning it with scheduling fences (TSF_BATCH_FRAGS=1) costs
@@ -279,7 +421,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
 #pragma unroll
                     for (int k = 0; k < 3; ++k) w[k] = lfrag<F16>(blk, f0 + k, lane);
                 };
-                auto fence = [&]() { if (TSF_BATCH_FRAGS) __builtin_amdgcn_sched_barrier(0); };
+                auto fence = [&]() { if (TSF_BATCH_FRAGS || TSF_QKV_PIPE == 1) __builtin_amdgcn_sched_barrier(0); };
                 load3(wa, 0);
                 load3(wb, 3);
                 f32x16 q;
@@ -319,7 +461,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) vv = mfma16<F16>(xb[k], wa[k], vv);
-                if (h == 0) { kk[13] = 1.0f; kk[14] = tok_ok ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
                 *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
                 *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
                 fence();
@@ -328,9 +470,12 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
                 *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
+#endif
             TSF_PRIO_CHAIN(0);
+            TSF_STAMP(2 + 5 * hd);
             // K/V fragments visible to every wave; the in-flight weight DMA is NOT drained here
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TSF_STAMP(3 + 5 * hd);
 
             // ---- one pass over the key tiles: S^T = K Q^T - shift, P = exp2(S^T), O^T += V^T P^T
             f32x16 zero;
@@ -465,6 +610,51 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             //  profiles/r04_a_enc_ab_*.log.)
             auto fast_step = [&](f32x16& cur, f32x16& nxt, int kt, TileMask& tm, auto has_next) {
                 constexpr bool NEXT = decltype(has_next)::value;
+#if TSF_ATTN_IL
+                // Interleaved order (round 5): a wave issues in order, so a matrix product right behind the product it depends on, or right behind the
+                // packs that feed it, stalls the wave's whole instruction stream for the product's 32 cycles.  Here every product has >= 32 cycles of
+                // independent vector work behind it: score product 1 | second half of the exponentials + row sums | score product 2 (needs 1) |
+                // first eight selects + packs | P V product 1 | last eight selects + packs | P V product 2 (needs 1).  Same arithmetic, same order
+                // inside every chain: bit-identical results.
+                if constexpr (NEXT) {
+                    const op8 k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane), k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane);
+                    const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) cur[i] = __builtin_amdgcn_exp2f(cur[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = mfma16<F16>(k0, qb[0], zero);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 8; i < 16; ++i) cur[i] = __builtin_amdgcn_exp2f(cur[i]);
+                    if constexpr (drop) row_sums(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = mfma16<F16>(k1, qb[1], nxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
+                    }
+                    const bf16x8 p0 = pack_half<false>(cur, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    o = mfma16<false>(v0, p0, o);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (drop) {
+#pragma unroll
+                        for (int i = 8; i < 16; ++i) cur[i] = __builtin_amdgcn_inverse_ballot_w64(tm.w[i]) ? cur[i] : 0.f;
+                        // (the last fragment read of the step is waited for HERE: behind the scalar loads below, a wait for it would be a wait
+                        //  for them as well -- they return out of order -- and expose their whole latency in every step)
+                        asm volatile("" :: "v"(v1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        tm = load_mask(kt + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const bf16x8 p1 = pack_half<false>(cur, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    o = mfma16<false>(v1, p1, o);
+                    return;
+                }
+#endif
                 const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
                 op8 k0, k1;
                 if constexpr (NEXT) {
@@ -476,8 +666,11 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 if constexpr (drop) row_sums(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (NEXT) {
-                    nxt = mfma16<F16>(k0, qb[0], zero);
-                    nxt = mfma16<F16>(k1, qb[1], nxt);
+                    if (TSF_ABLATE & 256) { asm volatile("" :: "v"(k0), "v"(k1)); nxt = cur; }
+                    else {
+                        nxt = mfma16<F16>(k0, qb[0], zero);
+                        nxt = mfma16<F16>(k1, qb[1], nxt);
+                    }
                 }
                 if constexpr (drop) {
 #pragma unroll
@@ -489,8 +682,11 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                     }
                 }
                 const bf16x8 p0 = pack_half<false>(cur, 0), p1 = pack_half<false>(cur, 1);
-                o = mfma16<false>(v0, p0, o);
-                o = mfma16<false>(v1, p1, o);
+                if (TSF_ABLATE & 256) { asm volatile("" :: "v"(p0), "v"(p1), "v"(v0), "v"(v1)); }
+                else {
+                    o = mfma16<false>(v0, p0, o);
+                    o = mfma16<false>(v1, p1, o);
+                }
             };
             // The LAST key tile when only its first 8 * NG keys exist (P = 168: 8 of 32, NG = 1; P = 336: 16, NG = 2).  Keys 8 g .. 8 g + 7 are
             // accumulator registers 4 g .. 4 g + 3 of both lane halves (tsformer_layout.h), and the probability of a padded key is exactly 0
@@ -498,9 +694,10 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // k-step of the P V product -- are skipped: same bits, 3/4 (1/2) of this tile's vector work less.
             auto fast_last = [&](f32x16& cur, int kt, TileMask& tm, auto groups) {
                 constexpr int NG = decltype(groups)::value;
-                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane);
+                const int lane_l = fresh_lane_id();          // (as a value kept alive from the kernel's start the address below lands in scratch memory)
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane_l);
                 bf16x8 v1;
-                if constexpr (NG > 2) v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                if constexpr (NG > 2) v1 = lfrag<false>(vbuf, kt * 2 + 1, lane_l);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) cur[i] = i < 4 * NG ? ((TSF_ABLATE & 1) ? cur[i] : __builtin_amdgcn_exp2f(cur[i])) : 0.f;
@@ -543,7 +740,14 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 int kt = 0;
 #pragma unroll 1
                 for (; kt + 2 < nkt; kt += 2) {             // both tiles of the pair have a successor
+                    if (TSF_PROGRESS_PRIO == 1) prio_level(3 - (kt * 4) / nkt);
+                    if (TSF_PROGRESS_PRIO == 2) prio_level(((kt + (wave >> 2)) % 3 == 0) ? 1 : 0);                 // round-robin token per step
+                    if (TSF_PROGRESS_PRIO == 3) prio_level(2 * (kt * 2 < nkt ? 1 : 0) + (((kt + (wave >> 2)) % 3 == 0) ? 1 : 0));
+                    if (TSF_PROGRESS_PRIO == 4) prio_level(3 - (kt * 4) / nkt);
                     fast_step(sa, sb, kt, tm, Yes{});
+                    if (TSF_PROGRESS_PRIO == 2) prio_level(((kt + 1 + (wave >> 2)) % 3 == 0) ? 1 : 0);
+                    if (TSF_PROGRESS_PRIO == 3) prio_level(2 * (kt * 2 < nkt ? 1 : 0) + (((kt + 1 + (wave >> 2)) % 3 == 0) ? 1 : 0));
+                    if (TSF_PROGRESS_PRIO == 4) prio_level(3 - ((kt + 1) * 4) / nkt);
                     fast_step(sb, sa, kt + 1, tm, Yes{});
                 }
                 if (kt + 1 < nkt) {
@@ -552,8 +756,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 } else {
                     last_step(sa, sb, kt, tm);
                 }
+                if (TSF_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(0);
                 den = denominator();
-                redo = __builtin_amdgcn_ballot_w64(!(den < TSF_LIMIT)) != 0;
+                redo = (TSF_ABLATE & 256) ? false : __builtin_amdgcn_ballot_w64(!(den < TSF_LIMIT)) != 0;
                 if (redo) {
                     skip_fast = true;                // the other heads of this layer see the same tokens: straight to the re-shifting loop
 #pragma unroll
@@ -593,6 +798,13 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 }
             }
             if (redo) den = denominator();
+            TSF_STAMP(4 + 5 * hd);
+            op8 wo[6];
+            if (TSF_QKV_PIPE >= 2) {           // the out-projection's fragments are requested in front of the normalisation's vector work
+#pragma unroll
+                for (int f = 0; f < 6; ++f) wo[f] = lfrag<F16>(blk, 18 + f, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const float inv = 1.0f / den;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] *= inv;
@@ -600,9 +812,10 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // ---- out-projection of this head accumulates onto the residual
             TSF_PRIO_CHAIN(1);
             {
-                op8 wo[6];
+                if (TSF_QKV_PIPE < 2) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) wo[f] = lfrag<F16>(blk, 18 + f, lane);
+                    for (int f = 0; f < 6; ++f) wo[f] = lfrag<F16>(blk, 18 + f, lane);
+                }
                 if (TSF_BATCH_FRAGS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -611,6 +824,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 }
             }
             TSF_PRIO_CHAIN(0);
+            TSF_STAMP(5 + 5 * hd);
         }  // heads
         if constexpr (drop) {
             // dropout1 on (attention output + b_o); residual re-read from its 16-bit operand copy
@@ -625,7 +839,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
+        TSF_STAMP(21);
         blk = stage_begin(g, PAIR ? 3 : 1);
+        TSF_STAMP(22);
         tail = (const float*)(blk + TSF_TAIL);
         {
 #pragma unroll
@@ -638,10 +854,105 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = drop ? b2[t * 16 + i] * keep : acc[t][i] + b2[t * 16 + i];
         }
+#if TSF_FFN_PIPE
+        // Groups of NC chunks between two stage boundaries (PAIR: four chunks = two blocks, else two).  Inside a group the fragment reads run one
+        // matrix-product group ahead of their use: U (the six W1 fragments of chunk q + 1) is requested behind the W1 chain of chunk q and has
+        // the chunk's vector work and its W2 products to arrive; D (W2 of chunk q) is requested behind the first product of the chunk's W1 chain
+        // and has the rest of the chain and the vector work.  The scheduling fences keep the compiler from sinking the reads back to their uses.
+        {
+        constexpr int NBLK = PAIR ? 2 : 1, NC = 2 * NBLK;
+#pragma unroll 1
+        for (int j = 0; j < 6; j += NBLK, g += NBLK) {
+            if (j > 0) {
+                TSF_STAMP(21 + 2 * j);
+                blk = stage_begin(g, PAIR ? 3 : 1);
+                TSF_STAMP(22 + 2 * j);
+                if (TSF_PERSIST && PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                    issue_fill(0);
+                    first_block_requested = true;
+                }
+            }
+            const char* blk2 = PAIR ? slot_of(g + 1) : blk;
+            tail = (const float*)(blk2 + TSF_TAIL);                 // after the loop: the LN2 parameters ride in the last block
+            op8 U[6], D[6];
+            f32x16 hh;
+            unsigned long long mw[16];
+            auto cblk = [&](int q) -> const char* { return q < 2 ? blk : blk2; };
+            auto load_U = [&](int q) {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) U[ks] = lfrag<F16>(cblk(q), (q & 1) * 12 + ks, lane);
+            };
+            auto load_D = [&](int q) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) D[f] = lfrag<F16>(cblk(q), (q & 1) * 12 + 6 + f, lane);
+            };
+            auto load_b1 = [&](int q) {
+                const float* b1 = (const float*)(cblk(q) + TSF_TAIL) + ((q & 1) * 2 + h) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hh[i] = b1[i];
+            };
+            auto load_mw = [&](int q) {
+                if constexpr (drop) {
+                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + q) * 16u);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mw[i] = mp[i];
+                }
+            };
+            load_U(0);
+            load_b1(0);
+            load_mw(0);
+            __builtin_amdgcn_sched_barrier(0);
+            TSF_PRIO_CHAIN(1);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                if (TSF_PROGRESS_PRIO) prio_level(3 - (j * 2 + q) / 3);
+                // (scalar loads return out of order, so the wait in front of the chain's first product is for EVERYTHING in flight: the reads of
+                //  D are issued behind that product, not in front of it)
+                hh = mfma16<F16>(U[0], xb[0], hh);
+                __builtin_amdgcn_sched_barrier(0);
+                load_D(q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 1; ks < 6; ++ks) hh = mfma16<F16>(U[ks], xb[ks], hh);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < NC) load_U(q + 1);
+                // every fragment of D has to be here BEFORE the next scalar load is issued: with scalar loads in flight any later wait for an LDS
+                // read becomes a wait for everything (they return out of order).  The empty statement below makes the compiler wait for D's
+                // last fragment now -- LDS reads return in order, so that is lgkmcnt(6) with U still in flight.
+                asm volatile("" :: "v"(D[5]));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (drop) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) hh[i] = __builtin_amdgcn_inverse_ballot_w64(mw[i]) ? hh[i] : 0.f;
+                    if (q + 1 < NC) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_mw(q + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const op8 hb0 = relu_packed<F16>(pack_half<F16>(hh, 0)), hb1 = relu_packed<F16>(pack_half<F16>(hh, 1));
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < NC) {
+                    load_b1(q + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    acc[t] = mfma16<F16>(D[t * 2], hb0, acc[t]);
+                    acc[t] = mfma16<F16>(D[t * 2 + 1], hb1, acc[t]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TSF_PRIO_CHAIN(0);
+        }
+        }
+#else
 #pragma unroll 1
         for (int j = 0; j < ((TSF_ABLATE & 64) ? 1 : 6); ++j, g += ((TSF_ABLATE & 64) ? 6 : 1)) {
             if (j > 0) {
+                if (!(PAIR && (j & 1))) TSF_STAMP(21 + 2 * j);
                 blk = (PAIR && (j & 1)) ? slot_of(g) : stage_begin(g, PAIR ? 3 : 1);      // PAIR: odd blocks arrived with their predecessor
+                if (!(PAIR && (j & 1))) TSF_STAMP(22 + 2 * j);
                 tail = (const float*)(blk + TSF_TAIL);
                 if (TSF_PERSIST && PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
                     issue_fill(0);            // slot 0 (block g - 2) is free since this stage's barrier: the next sequence's first block
@@ -651,6 +962,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             TSF_PRIO_CHAIN(1);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
+                if (TSF_PROGRESS_PRIO) prio_level(3 - (j * 2 + cc) / 3);
                 // both weight fragment sets of the chunk and its keep-mask words are requested up front
                 op8 wu[6], wd[6];
 #pragma unroll
@@ -698,12 +1010,16 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             }
             TSF_PRIO_CHAIN(0);
         }
+#endif
+        if (TSF_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(0);
+        TSF_STAMP(34);
         if constexpr (drop) {
             const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 1) * 16u),
                                     mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
         }
         layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
+        TSF_STAMP(35);
 #pragma unroll
         for (int t = 0; t < 3; ++t) xT[t] = acc[t];
     }  // layers
@@ -811,14 +1127,14 @@ int launch_enc_tg(const EncArgs& a, hipStream_t st) {
     static bool raised[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!raised[dev & 15]) {
+    if (!__atomic_load_n(&raised[dev & 15], __ATOMIC_ACQUIRE)) {          // (two host threads racing here both set the same attribute: harmless)
         hipError_t e = hipFuncSetAttribute((const void*)tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             step_set_error("tsformer_encode: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
             return STEP_ERR_HIP;
         }
-        raised[dev & 15] = true;
+        __atomic_store_n(&raised[dev & 15], true, __ATOMIC_RELEASE);
     }
     const int grid = (TSF_PERSIST > 0 && a.S > TSF_PERSIST) ? TSF_PERSIST : a.S;
     tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, a.nkt * 64, lds, st>>>(a);
@@ -877,6 +1193,16 @@ extern "C" int step_dropout_pool_fill_dyn(uint64_t* pool, long words, float drop
     STEP_LAUNCH_CHECK("step_dropout_pool_fill");
     return STEP_OK;
 }
+
+#if TSF_TIMING
+// timing builds only (tools/enc_ab.cpp): buffer of [ceil(S / 64)][16 waves][4 layers][TSF_NSTAMP] s_memtime stamps, written by the workgroups
+// whose sequence index is 7 mod 64; NULL switches the stamps off
+extern "C" int step_tsformer_set_timing(unsigned long long* buf) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_tsf_timing), &buf, sizeof(buf));
+    return e == hipSuccess ? STEP_OK : STEP_ERR_HIP;
+}
+extern "C" int step_tsformer_timing_stamps(void) { return TSF_NSTAMP; }
+#endif
 
 extern "C" long step_tsformer_dropout_words(int L, int depth) {
     if (L <= 0 || L % TSF_PATCH != 0 || depth < 1) return 0;

@@ -32,6 +32,9 @@ from .optim import FusedAdamClip
 from .step_loss import step_loss_native
 
 
+_KEEP = object()          # GraphedTrainStep.__call__(epoch=...): leave the epoch as it is
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_batch, scaler=(0.0, 1.0), epoch=1, null_val=0.0, warmup=3, seed=None):
         if not isinstance(optimizer, FusedAdamClip):
@@ -103,7 +106,12 @@ class GraphedTrainStep:
         self.dyn.view(torch.float32)[index:index + 1].fill_(float(value))
 
     # ------------------------------------------------------------------ per-step API
-    def __call__(self, hist=None, long_hist=None, fut=None):
+    def __call__(self, hist=None, long_hist=None, fut=None, epoch=_KEEP):
+        # a scheduler (the reference's MultiStepLR, STEP_PEMS04.py:98-102) edits param_groups[0]["lr"] on the host: follow it here rather than
+        # rely on the caller to remember set_lr() -- one float compare per replay; the epoch (graph-term coefficient) can ride along
+        self.set_lr(self.opt.param_groups[0]["lr"])
+        if epoch is not _KEEP:
+            self.set_epoch(epoch)
         if hist is not None:
             self.hist.copy_(hist, non_blocking=True)
         if long_hist is not None:

@@ -52,6 +52,16 @@ class FusedAdamClip(torch.optim.Optimizer):
             raise RuntimeError("FusedAdamClip: the model's flat parameter buffer changed after the optimizer was created "
                                f"({self.flat.numel()} parameters here, {g.numel()} gradient values): build the optimizer after "
                                "enable_native_data_parallel() / flatten_parameters()")
+        if hasattr(self.model, "_pt_params"):
+            # pre-training TSFormer: whatever averaged the gradients (DDP bucket views, a hand-written all-reduce over p.grad) must have acted
+            # on THIS buffer -- autograd may have cloned the views, DDP may have swapped in its own.  First and last parameter are enough
+            # to tell (the buffer is adopted or replaced as a whole).
+            ps = self.model._pt_params()
+            lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+            for q in (ps[0], ps[-1]):
+                if q.grad is not None and not (lo <= q.grad.data_ptr() < hi):
+                    raise RuntimeError("FusedAdamClip: a parameter's .grad is not a view of the native flat gradient buffer (cloned by autograd or "
+                                       "re-homed by a DDP wrapper): reduce model._flat_grad itself, or step with torch.optim.Adam")
         pg = self.param_groups[0]
         self.step_count += 1
         extra = None

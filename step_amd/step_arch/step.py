@@ -628,7 +628,15 @@ class STEP(nn.Module):
 
     def _apply(self, fn, recurse=True):
         self._zg_params = None
-        return super()._apply(fn, recurse)
+        out = super()._apply(fn, recurse)
+        flat = self._flat_param
+        if flat is not None:
+            # (see TSFormer._apply) parameters re-homed by .cuda() / .to() / .double(): the flat buffer is stale
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+            if not all(lo <= v.data_ptr() < hi and v.dtype == flat.dtype for _, v in self._trainable()):
+                self._flat_param = None
+                self._flat_grad = None
+        return out
 
     def load_state_dict(self, *a, **kw):
         self._zg_params = None

@@ -396,6 +396,12 @@ class _PretrainFunction(torch.autograd.Function):
         _BF16 = model.matmul_precision == "bf16"
         S, P, Pu, Pm = sv["dims"]
         p, seed = sv["p"], sv["seed"]
+        fz = sv.get("fz")
+        if fz is not None and fz["pool"] is not None and model._pt_pool_tag != (int(seed), float(p)):
+            # another training-mode forward has refilled the model's keep-mask pool since this one (fwd-fwd-bwd-bwd, a no_grad pass in
+            # between, two views): the feed-forward backward recomputes its hidden-layer masks from the pool, so the pool of THIS
+            # forward is rebuilt first -- the fill is a pure function of (seed, p)
+            fz["pool"], fz["words"] = model._pt_pool(dr.device, p, seed)
         P_ = {n: prm for n, prm in zip(model._pt_names, model._pt_params())}
         flat, G = model._pt_grad_buffers()
         dev = dr.device
@@ -493,6 +499,7 @@ class TSFormer(nn.Module):
         self.fused_ln = os.environ.get("STEP_PT_FUSED_LN", "1") != "0"           # residual add + dropout + LayerNorm as the output stage of the forward row kernels
         self._proj_pack_bufs = None
         self._pt_pool_buf = None
+        self._pt_pool_tag = None
         self._packed = None
         self._packed_key = None
         self._plist = None
@@ -519,7 +526,16 @@ class TSFormer(nn.Module):
     # ------------------------------------------------------------------ packed operand cache
     def _apply(self, fn, recurse=True):
         self._plist = None
-        return super()._apply(fn, recurse)
+        out = super()._apply(fn, recurse)
+        flat = self._flat_param
+        if flat is not None:
+            # .cuda() / .to(device) / .double() re-home p.data: the flat buffer (and an optimizer built on it) would go on updating
+            # storage the forward no longer reads.  Unchanged storage (a no-op .to()) keeps the buffer.
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+            if not all(lo <= q.data_ptr() < hi and q.dtype == flat.dtype for q in self._pt_params()):
+                self._flat_param = None
+                self._flat_grad = None
+        return out
 
     def _pack_key(self, P):
         ps = self._plist                      # the Parameter objects of the tree, listed once (the walk costs 0.1 ms per step)
@@ -665,6 +681,7 @@ class TSFormer(nn.Module):
         if self._pt_pool_buf is None or self._pt_pool_buf.device != device:
             self._pt_pool_buf = torch.empty(PT_POOL_WORDS + 16, dtype=torch.int64, device=device)
         _lib.call("step_dropout_pool_fill", _lib.ptr(self._pt_pool_buf), PT_POOL_WORDS, float(p), int(seed) ^ 0x5EED_F00D, _lib.stream())
+        self._pt_pool_tag = (int(seed), float(p))          # whose masks the buffer holds (checked by the backward)
         return self._pt_pool_buf, PT_POOL_WORDS
 
     def _next_seed(self):

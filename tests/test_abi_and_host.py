@@ -379,3 +379,8 @@ def test_tsformer_flatten_parameters_keeps_the_state_dict_and_shares_one_buffer(
     m._backward_count = 3
     m.zero_grad()
     assert m._backward_count == 0
+    # re-homing the parameters (.double(), .to(another device)) drops the stale flat buffer; a no-op .to() keeps it
+    m.to("cpu")
+    assert m._flat_param is flat
+    m.double()
+    assert m._flat_param is None and m._flat_grad is None

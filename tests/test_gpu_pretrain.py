@@ -768,3 +768,48 @@ def test_bf16_mode_fused_row_kernels_against_the_layer_by_layer_path():
     print("bf16 mode vs exact f32 (reconstruction, whole gradient):", e, " fused vs layer-by-layer:", d)
     assert max(e["fused"][0], e["layerwise"][0]) < 3e-2 and max(e["fused"][1], e["layerwise"][1]) < 0.15
     assert d[0] < 5e-3 and d[1] < 2e-2          # (measured 1.6e-3 / 5.3e-3)
+
+
+def test_two_forwards_before_the_first_backward_keep_their_own_dropout_masks():
+    """fwd(A), fwd(B), bwd(A), bwd(B) in training mode (bf16 mode, fused feed-forward): the feed-forward backward recomputes its hidden-layer
+    keep decisions from the model's ONE keep-mask pool, which the second forward has refilled -- the backward of A must see A's pool again
+    (it is rebuilt from A's saved seed, `_pt_pool_tag`).  Reference order fwd(A), bwd(A), fwd(B), bwd(B) with the same seeds gives the
+    same gradients (up to the summation order of the reductions); before the guard the first backward silently used B's masks."""
+    g = load_golden("tsformer_pretrain_tiny")
+    x = g["in.x"].cuda()
+    xb = torch.roll(x, 1, dims=0) * 0.9 + 0.05
+    um, mk = g["in.unmasked"].tolist(), g["in.masked"].tolist()
+
+    def grads(m):
+        out = torch.cat([p.grad.reshape(-1) for _, p in sorted(m.named_parameters()) if p.grad is not None]).clone()
+        m.zero_grad(set_to_none=True)
+        return out
+
+    def run(interleaved):
+        m = _model(g, x.shape[1])
+        m.train()
+        m.dropout_p = 0.3
+        m.matmul_precision = "bf16"
+        m.mask.forward = lambda: (um, mk)
+        m._seed_ctr2 = 0                                   # forward A draws seed 1, forward B seed 2 in either order
+        loss = lambda r, l: O.masked_mae(r * 150.0 + 200.0, l * 150.0 + 200.0, 0.0)
+        ra, la = m(history_data=x, future_data=None, batch_seen=0, epoch=1)
+        if interleaved:
+            rb, lb = m(history_data=xb, future_data=None, batch_seen=0, epoch=1)
+            loss(ra, la).backward()
+            ga = grads(m)
+        else:
+            loss(ra, la).backward()
+            ga = grads(m)
+            rb, lb = m(history_data=xb, future_data=None, batch_seen=0, epoch=1)
+        loss(rb, lb).backward()
+        gb = grads(m)
+        torch.cuda.synchronize()
+        return ga.cpu(), gb.cpu(), ra.detach().cpu(), rb.detach().cpu()
+
+    a0, b0, ra0, rb0 = run(False)
+    a1, b1, ra1, rb1 = run(True)
+    assert torch.equal(ra0, ra1) and torch.equal(rb0, rb1)             # same seeds, same forwards
+    ea, eb = rel_l2(a1, a0), rel_l2(b1, b0)
+    print(f"fwd-fwd-bwd-bwd vs fwd-bwd-fwd-bwd, whole gradient: first {ea:.1e}, second {eb:.1e}")
+    assert ea < 1e-4 and eb < 1e-4

@@ -42,6 +42,7 @@ struct Lib {
     std::string tag;
     std::string env_key, env_val;            // optional `tag=path@KEY=VAL`: KEY is set to VAL around every launch of this entry (the library reads its knobs per launch)
     int abi;
+    void* handle = nullptr;
     enc4_fn e4; enc3_fn e3; enc5_fn e5; fill_fn fill; err_fn err;
     unsigned int* counter = nullptr;         // ABI 5: device counter of softmax units on the re-shifting (slow) path
     // unified call: flags bit0 f16, bit1 always-reshift (ABI 4 only)
@@ -91,6 +92,7 @@ int main(int argc, char** argv) {
         l.err = (err_fn)dlsym(h, "step_last_error");
         if (!abi || !l.err) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
         l.abi = abi();
+        l.handle = h;
         l.e4 = (enc4_fn)dlsym(h, "step_tsformer_encode"); l.e3 = (enc3_fn)l.e4; l.e5 = (enc5_fn)l.e4;
         l.fill = (fill_fn)dlsym(h, "step_dropout_pool_fill");
         if (!l.e4 || (l.abi >= 4 && !l.fill)) { printf("[%s] missing symbol\n", l.tag.c_str()); return 1; }
@@ -224,6 +226,41 @@ int main(int argc, char** argv) {
                    libs[li].tag.c_str(), fl ? "f16 " : "bf16", mode >= 3 ? " bench-like data" : "", p, med, v.front(), v.back(), v.size(), S, P, flop / med / 1e9, flop / med / 1e9 / 25.0,
                    slow[li], S * 4 * 4 * ((P + 31) / 32));
         }
+    }
+    // ---------------------------------------------------------------- phase stamps (libraries built with -DTSF_TIMING=1)
+    for (const Lib& l : libs) {
+        typedef int (*sett_fn)(unsigned long long*);
+        typedef int (*nst_fn)(void);
+        sett_fn sett = (sett_fn)dlsym(l.handle, "step_tsformer_set_timing");
+        nst_fn nst = (nst_fn)dlsym(l.handle, "step_tsformer_timing_stamps");
+        if (!sett || !nst) continue;
+        const int NST = nst(), groups = (S + 63) / 64;
+        const size_t nw = (size_t)groups * 16 * 4 * NST;
+        unsigned long long* d_t;
+        HIPCK(hipMalloc(&d_t, nw * 8));
+        for (int p10 = 0; p10 < 2; ++p10) {           // dropout off / on, bench-like weights and series
+            const float p = p10 ? 0.1f : 0.f;
+            if (p > 0) l.fill(d_pool2, words2, p, 4242, st);
+            for (int rep = 0; rep < 3; ++rep) {       // the third launch is the one that is kept
+                HIPCK(hipMemsetAsync(d_t, 0, nw * 8, st));
+                HIPCK(hipStreamSynchronize(st));
+                if (sett(rep == 2 ? d_t : nullptr)) { printf("set_timing failed\n"); return 1; }
+                int rc = l.run(d_like, S, L, d_pack[2], (long)pack[2].size(), 1, d_hid16, nullptr, d_last, d_sqn, p, d_pool2, words2, 900 + rep, st);
+                if (rc) { printf("[%s] encode failed: %s\n", l.tag.c_str(), l.err()); return 1; }
+                HIPCK(hipStreamSynchronize(st));
+            }
+            sett(nullptr);
+            std::vector<unsigned long long> ht(nw);
+            HIPCK(hipMemcpy(ht.data(), d_t, nw * 8, hipMemcpyDeviceToHost));
+            const std::string fn = std::string(getenv("ENC_AB_OUT") ? getenv("ENC_AB_OUT") : ".") + "/enc_timing_" + l.tag + (p10 ? "_drop" : "_nodrop") + "_p" + std::to_string(P) + ".bin";
+            FILE* f = fopen(fn.c_str(), "wb");
+            if (f) {
+                const int hdr[4] = {groups, 16, 4, NST};
+                fwrite(hdr, 4, 4, f); fwrite(ht.data(), 8, nw, f); fclose(f);
+                printf("[%s] phase stamps of %d workgroups -> %s\n", l.tag.c_str(), groups, fn.c_str());
+            }
+        }
+        HIPCK(hipFree(d_t));
     }
     // sanity of the last dropout-on output of the last library: LayerNorm output, mean square ~1 per feature
     {

@@ -55,13 +55,17 @@ def main():
     for P in (336, 168):
         fixtures(O, TP, TSFormer, DH, P)
     subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-o", os.path.join(OUT, "enc_ab"), os.path.join(ROOT, "tools", "enc_ab.cpp"), "-ldl"])
-    for spec in sys.argv[1:] or ["default"]:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(spec):
         if "@" in spec:
             name, rev = spec.split("@", 1)
-            print(build_variant(name, [], rev))
-        else:
-            name, _, d = spec.partition(":")
-            print(build_variant(name, [x for x in d.split(",") if x]))
+            return build_variant(name, [], rev)
+        name, _, d = spec.partition(":")
+        return build_variant(name, [x for x in d.split(",") if x])
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:          # one hipcc per variant, in parallel
+        for lib in ex.map(one, sys.argv[1:] or ["default"]):
+            print(lib)
     print(sorted(os.listdir(OUT)))
 
 
