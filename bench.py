@@ -33,7 +33,11 @@ import time
 # torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
 # Only when bench.py IS the program: a process that imports it as a module (the tests do, for the configuration table) keeps its own
 # runtime settings -- a captured-graph replay (step_amd.GraphedTrainStep) crashes inside hipGraphLaunch with two hardware queues.
-if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--force-process-group" not in sys.argv and "--graph-child" not in sys.argv:
+# Round 5: the one-rank process-group runs (--force-process-group) take the same setting -- their extra cost in round 4 was the step's second
+# stream landing on the main stream's hardware queue (RCCL / torch.distributed create streams of their own), not the queue count; the streams
+# are now chosen with a concurrency probe (step_arch/step.py _concurrent_stream) and two queues win there too: 4.36 vs 4.44 ms
+# (profiles/r05_j_dp_one_rank.log).  Real multi-rank runs keep the runtime's default: main, side / aux and the all-reduce's stream overlap.
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--graph-child" not in sys.argv:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np  # noqa: E402
@@ -253,6 +257,55 @@ def cpu_baseline(cfg, data, seed=0, warm=2, timed=5, two_threads=True):
     return out
 
 
+def cpu_baseline_reference(cfg, data, warm=1, timed=3):
+    """The reference's OWN modules (kind "reference") timed on this host's cores, when its sources are here -- /root/reference in the build
+    container, oracle/_ref/reference on a GPU box after tools/stage_reference.sh: step_arch.STEP.forward + step_loss on re-scaled outputs +
+    backward + clip_grad_norm_(3.0) + Adam (the training step of step/STEP_PEMS04.py with easytorch's Runner.backward), fp32, train mode,
+    ONE window per step of the same synthetic workload; `warm` + `timed` steps on all cores (median), then one step on two threads (what
+    step/run.py:10 ships).  Returns None where the reference cannot run: no sources, or a graph it cannot build (the [N^2, N] one-hot
+    matrices, discrete_graph_learning.py:81-89, need 2 x N^3 x 4 bytes: 275 GB each at N = 4096)."""
+    from oracle.reference_loader import reference_root
+    N, L, Ttr = cfg["N"], cfg["L"], cfg["T_train"]
+    if reference_root() is None or N > 1024:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden as MG
+    ref = MG.import_reference()
+    step_loss = ref[5]
+    torch.manual_seed(0)
+    model = MG.build_step(ref, N, L, Ttr, data, cfg["k"])      # the reference's classes, attribute by attribute (its constructor reads files by dataset name)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)
+    d = torch.from_numpy(data)
+
+    def one_step(i):
+        t = L + 17 + (301 * i) % (data.shape[0] - L - 40)
+        hist, fut, longh = d[t - 12:t][None], d[t:t + 12][None], d[t - L:t][None]
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=1)
+        loss = step_loss(pred[..., [0]] * 150.0 + 200.0, fut[..., [0]] * 150.0 + 200.0, theta, knn, coef, null_val=0.0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=3.0)
+        opt.step()
+        return time.perf_counter() - t0
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    for i in range(warm):
+        one_step(i)
+    ts = sorted(one_step(warm + i) for i in range(timed))
+    med = ts[len(ts) // 2]
+    torch.set_num_threads(2)
+    t2 = one_step(warm + timed)
+    torch.set_num_threads(cores)
+    return {"value": 1.0 / med, "unit": "windows/s", "cores": cores, "kind": "reference",
+            "sample": f"the reference's own step_arch.STEP + step_loss + backward + clip_grad_norm_ + Adam (sources: {reference_root()}), torch "
+                      f"{torch.__version__} CPU fp32, full training steps of 1 window of the same workload: {warm} warm-up + {timed} timed on "
+                      f"{cores} threads ({ts[0]:.1f} .. {med:.1f} .. {ts[-1]:.1f} s, median reported), 1 step on 2 threads ({t2:.1f} s)",
+            "two_threads": {"value": 1.0 / t2, "unit": "windows/s", "cores": 2}}
+
+
 def cpu_baseline_pretrain(cfg, data, seed=0, warm=1, timed=3):
     """Config C3's CPU baseline: the oracle's masked pre-training step (tsformer_pretrain + masked MAE on rescaled values + backward +
     clip 5.0 + Adam, reference step/TSFormer_PEMS-BAY.py:52-76) of ONE window (N sequences of L steps) on this host's cores."""
@@ -461,7 +514,7 @@ class StepBench:
         if DIST["on"]:
             # each rank keeps one time slice of the graph learner's global branch and of fc.weight (bf16 mode)
             self.model.enable_native_data_parallel(shard_graph_learner=args.matmul == "bf16" and not args.no_shard and not args.torch_optim,
-                                                   single_rank_collectives=world == 1)
+                                                   single_rank_collectives=world == 1, collectives=args.collectives)
         self.sharded = self.model.discrete_graph_learning._shard is not None
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         if args.torch_optim:
@@ -627,15 +680,17 @@ class StepBench:
         fo, fn, _ = lay["items"]["dgl.fc_w"]
         buf = torch.zeros(lay["total"], device=dev)
         reps = 5
+        nc = model._comm                        # the step's own communicator (RCCL C API), or None: torch.distributed
+        red = (lambda t: nc.allreduce_(t, average=True)) if nc is not None else (lambda t: dist.all_reduce(t))
         for _ in range(2):
-            dist.all_reduce(buf[:fo])          # (with time slices the fc chunk has a different length on every rank and is never reduced)
+            red(buf[:fo])          # (with time slices the fc chunk has a different length on every rank and is never reduced)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             if not self.sharded:
-                dist.all_reduce(buf[fo:fo + fn])
-            dist.all_reduce(buf[:fo])
+                red(buf[fo:fo + fn])
+            red(buf[:fo])
         e1.record()
         torch.cuda.synchronize()
         iso = e0.elapsed_time(e1) / reps
@@ -651,6 +706,8 @@ class StepBench:
                 "per_rank_exposed_wait_ms": [float(g[1]) for g in gathered],
                 "overlap_fraction": [float(1.0 - g[1] / g[0]) if float(g[0]) > 0 else None for g in gathered],
                 "small_collectives": small,
+                "collectives": ("rccl C API through libstep_hip (step_grad_allreduce_begin / _join, step_comm_allreduce), RCCL "
+                                + str(nc.version)) if nc is not None else "torch.distributed (" + str(dist.get_backend()) + ")",
                 "what": "isolated = the chunked all-reduces of the flat gradient alone; exposed = time the compute stream waits "
                         "for them at the end of backward (events around the waits), averaged over the timed steps; small_collectives = "
                         "count and exposed ms per step of the time-sliced graph learner's blocking sums"}
@@ -694,6 +751,9 @@ def main():
                          "broadcast, chunked async all-reduce, the time-sliced graph learner's small sums) through it, so that RCCL, its "
                          "stream and the event ordering against the step's streams run on a one-GPU box; leaves GPU_MAX_HW_QUEUES at the "
                          "runtime default unless set explicitly")
+    ap.add_argument("--collectives", default="auto", choices=["auto", "rccl", "torch"],
+                    help="data-parallel collectives of the step: RCCL C-API calls issued in stream order by libstep_hip (rccl; auto picks it on "
+                         "the nccl backend) or torch.distributed.all_reduce (torch)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -905,7 +965,11 @@ def main():
         if others is not None:
             out["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, data)
+            # the reference's own modules when their sources are on this box (tools/stage_reference.sh), with the oracle's figure next to it;
+            # otherwise the oracle ("port")
+            refb = cpu_baseline_reference(cfg, data)
+            port = cpu_baseline(cfg, data, warm=1 if refb else 2, timed=3 if refb else 5)
+            out["cpu_baseline"] = dict(refb, port=port) if refb else port
         print(json.dumps(out), flush=True)
     shutil.rmtree(workdir, ignore_errors=True)
     if DIST["on"]:

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear, step_pt_proj_wgrad, step_pt_embed_unmasked_*; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 9: step_comm_* / step_grad_allreduce* (data-parallel collectives on RCCL's C API); 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear, step_pt_proj_wgrad, step_pt_embed_unmasked_*; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -460,10 +460,43 @@ int step_loss_scaled_fwd_bwd_dyn(const float* pred, const float* real, long n_pr
                                  const float* theta, const float* prior, long n_adj, float null_val, double* work, float* loss,
                                  float* dpred, float* dtheta, const StepDynState* dyn, void* stream);
 
+/* ---------------------------------------------------------------- data-parallel collectives ---
+ * The exchange step of the path (SURVEY.md 8b "grad_allreduce(handle, stream, flat_grad*, n)", 8e): ONE gradient all-reduce (mean) per
+ * training step over the flat gradient buffer, plus -- with the graph learner cut into time slices (8f row 2) -- six small sums.  Replaces
+ * what torch.nn.parallel.DistributedDataParallel does for the reference when GPU_NUM > 1 (step/STEP_PEMS04.py:30, STEP_PEMS07.py:29,83,117,
+ * wrapped by easytorch's launcher): bucketed ncclAllReduce calls behind autograd hooks.  Here the calls are RCCL's C API in stream order:
+ * no work objects, no host synchronisation.  librccl is resolved with dlopen at the first call (the copy already in the process first).
+ * A communicator is a handle: created from a 128-byte unique id that rank 0 makes and the caller distributes (any side channel:
+ * torch.distributed's store, MPI, a file), destroyed explicitly.  Reductions are in place on the caller's buffers.
+ *   step_comm_available      1 when librccl could be loaded
+ *   step_comm_allreduce      buf <- sum / mean over the ranks, queued on `stream`
+ *   step_grad_allreduce      = step_comm_allreduce(f32, mean) of the flat gradient buffer on `stream`
+ *   step_grad_allreduce_begin / _join   the same OVERLAPPED with the rest of the backward: begin orders the reduction behind what is queued
+ *                            on `stream` and runs it on the communicator's own stream; join makes `stream` wait for every reduction begun
+ *                            since the last join (the fc weight gradient, 98 % of the bytes, is finished early in the backward) */
+#define STEP_COMM_ID_BYTES 128
+#define STEP_COMM_F32 0
+#define STEP_COMM_F64 1
+#define STEP_COMM_U8 2
+int step_comm_available(void);
+int step_comm_version(void);          /* RCCL's version code (0 when unavailable) */
+int step_comm_unique_id(void* id128);
+int step_comm_init_rank(const void* id128, int nranks, int rank, void** comm_out);
+int step_comm_destroy(void* comm);
+int step_comm_set_side_stream(void* comm, void* stream);      /* run the overlapped all-reduce on the caller's stream (kept by reference) */
+int step_comm_allreduce(void* comm, void* buf, long n, int dtype, int average, void* stream);
+int step_comm_broadcast(void* comm, void* buf, long n, int dtype, int root, void* stream);
+int step_grad_allreduce(void* comm, float* flat_grad, long n, void* stream);
+int step_grad_allreduce_begin(void* comm, float* flat_grad, long n, void* stream);
+int step_grad_allreduce_join(void* comm, void* stream);
+
 /* ---------------------------------------------------------------- self test --------------
  * Verifies on the device the MFMA operand/accumulator lane maps this library is built on
  * (cdna_hip_programming.md section 3).  out: int32[8] failure counters, all zero when ok. */
 int step_selftest_mfma(int32_t* out, void* stream);
+/* Set-up helper of the host side: *concurrent = 1 when work queued on the two streams overlaps on this device (the runtime maps streams
+ * onto a few hardware queues; two streams on one queue serialise).  Host-blocking: a 200 us probe. */
+int step_streams_concurrent(void* stream_a, void* stream_b, int* concurrent);
 
 #ifdef __cplusplus
 }

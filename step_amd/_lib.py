@@ -72,6 +72,7 @@ _SIGS = {
     "step_knn_graph": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "step_topk_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp]),
     "step_selftest_mfma": (_i, [_vp, _vp]),
+    "step_streams_concurrent": (_i, [_vp, _vp, ctypes.POINTER(_i)]),
     "step_dgl_global_saved_floats": (_l, [_i, _i]),
     "step_dgl_global_work_floats": (_l, [_i, _i, _i]),
     "step_dgl_global_forward": (_i, [_vp, _i, _i, _PD, _i, _f, _vp, _vp, _vp, _vp]),
@@ -138,6 +139,18 @@ _SIGS = {
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     "step_adam_clip_sharded": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp]),
+    # data-parallel collectives on RCCL's C API (csrc/comm.cpp)
+    "step_comm_available": (_i, []),
+    "step_comm_version": (_i, []),
+    "step_comm_unique_id": (_i, [_vp]),
+    "step_comm_init_rank": (_i, [_vp, _i, _i, ctypes.POINTER(_vp)]),
+    "step_comm_destroy": (_i, [_vp]),
+    "step_comm_set_side_stream": (_i, [_vp, _vp]),
+    "step_comm_allreduce": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "step_comm_broadcast": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "step_grad_allreduce": (_i, [_vp, _vp, _l, _vp]),
+    "step_grad_allreduce_begin": (_i, [_vp, _vp, _l, _vp]),
+    "step_grad_allreduce_join": (_i, [_vp, _vp]),
     # replayable steps: per-step scalars in a device-resident StepDynState (include/step_hip.h)
     "step_dyn_advance": (_i, [_vp, _vp]),
     "step_dropout_pool_fill_dyn": (_i, [_vp, _l, _f, _u64, _vp, _vp]),
@@ -150,8 +163,9 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
+COMM_F32, COMM_F64, COMM_U8, COMM_ID_BYTES = 0, 1, 2, 128
 
 
 def lib():

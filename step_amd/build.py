@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstep_hip.so")
-SOURCES = ["errors.cpp", "gemm.hip", "gemm_bf16.hip", "tsformer_encoder.hip", "knn.hip", "selftest.hip",
+SOURCES = ["errors.cpp", "comm.cpp", "gemm.hip", "gemm_bf16.hip", "tsformer_encoder.hip", "knn.hip", "selftest.hip",
            "dgl.hip", "dgl_conv_mfma.hip", "gwnet.hip", "optim.hip", "pretrain.hip", "pretrain_fused.hip"]
 
 
@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on " + s)
     if force or _newer(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -40,7 +40,51 @@ __global__ void selftest_kernel(int32_t* out) {
     if (l == 0) out[7] = 0x600DC0DE;
 }
 
+// ~us of wall time on one wave (s_memrealtime ticks at 100 MHz)
+__global__ void spin_kernel(long ticks, int* sink) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (sink && ticks < 0) *sink = 1;
+}
+
 }  // namespace
+
+// Do two streams run CONCURRENTLY on this device?  The HIP runtime multiplexes a process's streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES, four by default, handed out by least use): two streams that share a queue serialise, silently.  With a process group
+// in the process (RCCL and torch.distributed create streams of their own) the step's second stream has been seen to land on the main
+// stream's queue -- every kernel of the graph learner then waits for the encoder, +0.5 ms per step (profiles/r05_h_*, r05_i_*).  The
+// probe: a 200 us spin on `a`, an empty kernel + event on `b`; `b` finishing within 100 us of the spin's start means they overlap.
+// Host-blocking (synchronises both streams): for set-up code only.
+extern "C" int step_streams_concurrent(void* stream_a, void* stream_b, int* concurrent) {
+    STEP_REQUIRE(concurrent != nullptr, "streams_concurrent: null output");
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {          // (the first round also pays the kernels' load)
+        e = hipEventRecord(e0, a);
+        if (e != hipSuccess) break;
+        spin_kernel<<<1, 64, 0, a>>>(20000, nullptr);
+        spin_kernel<<<1, 64, 0, b>>>(0, nullptr);
+        e = hipEventRecord(e1, b);
+        if (e == hipSuccess) e = hipStreamSynchronize(a);
+        if (e == hipSuccess) e = hipStreamSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && rep == 1) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) {
+        step_set_error("streams_concurrent: %s", hipGetErrorString(e));
+        return STEP_ERR_HIP;
+    }
+    *concurrent = best < 0.1f ? 1 : 0;
+    return STEP_OK;
+}
 
 extern "C" int step_selftest_mfma(int32_t* out, void* stream) {
     STEP_REQUIRE(out != nullptr, "selftest: null output");

@@ -197,8 +197,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // only the four first-dispatched waves (one per SIMD) request the pieces: they are the ones that reach every barrier early and wait
             // there (49 % of their time, profiles/r05_a_encoder_phase_table.md), while a piece costs the last-arriving wave 100+ cycles of the
             // workgroup's critical path behind every stage boundary
-            if (wave < 4)
-                for (int pc = wave; pc < 25; pc += 4) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
+            const int nf = nkt < 4 ? nkt : 4;            // (workgroups of fewer than four waves: all of them)
+            if (wave < nf)
+                for (int pc = wave; pc < 25; pc += nf) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
             return;
         }
         for (int pc = wave; pc < 25; pc += nkt) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);

@@ -125,6 +125,7 @@ class GraphedTrainStep:
     def set_lr(self, lr):
         """the scheduler changed the learning rate (``torch.optim.lr_scheduler.MultiStepLR.step()`` on the optimizer, STEP_PEMS04.py:98-102)"""
         lr = float(lr)
+        self.opt.param_groups[0]["lr"] = lr          # one source of truth: __call__ follows the optimizer's value
         if lr != self._host.lr:
             self._host.lr = lr
             self._set_f32(3, lr)

@@ -307,6 +307,35 @@ class _StepFunction(torch.autograd.Function):
 _STREAMS = {}        # (name, device type, device index) -> torch.cuda.Stream, see STEP._side_stream
 
 
+def _concurrent_stream(dev, tries=8):
+    """A new stream that RUNS CONCURRENTLY with the current stream.  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues by
+    least use, and a stream that lands on the main stream's queue serialises behind it -- silently: with a process group in the process
+    (RCCL, torch.distributed and the native communicator create streams of their own) the step's second stream did, and the graph
+    learner's whole forward chain waited for the encoder (+0.5 ms per step at PEMS04, profiles/r05_h_dp_one_rank.log).  So candidates are
+    created until the probe of libstep_hip (step_streams_concurrent: a 200 us spin against an empty kernel) sees one overlap with the
+    current stream; the rejected ones are dropped, which frees their queue slots.  STEP_STREAM_PROBE=0 takes the first stream."""
+    if os.environ.get("STEP_STREAM_PROBE", "1") == "0":
+        return torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    mine = [v for (n, t, i), v in _STREAMS.items() if t == dev.type and i == dev.index]      # the step's other streams on this device
+    rejected, flag = [], ctypes.c_int(0)
+
+    def overlaps(a, b):
+        _lib.call("step_streams_concurrent", ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream), ctypes.byref(flag))
+        return bool(flag.value)
+    second_best = None
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=dev)
+        if overlaps(main, s):
+            # the main stream is the one that matters (everything else forks from it and joins it); a queue of its own against the step's
+            # other streams as well when the runtime has one left (four hardware queues by default; two under GPU_MAX_HW_QUEUES=2)
+            if all(overlaps(o, s) for o in mine):
+                return s
+            second_best = second_best or s
+        rejected.append(s)          # kept alive until the search ends, so that the next candidate gets another queue
+    return second_best or rejected[0]
+
+
 class STEP(nn.Module):
     """Pre-training Enhanced Spatial-temporal Graph Neural Network -- MI355X-native drop-in."""
 
@@ -332,6 +361,7 @@ class STEP(nn.Module):
         self._seed_ctr = 0
         self._dyn = None                    # device StepDynState of a replayed (graph-captured) step (step_amd/graphed.py); None: eager
         self._process_group = None
+        self._comm = None                   # step_amd.comm.NativeComm when the collectives are RCCL C-API calls (enable_native_data_parallel)
         self._min_world = 1                 # collectives are issued for groups larger than this (0: also for a single rank)
         self._layout = None
         self._zg_params = None
@@ -367,7 +397,7 @@ class STEP(nn.Module):
         # instead of 6.07 ms (profiles/r03_ag_*, r03_ah_*).
         key = (name, dev.type, dev.index)
         if key not in _STREAMS:
-            _STREAMS[key] = torch.cuda.Stream(device=dev)
+            _STREAMS[key] = _concurrent_stream(dev)
         return _STREAMS[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
@@ -511,17 +541,40 @@ class STEP(nn.Module):
         self._flat_param = flat
         return flat
 
-    def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False, single_rank_collectives=False):
+    def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False, single_rank_collectives=False,
+                                    collectives="auto"):
         """Average the flat gradient buffer over ranks inside backward (RCCL all-reduce of the flat buffer, in two asynchronous
         chunks; replaces DDP's bucketed reducer -- do not also wrap the module in DistributedDataParallel).  Like DDP's
         constructor, it first broadcasts rank 0's parameters and buffers (``sync_module_states``).
         ``single_rank_collectives``: issue every collective of the data-parallel path even in a group of ONE rank (the parameter
         broadcast, the chunked asynchronous all-reduce, the time-sliced graph learner's small sums with a single slice), so that
         the collective library, its stream and the event ordering against the step's three streams run on a one-GPU box
-        (`bench.py --gpus 1 --force-process-group`); arithmetically a no-op."""
+        (`bench.py --gpus 1 --force-process-group`); arithmetically a no-op.
+        ``collectives``: "rccl" -- the step's collectives are RCCL C-API calls issued in stream order by libstep_hip
+        (`step_amd.comm.NativeComm`: `step_grad_allreduce_begin / _join`, `step_comm_allreduce`; torch.distributed only carries the
+        communicator's unique id and the initial parameter broadcast); "torch" -- `torch.distributed.all_reduce` (any backend; what
+        the CPU tests run over gloo); "auto" (default) -- "rccl" when the group's backend is nccl (= RCCL) and the parameters live on a
+        GPU, else "torch"."""
         import torch.distributed as dist
         self._process_group = process_group if process_group is not None else dist.group.WORLD
         self._min_world = 0 if single_rank_collectives else 1
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+        on_gpu = self.backend.nodevec1.is_cuda
+        if collectives == "auto":
+            collectives = "rccl" if (on_gpu and dist.get_backend(self._process_group) == "nccl") else "torch"
+        if collectives not in ("rccl", "torch"):
+            raise ValueError(f"collectives = {collectives!r}: expected 'auto', 'rccl' or 'torch'")
+        if collectives == "rccl" and dist.get_world_size(self._process_group) > self._min_world:
+            from .. import comm as _comm
+            if not on_gpu:
+                raise RuntimeError("collectives='rccl' needs the module on a GPU (move it first)")
+            if not _comm.available():
+                raise RuntimeError("collectives='rccl': librccl could not be loaded into this process (STEP_RCCL_LIB names another copy)")
+            self._comm = _comm.NativeComm(self._process_group)
+            # the all-reduce's stream: one that demonstrably overlaps with the compute stream (created AFTER RCCL's own streams exist)
+            self._comm.use_side_stream(self._side_stream(self.backend.nodevec1.device, "comm"))
         if sync_module_states and dist.get_world_size(self._process_group) > self._min_world:
             # what DistributedDataParallel does when it wraps a module: every rank starts from rank 0's parameters and buffers
             src = dist.get_global_rank(self._process_group, 0)
@@ -551,6 +604,10 @@ class STEP(nn.Module):
         import torch.distributed as dist
         if dist.get_world_size(self._process_group) <= self._min_world or chunk.numel() == 0:
             return []
+        if self._comm is not None:
+            # RCCL C API: the mean all-reduce runs on the communicator's own stream behind what is queued here; _reduce_finish joins it
+            self._comm.grad_allreduce_begin(chunk)
+            return [None]
         return [dist.all_reduce(chunk, group=self._process_group, async_op=True)]
 
     def _sum_over_ranks(self, t):
@@ -561,7 +618,10 @@ class STEP(nn.Module):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dist.all_reduce(t, group=self._process_group)
+            if self._comm is not None:
+                self._comm.allreduce_(t)           # in stream order, no host wait
+            else:
+                dist.all_reduce(t, group=self._process_group)
             if timed:
                 e1.record()
                 self._small_events.append((e0, e1, t.numel() * t.element_size()))
@@ -576,12 +636,16 @@ class STEP(nn.Module):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for w in pending:
-            w.wait()
+        if self._comm is not None:
+            self._comm.grad_allreduce_join()       # (ncclAvg: the chunks already hold means)
+        else:
+            for w in pending:
+                w.wait()
         if timed:
             e1.record()
             self._reduce_events.append((e0, e1))
-        (flat if reduced is None else reduced).mul_(1.0 / dist.get_world_size(self._process_group))
+        if self._comm is None:
+            (flat if reduced is None else reduced).mul_(1.0 / dist.get_world_size(self._process_group))
 
     def collect_reduce_waits(self):
         """ms the compute stream waited for the gradient all-reduce in each backward since the last call (needs a synchronize)."""

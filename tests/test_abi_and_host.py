@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/step_hip.h but not exported"
     assert set(_lib.exported_symbols()) == declared, set(_lib.exported_symbols()) ^ declared
-    assert lib.step_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.step_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_error_reporting_without_compute():

@@ -31,7 +31,7 @@ def main():
             sys.stderr.write(out.decode())
             raise SystemExit("hipcc failed on " + s)
     lib = os.path.join(B.HERE, f"libstep_hip_{name}.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
     print(lib)
 
 

@@ -21,7 +21,10 @@ import types
 import numpy as np
 import torch
 
-REF = "/root/reference"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle.reference_loader import reference_root  # noqa: E402
+
+REF = reference_root() or "/root/reference"          # the build container's checkout, or the staged copy (tools/stage_reference.sh)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
