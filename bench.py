@@ -1,8 +1,9 @@
 """bench.py -- STEP training windows/s on MI355X (BASELINE.json metric, config C2 = STEP_PEMS04).
 
-One "step" = one full training step of the native STEP model on one synthetic minibatch that is already
-resident in HBM: TSFormer encoder forward (frozen, pre-trained weights) + kNN prior + DiscreteGraphLearning forward/backward +
-GraphWaveNet forward/backward + step_loss + gradient all-reduce (N>1) + clip_grad_norm_(3.0) + Adam.
+One "step" = one full training step of the native STEP model on one synthetic minibatch whose data is already resident in HBM (the
+processed series; the windows are gathered from it on the device, inside the timed region, by forecast origin): TSFormer encoder
+forward (frozen, pre-trained weights) + kNN prior + DiscreteGraphLearning forward/backward + GraphWaveNet forward/backward +
+step_loss + gradient all-reduce (N>1) + clip_grad_norm_(3.0) + Adam.
 Prints ONE JSON line (rank 0).  Launch:  python bench.py [--gpus N --steps K --warmup W]
 (for N>1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...).
 
@@ -12,10 +13,14 @@ path) on the same synthetic series -- saved in the reference's format and loaded
 softmax schedule is data dependent (units whose scores outrun the fixed shift are redone by the re-shifting loop); the line reports
 how many did (`roofline.fallback_units_per_launch`) and a second figure with random-init weights (`random_init`).
 
-`prefetch` (second figure of the line): the frozen branch (TSFormer + kNN prior) of batch i+1 queued on its own stream before the
-backward pass of batch i (`STEP.prefetch`, step_amd/step_arch/step.py; it reads nothing the optimizer updates, its outputs are
-bit-identical, tests/test_gpu_step.py::test_prefetched_frozen_branch_is_bit_identical).  Measured neutral on one GPU, hence off
-in the headline loop.
+Schedule of the training loop (`schedule` in the line; round 5): the frozen branch (TSFormer + kNN prior) of batch i+1 is queued on its
+own stream before the backward pass of batch i (`STEP.prefetch`, step_amd/step_arch/step.py: it reads nothing the optimizer updates
+and its outputs are bit-identical, tests/test_gpu_step.py::test_prefetched_frozen_branch_is_bit_identical), and the encoder runs as a
+PERSISTENT launch on part of the compute units (`TSFormer.encoder_workgroups`, ENC_SPLIT below) next to the rest of the step on the
+others: 4.26 -> 3.73 ms per step at PEMS04 (profiles/r05_k_*, r05_l_*).  Every timed step still holds exactly one encoder launch, one
+forward, one backward and one optimizer step.  `other_schedule` = the round-4 schedule (frozen branch inside forward(), encoder over
+the whole chip), `other_input_feed` = eight resident batches cycled (the round 1-4 headline loop); `--no-prefetch` /
+`--resident-batches` make them the headline.
 """
 import argparse
 import json
@@ -33,12 +38,27 @@ import time
 # torch is imported; an explicit setting wins, and multi-process runs keep the default (the collective library brings its own stream).
 # Only when bench.py IS the program: a process that imports it as a module (the tests do, for the configuration table) keeps its own
 # runtime settings -- a captured-graph replay (step_amd.GraphedTrainStep) crashes inside hipGraphLaunch with two hardware queues.
-# Round 5: the one-rank process-group runs (--force-process-group) take the same setting -- their extra cost in round 4 was the step's second
-# stream landing on the main stream's hardware queue (RCCL / torch.distributed create streams of their own), not the queue count; the streams
-# are now chosen with a concurrency probe (step_arch/step.py _concurrent_stream) and two queues win there too: 4.36 vs 4.44 ms
-# (profiles/r05_j_dp_one_rank.log).  Real multi-rank runs keep the runtime's default: main, side / aux and the all-reduce's stream overlap.
+# Round 5: (a) the one-rank process-group runs (--force-process-group) take the same setting -- their extra cost in round 4 was the step's
+# second stream landing on the main stream's hardware queue (RCCL / torch.distributed create streams of their own), not the queue count; the
+# streams are now chosen with a concurrency probe (step_arch/step.py _concurrent_stream) and two queues win there too: 4.36 vs 4.44 ms
+# (profiles/r05_j_dp_one_rank.log).  (b) With the next batch's frozen branch prefetched (the default where ENC_SPLIT has an entry) FOUR
+# streams carry work -- main, side / aux, and the prefetch stream with the persistent encoder -- and need a queue each: 3.73 ms with four
+# queues against 5.4 with two and 5.6 with three (profiles/r05_k_persist_prefetch.log, r05_l_*).  Real multi-rank runs keep the default.
+ENC_SPLIT = {"STEP_PEMS04": 160, "STEP_PEMS07": 416}      # config -> workgroups of the persistent encoder launch when the frozen branch is prefetched
+
+
+def _prefetch_policy(argv):
+    """(prefetch on?, encoder workgroups) from the command line, before torch is imported"""
+    name = argv[argv.index("--config") + 1] if "--config" in argv and argv.index("--config") + 1 < len(argv) else "STEP_PEMS04"
+    if "--no-prefetch" in argv or "--forward-only" in argv or "--graph-child" in argv:
+        return False, 0
+    if "--prefetch" in argv or name in ENC_SPLIT:
+        return True, ENC_SPLIT.get(name, 0)
+    return False, 0
+
+
 if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--graph-child" not in sys.argv:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if _prefetch_policy(sys.argv)[0] else "2")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -508,6 +528,13 @@ class StepBench:
         self.model = make_model(cfg, self.data, ckpt).to(dev)
         self.model.train()
         self.model.matmul_precision = args.matmul
+        self.prefetch = (args.prefetch or (name in ENC_SPLIT)) and not args.no_prefetch and not args.forward_only
+        self.enc_wgs = 0
+        if self.prefetch:
+            self.enc_wgs = int(args.encoder_workgroups) if getattr(args, "encoder_workgroups", None) is not None else ENC_SPLIT.get(name, 0)
+        elif getattr(args, "encoder_workgroups", None):
+            self.enc_wgs = int(args.encoder_workgroups)
+        self.model.tsformer.encoder_workgroups = self.enc_wgs
         if args.eval_dropout_off:
             self.model.backend.dropout = 0.0
             self.model.tsformer.dropout_p = 0.0
@@ -532,7 +559,14 @@ class StepBench:
             longh = torch.stack([self.dser[t - Lh:t] for t in ts])
             self.batches.append((hist, longh, fut))
         self.mean, self.std = 200.0, 150.0
-        self.prefetch = args.prefetch
+        # the training loop's input: the index-only loader over the device-resident series ("H2D + gather inside the timed
+        # region"), one batch ahead like a DataLoader's prefetch; forecast origins uniform over the training split, INCLUDING the windows
+        # that start before a full long history exists (all-zero history, forecasting_dataset.py:66-67: 36-39 % at PEMS04)
+        from step_amd.step_arch.step import DeviceWindowLoader
+        self.use_loader = not args.resident_batches and not args.forward_only
+        self.loader = DeviceWindowLoader(self.dser, Lh)
+        self.n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
+        self._staged = None
 
     def barrier(self):
         if DIST["on"]:
@@ -546,12 +580,32 @@ class StepBench:
             pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=None)
             return masked_mae(pred[..., :1] * self.std + self.mean, fut[..., :1] * self.std + self.mean, 0.0)       # base_tsf_runner.py:257-318
 
+    def origins(self, i):
+        """forecast origins of step i (reproducible per step and rank)"""
+        r = np.random.default_rng([4321, self.rank, i])
+        return torch.from_numpy(r.integers(12, 12 + self.n_train, size=self.cfg["B"])).to(self.dev, non_blocking=True)
+
+    def batch(self, i):
+        if not self.use_loader:
+            return self.batches[i % len(self.batches)]
+        if self._staged is not None and self._staged[0] == i:
+            return self._staged[1]
+        return self.loader.batch(self.origins(i))
+
+    def stage(self, i):
+        """the loader is one batch ahead: gather batch i now (during step i - 1)"""
+        if not self.use_loader:
+            return self.batches[i % len(self.batches)]
+        self._staged = (i, self.loader.batch(self.origins(i)))
+        return self._staged[1]
+
     def train_step(self, i, epoch=1):
-        hist, longh, fut = self.batches[i % len(self.batches)]
+        hist, longh, fut = self.batch(i)
         self.opt.zero_grad(set_to_none=True)
         pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
+        nxt = self.stage(i + 1)
         if self.prefetch:                 # the next batch's frozen branch (TSFormer + kNN prior) runs next to this batch's backward + Adam
-            self.model.prefetch(self.batches[(i + 1) % len(self.batches)][1])
+            self.model.prefetch(nxt[1])
         # target-feature selection + inverse scaling, as the runner does (step_runner.py:86-92); slices, not index kernels
         loss = self.step_loss(pred[..., :1], fut[..., :1], theta, knn, coef, null_val=0.0, rescale=(self.mean, self.std))
         loss.backward()
@@ -599,52 +653,33 @@ class StepBench:
     def encoder_alone_ms(self, start):
         """the kernel's own duration: a few untimed steps with neither the second stream nor the prefetch next to it"""
         m = self.model
-        keep = (m.overlap_streams, self.prefetch)
-        m.overlap_streams, self.prefetch = False, False
+        keep = (m.overlap_streams, self.prefetch, m.tsformer.encoder_workgroups)
+        m.overlap_streams, self.prefetch, m.tsformer.encoder_workgroups = False, False, 0       # one workgroup per sequence: the whole chip
         m.cancel_prefetch()
+        self._staged = None
         m.tsformer._events = []
         for i in range(6):
             self.step(start + i)
         torch.cuda.synchronize()
         ev = m.tsformer._events[1:]
         m.tsformer._events = None
-        m.overlap_streams, self.prefetch = keep
+        m.overlap_streams, self.prefetch, m.tsformer.encoder_workgroups = keep
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
 
-    def loader_figure(self, steps):
-        """the same step fed by the index-only loader over the device-resident series, forecast origins drawn over the
-        WHOLE training split -- including the windows that start before a full long history exists (all-zero history,
-        forecasting_dataset.py:66-67: 39 % of PEMS04's training windows) -- gather launches inside the timed region"""
-        from step_amd.step_arch.step import DeviceWindowLoader
-        cfg, B, Lh = self.cfg, self.cfg["B"], self.cfg["L"]
-        loader = DeviceWindowLoader(self.dser, Lh)
-        n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
-        lrng = np.random.default_rng(4321 + self.rank)
-        origins = [torch.from_numpy(lrng.integers(12, 12 + n_train, size=B)).to(self.dev) for _ in range(steps + 5)]
-        zero_frac = float(np.mean([float((o < Lh).float().mean()) for o in origins[3:]]))
-        state = {"next": loader.batch(origins[0])}
-
-        def loader_step(i):
-            hist, ref, fut = state["next"]
-            self.opt.zero_grad(set_to_none=True)
-            pred, theta, knn, coef = self.model(history_data=hist, long_history_data=ref, future_data=None, batch_seen=i, epoch=1)
-            state["next"] = loader.batch(origins[i + 1])          # the loader is one batch ahead, like a DataLoader's prefetch
-            if self.prefetch:
-                self.model.prefetch(state["next"][1])
-            loss = self.step_loss(pred[..., :1], fut[..., :1], theta, knn, coef, null_val=0.0, rescale=(self.mean, self.std))
-            loss.backward()
-            if self.args.torch_optim:
-                torch.nn.utils.clip_grad_norm_(self.params, max_norm=3.0)
-            self.opt.step()
-            return loss
-        self.model.cancel_prefetch()
-        dtl, _, _ = timed_loop(loader_step, 3, steps, self.barrier)
-        dtl = max_over_ranks(dtl, self.world, self.dev)
-        self.model.cancel_prefetch()
-        return {"value": B * self.world * steps / dtl, "unit": "windows/s", "ms_per_step": dtl / steps * 1e3, "steps": steps,
-                "zero_history_fraction": zero_frac,
-                "what": "same training step, windows gathered on the device from the resident series by forecast origin "
-                        "(step_gather_windows, LongHistoryRef), origins uniform over the training split, loader one batch ahead"}
+    def alternative_figure(self, steps, start, prefetch, enc_wgs, loader, what):
+        """the same training step under another schedule / input feed, in this process (same runtime settings)"""
+        m = self.model
+        keep = (self.prefetch, m.tsformer.encoder_workgroups, self.use_loader)
+        m.cancel_prefetch()
+        self._staged = None
+        self.prefetch, m.tsformer.encoder_workgroups, self.use_loader = prefetch, enc_wgs, loader
+        r = self.run(3, steps, start)
+        m.cancel_prefetch()
+        self._staged = None
+        self.prefetch, m.tsformer.encoder_workgroups, self.use_loader = keep
+        torch.cuda.synchronize()
+        return {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": steps, "encoder_ms_per_launch": r["enc_ms"],
+                "what": what}
 
     def graph_figure(self, steps):
         """the same training step replayed from ONE captured hipGraph (step_amd.GraphedTrainStep): host time per step = one graph launch
@@ -735,7 +770,10 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 counter passes (roofline.traffic falls back to the committed record)")
     ap.add_argument("--pretrain-steps", type=int, default=300, help="native TSFormer pre-training steps behind the loaded checkpoint (0: random init)")
     ap.add_argument("--prefetch", action="store_true", help="queue the frozen branch (encoder + kNN prior) of the next batch on its own stream "
-                    "before this batch's backward (STEP.prefetch); measured neutral on one GPU (the `prefetch` figure of the default line)")
+                    "before this batch's backward (STEP.prefetch).  DEFAULT for the configs of ENC_SPLIT, where the encoder then runs as a "
+                    "persistent launch on part of the compute units (--encoder-workgroups) next to the rest of the step")
+    ap.add_argument("--no-prefetch", action="store_true", help="frozen branch inside forward(), encoder over the whole chip (the round-4 schedule)")
+    ap.add_argument("--resident-batches", action="store_true", help="cycle eight resident input batches instead of the index-only device loader")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -751,6 +789,9 @@ def main():
                          "broadcast, chunked async all-reduce, the time-sliced graph learner's small sums) through it, so that RCCL, its "
                          "stream and the event ordering against the step's streams run on a one-GPU box; leaves GPU_MAX_HW_QUEUES at the "
                          "runtime default unless set explicitly")
+    ap.add_argument("--encoder-workgroups", type=int, default=None,
+                    help="persistent TSFormer encoder launch of at most this many workgroups (TSFormer.encoder_workgroups; a workgroup fills a "
+                         "compute unit at 336 tokens, two share one at 168); 0 = one workgroup per sequence")
     ap.add_argument("--collectives", default="auto", choices=["auto", "rccl", "torch"],
                     help="data-parallel collectives of the step: RCCL C-API calls issued in stream order by libstep_hip (rccl; auto picks it on "
                          "the nccl backend) or torch.distributed.all_reduce (torch)")
@@ -810,7 +851,12 @@ def main():
     nxt = args.warmup + args.steps
     extras = not args.no_extras
     enc_alone_ms = bench.encoder_alone_ms(nxt) if (not args.forward_only and extras) else None
-    loader_fig = bench.loader_figure(max(args.steps // 2, 10)) if (not args.forward_only and not args.no_loader_figure and extras) else None
+    loader_fig = None
+    if not args.forward_only and not args.no_loader_figure and extras:
+        loader_fig = bench.alternative_figure(max(args.steps // 2, 10), nxt + 8, bench.prefetch, bench.enc_wgs, not bench.use_loader,
+                                              ("same step fed by the index-only loader over the device-resident series (step_gather_windows inside the timed region)"
+                                               if not bench.use_loader else
+                                               "same step cycling eight RESIDENT input batches (the round 1-4 headline): no gather launches, no zero-history windows"))
     comm = bench.comm_figure() if (DIST["on"] and not args.forward_only) else None
     if args.graph_child:
         # child of graph_replay_figure(): the eager loop above and the replayed loop in ONE process with the runtime's default hardware queues
@@ -825,17 +871,15 @@ def main():
     no_prefetch, random_init = None, None
     short = max(min(args.steps // 3, 40), 5)
     if extras and not args.forward_only:
-        if not bench.prefetch:
-            bench.prefetch = True
-            r2 = bench.run(3, short, nxt + 16)
-            no_prefetch = {"value": r2["value"], "unit": "windows/s", "ms_per_step": r2["ms_per_step"], "steps": short,
-                           "encoder_ms_per_launch": r2["enc_ms"],
-                           "what": "same step with the frozen branch (encoder + kNN prior) of the NEXT batch queued on its own stream before this "
-                                   "batch's backward (STEP.prefetch: bit-identical outputs); not the default because it buys nothing on one GPU -- "
-                                   "the encoder's 704-thread, 147 KB workgroups leave no room for the backward's kernels next to them"}
-            bench.prefetch = False
-            bench.model.cancel_prefetch()
-            torch.cuda.synchronize()
+        if bench.prefetch:
+            no_prefetch = bench.alternative_figure(short, nxt + 16, False, 0, bench.use_loader,
+                                                   "same step with the frozen branch INSIDE forward() and the encoder over the whole chip (one workgroup per "
+                                                   "sequence): the round-4 schedule, in this process (GPU_MAX_HW_QUEUES as in runtime_env; two queues suit it "
+                                                   "1.6 % better)")
+        else:
+            no_prefetch = bench.alternative_figure(short, nxt + 16, True, ENC_SPLIT.get(args.config, 160), bench.use_loader,
+                                                   "same step with the frozen branch of the NEXT batch prefetched next to this batch's backward and the "
+                                                   "encoder as a persistent launch on part of the compute units (needs four hardware queues to pay)")
         if ckpt is not None:
             from step_amd import TSFormer
             torch.manual_seed(0)
@@ -847,6 +891,7 @@ def main():
                            "what": "same step with the TSFormer at its random initialisation (no checkpoint): the encoder's softmax schedule is data dependent"}
             bench.model.tsformer.load_state_dict(ckpt_info["sd"])
     sharded = bench.sharded
+    prefetch_on, enc_wgs, loader_on = bench.prefetch, bench.enc_wgs, bench.use_loader
     units = bench.softmax_units()
     data = bench.data
     bench.close()
@@ -920,7 +965,8 @@ def main():
               + (f"pre-trained TSFormer (native C3 path, {ckpt_info['steps']} steps, masked MAE {ckpt_info['first_loss']:.1f} -> {ckpt_info['last_loss']:.1f}) "
                  f"loaded from tsformer_ckpt/, " if ckpt_info else "random-init weights, ")
               + ("eval forward" if args.forward_only else "full train step (fwd+bwd+clip+Adam)")
-              + (", frozen branch of the next batch prefetched on its own stream" if (args.prefetch and not args.forward_only) else ""))
+              + (f", frozen branch of the next batch prefetched on its own stream (encoder: persistent launch on {enc_wgs} compute units)" if prefetch_on else "")
+              + (", windows gathered on the device by forecast origin" if loader_on else ""))
         sfl = step_flops(cfg, B)
         out = {
             "metric": ("validation windows/sec (eval-mode forward + masked MAE)" if args.forward_only else
@@ -947,17 +993,25 @@ def main():
                          "achieved_alone": (flops / (enc_alone_ms * 1e-3) / 1e12) if enc_alone_ms else None,
                          "frac_alone": (flops / (enc_alone_ms * 1e-3) / 1e12 / PEAK_TFLOPS) if enc_alone_ms else None,
                          "fallback_units_per_launch": res["fallback_units_per_launch"], "softmax_units_per_launch": units,
-                         "note": "achieved / ms_per_launch: events around the kernel on its launch stream inside the timed steps, where it shares "
-                                 "the GPU with the second stream's kernels (graph learner + WaveNet layers); *_alone: "
-                                 "the same kernel in 5 extra steps with nothing next to it; fallback_units: (32-token tile, head, layer, "
-                                 "sequence) units whose softmax left the fixed-shift schedule (device counter)"},
+                         "compute_units": (enc_wgs if enc_wgs else 256), "compute_units_of_chip": 256,
+                         "frac_of_occupied_units": ach / PEAK_TFLOPS * 256.0 / (enc_wgs if enc_wgs else 256),
+                         "note": "achieved / ms_per_launch: events around the kernel on its launch stream inside the timed steps; frac is against "
+                                 "the WHOLE chip's peak.  With the frozen branch prefetched (the default here) the kernel is a persistent launch of "
+                                 "`compute_units` workgroups -- one per compute unit -- running next to the rest of the step on the others, so its "
+                                 "launch lasts longer on purpose (frac_of_occupied_units = frac x 256 / compute_units); *_alone: "
+                                 "the same kernel over the whole chip (one workgroup per sequence) in 5 extra steps with nothing next to it; "
+                                 "fallback_units: (32-token tile, head, layer, sequence) units whose softmax left the fixed-shift schedule"},
         }
+        out["schedule"] = {"frozen_branch": "prefetched: the encoder + kNN prior of batch i + 1 queued on their own stream before the backward of batch i "
+                                            "(STEP.prefetch; bit-identical outputs)" if prefetch_on else "inside forward()",
+                           "encoder_workgroups": enc_wgs, "input": "index-only loader over the device-resident series, one batch ahead (gather inside "
+                           "the timed region)" if loader_on else "eight resident batches, cycled"}
         if no_prefetch is not None:
-            out["prefetch"] = no_prefetch
+            out["other_schedule"] = no_prefetch
         if random_init is not None:
             out["random_init"] = random_init
         if loader_fig is not None:
-            out["device_loader"] = loader_fig
+            out["other_input_feed"] = loader_fig
         if graph_fig is not None:
             out["graph_replay"] = graph_fig
         if comm is not None:

@@ -105,6 +105,8 @@ int step_gemm(const StepGemm* g, void* stream);
  */
 #define STEP_ENC_F16 1
 #define STEP_ENC_ALWAYS_RESHIFT 2
+#define STEP_ENC_WORKGROUPS(n) (((n) & 0xffff) << 8)   /* persistent launch: at most n workgroups (= compute units: a workgroup fills one), each
+                                                          looping over sequences; 0 = one workgroup per sequence */
 int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,
                          int depth, int flags, uint16_t* hidden_bf16, float* hidden_f32, float* last_f32,
                          float* sqnorm_part, float dropout_p, const uint64_t* drop_pool, long pool_words, uint64_t seed,

@@ -81,12 +81,14 @@ constexpr int parked_frags() { return PARK ? 6 : ((MAXW == 12 || MAXW == 8) && T
 #ifndef TSF_STATIC_PRIO
 #define TSF_STATIC_PRIO 0   // 1: the later-dispatched half of the workgroup's waves runs at s_setprio 1 for the whole kernel (A/B builds; 1.994 vs 2.002 ms)
 #endif
-#ifndef TSF_PERSIST
-#define TSF_PERSIST 0       // N > 0: persistent launch of at most N workgroups, each looping over sequences blockIdx.x, + gridDim.x, ...; the next
-#endif                      // sequence's first weight block is requested during the last feed-forward stage of the current one (A/B builds).
-                            // Measured (profiles/r03_i_persistent_encoder_ab.log): alone 1.882 vs 1.871 ms at N = 256 (no gain: the 4 % tail
-                            // of 2456 workgroups over 256 compute units is not where the time goes); whole step 4.78 (256), 4.88 (240),
-                            // 4.70 (224: 32 compute units left to the second stream, encoder 2.41 ms) against 4.73 ms
+// Persistent launch (EncArgs.grid_limit > 0, flags bits 8..23 of step_tsformer_encode): at most that many workgroups, each looping over the
+// sequences blockIdx.x, + gridDim.x, ...; the next sequence's first weight block is requested during the last feed-forward stage of the
+// current one.  A workgroup fills its compute unit (704 threads x 168 registers, ~150 KB of LDS), so the limit IS the number of compute units
+// the encoder takes.  Round 3 measured it alone and inside one step (profiles/r03_i_persistent_encoder_ab.log: no gain -- the tail of 2456
+// workgroups over 256 units is not where the time goes, and within ONE step the rest of the forward needs the encoder's output anyway).
+// Round 5: with the frozen branch of the NEXT batch queued next to this batch's backward (STEP.prefetch) the split pays -- the encoder on
+// 160 units for 3.1 ms next to a 3.7 ms chain of small kernels on the other 96, instead of 2.1 ms + 2.1 ms one after the other
+// (4.26 -> 3.73 ms per step at PEMS04, profiles/r05_k_persist_prefetch.log).
 #ifndef TSF_BATCH_FRAGS
 #define TSF_BATCH_FRAGS 0   // 1: scheduling fences around the batched weight-fragment reads (measured: forces the operand copy into scratch, 1.93 -> 2.22 ms)
 #endif
@@ -221,13 +223,8 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
     bool first_block_requested = false;       // (persistent launch) block 0 of this sequence was requested during the previous one
-#if TSF_PERSIST
 #pragma unroll 1
-    for (int seq = blockIdx.x; seq < A.S; seq += gridDim.x) {
-#else
-    const int seq = blockIdx.x;
-    {
-#endif
+    for (int seq = blockIdx.x; seq < A.S; seq += gridDim.x) {          // one iteration unless the launch is persistent (grid_limit)
     // no barrier between sequences: the first stage_begin() of a sequence is one, and ring slot 0 was released two stages before the end
     if (!first_block_requested) issue_fill(0);
     issued = 1;
@@ -338,7 +335,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
-                const float bv = tail[32 + c];
+                const float bv = tail[32 + (fresh_lane_id() & 31)];      // (c kept alive across the sequence loop lands in scratch memory)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { kk[i] = 0.f; vv[i] = bv; }
                 __builtin_amdgcn_sched_barrier(0);
@@ -381,7 +378,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
-                const float bv = tail[32 + c];
+                const float bv = tail[32 + (fresh_lane_id() & 31)];      // (c kept alive across the sequence loop lands in scratch memory)
                 __builtin_amdgcn_sched_barrier(0);
                 q = mfma16<F16>(wA[0], xb[0], q);
                 __builtin_amdgcn_sched_barrier(0);
@@ -429,7 +426,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 const float* bq = tail + h * 16;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = bq[i];           // bias rides in the accumulator
-                const float bv = tail[32 + c];
+                const float bv = tail[32 + (fresh_lane_id() & 31)];      // (c kept alive across the sequence loop lands in scratch memory)
                 fence();
 #pragma unroll
                 for (int k = 0; k < 3; ++k) q = mfma16<F16>(wa[k], xb[k], q);
@@ -868,7 +865,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 TSF_STAMP(21 + 2 * j);
                 blk = stage_begin(g, PAIR ? 3 : 1);
                 TSF_STAMP(22 + 2 * j);
-                if (TSF_PERSIST && PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                if (PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
                     issue_fill(0);
                     first_block_requested = true;
                 }
@@ -955,7 +952,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 blk = (PAIR && (j & 1)) ? slot_of(g) : stage_begin(g, PAIR ? 3 : 1);      // PAIR: odd blocks arrived with their predecessor
                 if (!(PAIR && (j & 1))) TSF_STAMP(22 + 2 * j);
                 tail = (const float*)(blk + TSF_TAIL);
-                if (TSF_PERSIST && PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                if (PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
                     issue_fill(0);            // slot 0 (block g - 2) is free since this stage's barrier: the next sequence's first block
                     first_block_requested = true;
                 }
@@ -1137,7 +1134,7 @@ int launch_enc_tg(const EncArgs& a, hipStream_t st) {
         }
         __atomic_store_n(&raised[dev & 15], true, __ATOMIC_RELEASE);
     }
-    const int grid = (TSF_PERSIST > 0 && a.S > TSF_PERSIST) ? TSF_PERSIST : a.S;
+    const int grid = (a.grid_limit > 0 && a.S > a.grid_limit) ? a.grid_limit : a.S;
     tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, a.nkt * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
@@ -1223,7 +1220,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     STEP_REQUIRE(wpack_bytes >= TSF_TOTAL_BYTES(depth, P), "tsformer_encode: packed weights too small (%ld < %ld)",
                  wpack_bytes, (long)TSF_TOTAL_BYTES(depth, P));
     STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "tsformer_encode: bad dropout %f", dropout_p);
-    STEP_REQUIRE((flags & ~3) == 0, "tsformer_encode: unknown flag bits 0x%x", flags);
+    STEP_REQUIRE((flags & ~(3 | (0xffff << 8))) == 0, "tsformer_encode: unknown flag bits 0x%x", flags);
     const bool dr = dropout_p > 0.f;
     EncArgs a;
     a.series = series; a.S = S; a.L = L; a.P = P; a.depth = depth; a.nkt = (P + 31) / 32;
@@ -1241,6 +1238,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.fallback = fallback_count;
     a.f16 = (flags & STEP_ENC_F16) != 0;
     a.always_rescale = (flags & STEP_ENC_ALWAYS_RESHIFT) != 0;
+    a.grid_limit = (flags >> 8) & 0xffff;               // STEP_ENC_WORKGROUPS(n): persistent launch of at most n workgroups
     hipStream_t st = (hipStream_t)stream;
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
     if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);

@@ -509,6 +509,11 @@ class TSFormer(nn.Module):
         # overflows at 65 504: operands on this path stay below ~200 (tools/encoder_precision_study.py); the attention
         # probabilities and V, which need exponent range rather than mantissa, are bfloat16 in both modes.
         self.encoder_operand = "f16"
+        # 0 / None: one workgroup per sequence (the whole chip, 2456 workgroups at PEMS04).  n > 0: a persistent launch of n workgroups --
+        # a workgroup fills a compute unit, so the encoder takes n of the 256 units and leaves the others to whatever runs on the other
+        # streams.  That is what makes STEP.prefetch pay: the frozen branch of the next batch on 160 units for 3.1 ms next to this batch's
+        # 3.7 ms chain of small kernels, instead of 2.1 ms + 2.1 ms one after the other (profiles/r05_k_persist_prefetch.log).
+        self.encoder_workgroups = 0
         self._seed_counter = 0
         # training-mode dropout: pool of Bernoulli(1 - p) keep bits the encoder kernel reads its lane masks from, refilled from
         # the step's seed before every launch (step_dropout_pool_fill).  2^18 words = 2 MB stay resident in every XCD's L2 (with
@@ -596,6 +601,8 @@ class TSFormer(nn.Module):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         flags = (_lib.ENC_F16 if self.encoder_operand == "f16" else 0) | self.encoder_debug_flags
+        if self.encoder_workgroups:
+            flags |= (int(self.encoder_workgroups) & 0xffff) << 8          # STEP_ENC_WORKGROUPS(n): persistent launch on n compute units
         _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
                   flags, _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
                   _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.ptr(self.fallback_counter),
