@@ -333,14 +333,19 @@ def test_loss_target_stride_detection():
 
 
 def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
-    """bench.py puts GPU_MAX_HW_QUEUES=2 into the environment before torch (the HIP runtime) is imported -- for single-process runs of the
-    program itself, unless the caller set it; multi-process runs (WORLD_SIZE > 1: the collective library has its own stream) keep the runtime's default."""
+    """bench.py puts GPU_MAX_HW_QUEUES into the environment before torch (the HIP runtime) is imported -- for single-process runs of the
+    program itself, unless the caller set it: FOUR when the next batch's frozen branch is prefetched (the default at PEMS04 / PEMS07: main,
+    side / aux and the prefetch stream with the persistent encoder need a queue each), TWO for the round-4 schedule (--no-prefetch, the
+    configs without an ENC_SPLIT entry, the validation forward); multi-process runs (WORLD_SIZE > 1) keep the runtime's default."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import os, sys, runpy\nsys.argv = ['bench.py', '--help']\ntry:\n    runpy.run_path('bench.py', run_name='__main__')\n"
-            "except SystemExit:\n    pass\nprint(os.environ.get('GPU_MAX_HW_QUEUES'))")
+    body = ("try:\n    runpy.run_path('bench.py', run_name='__main__')\nexcept SystemExit:\n    pass\nprint(os.environ.get('GPU_MAX_HW_QUEUES'))")
+    code = "import os, sys, runpy\nsys.argv = ['bench.py', '--help']\n" + body
     as_module = "import os, sys; sys.argv = ['bench.py']; import bench; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+
+    def argv(*a):
+        return "import os, sys, runpy\nsys.argv = ['bench.py', " + ", ".join(repr(x) for x in a) + ", '--help']\n" + body
 
     def run(extra, code=code):
         env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE")}
@@ -348,10 +353,14 @@ def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
         out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         return out.stdout.strip().splitlines()[-1]
-    assert run({}) == "2"
-    assert run({"WORLD_SIZE": "1"}) == "2"
-    assert run({"WORLD_SIZE": "8"}) == "None"
-    assert run({"GPU_MAX_HW_QUEUES": "4"}) == "4"
+    assert run({}) == "4"                                                   # PEMS04: prefetch + persistent encoder
+    assert run({}, argv("--no-prefetch")) == "2"
+    assert run({}, argv("--config", "SYNTH_4096")) == "2"
+    assert run({}, argv("--config", "STEP_PEMS07")) == "4"
+    assert run({}, argv("--forward-only")) == "2"
+    assert run({}, argv("--force-process-group", "--no-prefetch")) == "2"   # one-rank process group: the streams are probed for concurrency
+    assert run({"GPU_MAX_HW_QUEUES": "3"}) == "3"                           # an explicit setting wins
+    assert run({"WORLD_SIZE": "2"}) == "None"                               # real multi-rank runs: the runtime's default
     assert run({}, as_module) == "None"                                    # imported as a module (the tests): the process's settings stay
 
 
