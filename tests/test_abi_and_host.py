@@ -393,3 +393,21 @@ def test_tsformer_flatten_parameters_keeps_the_state_dict_and_shares_one_buffer(
     assert m._flat_param is flat
     m.double()
     assert m._flat_param is None and m._flat_grad is None
+
+
+def test_product_never_imports_the_oracle_or_the_reference():
+    """The oracle (oracle/), the staged reference sources (oracle/_ref/, tools/stage_reference.sh) and /root/reference are test
+    infrastructure: nothing under step_amd/ or include/ may import, load or execute them (only tests/, bench.py's cpu_baseline leg,
+    __graft_entry__.smoke() and the golden-generating tools do)."""
+    bad = []
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b|reference_loader|oracle/_ref|oracle\._ref|/root/reference|import_reference|step_oracle)")
+    for base in ("step_amd", "include"):
+        for dirpath, dirnames, files in os.walk(os.path.join(ROOT, base)):
+            dirnames[:] = [d for d in dirnames if d not in ("build", "__pycache__")]
+            for f in files:
+                if not f.endswith((".py", ".h", ".hip", ".cpp")):
+                    continue
+                for n, line in enumerate(open(os.path.join(dirpath, f), errors="replace"), 1):
+                    if pat.search(line) and "import" in line or ("CDLL" in line and "oracle" in line) or ("dlopen" in line and "oracle" in line):
+                        bad.append(f"{os.path.relpath(os.path.join(dirpath, f), ROOT)}:{n}: {line.strip()}")
+    assert not bad, bad

@@ -94,6 +94,15 @@ def test_full_size_training_step_parity(case, mode):
     print(f"full size {case} [{mode}]: worst gradient rel-L2:", [(a, round(b, 5)) for a, b in worst])
     if tight:
         assert max(errs.values()) < 2e-2, worst
+    else:
+        # bf16 mode, per tensor.  The graph learner's small tensors in front of / behind a train-mode BatchNorm
+        # (conv / fc biases, BatchNorm affines, conv weights) are masked parts of sums that cancel exactly in f32, and the adaptive adjacency's
+        # node embeddings (K = 10 products of softmax gradients): 6-13 % measured.  Everything else -- every GraphWaveNet weight, the fc
+        # weight (98 % of the gradient bytes), the edge MLP -- within 5 %.
+        loose = ("dgl.conv1_", "dgl.conv2_", "dgl.bn1_", "dgl.bn2_", "dgl.bn3_", "dgl.fc_b", "be.nodevec")
+        for kname, e in errs.items():
+            bound = 0.2 if kname.startswith(loose) else 0.05
+            assert e < bound, (kname, e, bound, worst)
     num = sum(float(((dict(model._trainable())[a].grad.cpu() - p[ref_name(a)].grad) ** 2).sum()) for a in errs)
     den = sum(float((p[ref_name(a)].grad ** 2).sum()) for a in errs)
     print(f"full size {case} [{mode}]: whole-gradient rel-L2", (num / den) ** 0.5)
@@ -205,6 +214,15 @@ def test_full_size_c5_4096_nodes_parity(mode):
     print(f"C5 N=4096 [{mode}]: {len(errs)} gradients compared, whole-gradient rel-L2 {whole:.3e}, worst:", [(a_, round(b_, 5)) for a_, b_ in worst])
     if tight:
         assert max(errs.values()) < 2e-2, worst
+    else:
+        # bf16 mode, per tensor.  The graph learner's small tensors in front of / behind a train-mode BatchNorm
+        # (conv / fc biases, BatchNorm affines, conv weights) are masked parts of sums that cancel exactly in f32, and the adaptive adjacency's
+        # node embeddings (K = 10 products of softmax gradients): 6-13 % measured.  Everything else -- every GraphWaveNet weight, the fc
+        # weight (98 % of the gradient bytes), the edge MLP -- within 5 %.
+        loose = ("dgl.conv1_", "dgl.conv2_", "dgl.bn1_", "dgl.bn2_", "dgl.bn3_", "dgl.fc_b", "be.nodevec")
+        for kname, e in errs.items():
+            bound = 0.2 if kname.startswith(loose) else 0.05
+            assert e < bound, (kname, e, bound, worst)
     assert whole < (5e-3 if tight else 5e-2)
     assert e_pred < (2e-3 if tight else 1e-2)
     if mode == "bf16":

@@ -177,7 +177,7 @@ def test_h12_mae_parity(mode):
     minibatches and Gumbel noise) on N=64 nodes x 168 tokens, batch 4, then an eval-mode forward on 64 held-out windows.
     The oracle side (its own fp32 TSFormer states) was run in the build container six times with round-off sized input
     perturbations (tools/make_n1_golden.py -> tests/golden/n1_oracle.npz): horizon-12 masked MAE 38.79 +- 0.53 %, all
-    horizons 38.38 +- 0.16 %.  The native module must land within 2 % (horizon 12) / 1 % (all horizons) of the oracle's mean."""
+    horizons 38.38 +- 0.16 %.  The native module must land within 1.5 % (horizon 12) / 1 % (all horizons) of the oracle's mean."""
     z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "n1_oracle.npz"))
     N, L, T_train, steps, B, k = [int(x) for x in z["cfg"]]
     runs = z["runs"]
@@ -219,7 +219,7 @@ def test_h12_mae_parity(mode):
     assert losses[0] == pytest.approx(float(z["first_loss"]), rel=5e-3)
     assert tail < 0.6 * losses[0]                                   # it trains
     assert tail == pytest.approx(o_tail, rel=2e-2)
-    assert h12 == pytest.approx(o_h12, rel=2e-2)
+    assert h12 == pytest.approx(o_h12, rel=1.5e-2)          # (+-2 % until round 4; measured -0.50 .. +1.07 % over the rounds' commits, oracle's own spread 0.53 %)
     assert mae == pytest.approx(o_mae, rel=1e-2)
 
 
