@@ -548,7 +548,8 @@ class StepBench:
             self.opt = torch.optim.Adam(self.params, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8)    # step/STEP_PEMS04.py:90-96
         else:
             from step_amd.optim import FusedAdamClip
-            self.opt = FusedAdamClip(self.model, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8, max_norm=3.0)   # same rule, one fused pass
+            # same rule, one fused pass over the flat buffers; the gradients stay in the native backward's flat buffer (no per-parameter .grad)
+            self.opt = FusedAdamClip(self.model, lr=0.002, weight_decay=1.0e-5, eps=1.0e-8, max_norm=3.0, param_grads=False)
         self.dser = torch.from_numpy(self.data).to(dev)
         rng = np.random.default_rng(1234 + rank)
         self.batches = []

@@ -90,10 +90,8 @@ class _StepFunction(torch.autograd.Function):
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 raise RuntimeError("a time-sliced graph learner evaluates without gradients only (wrap the call in torch.no_grad())")
             sh = None
-        dt = dgl.native_tensors(full=sh is None)
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
-        dstruct = fill_dgl_struct(dt, bf)
-        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
+        dstruct, bstruct = model._param_structs(bf, full=sh is None)
         Ttr = dgl.train_length if sh is None else sh["Ts"]
         series_nt = dgl._series_nt if sh is None else dgl._series_slice
         drop = be.dropout if training else 0.0
@@ -202,16 +200,12 @@ class _StepFunction(torch.autograd.Function):
         # the flat gradient buffer: everything in front of the fc weight (gradients accumulate into zeros, 18 MB at PEMS04) is cleared; the fc
         # weight's 87 MB are STORED by the graph learner's backward (STEP_DGL_FRESH_FC_GRAD), neither cleared here nor read there
         fo, fn, _ = layout["items"]["dgl.fc_w"]
-        flat = torch.empty(layout["total"], device=dev, dtype=torch.float32)
+        flat, views, gw_grads, dg_grads, grad_tuple = model._grad_buffers(layout, dev)
         flat[:fo].zero_()
         if fo + fn < layout["total"]:
             flat[fo + fn:].zero_()
-        views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
-        gw_grads = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
-        dg_grads = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
         bf = {"f32": 0, "bf16": 1}[model.matmul_precision]
-        bstruct = fill_gwnet_struct(be.native_tensors(), bf)
-        dstruct = fill_dgl_struct(dgl.native_tensors(), bf)
+        dstruct, bstruct = model._param_structs(bf, full=False)
         dpred = dpred.contiguous().float().view(B, 12, N) if dpred is not None else torch.zeros(B, 12, N, device=dev)
         dadj = _f32(B * N * N, dev)
         wwork = _f32(L.lib().step_gwnet_work_floats(B, N, 1), dev)
@@ -298,16 +292,21 @@ class _StepFunction(torch.autograd.Function):
         model._flat_grad = flat
         model._backward_count = getattr(model, "_backward_count", 0) + 1
         ctx.held = None
+        del views, gw_grads, dg_grads
+        if model.flat_gradients_only:
+            # the caller reads model._flat_grad (step_amd.optim.FusedAdamClip does): no per-parameter .grad tensors, no AccumulateGrad work
+            return (None, None, None, None) + (None,) * len(layout["order"])
+        if grad_tuple is not None:
+            return (None, None, None, None) + grad_tuple
         # fresh views with no other owner: autograd's AccumulateGrad then adopts them as .grad (aliases of the flat buffer)
         # instead of cloning every gradient (the clone of the fc weight gradient alone is an 87 MB copy)
-        del views, gw_grads, dg_grads
         return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in (layout["items"][k] for k in layout["order"]))
 
 
 _STREAMS = {}        # (name, device type, device index) -> torch.cuda.Stream, see STEP._side_stream
 
 
-def _concurrent_stream(dev, tries=8):
+def _concurrent_stream(dev, tries=8, priority=0):
     """A new stream that RUNS CONCURRENTLY with the current stream.  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues by
     least use, and a stream that lands on the main stream's queue serialises behind it -- silently: with a process group in the process
     (RCCL, torch.distributed and the native communicator create streams of their own) the step's second stream did, and the graph
@@ -315,7 +314,7 @@ def _concurrent_stream(dev, tries=8):
     created until the probe of libstep_hip (step_streams_concurrent: a 200 us spin against an empty kernel) sees one overlap with the
     current stream; the rejected ones are dropped, which frees their queue slots.  STEP_STREAM_PROBE=0 takes the first stream."""
     if os.environ.get("STEP_STREAM_PROBE", "1") == "0":
-        return torch.cuda.Stream(device=dev)
+        return torch.cuda.Stream(device=dev, priority=priority)
     main = torch.cuda.current_stream(dev)
     mine = [v for (n, t, i), v in _STREAMS.items() if t == dev.type and i == dev.index]      # the step's other streams on this device
     rejected, flag = [], ctypes.c_int(0)
@@ -325,7 +324,7 @@ def _concurrent_stream(dev, tries=8):
         return bool(flag.value)
     second_best = None
     for _ in range(tries):
-        s = torch.cuda.Stream(device=dev)
+        s = torch.cuda.Stream(device=dev, priority=priority)
         if overlaps(main, s):
             # the main stream is the one that matters (everything else forks from it and joins it); a queue of its own against the step's
             # other streams as well when the runtime has one left (four hardware queues by default; two under GPU_MAX_HW_QUEUES=2)
@@ -361,6 +360,12 @@ class STEP(nn.Module):
         self._seed_ctr = 0
         self._dyn = None                    # device StepDynState of a replayed (graph-captured) step (step_amd/graphed.py); None: eager
         self._process_group = None
+        self._struct_cache = {}             # (bf16 flag, full) -> (address key, StepDglParams, StepGwnetParams), see _param_structs
+        self._bwd_cache = None              # the reused flat gradient buffer with its views and pointer structs, see _grad_buffers
+        self._trainable_cache = None
+        # True (set by FusedAdamClip(..., param_grads=False)): backward leaves the gradients in model._flat_grad ONLY -- no per-parameter
+        # .grad tensors are handed to autograd (that is ~100 AccumulateGrad nodes, 0.3-0.5 ms of host time per step)
+        self.flat_gradients_only = False
         self._comm = None                   # step_amd.comm.NativeComm when the collectives are RCCL C-API calls (enable_native_data_parallel)
         self._min_world = 1                 # collectives are issued for groups larger than this (0: also for a single rank)
         self._layout = None
@@ -397,7 +402,7 @@ class STEP(nn.Module):
         # instead of 6.07 ms (profiles/r03_ag_*, r03_ah_*).
         key = (name, dev.type, dev.index)
         if key not in _STREAMS:
-            _STREAMS[key] = _concurrent_stream(dev)
+            _STREAMS[key] = _concurrent_stream(dev, priority=int(os.environ.get("STEP_PRIORITY_" + name.upper(), "0")))
         return _STREAMS[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
@@ -510,6 +515,50 @@ class STEP(nn.Module):
         items.sort(key=lambda kv: kv[0] == "dgl.fc_w")
         return items
 
+    def _param_structs(self, bf, full):
+        """(StepDglParams, StepGwnetParams) of the CURRENT parameter / buffer storage for the library calls.  Filling them is a walk over
+        ~130 tensors (0.1-0.2 ms of host time, twice per step); once the parameters live in the flat buffer (flatten_parameters(), which
+        FusedAdamClip calls) their addresses do not move, so the structs are kept and re-checked against a few addresses per call --
+        .to() / .cuda() / load of another flat buffer drop them (_apply, flatten_parameters)."""
+        dgl, be = self.discrete_graph_learning, self.backend
+        if self._flat_param is None:
+            return fill_dgl_struct(dgl.native_tensors(full=full), bf), fill_gwnet_struct(be.native_tensors(), bf)
+        fcw = dgl.fc.weight if (dgl._shard is None or full) else dgl.fc_weight_slice
+        key = (bf, full, self._flat_param.data_ptr(), fcw.data_ptr(), be.nodevec1.data_ptr(), be.bn[0].running_mean.data_ptr(),
+               dgl.bn3.running_var.data_ptr(), be.end_conv_2.bias.data_ptr())
+        c = self._struct_cache.get((bf, full))
+        if c is None or c[0] != key:
+            c = (key, fill_dgl_struct(dgl.native_tensors(full=full), bf), fill_gwnet_struct(be.native_tensors(), bf))
+            self._struct_cache[(bf, full)] = c
+        return c[1], c[2]
+
+    def _grad_buffers(self, layout, dev):
+        """-> (flat gradient buffer, name -> view, StepGwnetParams of the views, StepDglParams of the views, tuple of views in layout order
+        or None).  With flattened parameters and no .grad left on the parameters (zero_grad(set_to_none=True), the training loop's normal
+        state) ONE buffer and its ~100 views / two pointer structs are reused step after step: creating them took 0.7 ms of host time per
+        backward (profiles/r05_t_host_sections_C2.log).  Any other situation -- gradients being accumulated over several backwards, no flat
+        parameter buffer -- gets fresh ones, with autograd's usual accumulate semantics."""
+        tr = self._trainable_list()
+        reuse = self._flat_param is not None and tr[0].grad is None and tr[-1].grad is None and tr[len(tr) // 2].grad is None
+        c = self._bwd_cache
+        if reuse and c is not None and c["layout"] is layout and c["flat"].device == dev:
+            return c["flat"], c["views"], c["gw"], c["dg"], c["tuple"]
+        flat = torch.empty(layout["total"], device=dev, dtype=torch.float32)
+        views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
+        gw = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
+        dg = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
+        if reuse:
+            self._bwd_cache = {"layout": layout, "flat": flat, "views": views, "gw": gw, "dg": dg,
+                               "tuple": tuple(flat[o:o + n].view(shape) for o, n, shape in (layout["items"][k] for k in layout["order"]))}
+            return flat, views, gw, dg, self._bwd_cache["tuple"]
+        return flat, views, gw, dg, None
+
+    def _trainable_list(self):
+        t = self._trainable_cache
+        if t is None:
+            t = self._trainable_cache = [v for _, v in self._trainable()]
+        return t
+
     def _grad_layout(self):
         if self._layout is None:
             off, items, order = 0, {}, []
@@ -539,6 +588,7 @@ class STEP(nn.Module):
             flat[o:o + n].copy_(v.detach().reshape(-1))
             v.data = flat[o:o + n].view(shape)
         self._flat_param = flat
+        self._struct_cache, self._bwd_cache, self._trainable_cache = {}, None, None
         return flat
 
     def enable_native_data_parallel(self, process_group=None, sync_module_states=True, shard_graph_learner=False, single_rank_collectives=False,
@@ -595,6 +645,7 @@ class STEP(nn.Module):
             self._layout = None
             self._flat_param = None
             self._zg_params = None
+            self._struct_cache, self._bwd_cache, self._trainable_cache = {}, None, None
 
     def _reduce_begin(self, chunk):
         """Start the sum of one contiguous chunk of the flat gradient buffer over the data-parallel group (RCCL all-reduce on
@@ -692,6 +743,7 @@ class STEP(nn.Module):
 
     def _apply(self, fn, recurse=True):
         self._zg_params = None
+        self._struct_cache, self._bwd_cache, self._trainable_cache = {}, None, None
         out = super()._apply(fn, recurse)
         flat = self._flat_param
         if flat is not None:
@@ -704,6 +756,7 @@ class STEP(nn.Module):
 
     def load_state_dict(self, *a, **kw):
         self._zg_params = None
+        self._struct_cache, self._bwd_cache, self._trainable_cache = {}, None, None
         return super().load_state_dict(*a, **kw)
 
     # ------------------------------------------------------------------ forward
@@ -717,7 +770,7 @@ class STEP(nn.Module):
             u = torch.rand(B, N * N, 2).to(history_data.device)
         else:
             u = None
-        params = [v for _, v in self._trainable()]
+        params = self._trainable_list()
         pred, theta, adj_knn = _StepFunction.apply(self, history_data, long_history_data, u, *params)
         if epoch is not None:
             gsl_coefficient = 1 / (int(epoch / 6) + 1)

@@ -17,7 +17,8 @@ import bench  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "STEP_METR-LA"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    args = argparse.Namespace(matmul="bf16", eval_dropout_off=False, no_shard=False, torch_optim=False, prefetch=False, forward_only=False)
+    args = argparse.Namespace(matmul="bf16", eval_dropout_off=False, no_shard=False, torch_optim=False, prefetch=False, forward_only=False,
+                              no_prefetch="--no-prefetch" in sys.argv, resident_batches=False, encoder_workgroups=None, collectives="auto")
     dev = torch.device("cuda:0")
     sb = bench.StepBench(name, bench.CONFIGS[name], args, 1, 0, dev, None)
     for i in range(20):
@@ -33,7 +34,7 @@ def main():
     # phases of a step, host time only
     ph = {"zero_grad": 0.0, "forward": 0.0, "loss": 0.0, "backward": 0.0, "optimizer": 0.0}
     for i in range(steps):
-        hist, longh, fut = sb.batches[i % len(sb.batches)]
+        hist, longh, fut = sb.batch(1000 + i)
         a = time.perf_counter()
         sb.opt.zero_grad(set_to_none=True)
         b = time.perf_counter()
