@@ -45,6 +45,10 @@ import time
 # streams carry work -- main, side / aux, and the prefetch stream with the persistent encoder -- and need a queue each: 3.73 ms with four
 # queues against 5.4 with two and 5.6 with three (profiles/r05_k_persist_prefetch.log, r05_l_*).  Real multi-rank runs keep the default.
 ENC_SPLIT = {"STEP_PEMS04": 160, "STEP_PEMS07": 416}      # config -> workgroups of the persistent encoder launch when the frozen branch is prefetched
+# ... and WHEN the next batch's frozen branch is queued: at the start of the step (next to the whole step: 3.73 -> 3.48 ms at PEMS04, where the
+# encoder is then done before the bandwidth-bound backward of the graph learner starts) or behind the forward (next to the backward only: better
+# at PEMS07, 5.57 vs 5.97 ms: there the graph learner's forward wants the whole chip too) -- profiles/r05_w_prefetch_early_sweep.log
+PREFETCH_EARLY = {"STEP_PEMS04": True, "STEP_PEMS07": False}
 
 
 def _prefetch_policy(argv):
@@ -530,6 +534,7 @@ class StepBench:
         self.model.matmul_precision = args.matmul
         self.prefetch = (args.prefetch or (name in ENC_SPLIT)) and not args.no_prefetch and not args.forward_only
         self.enc_wgs = 0
+        self.prefetch_early = (PREFETCH_EARLY.get(name, False) or getattr(args, "prefetch_early", False)) and not getattr(args, "prefetch_late", False)
         if self.prefetch:
             self.enc_wgs = int(args.encoder_workgroups) if getattr(args, "encoder_workgroups", None) is not None else ENC_SPLIT.get(name, 0)
         elif getattr(args, "encoder_workgroups", None):
@@ -602,11 +607,15 @@ class StepBench:
 
     def train_step(self, i, epoch=1):
         hist, longh, fut = self.batch(i)
+        early = self.prefetch and self.prefetch_early
+        if early:                         # the next batch's frozen branch (TSFormer + kNN prior) runs next to the whole of this step
+            self.model.prefetch(self.stage(i + 1)[1])
         self.opt.zero_grad(set_to_none=True)
         pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
-        nxt = self.stage(i + 1)
-        if self.prefetch:                 # the next batch's frozen branch (TSFormer + kNN prior) runs next to this batch's backward + Adam
-            self.model.prefetch(nxt[1])
+        if not early:
+            nxt = self.stage(i + 1)
+            if self.prefetch:             # ... or only next to this batch's backward + Adam (round-3 placement)
+                self.model.prefetch(nxt[1])
         # target-feature selection + inverse scaling, as the runner does (step_runner.py:86-92); slices, not index kernels
         loss = self.step_loss(pred[..., :1], fut[..., :1], theta, knn, coef, null_val=0.0, rescale=(self.mean, self.std))
         loss.backward()
@@ -774,6 +783,9 @@ def main():
                     "before this batch's backward (STEP.prefetch).  DEFAULT for the configs of ENC_SPLIT, where the encoder then runs as a "
                     "persistent launch on part of the compute units (--encoder-workgroups) next to the rest of the step")
     ap.add_argument("--no-prefetch", action="store_true", help="frozen branch inside forward(), encoder over the whole chip (the round-4 schedule)")
+    ap.add_argument("--prefetch-early", action="store_true", help="queue the next batch's frozen branch at the start of the step (default at PEMS04)")
+    ap.add_argument("--prefetch-late", action="store_true", help="queue the next batch's frozen branch behind this batch's forward (before its backward) "
+                    "instead of at the start of the step")
     ap.add_argument("--resident-batches", action="store_true", help="cycle eight resident input batches instead of the index-only device loader")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
@@ -892,7 +904,7 @@ def main():
                            "what": "same step with the TSFormer at its random initialisation (no checkpoint): the encoder's softmax schedule is data dependent"}
             bench.model.tsformer.load_state_dict(ckpt_info["sd"])
     sharded = bench.sharded
-    prefetch_on, enc_wgs, loader_on = bench.prefetch, bench.enc_wgs, bench.use_loader
+    prefetch_on, enc_wgs, loader_on, early_on = bench.prefetch, bench.enc_wgs, bench.use_loader, bench.prefetch_early
     units = bench.softmax_units()
     data = bench.data
     bench.close()
@@ -1003,8 +1015,9 @@ def main():
                                  "the same kernel over the whole chip (one workgroup per sequence) in 5 extra steps with nothing next to it; "
                                  "fallback_units: (32-token tile, head, layer, sequence) units whose softmax left the fixed-shift schedule"},
         }
-        out["schedule"] = {"frozen_branch": "prefetched: the encoder + kNN prior of batch i + 1 queued on their own stream before the backward of batch i "
-                                            "(STEP.prefetch; bit-identical outputs)" if prefetch_on else "inside forward()",
+        out["schedule"] = {"frozen_branch": ("prefetched: the encoder + kNN prior of batch i + 1 queued on their own stream "
+                                             + ("at the start of step i" if early_on else "before the backward of batch i")
+                                             + " (STEP.prefetch; bit-identical outputs)") if prefetch_on else "inside forward()",
                            "encoder_workgroups": enc_wgs, "input": "index-only loader over the device-resident series, one batch ahead (gather inside "
                            "the timed region)" if loader_on else "eight resident batches, cycled"}
         if no_prefetch is not None:

@@ -316,23 +316,31 @@ def _concurrent_stream(dev, tries=8, priority=0):
     if os.environ.get("STEP_STREAM_PROBE", "1") == "0":
         return torch.cuda.Stream(device=dev, priority=priority)
     main = torch.cuda.current_stream(dev)
-    mine = [v for (n, t, i), v in _STREAMS.items() if t == dev.type and i == dev.index]      # the step's other streams on this device
-    rejected, flag = [], ctypes.c_int(0)
+    mine = [(n, v) for (n, t, i), v in _STREAMS.items() if t == dev.type and i == dev.index]      # the step's other streams on this device
+    kept, flag = [], ctypes.c_int(0)
 
     def overlaps(a, b):
         _lib.call("step_streams_concurrent", ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream), ctypes.byref(flag))
         return bool(flag.value)
-    second_best = None
+    best, best_score = None, -1
+    full = 100 + 10 * sum(1 for n, _ in mine if n == "prefetch") + sum(1 for n, _ in mine if n != "prefetch")
     for _ in range(tries):
         s = torch.cuda.Stream(device=dev, priority=priority)
+        kept.append(s)          # kept alive until the search ends, so that the next candidate gets another queue
+        # what matters, in this order: the main stream (everything forks from it and joins it); the prefetch stream (it carries the
+        # persistent encoder for ~3 ms: anything queued behind it waits that long); then a queue of its own against the rest, when the
+        # runtime has one left (four hardware queues by default)
+        score = 0
         if overlaps(main, s):
-            # the main stream is the one that matters (everything else forks from it and joins it); a queue of its own against the step's
-            # other streams as well when the runtime has one left (four hardware queues by default; two under GPU_MAX_HW_QUEUES=2)
-            if all(overlaps(o, s) for o in mine):
-                return s
-            second_best = second_best or s
-        rejected.append(s)          # kept alive until the search ends, so that the next candidate gets another queue
-    return second_best or rejected[0]
+            score = 100
+            for n, o in mine:
+                if overlaps(o, s):
+                    score += 10 if n == "prefetch" else 1
+        if score > best_score:
+            best, best_score = s, score
+        if score >= full:
+            break
+    return best
 
 
 class STEP(nn.Module):
@@ -376,7 +384,7 @@ class STEP(nn.Module):
         self._flat_grad = None
         self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
-        self._prefetched = None             # record of the frozen branch queued by prefetch() for the next batch
+        self._prefetched = None             # FIFO (list) of the frozen branches queued by prefetch() for upcoming batches
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
         self._reduce_events = []
@@ -478,27 +486,44 @@ class STEP(nn.Module):
             if t is not None:
                 t.record_stream(main)
         rec["key"], rec["training"] = self._batch_key(long_history_data), mode
-        self._prefetched = rec
+        # a short FIFO: the branch of batch i + 1 may be queued before forward() has consumed the one of batch i (the encoder then runs
+        # next to the WHOLE of step i, not only its backward)
+        q = self._prefetched if isinstance(self._prefetched, list) else []
+        q.append(rec)
+        while len(q) > 2:                    # nobody came for the oldest: keep the stream order, drop the record
+            old = q.pop(0)
+            main.wait_event(old["done"])
+        self._prefetched = q
 
     def cancel_prefetch(self):
         """Drop a frozen branch queued by ``prefetch()`` that will not be consumed.  The prefetch stream's encoder reads the TSFormer's
         keep-mask pool, which the next encoder launch refills: the CURRENT stream is made to wait for the queued branch first, so no
         later launch -- a forward() of another batch, a direct ``model.tsformer(...)`` / ``DiscreteGraphLearning.forward`` call -- can
         refill the pool under a running kernel (that would make the dropout masks irreproducible)."""
-        rec, self._prefetched = self._prefetched, None
-        if rec is not None and rec.get("done") is not None:
-            torch.cuda.current_stream().wait_event(rec["done"])
+        q, self._prefetched = self._prefetched, None
+        for rec in (q or []):
+            if rec.get("done") is not None:
+                torch.cuda.current_stream().wait_event(rec["done"])
 
     def _take_prefetched(self, long_hist):
-        rec, self._prefetched = self._prefetched, None
-        if rec is None:
+        q = self._prefetched
+        if not q:
             return None
+        key = self._batch_key(long_hist)
         main = torch.cuda.current_stream()
-        if rec["key"] != self._batch_key(long_hist) or rec["training"] != self.training:
-            # not the batch that was announced: order the streams (the keep-mask pool is shared) and compute inline
+        for idx, rec in enumerate(q):
+            if rec["key"] == key and rec["training"] == self.training:
+                for skipped in q[:idx]:              # announced but never consumed: keep the stream order, drop them
+                    main.wait_event(skipped["done"])
+                del q[:idx + 1]
+                if not q:
+                    self._prefetched = None
+                return rec
+        # not an announced batch (e.g. the very first step): the inline encoder launch refills the shared keep-mask pool, so it is ordered
+        # behind the queued branches -- which stay queued for the batches they were announced for
+        for rec in q:
             main.wait_event(rec["done"])
-            return None
-        return rec
+        return None
 
     def _prefetch_stream(self, dev):
         return self._side_stream(dev, "prefetch")

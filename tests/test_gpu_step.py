@@ -504,7 +504,15 @@ def test_prefetched_frozen_branch_is_bit_identical():
     assert torch.equal(rec["enc"]["hidden_bf16"], inline["enc"]["hidden_bf16"]) and torch.equal(rec["enc"]["last"], inline["enc"]["last"])
     assert rel_l2(rec["sim"].cpu(), inline["sim"].cpu()) < 1e-6 and int((rec["adj_knn"] != inline["adj_knn"]).sum()) <= 2
     model.prefetch(batches[2][1])
-    assert model._take_prefetched(batches[1][1]) is None and model._prefetched is None        # another batch: not used
+    # another batch: not used -- and not dropped either: the queue is a short FIFO (the branch of batch i + 1 may be announced before
+    # forward() has consumed the one of batch i), a record nobody comes for is evicted by the second prefetch after it or by cancel_prefetch()
+    assert model._take_prefetched(batches[1][1]) is None and len(model._prefetched) == 1
+    model.prefetch(batches[3][1])
+    rec3 = None
+    assert model._take_prefetched(batches[3][1]) is not None and model._prefetched is None   # found behind the stale record, which is dropped
+    model.prefetch(batches[2][1])
+    model.cancel_prefetch()
+    assert model._prefetched is None
     torch.cuda.synchronize()
 
     # ---- (b), (c)

@@ -1,0 +1,17 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+t=${1:-r05w}
+rm -f gpurun_out/${t}_early.log
+run() { # env..., then -- then args
+  envs=""; while [ "$1" != "--" ]; do envs="$envs $1"; shift; done; shift
+  env $envs timeout 600 python bench.py --no-extras --no-pmc --no-cpu-baseline --no-loader-figure --steps 50 --warmup 12 "$@" 2> gpurun_out/${t}_last.err | grep '^{"metric"' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().split('\n')[-1])
+print('[$envs | $*]', 'ms_per_step', round(d['ms_per_step'], 3), '| enc in-step', round(d['roofline']['ms_per_launch'], 3), '| host', round(d.get('host_enqueue_ms_per_step') or 0, 2), '| queues', d.get('runtime_env'))" >> gpurun_out/${t}_early.log 2>&1
+}
+run X=0 -- --prefetch-late
+for n in 160 168 176 184 192 208 224; do run X=0 -- --encoder-workgroups $n; done
+run X=0 -- --config STEP_METR-LA --prefetch --encoder-workgroups 128
+run X=0 -- --config STEP_PEMS07 --prefetch-late
+timeout 300 python -m pytest tests/test_gpu_step.py -m gpu -q -x -k "prefetch" > gpurun_out/${t}_tests.log 2>&1; tail -2 gpurun_out/${t}_tests.log
+cat gpurun_out/${t}_early.log
