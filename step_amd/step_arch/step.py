@@ -637,7 +637,8 @@ class STEP(nn.Module):
             self._comm.close()
             self._comm = None
         on_gpu = self.backend.nodevec1.is_cuda
-        if collectives == "auto":
+        auto = collectives == "auto"
+        if auto:
             collectives = "rccl" if (on_gpu and dist.get_backend(self._process_group) == "nccl") else "torch"
         if collectives not in ("rccl", "torch"):
             raise ValueError(f"collectives = {collectives!r}: expected 'auto', 'rccl' or 'torch'")
@@ -645,9 +646,18 @@ class STEP(nn.Module):
             from .. import comm as _comm
             if not on_gpu:
                 raise RuntimeError("collectives='rccl' needs the module on a GPU (move it first)")
-            if not _comm.available():
+            if not _comm.available() and not auto:
                 raise RuntimeError("collectives='rccl': librccl could not be loaded into this process (STEP_RCCL_LIB names another copy)")
-            self._comm = _comm.NativeComm(self._process_group)
+            try:
+                self._comm = _comm.NativeComm(self._process_group)
+            except Exception as ex:          # noqa: BLE001
+                if not auto:
+                    raise
+                # "auto" promised a working data-parallel step, not a particular transport: say so and stay on torch.distributed
+                import warnings
+                warnings.warn(f"step_amd: RCCL C-API communicator could not be created ({ex}); the step's collectives stay on torch.distributed")
+                self._comm = None
+        if self._comm is not None:
             # the all-reduce's stream: one that demonstrably overlaps with the compute stream (created AFTER RCCL's own streams exist)
             self._comm.use_side_stream(self._side_stream(self.backend.nodevec1.device, "comm"))
         if sync_module_states and dist.get_world_size(self._process_group) > self._min_world:
