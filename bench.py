@@ -150,7 +150,7 @@ def static_pmc_traffic(config, B):
         return None
 
 
-def live_pmc_traffic(config, B, ckpt, timeout=150):
+def live_pmc_traffic(config, B, ckpt, timeout=150, enc_wgs=0):
     """HBM bytes of the encoder launch measured IN THIS RUN: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE -- they do
     not fit one pass; --kernel-trace only, no other trace domain) over a child process that loads the same checkpoint and launches
     the training-mode encoder at this config's size (bench.py --pmc-child).  Units and the gfx950 correction as
@@ -166,7 +166,7 @@ def live_pmc_traffic(config, B, ckpt, timeout=150):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         out = os.path.join(work, ctr)
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", ckpt or "-",
-               "--config", config, "--batch", str(B)]
+               "--config", config, "--batch", str(B), "--encoder-workgroups", str(int(enc_wgs))]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             for db in glob.glob(os.path.join(out, "**", "*.db"), recursive=True):
@@ -218,6 +218,7 @@ def pmc_child(args):
     if args.pmc_child != "-":
         m.load_state_dict(torch.load(args.pmc_child, map_location="cpu")["model_state_dict"])
     m.train()
+    m.encoder_workgroups = int(args.encoder_workgroups or 0)          # the launch form the timed loop uses (persistent, or one workgroup per sequence)
     S = B * cfg["N"]
     rng = np.random.default_rng(0)
     t = np.arange(cfg["L"], dtype=np.float32)[None]
@@ -950,7 +951,8 @@ def main():
                     others[name]["roofline"] = {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": efl / (r["enc_ms"] * 1e-3) / 1e12,
                                                 "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": efl / (r["enc_ms"] * 1e-3) / 1e12 / PEAK_TFLOPS,
                                                 "ms_per_launch": r["enc_ms"], "algorithmic_flop_per_launch": efl,
-                                                "traffic": static_pmc_traffic(name, c2["B"]),
+                                                "traffic": (static_pmc_traffic(name, c2["B"]) or {}).get("hbm_bytes_per_launch"),
+                                                "traffic_detail": static_pmc_traffic(name, c2["B"]),
                                                 "note": "events around the encoder on its launch stream inside the timed steps (it shares the GPU with "
                                                         "the second stream's kernels there)"}
                     dom = static_dominant_kernels(name)
@@ -971,7 +973,7 @@ def main():
         ach = flops / (enc_ms * 1e-3) / 1e12
         traffic = None
         if extras and not args.no_pmc and world == 1:
-            traffic = live_pmc_traffic(args.config, B, ckpt)
+            traffic = live_pmc_traffic(args.config, B, ckpt, enc_wgs=enc_wgs)
         if traffic is None:
             traffic = static_pmc_traffic(args.config, B)
         wl = (f"{args.config}: N={N} nodes, long history L={Lh} (P={Lh // 12} patches), 12->12, train series T={cfg['T_train']}, batch {B}/GPU, "
@@ -999,7 +1001,9 @@ def main():
             "whole_step": {"algorithmic_flop": sfl, "tflops": sfl / (res["ms_per_step"] * 1e-3) / 1e12,
                            "frac_of_mfma_peak": sfl / (res["ms_per_step"] * 1e-3) / 1e12 / PEAK_TFLOPS},
             "roofline": {"kernel": "tsformer_encoder_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": traffic, "ms_per_launch": enc_ms,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
+                         "traffic": (traffic or {}).get("hbm_bytes_per_launch"), "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE)",
+                         "traffic_detail": traffic, "ms_per_launch": enc_ms,
                          "launches_in_timed_region": res["enc_launches"],
                          "algorithmic_flop_per_launch": flops,
                          "ms_per_launch_alone": enc_alone_ms,
