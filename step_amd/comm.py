@@ -31,19 +31,45 @@ class NativeComm:
             raise RuntimeError("NativeComm needs a GPU (RCCL); CPU groups keep using torch.distributed")
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
-        ident = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        # every rank must leave this constructor the same way: a failure on rank 0 travels to the others as an empty id instead of
+        # leaving them in the broadcast, and the finished communicator is checked with one collective of each kind before it is used
+        ident, err = None, None
         if self.rank == 0:
-            _lib.call("step_comm_unique_id", ident)
-        box = [ident.raw if self.rank == 0 else None]
+            try:
+                buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+                _lib.call("step_comm_unique_id", buf)
+                ident = buf.raw
+            except Exception as ex:          # noqa: BLE001
+                err = ex
+        box = [ident]
         if self.world > 1:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             dist.broadcast_object_list(box, src=src, group=process_group)
+        if box[0] is None:
+            raise RuntimeError(f"rank 0 could not make an RCCL unique id{'' if err is None else f' ({err})'}")
         ident = ctypes.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
         h = ctypes.c_void_p()
         _lib.call("step_comm_init_rank", ident, self.world, self.rank, ctypes.byref(h))
         self._h = h
         self.version = int(_lib.lib().step_comm_version())
         self._side = None
+        self.self_check()
+
+    def self_check(self):
+        """one mean all-reduce (f32), one sum (f64) and one broadcast over the new communicator against their closed forms; raises on a
+        wrong answer, so that a communicator that does not work is found here and not inside a backward pass"""
+        w, r = self.world, self.rank
+        a = torch.full((1024,), float(r + 1), device="cuda")
+        b = torch.full((48,), float(r + 1), device="cuda", dtype=torch.float64)
+        c = torch.full((256,), r + 7, device="cuda", dtype=torch.int64)
+        self.allreduce_(a, average=True)
+        self.allreduce_(b)
+        self.broadcast_(c, root=0)
+        torch.cuda.current_stream().synchronize()
+        want_a, want_b = (w + 1) / 2.0, w * (w + 1) / 2.0
+        if not (bool((a - want_a).abs().max() < 1e-5) and bool((b == want_b).all()) and bool((c == 7).all())):
+            raise RuntimeError(f"RCCL communicator self-check failed on rank {r} of {w}: mean {float(a[0])} (want {want_a}), "
+                               f"sum {float(b[0])} (want {want_b}), broadcast {int(c[0])} (want 7)")
 
     def use_side_stream(self, stream):
         """run the overlapped gradient all-reduce on `stream` (a torch.cuda.Stream the caller has checked to run concurrently with its

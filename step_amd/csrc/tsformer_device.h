@@ -138,6 +138,20 @@ __device__ __forceinline__ int fresh_lane_id() {
     return l;
 }
 
+// a wave-uniform value (kernel argument, pointer base) made opaque at its point of use: inside the persistent sequence loop the compiler
+// otherwise hoists what it derives from it -- a VGPR copy of a table base, a scale product -- out of the loop and keeps it alive in
+// SCRATCH memory for the whole sequence (12 B/lane = 20 MB of HBM writes per launch at PEMS04, profiles/r05_zz_encoder_pmc.json)
+template <typename T>
+__device__ __forceinline__ T* fresh_uniform(T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ float fresh_uniform(float x) {
+    uint32_t b = __float_as_uint(x);
+    asm volatile("" : "+s"(b));
+    return __uint_as_float(b);
+}
+
 // value of the 16-bit operand type nearest to x (what the MFMA will see when x is stored into an operand slot)
 template <bool F16>
 __device__ __forceinline__ float round_to_operand(float x) {

@@ -193,13 +193,14 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
 
     auto slot_of = [&](int g) -> const char* { return ring + (g & (NSLOT - 1)) * TSF_BLOCK; };
     auto issue_fill = [&](int g) {            // stage block g -> ring slot g mod NSLOT, pieces spread over the waves
-        const char* src = W + TSF_LAYER0 + (long)g * TSF_BLOCK + lane * 16;
+        const char* src = W + TSF_LAYER0 + (long)g * TSF_BLOCK + fresh_lane_id() * 16;
         const uint32_t dst = ring_addr + (uint32_t)(g & (NSLOT - 1)) * TSF_BLOCK;
         if (TSF_FILL_OLD) {
             // only the four first-dispatched waves (one per SIMD) request the pieces: they are the ones that reach every barrier early and wait
             // there (49 % of their time, profiles/r05_a_encoder_phase_table.md), while a piece costs the last-arriving wave 100+ cycles of the
             // workgroup's critical path behind every stage boundary
-            const int nf = nkt < 4 ? nkt : 4;            // (workgroups of fewer than four waves: all of them)
+            int nf = nkt < 4 ? nkt : 4;                  // (workgroups of fewer than four waves: all of them)
+            asm volatile("" : "+s"(nf));                 // (compared at every call: hoisted, `wave < nf` is kept as a 0 / 1 vector register in scratch memory)
             if (wave < nf)
                 for (int pc = wave; pc < 25; pc += nf) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
             return;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         // x W_pe^T on the matrix cores in full f32 (v_mfma_f32_32x32x2_f32, K = 12 in six steps): A = W_pe rows (features) of
         // block t, stored per lane by the packer ([3][6][64] floats, one coalesced dword load each), B = this token's inputs
         // 2s + h; the accumulators start from pos + b_pe (pre-added by the packer) and come out in the layout of every other tile
-        const float4* pos = (const float4*)(W + TSF_POS_OFF(A.depth)) + ((long)tokc_p * 2 + h_p) * 12;
+        const float4* pos = (const float4*)(fresh_uniform(W) + TSF_POS_OFF(A.depth)) + ((long)tokc_p * 2 + h_p) * 12;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             const uint32_t chunk = drop_chunk_base(A.seed, (uint32_t)seq, (uint32_t)A.depth, pmask);
 #pragma unroll
             for (int t = 0; t < 3; ++t) keep16(xT[t], mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + t) * 16u));
-            sc *= inv_keep;
+            sc *= fresh_uniform(inv_keep);
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -316,6 +317,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 tail = (const float*)(blk + TSF_TAIL);
             }
             TSF_STAMP(1 + 5 * hd);
+            // the lane's K / V fragment addresses are derived per head from a fresh lane id: as kernel-lifetime values the register allocator
+            // keeps them in scratch memory
+            const int lane_a = fresh_lane_id();
             if constexpr (NPARK > 0) {
 #pragma unroll
                 for (int f = 6 - NPARK; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f - (6 - NPARK), lane);
@@ -481,8 +485,8 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             for (int i = 0; i < 16; ++i) zero[i] = 0.f;
             auto score_tile = [&](int kt) -> f32x16 {
                 TSF_PRIO_ATTN(1);
-                f32x16 s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2, lane), qb[0], zero);
-                s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2 + 1, lane), qb[1], s);
+                f32x16 s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2, lane_a), qb[0], zero);
+                s = mfma16<F16>(lfrag<F16>(kbuf, kt * 2 + 1, lane_a), qb[1], s);
                 TSF_PRIO_ATTN(0);
                 return s;
             };
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             };
             // the tail of a tile's step: (drop: keep-masks), pack to bfloat16, O^T += V^T P^T
             auto finish_tile = [&](f32x16& pr, int kt, const TileMask& tm) {
-                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane_a), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane_a);
                 if constexpr (drop) {
                     if (!(TSF_ABLATE & 2)) {
 #pragma unroll
@@ -615,8 +619,8 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 // first eight selects + packs | P V product 1 | last eight selects + packs | P V product 2 (needs 1).  Same arithmetic, same order
                 // inside every chain: bit-identical results.
                 if constexpr (NEXT) {
-                    const op8 k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane), k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane);
-                    const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                    const op8 k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane_a), k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane_a);
+                    const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane_a), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane_a);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) cur[i] = __builtin_amdgcn_exp2f(cur[i]);
@@ -653,11 +657,11 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                     return;
                 }
 #endif
-                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane);
+                const bf16x8 v0 = lfrag<false>(vbuf, kt * 2, lane_a), v1 = lfrag<false>(vbuf, kt * 2 + 1, lane_a);
                 op8 k0, k1;
                 if constexpr (NEXT) {
-                    k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane);
-                    k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane);
+                    k0 = lfrag<F16>(kbuf, kt * 2 + 2, lane_a);
+                    k1 = lfrag<F16>(kbuf, kt * 2 + 3, lane_a);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 exp_tile(cur, cur);

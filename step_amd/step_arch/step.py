@@ -657,6 +657,13 @@ class STEP(nn.Module):
                 import warnings
                 warnings.warn(f"step_amd: RCCL C-API communicator could not be created ({ex}); the step's collectives stay on torch.distributed")
                 self._comm = None
+            if auto and dist.get_world_size(self._process_group) > 1:
+                # all ranks take the same transport: one rank without a communicator puts every rank on torch.distributed
+                ok = torch.tensor([1 if self._comm is not None else 0], device=self.backend.nodevec1.device, dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self._process_group)
+                if int(ok.item()) == 0 and self._comm is not None:
+                    self._comm.close()
+                    self._comm = None
         if self._comm is not None:
             # the all-reduce's stream: one that demonstrably overlaps with the compute stream (created AFTER RCCL's own streams exist)
             self._comm.use_side_stream(self._side_stream(self.backend.nodevec1.device, "comm"))
