@@ -574,6 +574,7 @@ class StepBench:
         self.loader = DeviceWindowLoader(self.dser, Lh)
         self.n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
         self._staged = None
+        self._pin = None
 
     def barrier(self):
         if DIST["on"]:
@@ -590,7 +591,16 @@ class StepBench:
     def origins(self, i):
         """forecast origins of step i (reproducible per step and rank)"""
         r = np.random.default_rng([4321, self.rank, i])
-        return torch.from_numpy(r.integers(12, 12 + self.n_train, size=self.cfg["B"])).to(self.dev, non_blocking=True)
+        idx = torch.from_numpy(r.integers(12, 12 + self.n_train, size=self.cfg["B"]))
+        if getattr(self.args, "pageable_origins", False):
+            return idx.to(self.dev, non_blocking=True)          # (A/B) from pageable memory the copy blocks the host until the stream has drained
+        # through a ring of PINNED slots, like the reference's DataLoader (pin_memory=True, STEP_PEMS04.py:122): the copy is asynchronous and
+        # the host keeps enqueueing ahead of the device (64 slots: a slot is rewritten 64 steps later)
+        if self._pin is None:
+            self._pin = torch.empty((64, self.cfg["B"]), dtype=torch.int64).pin_memory()
+        slot = self._pin[i % 64]
+        slot.copy_(idx)
+        return slot.to(self.dev, non_blocking=True)
 
     def batch(self, i):
         if not self.use_loader:
@@ -787,6 +797,7 @@ def main():
     ap.add_argument("--prefetch-early", action="store_true", help="queue the next batch's frozen branch at the start of the step (default at PEMS04)")
     ap.add_argument("--prefetch-late", action="store_true", help="queue the next batch's frozen branch behind this batch's forward (before its backward) "
                     "instead of at the start of the step")
+    ap.add_argument("--pageable-origins", action="store_true", help="(A/B) copy the forecast origins from pageable host memory: the copy then blocks the host every step")
     ap.add_argument("--resident-batches", action="store_true", help="cycle eight resident input batches instead of the index-only device loader")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")
     ap.add_argument("--matmul", default="bf16", choices=["bf16", "f32"], help="operand precision of the GraphWaveNet / DGL contractions")
