@@ -31,12 +31,18 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void load_rccl() {
-    const char* names[] = {getenv("STEP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    // a copy that is already in the process first (RTLD_NOLOAD), then the usual search
+    // $STEP_RCCL_LIB is an override: that file and no other (RTLD_LOCAL: its symbols must not interpose the copy torch has loaded; the
+    // two-rank test on one device points it at tests/fake_rccl).  Otherwise a copy that is already in the process first (RTLD_NOLOAD), then
+    // the usual search.
+    const char* forced = getenv("STEP_RCCL_LIB");
+    if (forced && forced[0]) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+    }
     for (int pass = 0; pass < 2 && !h; ++pass)
         for (const char* n : names) {
-            if (!n || !n[0]) continue;
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (h) break;
         }
