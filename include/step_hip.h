@@ -411,7 +411,10 @@ int step_adam_clip(float* params, const float* grads, float* exp_avg, float* exp
                    float beta2, float eps, float weight_decay, int step, float max_norm, float* work, float* out_norm,
                    void* stream);
 /* The same with extra_sumsq (device scalar, NULL = 0): the sum of squares of gradient elements held by OTHER ranks (the fc weight
- * slices of a sharded graph learner), so that every rank clips with the norm of the whole model. */
+ * slices of a sharded graph learner), so that every rank clips with the norm of the whole model.  max_norm < 0: *extra_sumsq IS the
+ * whole squared norm (this buffer's own sum is not added) and the clip threshold is -max_norm -- data-parallel ranks that hold different
+ * shards pass the same number (sum over the replicated part + all-reduced sum over the shards) and so form bit-identically the same clip
+ * factor: own + others, added in a different order on every rank, differs in the last bit and lets the replicated parameters drift. */
 int step_adam_clip_sharded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int step, float max_norm, const float* extra_sumsq,
                            float* work, float* out_norm, void* stream);

@@ -49,8 +49,12 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float norm = sqrtf(red[0] + red[1] + red[2] + red[3] + (extra_sumsq ? *extra_sumsq : 0.f));
-            float c = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;      // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
+            // max_norm < 0: the caller supplies the WHOLE squared norm in extra_sumsq (every rank of a sharded model passes the same
+            // number, so every rank forms bit-identically the same clip factor and the replicated parameters stay identical), clip at -max_norm
+            const bool given = max_norm < 0.f;
+            const float mx = given ? -max_norm : max_norm;
+            const float norm = sqrtf(given ? *extra_sumsq : red[0] + red[1] + red[2] + red[3] + (extra_sumsq ? *extra_sumsq : 0.f));
+            float c = mx > 0.f ? mx / (norm + 1e-6f) : 1.f;      // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
             s_coef = c < 1.f ? c : 1.f;
             if (out_norm && blockIdx.x == 0) *out_norm = norm;
         }
@@ -116,6 +120,7 @@ static int adam_clip_launch(float* params, const float* grads, float* exp_avg, f
                             float* work, float* out_norm, const StepDynState* dyn, void* stream) {
     STEP_REQUIRE(params && grads && exp_avg && exp_avg_sq && work && n > 0 && step >= 1, "adam_clip: bad arguments");
     STEP_REQUIRE((((uintptr_t)grads) & 15) == 0, "adam_clip: gradient buffer must be 16-byte aligned");
+    STEP_REQUIRE(max_norm >= 0.f || extra_sumsq, "adam_clip: max_norm < 0 (squared norm supplied by the caller) needs extra_sumsq");
     hipStream_t st = (hipStream_t)stream;
     sumsq_partial_kernel<<<NB, 256, 0, st>>>(grads, n, work);
     STEP_LAUNCH_CHECK("sumsq_partial");

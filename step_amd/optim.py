@@ -74,6 +74,10 @@ class FusedAdamClip(torch.optim.Optimizer):
             # the fc weight slices of the other ranks belong to the model's gradient norm: the sum of their squared norms came back
             # in the layout's spare slot with the gradient all-reduce (step.py backward) -- no collective of its own
             extra = self.model._other_slices_sumsq
+        max_norm = float(self.max_norm or 0.0)
+        if extra is not None and self.dyn is None and getattr(self.model, "_total_sumsq", None) is not None:
+            # ... as the whole squared norm, formed identically on every rank (step.py backward): max_norm < 0 tells the kernel to take it as is
+            extra, max_norm = self.model._total_sumsq, -max_norm
         if self.dyn is not None:
             # replayed (graph-captured) step: the step count and the learning rate are read from the device state (step_amd/graphed.py
             # advances the count at the head of every replay and copies the scheduler's rate when it changes)
@@ -84,7 +88,7 @@ class FusedAdamClip(torch.optim.Optimizer):
             return
         _lib.call("step_adam_clip_sharded", _lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                   self.flat.numel(), float(pg["lr"]), float(pg["betas"][0]), float(pg["betas"][1]), float(pg["eps"]),
-                  float(pg["weight_decay"]), self.step_count, float(self.max_norm or 0.0), _lib.ptr(extra), _lib.ptr(self.work),
+                  float(pg["weight_decay"]), self.step_count, max_norm, _lib.ptr(extra), _lib.ptr(self.work),
                   _lib.ptr(self.grad_norm), _lib.stream())
 
     def state_dict(self):

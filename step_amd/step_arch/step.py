@@ -282,7 +282,13 @@ class _StepFunction(torch.autograd.Function):
                 # the slot now holds sum_r |g_fc slice of rank r|^2 (mean of world * own_r^2): keep the other ranks' part for the clip norm
                 # (FusedAdamClip) and clear the slot, so that the flat buffer holds gradients only
                 model._other_slices_sumsq = torch.addcmul(flat[ns:ns + 1], own, own, value=-1.0)
+                slices = flat[ns:ns + 1].clone()
                 flat[ns:ns + 1].zero_()
+                # ... and the squared norm of the WHOLE gradient, formed the same way on every rank: replicated part (identical everywhere after
+                # the all-reduce) + the reduced slot.  "own buffer + other slices" is added in a different order on every rank, differs in the
+                # last bit, and the clip factor then lets the replicated parameters drift apart (tests/test_gpu_comm_two_ranks.py found it)
+                rep = torch.linalg.vector_norm(flat[:fo])
+                model._total_sumsq = torch.addcmul(slices, rep, rep)
         finally:
             # also on the error path: the unjoined leaves still read wwork / ework / wsaved / g / hidden_last and write `flat`; once this frame's
             # locals go back to the caching allocator, main-stream work must be ordered behind them (mirrors the forward's guard)

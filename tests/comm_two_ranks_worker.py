@@ -90,11 +90,12 @@ for shard in (False, True):
         # second step on Adam's +-lr steps on round-off-sized gradients (tests/shard_worker.py, part III)
         tol = 2e-5 if it == 0 else 2e-2
         assert e["pred"] < tol and e["loss"] < tol and e["grad"] < (2e-4 if it == 0 else 5e-2) and e["grad_norm"] < tol * 10, e
-    # every rank ends with the same parameters (the all-reduce gave every rank the same gradient)
-    flat = mn._flat_param.detach().double().cpu() if not shard else mn.backend.nodevec1.detach().double().cpu()
-    both = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(both, flat)
-    assert all(torch.equal(both[0], t) for t in both), "ranks diverged"
+    # every rank ends with bit-identical replicated parameters (same reduced gradient, same clip factor, same Adam step)
+    for pname in ("backend.nodevec1", "backend.end_conv_2.weight", "discrete_graph_learning.conv1.weight"):
+        t = dict(mn.named_parameters())[pname].detach().double().cpu()
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        assert all(torch.equal(every[0], q) for q in every), f"{pname} differs between the ranks ({'time slices' if shard else 'whole graph learner'})"
     mn._comm.close(); mn._comm = None
 dist.destroy_process_group()
 print("rank", rank, "ok", flush=True)

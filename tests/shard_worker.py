@@ -134,6 +134,14 @@ assert worst[0] < 2e-2 and dmax <= 2.05 * 2e-3, (worst, dmax)
 e, _ = compare(1, None, False)
 print(f"rank {rank} second step: {e}", flush=True)
 assert e["loss"] < 1e-2 and e["g"] < 2e-2, e
+# data-parallel replicas stay bit-identical (what DistributedDataParallel guarantees): same reduced gradient, same clip factor, same Adam
+# step on every rank -- for the time slices this needs the gradient norm formed identically everywhere (step.py: _total_sumsq)
+for name, m in (("whole graph learner", A), ("time slices", Bm)):
+    for pname in ("backend.nodevec1", "backend.end_conv_2.weight", "discrete_graph_learning.conv1.weight"):
+        t = dict(m.named_parameters())[pname].detach().double().cpu()
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        assert all(torch.equal(every[0], x) for x in every), f"{name}: {pname} differs between the ranks after two optimizer steps"
 # every rank holds the same gathered fc.weight
 w = Bm.discrete_graph_learning.fc.weight.detach().double().cpu()
 both = [torch.empty_like(w) for _ in range(world)]
