@@ -89,7 +89,7 @@ for shard in (False, True):
         # same arithmetic on both transports ((a + b) / 2 either way); what is left is the order of the kernels' own f32 atomics, and from the
         # second step on Adam's +-lr steps on round-off-sized gradients (tests/shard_worker.py, part III)
         tol = 2e-5 if it == 0 else 2e-2
-        assert e["pred"] < tol and e["loss"] < tol and e["grad"] < (2e-4 if it == 0 else 5e-2) and e["grad_norm"] < tol * 10, e
+        assert e["pred"] < tol and e["loss"] < tol and e["grad"] < (1e-3 if it == 0 else 5e-2) and e["grad_norm"] < tol * 10, e      # step 0 measured 3.0 .. 4.5e-5
     # every rank ends with bit-identical replicated parameters (same reduced gradient, same clip factor, same Adam step)
     for pname in ("backend.nodevec1", "backend.end_conv_2.weight", "discrete_graph_learning.conv1.weight"):
         t = dict(mn.named_parameters())[pname].detach().double().cpu()
