@@ -467,7 +467,9 @@ class STEP(nn.Module):
         (step.py:34-35): nothing the optimizer updates is read, and the branch's outputs are bit-identical to computing them inside
         forward() -- dropout seeds are drawn per encoder launch in the same order either way.  forward() recognises the batch by
         the identity of ``long_history_data`` (storage, shape, version) and falls back to the inline path for any other input.
-        Training-loop use:  ``out = model(batch_i); model.prefetch(long_history_of_batch_i+1); loss.backward(); opt.step()``."""
+        Training-loop use:  ``out = model(batch_i); model.prefetch(long_history_of_batch_i+1); loss.backward(); opt.step()`` -- or, with
+        ``tsformer.encoder_workgroups`` set, ``model.prefetch(long_history_of_batch_i+1)`` BEFORE ``model(batch_i)`` (up to two batches may be
+        queued): the next batch's encoder then shares the chip with the whole of step i ("Step schedule")."""
         if not self.prefetch_enabled:
             return
         if isinstance(long_history_data, LongHistoryRef):
