@@ -10,8 +10,9 @@ set -e
 src=${1:-/root/reference}
 dst="$(cd "$(dirname "$0")/.." && pwd)/oracle/_ref/reference"
 if [ ! -d "$src/step/step_arch" ]; then echo "no reference checkout at $src"; exit 1; fi
-rm -rf "$dst"; mkdir -p "$dst"
+[ -d "$dst" ] && chmod -R u+w "$dst"; rm -rf "$dst"; mkdir -p "$dst"
 cp -r "$src/step" "$src/basicts" "$dst/"
+chmod -R u+w "$dst"
 find "$dst" -name "__pycache__" -type d -prune -exec rm -rf {} +
 find "$dst" -name "*.log" -delete
 [ -f "$src/LICENSE" ] && cp "$src/LICENSE" "$dst/" || true
