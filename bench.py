@@ -454,6 +454,36 @@ def timed_loop(step, warmup, steps, barrier, start=0):
 DIST = {"on": False}        # a process group exists (world > 1, or --force-process-group on one rank)
 
 
+def _c_stdio_flush():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:          # noqa: BLE001
+        pass
+    sys.stdout.flush()
+
+
+def stdout_is_for_the_json_line(rank):
+    """The driver reads ONE JSON line from this job's stdout.  RCCL prints a version banner through C stdio when a communicator is created;
+    on a pipe that buffer is flushed at process exit, i.e. AFTER the line (seen with --force-process-group).  Ranks other than 0 therefore
+    send their stdout to stderr from the start; rank 0 flushes C stdio before the line and sends whatever comes after it to stderr."""
+    if rank != 0:
+        _c_stdio_flush()
+        os.dup2(2, 1)
+
+
+def print_json_line(obj):
+    sys.stdout.flush()
+    saved = os.dup(1)                   # what C stdio has buffered so far (the banner) leaves through stderr: the line is the ONLY one on stdout
+    os.dup2(2, 1)
+    _c_stdio_flush()
+    os.dup2(saved, 1)
+    os.close(saved)
+    print(json.dumps(obj), flush=True)
+    _c_stdio_flush()
+    os.dup2(2, 1)
+
+
 def max_over_ranks(dt, world, dev):
     if DIST["on"]:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -832,6 +862,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    stdout_is_for_the_json_line(rank)
     local = local % max(torch.cuda.device_count(), 1)          # (test rigs with fewer devices than ranks share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -855,14 +886,14 @@ def main():
     if cfg.get("pretrain"):
         r = pretrain_run(args, cfg, world, rank, dev, args.warmup, args.steps)
         if rank == 0:
-            print(json.dumps({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": r["value"], "unit": "windows/s",
+            print_json_line({"metric": "TSFormer masked pre-training windows/s (config C3)", "value": r["value"], "unit": "windows/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "bf16 operands, f32 accumulate" if args.matmul == "bf16" else "f32", "data": "synthetic",
                               "config": {"workload": r["workload"], "global_batch": B * world, "parallelism": f"dp{world}",
                                          "final_loss": r["final_loss"]},
                               "whole_step": {"tflops": r["whole_step_tflops"], "frac_of_mfma_peak": r["whole_step_frac_of_mfma_peak"]},
-                              "roofline": static_roofline(args.config), "dominant_kernels": static_dominant_kernels(args.config)}), flush=True)
+                              "roofline": static_roofline(args.config), "dominant_kernels": static_dominant_kernels(args.config)})
         if DIST["on"]:
             torch.distributed.destroy_process_group()
         return
@@ -1053,7 +1084,7 @@ def main():
             refb = cpu_baseline_reference(cfg, data)
             port = cpu_baseline(cfg, data, warm=1 if refb else 2, timed=3 if refb else 5)
             out["cpu_baseline"] = dict(refb, port=port) if refb else port
-        print(json.dumps(out), flush=True)
+        print_json_line(out)
     shutil.rmtree(workdir, ignore_errors=True)
     if DIST["on"]:
         torch.distributed.destroy_process_group()
