@@ -364,6 +364,29 @@ def test_bench_sets_two_hardware_queues_for_single_process_runs_only():
     assert run({}, as_module) == "None"                                    # imported as a module (the tests): the process's settings stay
 
 
+def test_bench_json_line_is_the_only_line_on_stdout():
+    """The driver reads ONE JSON line from bench.py's stdout.  Text that C code left in the stdio buffer before the line (RCCL's version
+    banner under a process group: on a pipe it is flushed at process exit, i.e. after the line) must leave through stderr, a rank other
+    than 0 must write nothing to stdout at all, and whatever C code prints after the line goes to stderr too (bench.print_json_line,
+    bench.stdout_is_for_the_json_line; seen on the GPU box: profiles/r05_zr_stdout_one_json_line_under_a_process_group.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys, bench\n"
+            "libc = ctypes.CDLL(None)\n"
+            "rank = int(sys.argv[1])\n"
+            "bench.stdout_is_for_the_json_line(rank)\n"
+            "libc.printf(b'banner through C stdio before the line\\n')\n"
+            "if rank == 0:\n"
+            "    bench.print_json_line({'metric': 'm', 'value': 1.5})\n"
+            "libc.printf(b'banner through C stdio after the line\\n')\n")
+    for rank, want in ((0, ['{"metric": "m", "value": 1.5}']), (1, [])):
+        out = subprocess.run([sys.executable, "-c", code, str(rank)], cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.splitlines() == want, (rank, out.stdout)
+        assert out.stderr.count("banner through C stdio") == 2, out.stderr[-500:]
+
+
 def test_tsformer_flatten_parameters_keeps_the_state_dict_and_shares_one_buffer():
     """TSFormer.flatten_parameters() (host logic, no device needed): every parameter becomes a view into ONE f32 buffer laid out like the
     native backward's flat gradient buffer (parameters in `_pt_names` order, each at a multiple of 4 floats), values, `state_dict` keys and
