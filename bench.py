@@ -284,7 +284,7 @@ def cpu_baseline(cfg, data, seed=0, warm=2, timed=5, two_threads=True):
 
 def cpu_baseline_reference(cfg, data, warm=1, timed=3):
     """The reference's OWN modules (kind "reference") timed on this host's cores, when its sources are here -- /root/reference in the build
-    container, oracle/_ref/reference on a GPU box after tools/stage_reference.sh: step_arch.STEP.forward + step_loss on re-scaled outputs +
+    container, the archive oracle/_ref/reference.tar.gz (unpacked into the temporary directory) on a GPU box after tools/stage_reference.sh: step_arch.STEP.forward + step_loss on re-scaled outputs +
     backward + clip_grad_norm_(3.0) + Adam (the training step of step/STEP_PEMS04.py with easytorch's Runner.backward), fp32, train mode,
     ONE window per step of the same synthetic workload; `warm` + `timed` steps on all cores (median), then one step on two threads (what
     step/run.py:10 ships).  Returns None where the reference cannot run: no sources, or a graph it cannot build (the [N^2, N] one-hot

@@ -1,6 +1,6 @@
 """R1 / R2 in ONE process (missing #4): the REFERENCE's own config file, STEPRunner.forward,
 BaseTimeSeriesForecastingRunner.train_iters, ForecastingDataset and scaler registry -- unmodified sources, found under /root/reference in
-the build container or under oracle/_ref/reference on the GPU box (tools/stage_reference.sh; git-ignored, shipped by gpurun) -- drive
+the build container or unpacked from oracle/_ref/reference.tar.gz on the GPU box (tools/stage_reference.sh; one git-ignored archive, shipped by gpurun) -- drive
 ``step_amd.STEP`` ON THE GPU through libstep_hip: ``CFG.MODEL.ARCH = step_amd.STEP`` and nothing else.  The two
 training losses the runner returns must match the record the same runner produced around the fp32 oracle
 (tests/golden/runner_metr_la.json, written by tests/test_reference_runner_dropin.py).

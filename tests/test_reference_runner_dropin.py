@@ -7,7 +7,7 @@ the oracle THROUGH THE NATIVE MODULE'S OWN PARAMETERS (the module surface, its s
 and the loss hook are the real ones); the numbers the reference runner produces are stored in
 tests/golden/runner_metr_la.json, and tests/test_gpu_runner_golden.py replays the same two iterations on the GPU against them.
 
-Needs /root/reference (skipped where it is absent, i.e. on the GPU box)."""
+Needs the reference sources: /root/reference, or the staged archive (oracle/reference_loader.py)."""
 import importlib
 import json
 import os
@@ -21,8 +21,10 @@ from oracle import step_oracle as O
 from tests import dropin_common as DC
 from tests.train_problem import update_running_stats
 
-REF = "/root/reference"
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "step")), reason="needs the reference checkout")
+from oracle.reference_loader import reference_root
+
+REF = reference_root()              # the build container's checkout, or the archive tools/stage_reference.sh packs, unpacked
+pytestmark = pytest.mark.skipif(REF is None, reason="needs the reference sources")
 DS = "METR-LA"
 GUMBEL_SEED = 1234
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_metr_la.json")
