@@ -1068,6 +1068,15 @@ def main():
                            "the timed region)" if loader_on else "eight resident batches, cycled"}
         if no_prefetch is not None:
             out["other_schedule"] = no_prefetch
+            try:        # the figure earlier rounds quoted as roofline.frac: the same kernel over the WHOLE chip inside forward(), next to the side stream
+                ms4 = float(no_prefetch.get("encoder_ms_per_launch") or 0.0)
+                if ms4 > 0.0 and ms4 == ms4:
+                    out["roofline"]["whole_chip_in_step"] = {
+                        "ms_per_launch": ms4, "achieved": flops / (ms4 * 1e-3) / 1e12, "frac": flops / (ms4 * 1e-3) / 1e12 / PEAK_TFLOPS,
+                        "what": "the same kernel launched over the whole chip inside forward() (`other_schedule`, this process): how rounds 1-4 "
+                                "measured roofline.frac; with the persistent launch on `compute_units` units `frac` is lower by construction"}
+            except (TypeError, ValueError, KeyError):
+                pass
         if random_init is not None:
             out["random_init"] = random_init
         if loader_fig is not None:
