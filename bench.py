@@ -676,7 +676,7 @@ class StepBench:
         for i in range(warmup):
             self.step(start + i)
         m.tsformer._events = []
-        m.tsformer.fallback_counter = torch.zeros(64, dtype=torch.int32, device=self.dev)
+        m.tsformer.fallback_counter = torch.zeros(65, dtype=torch.int32, device=self.dev)
         if DIST["on"]:
             m._reduce_wait_ms = []
         allocs0 = torch.cuda.memory_stats(self.dev).get("num_device_alloc", 0)
@@ -690,7 +690,7 @@ class StepBench:
         ev = m.tsformer._events
         enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
         launches = max(len(ev), 1)
-        slow = int(m.tsformer.fallback_counter.sum().item())
+        slow = int(m.tsformer.fallback_counter[:64].sum().item())
         m.tsformer._events, m.tsformer.fallback_counter = None, None
         B = self.cfg["B"]
         return {"value": B * self.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* step_last_error(void);
-int step_abi_version(void);        /* 9: step_comm_* / step_grad_allreduce* (data-parallel collectives on RCCL's C API); 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear, step_pt_proj_wgrad, step_pt_embed_unmasked_*; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
+int step_abi_version(void);        /* 10: step_tsformer_encode(STEP_ENC_RANGE_FLAG); 9: step_comm_* / step_grad_allreduce* (data-parallel collectives on RCCL's C API); 8: step_pt_ffn_pack / step_pt_ffn_fused_{fwd,bwd_data,bwd_weights} (the pre-training feed-forward block without a stored hidden layer), step_pt_attention_fwd_bf16(pool, pool_words), step_pt_rows_linear, step_pt_proj_wgrad, step_pt_embed_unmasked_*; 7: StepDynState + step_dyn_advance and the *_dyn entry points (captured / replayed training steps); 6: unjoined leaves on aux_stream / leaf_stream (step_gwnet_backward, step_dgl_edges_backward), StepGemm.splitk_ws, bf16 I/O of step_pt_attention_*_bf16, step_pt_linear_bf16out, step_pt_layernorm_bwd_dropout(out_colsum), step_loss_scaled_fwd_bwd, step_scale2, step_dgl_edges_theta_offset; 5: step_tsformer_encode(fallback_count), keep-mask chunks at word granularity + 16-word wrap copy, step_gwnet_backward(aux_stream), step_pt_ffn_hidden_{fwd,bwd}, step_pt_colsum_bf16, step_pt_add_layernorm_fwd, step_pt_layernorm_bwd_dropout; 4: step_tsformer_encode(flags, drop_pool), step_dropout_pool_fill; 3: step_tsformer_encode(operand_f16);
                                       2: StepGemm.compute_bf16, Step{Dgl,Gwnet}Params.gemm_bf16 */
 
 /* ---------------------------------------------------------------- generic contraction ---
@@ -105,6 +105,10 @@ int step_gemm(const StepGemm* g, void* stream);
  */
 #define STEP_ENC_F16 1
 #define STEP_ENC_ALWAYS_RESHIFT 2
+#define STEP_ENC_RANGE_FLAG 4       /* fallback_count holds 65 words; word [64] is OR-ed with 1 when a hidden state written by this launch is
+                                       not finite -- what a float16 operand beyond 65 504 ends as (the reference computes in fp32,
+                                       transformer_layers.py:13-20, and has no such limit).  The host mirror re-runs the launch on bfloat16
+                                       fragments (step_arch/tsformer.py, "range guard") */
 #define STEP_ENC_WORKGROUPS(n) (((n) & 0xffff) << 8)   /* persistent launch: at most n workgroups (= compute units: a workgroup fills one), each
                                                           looping over sequences; 0 = one workgroup per sequence */
 int step_tsformer_encode(const float* series, int S, int L, const void* wpack, long wpack_bytes,

@@ -163,8 +163,8 @@ _SIGS = {
 _lib = None
 
 
-ABI_VERSION = 9
-ENC_F16, ENC_ALWAYS_RESHIFT = 1, 2          # step_tsformer_encode flags (include/step_hip.h)
+ABI_VERSION = 10
+ENC_F16, ENC_ALWAYS_RESHIFT, ENC_RANGE_FLAG = 1, 2, 4          # step_tsformer_encode flags (include/step_hip.h)
 COMM_F32, COMM_F64, COMM_U8, COMM_ID_BYTES = 0, 1, 2, 128
 
 

@@ -29,6 +29,12 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_dlerror[512] = "";          // the loader's message of the failed dlopen, captured once where it happened
+
+void keep_dlerror() {
+    const char* e = dlerror();          // (one call: dlerror() clears the message it returns)
+    snprintf(g_rccl_dlerror, sizeof g_rccl_dlerror, "%s", e ? e : "");
+}
 
 void load_rccl() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
@@ -39,14 +45,14 @@ void load_rccl() {
     const char* forced = getenv("STEP_RCCL_LIB");
     if (forced && forced[0]) {
         h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-        if (!h) return;
+        if (!h) { keep_dlerror(); return; }
     }
     for (int pass = 0; pass < 2 && !h; ++pass)
         for (const char* n : names) {
             h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
             if (h) break;
         }
-    if (!h) return;
+    if (!h) { keep_dlerror(); return; }
     g_rccl.handle = h;
 #define STEP_RCCL_SYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(h, name)
     STEP_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
@@ -64,7 +70,7 @@ int need_rccl(const char* what) {
     std::call_once(g_rccl_once, load_rccl);
     if (!g_rccl.ok) {
         step_set_error("%s: librccl could not be loaded (dlopen of librccl.so / $STEP_RCCL_LIB failed or symbols are missing): %s", what,
-                       dlerror() ? dlerror() : "no dlerror");
+                       g_rccl_dlerror[0] ? g_rccl_dlerror : "no dlerror");
         return STEP_ERR_HIP;
     }
     return STEP_OK;

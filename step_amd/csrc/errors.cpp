@@ -13,4 +13,4 @@ void step_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* step_last_error(void) { return g_err; }
-extern "C" int step_abi_version(void) { return 9; }
+extern "C" int step_abi_version(void) { return 10; }

@@ -56,28 +56,28 @@ class FusedAdamClip(torch.optim.Optimizer):
             raise RuntimeError("FusedAdamClip: the model's flat parameter buffer changed after the optimizer was created "
                                f"({self.flat.numel()} parameters here, {g.numel()} gradient values): build the optimizer after "
                                "enable_native_data_parallel() / flatten_parameters()")
-        if hasattr(self.model, "_pt_params"):
-            # pre-training TSFormer: whatever averaged the gradients (DDP bucket views, a hand-written all-reduce over p.grad) must have acted
-            # on THIS buffer -- autograd may have cloned the views, DDP may have swapped in its own.  First and last parameter are enough
-            # to tell (the buffer is adopted or replaced as a whole).
-            ps = self.model._pt_params()
-            lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
-            for q in (ps[0], ps[-1]):
-                if q.grad is not None and not (lo <= q.grad.data_ptr() < hi):
-                    raise RuntimeError("FusedAdamClip: a parameter's .grad is not a view of the native flat gradient buffer (cloned by autograd or "
-                                       "re-homed by a DDP wrapper): reduce model._flat_grad itself, or step with torch.optim.Adam")
+        # Whatever averaged the gradients (DDP bucket views, a hand-written all-reduce over p.grad) must have acted on THIS buffer --
+        # autograd clones a view that has another owner, DDP may swap in its own.  First, middle and last parameter are enough to tell
+        # (the buffer is adopted or replaced as a whole).  Both the pre-training TSFormer and STEP hand out views of one flat buffer.
+        ps = self.model._pt_params() if hasattr(self.model, "_pt_params") else self.model._trainable_list()
+        lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+        for q in (ps[0], ps[len(ps) // 2], ps[-1]):
+            if q.grad is not None and not (lo <= q.grad.data_ptr() < hi):
+                raise RuntimeError("FusedAdamClip: a parameter's .grad is not a view of the native flat gradient buffer (cloned by autograd or "
+                                   "re-homed by a DDP wrapper): reduce model._flat_grad itself, or step with torch.optim.Adam")
         pg = self.param_groups[0]
         self.step_count += 1
         extra = None
+        max_norm = float(self.max_norm or 0.0)
         sh = getattr(getattr(self.model, "discrete_graph_learning", None), "_shard", None)      # (a TSFormer in pre-training mode has no graph learner)
-        if sh is not None and self.max_norm:
+        if sh is not None:
             # the fc weight slices of the other ranks belong to the model's gradient norm: the sum of their squared norms came back
             # in the layout's spare slot with the gradient all-reduce (step.py backward) -- no collective of its own
             extra = self.model._other_slices_sumsq
-        max_norm = float(self.max_norm or 0.0)
-        if extra is not None and self.dyn is None and getattr(self.model, "_total_sumsq", None) is not None:
-            # ... as the whole squared norm, formed identically on every rank (step.py backward): max_norm < 0 tells the kernel to take it as is
-            extra, max_norm = self.model._total_sumsq, -max_norm
+            if max_norm > 0.0 and self.dyn is None and getattr(self.model, "_total_sumsq", None) is not None:
+                # ... as the whole squared norm, formed identically on every rank (step.py backward): max_norm < 0 tells the kernel to take
+                # it as is.  Only with a real threshold: -0.0 is not "< 0" for the kernel, which would then add its own sum to the total
+                extra, max_norm = self.model._total_sumsq, -max_norm
         if self.dyn is not None:
             # replayed (graph-captured) step: the step count and the learning rate are read from the device state (step_amd/graphed.py
             # advances the count at the head of every replay and copies the scheduler's rate when it changes)

@@ -29,16 +29,43 @@ def _f32(n, device):
 class LongHistoryRef:
     """Stand-in for the ``long_history_data`` tensor [B, L, N, C] of a batch whose series lives on the device
     (SURVEY 8f-1): ``data`` f32 [T, N, C] resident in HBM, ``t0`` int64 [B] forecast origins, ``length`` = L.  STEP.forward
-    accepts it in place of the tensor and gathers the encoder input directly (no 14.9 MB/window copy)."""
+    accepts it in place of the tensor and gathers the encoder input directly (no 14.9 MB/window copy).
+    It answers the three things the reference's runner does to the batch tensor before the model sees it
+    (step/step_runner/step_runner.py:58-63): ``.to(device)`` / ``.cuda()`` (already there: itself), ``.shape``, and the feature
+    selection ``data[:, :, :, forward_features]`` (a reference to the same windows exposing those channels)."""
 
-    def __init__(self, data, t0, length):
+    def __init__(self, data, t0, length, channels=None):
         assert data.is_cuda and data.dtype == torch.float32 and data.dim() == 3 and data.is_contiguous()
         assert t0.is_cuda and t0.dtype == torch.int64 and t0.dim() == 1
         self.data, self.t0, self.length = data, t0, int(length)
+        self.channels = list(range(data.shape[2])) if channels is None else [int(c) for c in channels]      # data channels this reference exposes, in order
 
     @property
     def shape(self):
-        return (self.t0.shape[0], self.length, self.data.shape[1], self.data.shape[2])
+        return (self.t0.shape[0], self.length, self.data.shape[1], len(self.channels))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    is_cuda = True
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def cuda(self, *args, **kwargs):
+        return self
+
+    def __getitem__(self, idx):
+        full = slice(None)
+        if isinstance(idx, tuple) and len(idx) == 4 and all(i == full for i in idx[:3] if isinstance(i, slice)) and all(isinstance(i, slice) for i in idx[:3]):
+            sel = idx[3]
+            if isinstance(sel, slice):
+                sel = list(range(len(self.channels)))[sel]
+            elif torch.is_tensor(sel):
+                sel = sel.tolist()
+            return LongHistoryRef(self.data, self.t0, self.length, [self.channels[int(c)] for c in sel])
+        raise IndexError("LongHistoryRef supports the runner's feature selection only: ref[:, :, :, features]")
 
 
 class DeviceWindowLoader:
@@ -200,7 +227,7 @@ class _StepFunction(torch.autograd.Function):
         # the flat gradient buffer: everything in front of the fc weight (gradients accumulate into zeros, 18 MB at PEMS04) is cleared; the fc
         # weight's 87 MB are STORED by the graph learner's backward (STEP_DGL_FRESH_FC_GRAD), neither cleared here nor read there
         fo, fn, _ = layout["items"]["dgl.fc_w"]
-        flat, views, gw_grads, dg_grads, grad_tuple = model._grad_buffers(layout, dev)
+        flat, views, gw_grads, dg_grads = model._grad_buffers(layout, dev)
         flat[:fo].zero_()
         if fo + fn < layout["total"]:
             flat[fo + fn:].zero_()
@@ -302,10 +329,10 @@ class _StepFunction(torch.autograd.Function):
         if model.flat_gradients_only:
             # the caller reads model._flat_grad (step_amd.optim.FusedAdamClip does): no per-parameter .grad tensors, no AccumulateGrad work
             return (None, None, None, None) + (None,) * len(layout["order"])
-        if grad_tuple is not None:
-            return (None, None, None, None) + grad_tuple
-        # fresh views with no other owner: autograd's AccumulateGrad then adopts them as .grad (aliases of the flat buffer)
-        # instead of cloning every gradient (the clone of the fc weight gradient alone is an 87 MB copy)
+        # FRESH views with no other owner, built on every backward: autograd's AccumulateGrad adopts such a tensor as .grad (an alias of
+        # the flat buffer) but CLONES one that somebody else still references -- a cached tuple made every step copy 105 MB (the fc
+        # weight gradient alone is 87 MB) and left .grad pointing away from model._flat_grad, which a DistributedDataParallel wrap or
+        # FusedAdamClip(param_grads=True) rely on (tests/test_gpu_step.py::test_param_grads_alias_flat_buffer_every_step)
         return (None, None, None, None) + tuple(flat[o:o + n].view(shape) for o, n, shape in (layout["items"][k] for k in layout["order"]))
 
 
@@ -391,6 +418,7 @@ class STEP(nn.Module):
         self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
         self._prefetched = None             # FIFO (list) of the frozen branches queued by prefetch() for upcoming batches
+        self._alias = {}                    # batch key of a derived tensor -> key of the announced batch it was made from (alias_batch)
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
         self._reduce_events = []
@@ -420,7 +448,7 @@ class STEP(nn.Module):
         return _STREAMS[key]
 
     # ------------------------------------------------------------------ the frozen branch (TSFormer + kNN prior)
-    def _frozen_branch(self, long_hist, B, N, knn_stream=None):
+    def _frozen_branch(self, long_hist, B, N, knn_stream=None, channel=0):
         """[B,L,N,C] long history (or a LongHistoryRef) -> TSFormer hidden states -> cosine kNN prior graph, queued on the CURRENT
         stream.  Depends only on the input and the frozen TSFormer (step.py:34-35, discrete_graph_learning.py:139,164-166):
         no parameter the optimizer touches is read, which is what lets prefetch() run it a step ahead."""
@@ -431,11 +459,11 @@ class STEP(nn.Module):
         series = _f32(B * N * Lh, dev).view(B * N, Lh)
         if isinstance(long_hist, LongHistoryRef):          # index-only loader: gather straight from the resident series
             d = long_hist.data
-            L.call("step_gather_windows", L.ptr(d), d.shape[0], d.shape[1], d.shape[2], 0, L.ptr(long_hist.t0), B, Lh, 12,
+            L.call("step_gather_windows", L.ptr(d), d.shape[0], d.shape[1], d.shape[2], long_hist.channels[channel], L.ptr(long_hist.t0), B, Lh, 12,
                    L.ptr(series), None, None, st)
         else:
             long_hist = long_hist.contiguous().float()
-            L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], 0, L.ptr(series), st)
+            L.call("step_pack_long_history", L.ptr(long_hist), B, Lh, N, long_hist.shape[3], int(channel), L.ptr(series), st)
         P = Lh // 12
         enc = self.tsformer.encode_series(series)
         sim = _f32(B * N * N, dev).view(B, N, N)
@@ -457,11 +485,23 @@ class STEP(nn.Module):
         return {"enc": enc, "sim": sim, "adj_knn": adj_knn, "held": (series, kwork, long_hist), "done": None, "knn_done": knn_done}
 
     @staticmethod
-    def _batch_key(long_hist):
-        t = long_hist.t0 if isinstance(long_hist, LongHistoryRef) else long_hist
-        return (t.data_ptr(), tuple(t.shape), t._version, bool(isinstance(long_hist, LongHistoryRef)))
+    def _batch_key(long_hist, channel=0):
+        """identity of (a batch, the channel of it the TSFormer reads): storage, leading shape, version, data channel"""
+        if isinstance(long_hist, LongHistoryRef):
+            t = long_hist.t0
+            return (t.data_ptr(), tuple(long_hist.shape[:3]), t._version, True, long_hist.channels[channel])
+        return (long_hist.data_ptr(), tuple(long_hist.shape[:3]), long_hist._version, False, int(channel))
 
-    def prefetch(self, long_history_data):
+    def alias_batch(self, source, derived, channel=0):
+        """``derived`` (what forward() is about to be called with) carries, in its channel 0, the values of channel ``channel`` of
+        ``source`` -- the batch tensor the loader announced with ``prefetch(source, channel)``.  The reference's runner does exactly
+        this between its loader and the model (``data[:, :, :, forward_features]``, step_runner.py:25-26,61-63: advanced indexing,
+        a copy); step_amd.runner registers the pair so that forward() still finds the prefetched branch."""
+        if len(self._alias) > 8:
+            self._alias.clear()
+        self._alias[self._batch_key(derived, 0)] = self._batch_key(source, channel)
+
+    def prefetch(self, long_history_data, channel=0):
         """Queue the frozen branch (TSFormer encoder + kNN prior) of an UPCOMING batch on its own stream, so that it runs next to
         the backward pass and optimizer step of the current one.  Legal because the TSFormer is frozen in this stage
         (step.py:34-35): nothing the optimizer updates is read, and the branch's outputs are bit-identical to computing them inside
@@ -486,14 +526,14 @@ class STEP(nn.Module):
         ps.wait_event(ready)
         mode = self.training
         with torch.cuda.stream(ps):
-            rec = self._frozen_branch(long_history_data, B, N)
+            rec = self._frozen_branch(long_history_data, B, N, channel=channel)
             rec["done"] = torch.cuda.Event()
             rec["done"].record(ps)
         # everything the branch allocated is consumed on the main stream after the `done` event
         for t in (rec["enc"]["hidden_bf16"], rec["enc"]["last"], rec["enc"]["sqnorm"], rec["sim"], rec["adj_knn"]):
             if t is not None:
                 t.record_stream(main)
-        rec["key"], rec["training"] = self._batch_key(long_history_data), mode
+        rec["key"], rec["training"] = self._batch_key(long_history_data, channel), mode
         # a short FIFO: the branch of batch i + 1 may be queued before forward() has consumed the one of batch i (the encoder then runs
         # next to the WHOLE of step i, not only its backward)
         q = self._prefetched if isinstance(self._prefetched, list) else []
@@ -518,7 +558,20 @@ class STEP(nn.Module):
         if not q:
             return None
         key = self._batch_key(long_hist)
+        if self._alias:
+            key = self._alias.pop(key, key)
+            self._alias.clear()
         main = torch.cuda.current_stream()
+        stale = [rec for rec in q if rec["training"] != self.training]
+        if stale:
+            # queued in the other mode (a branch announced at the end of a training epoch, then validation): it would pin its encoder
+            # output and kNN buffers (160 MB and more each at PEMS04) and add an event wait to every forward of the whole eval loop
+            for rec in stale:
+                main.wait_event(rec["done"])
+            q[:] = [rec for rec in q if rec["training"] == self.training]
+            if not q:
+                self._prefetched = None
+                return None
         for idx, rec in enumerate(q):
             if rec["key"] == key and rec["training"] == self.training:
                 for skipped in q[:idx]:              # announced but never consumed: keep the stream order, drop them
@@ -566,8 +619,7 @@ class STEP(nn.Module):
         return c[1], c[2]
 
     def _grad_buffers(self, layout, dev):
-        """-> (flat gradient buffer, name -> view, StepGwnetParams of the views, StepDglParams of the views, tuple of views in layout order
-        or None).  With flattened parameters and no .grad left on the parameters (zero_grad(set_to_none=True), the training loop's normal
+        """-> (flat gradient buffer, name -> view, StepGwnetParams of the views, StepDglParams of the views).  With flattened parameters and no .grad left on the parameters (zero_grad(set_to_none=True), the training loop's normal
         state) ONE buffer and its ~100 views / two pointer structs are reused step after step: creating them took 0.7 ms of host time per
         backward (profiles/r05_t_host_sections_C2.log).  Any other situation -- gradients being accumulated over several backwards, no flat
         parameter buffer -- gets fresh ones, with autograd's usual accumulate semantics."""
@@ -575,22 +627,33 @@ class STEP(nn.Module):
         reuse = self._flat_param is not None and tr[0].grad is None and tr[-1].grad is None and tr[len(tr) // 2].grad is None
         c = self._bwd_cache
         if reuse and c is not None and c["layout"] is layout and c["flat"].device == dev:
-            return c["flat"], c["views"], c["gw"], c["dg"], c["tuple"]
+            return c["flat"], c["views"], c["gw"], c["dg"]
         flat = torch.empty(layout["total"], device=dev, dtype=torch.float32)
         views = {k: flat[o:o + n].view(shape) for k, (o, n, shape) in layout["items"].items()}
         gw = fill_gwnet_struct({k[3:]: v for k, v in views.items() if k.startswith("be.")})
         dg = fill_dgl_struct({k[4:]: v for k, v in views.items() if k.startswith("dgl.")})
         if reuse:
-            self._bwd_cache = {"layout": layout, "flat": flat, "views": views, "gw": gw, "dg": dg,
-                               "tuple": tuple(flat[o:o + n].view(shape) for o, n, shape in (layout["items"][k] for k in layout["order"]))}
-            return flat, views, gw, dg, self._bwd_cache["tuple"]
-        return flat, views, gw, dg, None
+            self._bwd_cache = {"layout": layout, "flat": flat, "views": views, "gw": gw, "dg": dg}
+        return flat, views, gw, dg
+
+    def _module_key(self):
+        """identity of everything a cached Parameter list depends on that does not go through _apply / load_state_dict:
+        shard_time_slices() swaps the graph learner's fc parameter, user code may replace a sub-module"""
+        dgl = self.discrete_graph_learning
+        return (id(self.tsformer), id(self.backend), id(dgl), id(dgl._parameters.get("fc_weight_slice")),
+                len(self._parameters), len(dgl._parameters), len(self.backend._parameters))
 
     def _trainable_list(self):
-        t = self._trainable_cache
+        t, key = self._trainable_cache, self._module_key()
+        if t is not None and t[0] != key:
+            # a direct discrete_graph_learning.shard_time_slices() or a replaced sub-module / Parameter: everything derived from the old
+            # Parameter objects is stale (the kernels would compute with the new tensors while gradients were attached to the old ones)
+            self._layout, self._zg_params, self._bwd_cache, self._struct_cache, t = None, None, None, {}, None
+            if self._flat_param is not None:
+                self._flat_param = self._flat_grad = None
         if t is None:
-            t = self._trainable_cache = [v for _, v in self._trainable()]
-        return t
+            t = self._trainable_cache = (key, [v for _, v in self._trainable()])
+        return t[1]
 
     def _grad_layout(self):
         if self._layout is None:
@@ -656,7 +719,16 @@ class STEP(nn.Module):
                 raise RuntimeError("collectives='rccl' needs the module on a GPU (move it first)")
             if not _comm.available() and not auto:
                 raise RuntimeError("collectives='rccl': librccl could not be loaded into this process (STEP_RCCL_LIB names another copy)")
+            usable = _comm.available()
+            if auto and dist.get_world_size(self._process_group) > 1:
+                # agree BEFORE anyone enters ncclCommInitRank: a rank whose librccl did not load would otherwise go on to the all-reduce
+                # below while the others block in the communicator's rendezvous
+                have = torch.tensor([1 if usable else 0], device=self.backend.nodevec1.device, dtype=torch.int32)
+                dist.all_reduce(have, op=dist.ReduceOp.MIN, group=self._process_group)
+                usable = bool(int(have.item()))
             try:
+                if not usable:
+                    raise RuntimeError("librccl could not be loaded on every rank")
                 self._comm = _comm.NativeComm(self._process_group)
             except Exception as ex:          # noqa: BLE001
                 if not auto:
@@ -778,8 +850,7 @@ class STEP(nn.Module):
             # of the tree do not change between steps, so the list is kept (dropped by _apply / load_state_dict / time slicing)
             # and re-checked against the identity of the sub-modules and of the graph learner's slice parameter, which is what
             # shard_time_slices() / a replaced sub-module change without going through _apply / load_state_dict)
-            dgl = self.discrete_graph_learning
-            key = (id(self.tsformer), id(self.backend), id(dgl), id(getattr(dgl, "fc_weight_slice", None)), len(self._parameters))
+            key = self._module_key()
             ps = self._zg_params
             if ps is None or self._zg_key != key:
                 ps = self._zg_params = list(self.parameters())
@@ -790,6 +861,11 @@ class STEP(nn.Module):
             super().zero_grad(set_to_none=False)
         self._flat_grad = None
         self._backward_count = 0
+
+    def train(self, mode=True):
+        if bool(mode) != self.training and self._prefetched:
+            self.cancel_prefetch()          # a branch queued for the other mode will not be consumed (see _take_prefetched)
+        return super().train(mode)
 
     def _apply(self, fn, recurse=True):
         self._zg_params = None

@@ -509,6 +509,22 @@ class TSFormer(nn.Module):
         # overflows at 65 504: operands on this path stay below ~200 (tools/encoder_precision_study.py); the attention
         # probabilities and V, which need exponent range rather than mantissa, are bfloat16 in both modes.
         self.encoder_operand = "f16"
+        # Range guard of the float16 path (the reference computes in fp32 and has no 65 504 limit, transformer_layers.py:13-20):
+        #  * pack time: a weight (or LayerNorm / bias value) that float16 cannot hold makes `packed_weights` pack bfloat16 fragments;
+        #  * run time: the kernel raises a device flag when a hidden state it writes is not finite (STEP_ENC_RANGE_FLAG, free: it rides on
+        #    the squared norms of the epilogue).  The first `range_check_launches` launches after every (re)pack are checked at once (one
+        #    stream synchronize each) and RE-RUN on bfloat16 fragments when it is up; later launches are polled without a synchronize every
+        #    `range_poll_every` launches: a raised flag then switches all following launches to bfloat16 and warns (the affected batches
+        #    already went on as NaN, which the loss shows).  `range_fallbacks` counts the switches, `encoder_operand_in_use` names the type.
+        self.range_guard = os.environ.get("STEP_ENC_RANGE_GUARD", "1") != "0"
+        self.range_check_launches = 2
+        self.range_poll_every = 32
+        self.range_fallbacks = 0
+        self._range_forced_bf16 = False     # the guard's decision; cleared when the weights change (a new pack is judged afresh)
+        self._range_checked = 0
+        self._range_status = None           # uint32 [65 + 15] device: 64 slow-path counters (bench / tests read them) + the flag word
+        self._range_poll = None             # (pinned host int32 [1], event) of the poll in flight
+        self._range_launches = 0
         # 0 / None: one workgroup per sequence (the whole chip, 2456 workgroups at PEMS04).  n > 0: a persistent launch of n workgroups --
         # a workgroup fills a compute unit, so the encoder takes n of the 256 units and leaves the others to whatever runs on the other
         # streams.  That is what makes STEP.prefetch pay: the frozen branch of the next batch on 160 units for 3.1 ms next to this batch's
@@ -526,7 +542,7 @@ class TSFormer(nn.Module):
         self._pool_override = None          # tests: int64 cuda tensor of keep-mask words used instead of the Philox fill
         self.encoder_debug_flags = 0        # tests: _lib.ENC_ALWAYS_RESHIFT
         self._events = None          # bench.py: list collecting (start, end) events around the encoder launch
-        self.fallback_counter = None # bench.py / tests: int32 cuda tensor [64] whose sum the kernel raises by its slow-path softmax units
+        self.fallback_counter = None # bench.py / tests: int32 cuda tensor [65] whose first 64 words the kernel raises by its slow-path softmax units (word 64: range flag)
 
     # ------------------------------------------------------------------ packed operand cache
     def _apply(self, fn, recurse=True):
@@ -548,13 +564,65 @@ class TSFormer(nn.Module):
             ps = self._plist = list(self.parameters())
         return (P, self.encoder_operand, tuple((p.data_ptr(), p._version) for p in ps))
 
+    @property
+    def encoder_operand_in_use(self):
+        """the 16-bit operand type the next launch packs / runs: `encoder_operand` unless the range guard took float16 away"""
+        return "bf16" if (self.encoder_operand == "f16" and self._range_forced_bf16) else self.encoder_operand
+
+    @staticmethod
+    def f16_operands_fit(sd, limit=65504.0):
+        """-> (fits, name, max-abs): can float16 hold every encoder-side value of this state_dict (the fragments are rounded to nearest:
+        anything beyond 65 504 becomes inf)?  Host-side, at pack time."""
+        worst, name = 0.0, None
+        for k, v in sd.items():
+            if not v.is_floating_point() or k.startswith(("decoder.", "mask_token", "enc_2_dec_emb", "output_layer", "decoder_norm")):
+                continue
+            m = float(v.abs().max()) if v.numel() else 0.0
+            if m != m:                        # NaN: nothing to fit
+                return False, k, m
+            if m > worst:
+                worst, name = m, k
+        return bool(worst <= limit), name, worst
+
     def packed_weights(self, P, device):
         key = self._pack_key(P)
+        if self._packed is None or self._packed_key[:1] + self._packed_key[2:] != key[:1] + key[2:] or self._packed.device != device:
+            self._range_forced_bf16, self._range_checked = False, 0          # other weights: judged afresh
+        key = (key[0], self.encoder_operand_in_use, key[2])
         if self._packed is None or self._packed_key != key or self._packed.device != device:
             sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
-            self._packed = pack_tsformer(sd, P, depth=self.encoder_depth, operand=self.encoder_operand).to(device)
+            if key[1] == "f16" and self.range_guard:
+                fits, name, m = self.f16_operands_fit(sd)
+                if not fits:
+                    import warnings
+                    warnings.warn(f"step_amd.TSFormer: {name} reaches {m:.4g}, beyond float16's 65504: the fused encoder packs bfloat16 "
+                                  "operand fragments instead (encoder_operand='f16' kept for weights that fit)")
+                    self._range_forced_bf16, self.range_fallbacks = True, self.range_fallbacks + 1
+                    key = (key[0], "bf16", key[2])
+            self._packed = pack_tsformer(sd, P, depth=self.encoder_depth, operand=key[1]).to(device)
             self._packed_key = key
         return self._packed
+
+    def _range_poll_result(self, wait=False):
+        """the flag word of the last poll, once its copy has landed (None: nothing landed yet)"""
+        if self._range_poll is None:
+            return None
+        host, ev = self._range_poll
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return None
+        self._range_poll = None
+        return int(host[0])
+
+    def _range_overflowed(self, where, status=None):
+        import warnings
+        self._range_forced_bf16, self.range_fallbacks = True, self.range_fallbacks + 1
+        for st in (status, self._range_status):
+            if st is not None:
+                st[64:65].zero_()
+        warnings.warn(f"step_amd.TSFormer: float16 operand overflow in the fused encoder ({where}): non-finite hidden states; "
+                      "the encoder now runs bfloat16 operand fragments (exponent range of fp32)")
 
     def dropout_pool(self, device, drop, seed, L):
         """The keep-mask pool for this launch: (int64 tensor viewed as 64-bit words, number of words).  ``_pool_override``
@@ -586,6 +654,9 @@ class TSFormer(nn.Module):
         if L % self.patch_size != 0:
             raise AssertionError("long history length must be a multiple of the patch size")   # patch.py:41
         P = L // self.patch_size
+        guard = self.range_guard and self.encoder_operand == "f16"
+        if guard and not self._range_forced_bf16 and self._range_poll_result() and not torch.cuda.is_current_stream_capturing():
+            self._range_overflowed("found by the periodic poll; batches since the previous poll carried NaN")
         pk = self.packed_weights(P, series.device)
         out = {"hidden_bf16": torch.empty(S, P, 96, device=series.device, dtype=torch.bfloat16) if want_bf16 else None,
                "hidden_f32": torch.empty(S, P, 96, device=series.device) if want_f32 else None,
@@ -600,13 +671,41 @@ class TSFormer(nn.Module):
         if self._events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        flags = (_lib.ENC_F16 if self.encoder_operand == "f16" else 0) | self.encoder_debug_flags
-        if self.encoder_workgroups:
-            flags |= (int(self.encoder_workgroups) & 0xffff) << 8          # STEP_ENC_WORKGROUPS(n): persistent launch on n compute units
-        _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
-                  flags, _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
-                  _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.ptr(self.fallback_counter),
-                  _lib.stream())
+        def launch(pk, operand, counters, extra_flags):
+            flags = (_lib.ENC_F16 if operand == "f16" else 0) | self.encoder_debug_flags | extra_flags
+            if self.encoder_workgroups:
+                flags |= (int(self.encoder_workgroups) & 0xffff) << 8          # STEP_ENC_WORKGROUPS(n): persistent launch on n compute units
+            _lib.call("step_tsformer_encode", _lib.ptr(series), S, L, _lib.ptr(pk), pk.numel(), self.encoder_depth,
+                      flags, _lib.ptr(out["hidden_bf16"]), _lib.ptr(out["hidden_f32"]), _lib.ptr(out["last"]),
+                      _lib.ptr(out["sqnorm"]), float(drop), _lib.ptr(pool), pool_words, int(seed), _lib.ptr(counters),
+                      _lib.stream())
+        operand = self.encoder_operand_in_use
+        guard = guard and operand == "f16" and not torch.cuda.is_current_stream_capturing()
+        if not guard:
+            launch(pk, operand, self.fallback_counter, 0)
+        else:
+            st = self._range_status
+            if st is None or st.device != series.device:
+                st = self._range_status = torch.zeros(80, dtype=torch.int32, device=series.device)
+            if self.fallback_counter is not None:
+                if self.fallback_counter.numel() < 65:
+                    raise ValueError("TSFormer.fallback_counter needs 65 words with the range guard on (64 counters + the range flag)")
+                st = self.fallback_counter          # bench / tests count the slow softmax units in the same words
+            launch(pk, "f16", st, _lib.ENC_RANGE_FLAG)
+            self._range_launches += 1
+            if self._range_checked < self.range_check_launches:
+                # the first launches on these weights: looked at right away (the frozen weights and the data's scale decide the operand
+                # range; one synchronize each), and re-run on bfloat16 fragments when float16 was not enough
+                self._range_checked += 1
+                if int(st[64].item()) != 0:
+                    self._range_overflowed("first launches on these weights; this launch is re-run", st)
+                    launch(self.packed_weights(P, series.device), "bf16", self.fallback_counter, 0)
+            elif self._range_poll is None and self._range_launches % self.range_poll_every == 0:
+                host = torch.empty(1, dtype=torch.int32).pin_memory()
+                host.copy_(st[64:65], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record()
+                self._range_poll = (host, landed)
         if self._events is not None:
             ev[1].record()
             self._events.append(ev)

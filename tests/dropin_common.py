@@ -53,8 +53,10 @@ def train_origins(ds, n=6, seed=0):
     return sorted(int(t) for t in rng.choice(np.arange(L, T - 12), n, replace=False))
 
 
-def make_workspace(root, ds="METR-LA", seed=0):
-    """Write the four files under `root`; returns the series [T, N, 3]."""
+def make_workspace(root, ds="METR-LA", seed=0, n_train=6, full_history_only=True):
+    """Write the four files under `root`; returns the series [T, N, 3].  n_train forecast origins (6: the recorded runs); with
+    full_history_only=False they are drawn from the whole training split, windows without a full long history included (the reference's
+    dataset hands those an all-zero history, forecasting_dataset.py:66-67)."""
     from step_amd.step_arch.tsformer import TSFormer
     N, T, L = DATASETS[ds]
     series = synth_series(T, N, seed)
@@ -63,7 +65,11 @@ def make_workspace(root, ds="METR-LA", seed=0):
     os.makedirs(os.path.join(root, "tsformer_ckpt"), exist_ok=True)
     with open(os.path.join(d, "data_in12_out12.pkl"), "wb") as f:
         pickle.dump({"processed_data": series}, f)
-    idx = [(t - 12, t, t + 12) for t in train_origins(ds, seed=seed)]
+    if full_history_only:
+        idx = [(t - 12, t, t + 12) for t in train_origins(ds, n=n_train, seed=seed)]
+    else:
+        rng = np.random.default_rng(seed + 23)
+        idx = [(int(t) - 12, int(t), int(t) + 12) for t in rng.choice(np.arange(12, int(0.6 * T)), n_train, replace=False)]
     with open(os.path.join(d, "index_in12_out12.pkl"), "wb") as f:
         pickle.dump({"train": idx, "valid": idx[:2], "test": idx[:2]}, f)
     with open(os.path.join(d, "scaler_in12_out12.pkl"), "wb") as f:

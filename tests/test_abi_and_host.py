@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/step_hip.h but not exported"
     assert set(_lib.exported_symbols()) == declared, set(_lib.exported_symbols()) ^ declared
-    assert lib.step_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.step_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_error_reporting_without_compute():
@@ -434,3 +434,131 @@ def test_product_never_imports_the_oracle_or_the_reference():
                     if pat.search(line) and "import" in line or ("CDLL" in line and "oracle" in line) or ("dlopen" in line and "oracle" in line):
                         bad.append(f"{os.path.relpath(os.path.join(dirpath, f), ROOT)}:{n}: {line.strip()}")
     assert not bad, bad
+
+
+def test_f16_operand_fit_check_is_host_side():
+    """pack-time half of the encoder's float16 range guard (step_arch/tsformer.py): which state_dict values float16 cannot hold"""
+    from step_amd.step_arch.tsformer import TSFormer
+    from tests import train_problem as TPb
+    targs, _ = TPb.model_args(8, 480)
+    torch.manual_seed(0)
+    m = TSFormer(**targs)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert TSFormer.f16_operands_fit(sd)[0]
+    sd["decoder.transformer_encoder.layers.0.linear1.weight"][0, 0] = 1e6          # the decoder is not on the forecasting path
+    assert TSFormer.f16_operands_fit(sd)[0]
+    sd["encoder.transformer_encoder.layers.2.linear2.weight"][3, 5] = -7.0e4
+    fits, name, worst = TSFormer.f16_operands_fit(sd)
+    assert not fits and name == "encoder.transformer_encoder.layers.2.linear2.weight" and worst == 7.0e4
+    sd["encoder.transformer_encoder.layers.2.linear2.weight"][3, 5] = float("nan")
+    assert not TSFormer.f16_operands_fit(sd)[0]
+
+
+def test_stale_parameter_list_is_rebuilt_after_direct_resharding():
+    """the cached Parameter list handed to autograd (and the gradient layout) follow a Parameter swapped by a DIRECT
+    shard_time_slices() call, not only _apply / load_state_dict / enable_native_data_parallel()."""
+    from tests import train_problem as TPb
+    model = TPb.build_native(16, 96, 400, TPb.make_series(16, 600))
+    before = list(model._trainable_list())
+    whole = model.discrete_graph_learning.fc.weight
+    assert any(a is whole for a in before)
+    n_whole = model._grad_layout()["items"]["dgl.fc_w"][1]
+    model.discrete_graph_learning.shard_time_slices(0, 2)
+    after = model._trainable_list()
+    sl = model.discrete_graph_learning.fc_weight_slice
+    assert any(a is sl for a in after) and not any(a is whole for a in after)
+    assert model._grad_layout()["items"]["dgl.fc_w"][1] == sl.numel() < n_whole
+
+
+# ---------------------------------------------------------------------------------------------- step_amd.runner (host logic)
+class _DummyBase:
+    """the hooks of the reference's runner classes that native_runner() overrides, reduced to their contracts"""
+
+    def __init__(self, cfg):
+        self.model = torch.nn.Linear(2, 2)
+        self.loss = lambda a, b, null_val=0.0: (a - b).abs().mean()
+        self.metrics = {"MAE": lambda a, b, null_val=0.0: (a - b).abs().mean(), "MSE": lambda a, b, null_val=0.0: ((a - b) ** 2).mean()}
+        self.meters = {}
+        self.forward_features = [0, 1, 2]
+        self.printed = []
+
+    def build_train_data_loader(self, cfg):
+        return torch.utils.data.DataLoader(cfg["dataset"], batch_size=2, shuffle=False)
+
+    def build_val_data_loader(self, cfg):
+        return None
+
+    def build_test_data_loader(self, cfg):
+        return None
+
+    def select_input_features(self, data):
+        return data[:, :, :, self.forward_features]
+
+    def init_training(self, cfg):
+        self.optim = torch.optim.SGD(self.model.parameters(), lr=0.1)
+
+    def metric_forward(self, f, args):
+        return f(*args, null_val=0.0)
+
+    def update_epoch_meter(self, name, value, n=1):
+        s, c = self.meters.get(name, (0.0, 0))
+        self.meters[name] = (s + float(value) * n, c + n)
+
+    def print_epoch_meters(self, kind):
+        self.printed.append({k: s / c for k, (s, c) in self.meters.items()})
+
+    def plt_epoch_meters(self, kind, step):
+        pass
+
+    def train_iters(self, epoch, it, data):          # base_tsf_runner.py:225-255 in miniature
+        a, b = data
+        loss = self.metric_forward(self.loss, [a, b])
+        for name, f in self.metrics.items():
+            self.update_epoch_meter("train_" + name, self.metric_forward(f, [a, b]).item())
+        return loss
+
+
+def test_native_runner_hooks_on_the_host():
+    from step_amd.runner import LookaheadLoader, native_runner
+    ds = torch.utils.data.TensorDataset(torch.arange(12.0).view(6, 2), torch.arange(12.0).view(6, 2) * 0.5)
+    R = native_runner(_DummyBase)
+    assert R.__name__ == "Native_DummyBase" and issubclass(R, _DummyBase)
+    r = R({})
+    loader = r.build_train_data_loader({"dataset": ds})
+    assert isinstance(loader, LookaheadLoader) and len(loader) == 3 and loader.batch_size == 2
+    assert r.build_val_data_loader({}) is None
+    plain = list(torch.utils.data.DataLoader(ds, batch_size=2))
+    got = list(loader)                      # CPU model: batches pass through, in order, nothing is announced
+    assert len(got) == 3 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, plain))
+    assert loader.staged_batches == 3 and loader.prefetched_batches == 0
+    # CPU tensors: metrics are not deferred (nothing to wait for), the meters behave like the base class's
+    for it, d in enumerate(plain):
+        r.train_iters(1, it, d)
+    base = _DummyBase({})
+    for it, d in enumerate(plain):
+        base.train_iters(1, it, d)
+    r.print_epoch_meters("train")
+    base.print_epoch_meters("train")
+    assert r.printed == base.printed and not r._pending
+    r.init_training({})
+    assert isinstance(r.optim, torch.optim.SGD)          # not a STEP module on a GPU / not Adam: left alone
+
+
+def test_device_forecasting_dataset_reads_the_reference_files(tmp_path):
+    import pickle
+    from step_amd.runner import DeviceForecastingDataset
+    series = np.random.default_rng(0).normal(size=(300, 5, 3)).astype(np.float32)
+    with open(tmp_path / "data.pkl", "wb") as f:
+        pickle.dump({"processed_data": series}, f)
+    idx = {"train": [(t - 12, t, t + 12) for t in (12, 50, 200)], "valid": [(88, 100, 112)], "test": [(88, 100, 112)]}
+    with open(tmp_path / "index.pkl", "wb") as f:
+        pickle.dump(idx, f)
+    ds = DeviceForecastingDataset(str(tmp_path / "data.pkl"), str(tmp_path / "index.pkl"), "train", 96)
+    assert len(ds) == 3 and [int(ds[i]) for i in range(3)] == [12, 50, 200] and ds[0].dtype == torch.int64
+    assert (ds.history_len, ds.future_len, ds.seq_len) == (12, 12, 96) and ds.index_only
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3)))
+    assert batch.tolist() == [12, 50, 200] and batch.dtype == torch.int64
+    with pytest.raises(FileNotFoundError):
+        DeviceForecastingDataset(str(tmp_path / "nope.pkl"), str(tmp_path / "index.pkl"), "train", 96)
+    with pytest.raises(AssertionError):
+        DeviceForecastingDataset(str(tmp_path / "data.pkl"), str(tmp_path / "index.pkl"), "all", 96)

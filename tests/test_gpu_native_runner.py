@@ -1,0 +1,179 @@
+"""The schedule bench.py times, reached from the REFERENCE's own training loop by config lines only ("missing" 3):
+``CFG.RUNNER = step_amd.runner.native_runner(STEPRunner)`` (look-ahead loader that calls ``STEP.prefetch``, meters without a device
+synchronisation per iteration, fused clip + Adam) and ``CFG.DATASET_CLS = step_amd.runner.DeviceForecastingDataset`` (index-only windows
+over the device-resident series).  The reference's unmodified config file, runner classes, dataset and scaler registry run in this
+process (found under /root/reference or unpacked from oracle/_ref/reference.tar.gz; tests/_shims stands in for easytorch).
+
+* same losses as the record the reference's runner produced around the fp32 oracle (tests/golden/runner_metr_la.json), for both datasets;
+* the prefetched branch is found although the runner's feature selection copies the batch tensor (``alias_batch``);
+* the epoch meters hold the same averages as with ``.item()`` per iteration;
+* at config C2 (PEMS04 shape, batch 8) the runner-driven loop is timed next to the plain reference runner around the same module."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+from oracle.reference_loader import reference_root
+from tests import dropin_common as DC
+
+REF = reference_root()
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(REF is None, reason="needs the reference sources (tools/stage_reference.sh stages them for the GPU box)")]
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_metr_la.json")
+PKGS = ("step", "basicts", "easytorch", "easydict", "timm", "setproctitle")
+
+
+class Workspace:
+    def __init__(self, root, ds, **kw):
+        self.root, self.ds = root, ds
+        self.series = DC.make_workspace(root, ds, **kw)
+
+    def __enter__(self):
+        self.old = os.getcwd()
+        os.chdir(self.root)
+        self.added = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shims"), REF]
+        for p in self.added:
+            sys.path.insert(0, p)
+        self.saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in PKGS}
+        for k in self.saved:
+            del sys.modules[k]
+        return self
+
+    def __exit__(self, *exc):
+        os.chdir(self.old)
+        for p in self.added:
+            sys.path.remove(p)
+        for k in [k for k in sys.modules if k.split(".")[0] in PKGS]:
+            del sys.modules[k]
+        sys.modules.update(self.saved)
+
+    def config(self, batch, dropout=False):
+        cfg = importlib.import_module("step.STEP_" + self.ds).CFG          # the reference's config file
+        from step_amd import STEP
+        cfg.MODEL.ARCH = STEP
+        if not dropout:
+            cfg.MODEL.PARAM["tsformer_args"]["dropout"] = 0.0
+            cfg.MODEL.PARAM["backend_args"]["dropout"] = 0.0
+        cfg.TRAIN.DATA.BATCH_SIZE = batch
+        cfg.TRAIN.DATA.SHUFFLE = False
+        cfg["_DEVICE"] = "cuda"
+        return cfg
+
+
+def _record_gumbel(native, gold, N, seen):
+    def hook(module, args, kwargs):
+        seen.append((tuple(kwargs["history_data"].shape), tuple(kwargs["long_history_data"].shape), kwargs["batch_seen"], kwargs["epoch"]))
+        torch.manual_seed(gold["gumbel_seed"] + kwargs["batch_seen"])
+        module._noise_override = torch.rand(kwargs["history_data"].shape[0], N * N, 2)
+    native.register_forward_pre_hook(hook, with_kwargs=True)
+
+
+@pytest.mark.parametrize("dataset", ["reference", "device"])
+def test_native_runner_reproduces_the_recorded_losses(tmp_path, dataset):
+    from step_amd.runner import DeviceForecastingDataset, LookaheadLoader, native_runner
+    with open(GOLDEN) as f:
+        gold = json.load(f)
+    with Workspace(str(tmp_path), "METR-LA") as ws:
+        cfg = ws.config(batch=2)
+        cfg.RUNNER = native_runner(cfg.RUNNER)                  # <- the integration: two (three) config lines
+        if dataset == "device":
+            cfg.DATASET_CLS = DeviceForecastingDataset
+        torch.manual_seed(gold["init_seed"])
+        runner = cfg.RUNNER(cfg)
+        native = runner.model
+        N = DC.DATASETS["METR-LA"][0]
+        seen = []
+        _record_gumbel(native, gold, N, seen)
+        taken = []
+        orig = native._take_prefetched
+        native._take_prefetched = lambda lh: _tap(orig, lh, taken)
+        losses = runner.train(cfg, max_iters=3)
+        torch.cuda.synchronize()
+        assert isinstance(runner.train_data_loader, LookaheadLoader)
+        assert [s[2] for s in seen] == [0, 1, 2] and all(s[0] == (2, 12, N, 3) and s[1] == (2, 2016, N, 3) for s in seen)
+        # batch 0 was never announced (nothing runs before it); batches 1 and 2 were, and forward() found them although the runner's
+        # feature selection hands the module a COPY of the batch tensor
+        assert taken == [False, True, True], taken
+        assert runner.train_data_loader.prefetched_batches == 2
+        print(f"native runner [{dataset} dataset]: losses", losses, "record (reference runner around the fp32 oracle)", gold["losses"])
+        assert losses[0] == pytest.approx(gold["losses"][0], rel=3e-3)
+        assert losses[1] == pytest.approx(gold["losses"][1], rel=2e-2)
+        # fused clip + Adam took the place of torch.optim.Adam + clip_grad_norm_ with the config's hyper-parameters
+        from step_amd.optim import FusedAdamClip
+        assert isinstance(runner.optim, FusedAdamClip) and runner.clip_grad_param is None
+        assert runner.optim.max_norm == cfg.TRAIN.CLIP_GRAD_PARAM["max_norm"] and runner.optim.param_groups[0]["lr"] == cfg.TRAIN.OPTIM.PARAM["lr"]
+        # the meters: nothing was read back per iteration, the epoch averages appear when they are printed
+        assert runner.meters["train_MAE"].n == 0 and len(runner._pending) == 3
+        runner.print_epoch_meters("train")
+        assert runner.meters["train_MAE"].n == 3 and runner.meters["train_RMSE"].n == 3 and runner.meters["train_MAPE"].n == 3
+        assert runner.meters["train_MAE"].avg > 0 and not runner._pending
+
+
+def _tap(orig, lh, taken):
+    rec = orig(lh)
+    taken.append(rec is not None)
+    return rec
+
+
+def test_deferred_meters_equal_the_reference_meters(tmp_path):
+    """same module, same batches: the reference's runner (.item() per iteration) and the native runner end the epoch with the same
+    train_MAE / RMSE / MAPE averages"""
+    from step_amd.runner import native_runner
+    with open(GOLDEN) as f:
+        gold = json.load(f)
+    res = {}
+    for kind in ("reference", "native"):
+        with Workspace(str(tmp_path / kind), "METR-LA") as ws:
+            cfg = ws.config(batch=2)
+            if kind == "native":
+                cfg.RUNNER = native_runner(cfg.RUNNER, fused_optimizer=False)
+            torch.manual_seed(gold["init_seed"])
+            runner = cfg.RUNNER(cfg)
+            _record_gumbel(runner.model, gold, DC.DATASETS["METR-LA"][0], [])
+            runner.train(cfg, max_iters=3)
+            runner.print_epoch_meters("train")
+            res[kind] = {k: runner.meters["train_" + k].avg for k in ("MAE", "RMSE", "MAPE")}
+    print("epoch meters", res)
+    for k in ("MAE", "RMSE", "MAPE"):
+        assert res["native"][k] == pytest.approx(res["reference"][k], rel=1e-4)
+
+
+def test_runner_driven_loop_timed_at_config_c2(tmp_path):
+    """>= 50 timed ``runner.train`` iterations at PEMS04 shape, batch 8, bf16 mode, dropout on: (a) the native runner over the
+    device-resident dataset -- the bench.py schedule reached from the reference's loop; (b) the native runner over the reference's
+    host dataset (pinned batches, asynchronous copies, 14.9 MB per window over PCIe); (c) the reference's runner as it is."""
+    from step_amd.runner import DeviceForecastingDataset, native_runner
+    res = {}
+    for kind, iters in (("native_device", 60), ("native_host", 24), ("reference_runner", 24)):
+        with Workspace(str(tmp_path / kind), "PEMS04", n_train=8 * 70, full_history_only=False) as ws:
+            cfg = ws.config(batch=8, dropout=True)
+            cfg.TRAIN.DATA.SHUFFLE = True
+            if kind != "reference_runner":
+                cfg.RUNNER = native_runner(cfg.RUNNER)
+            if kind == "native_device":
+                cfg.DATASET_CLS = DeviceForecastingDataset
+            torch.manual_seed(0)
+            runner = cfg.RUNNER(cfg)
+            runner.model.matmul_precision = "bf16"
+            warm = 8
+            t = {}
+
+            def clock(module, args, kwargs):
+                if kwargs["batch_seen"] == warm:
+                    torch.cuda.synchronize()
+                    t["t0"] = time.perf_counter()
+            runner.model.register_forward_pre_hook(clock, with_kwargs=True)
+            losses = runner.train(cfg, max_iters=warm + iters)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t["t0"]
+            res[kind] = {"ms_per_step": 1e3 * dt / iters, "windows_per_s": 8 * iters / dt, "iters": iters, "final_loss": losses[-1]}
+            assert all(l == l for l in losses)
+    print("runner-driven loop at C2 (STEP_PEMS04 shape, B = 8, bf16 mode, dropout on):", json.dumps(res))
+    out = os.environ.get("STEP_RUNNER_TIMING_JSON")
+    if out:
+        with open(out, "w") as f:
+            json.dump(res, f)
+    assert res["native_device"]["ms_per_step"] < res["reference_runner"]["ms_per_step"]

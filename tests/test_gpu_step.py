@@ -275,6 +275,81 @@ def test_fused_adam_clip_matches_torch():
         opt.step()
 
 
+def _opt_setup(param_grads, seed=0):
+    from step_amd.optim import FusedAdamClip
+    g = load_golden("step_tiny")
+    torch.manual_seed(seed)
+    model = build_native(g)
+    model.train()
+    model.backend.dropout = 0.0
+    model.tsformer.dropout_p = 0.0
+    model._noise_override = g["in.u"]
+    return g, model, FusedAdamClip(model, lr=2e-3, weight_decay=1e-5, eps=1e-8, max_norm=3.0, param_grads=param_grads)
+
+
+def _opt_steps(g, model, opt, n, check=None):
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    hist, long_hist, fut = inputs_of(g)
+    losses = []
+    for it in range(n):
+        opt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=it, epoch=1)
+        loss = O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef)
+        loss.backward()
+        if check is not None:
+            check(it)
+        opt.step()
+        losses.append(float(loss))
+    return losses
+
+
+def test_param_grads_alias_flat_buffer_every_step():
+    """every .grad must be a VIEW of model._flat_grad on every step (autograd clones a returned view that has another
+    owner -- a cached tuple of views did that from the second step on: 105 MB of copies per step, and a DistributedDataParallel wrap
+    would have reduced the clones while FusedAdamClip stepped on the unreduced flat buffer)."""
+    g, model, opt = _opt_setup(param_grads=True)
+
+    def check(it):
+        flat = model._flat_grad
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        lay = model._grad_layout()
+        for (k, p) in model._trainable():
+            assert p.grad is not None and lo <= p.grad.data_ptr() < hi, (it, k)
+            assert p.grad.data_ptr() == lo + 4 * lay["items"][k][0], (it, k)
+    _opt_steps(g, model, opt, 3, check)
+    # a cloned gradient is refused instead of silently ignored
+    opt.zero_grad(set_to_none=True)
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    hist, long_hist, fut = inputs_of(g)
+    pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=1)
+    O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef).backward()
+    for p in model._trainable_list():
+        p.grad = p.grad.clone()
+    with pytest.raises(RuntimeError, match="not a view of the native flat gradient buffer"):
+        opt.step()
+
+
+def test_flat_gradients_only_matches_param_grads():
+    """FusedAdamClip(param_grads=False) -- the path bench.py times -- takes the same steps as param_grads=True (which the torch comparison
+    above covers): same losses, same parameters, and no .grad is materialised."""
+    ga, ma, oa = _opt_setup(param_grads=True)
+    gb, mb, ob = _opt_setup(param_grads=False)
+    la = _opt_steps(ga, ma, oa, 4)
+    lb = _opt_steps(gb, mb, ob, 4, check=lambda it: [None for p in mb._trainable_list() if p.grad is not None and pytest.fail("a .grad exists")])
+    assert mb.flat_gradients_only and not ma.flat_gradients_only
+    print("param_grads True / False losses", la, lb)
+    for a, b in zip(la, lb):
+        assert a == pytest.approx(b, rel=2e-5)
+    # (two independent runs: split-K / bias-column reductions use atomics and Adam turns round-off on near-zero gradients into +-lr steps,
+    #  see test_fused_adam_clip_matches_torch -- so single elements may sit a few lr apart, the parameter vector as a whole may not)
+    num = sum(float((pa.detach().double() - pb.detach().double()).pow(2).sum()) for (_, pa), (_, pb) in zip(ma._trainable(), mb._trainable()))
+    den = sum(float(pa.detach().double().pow(2).sum()) for _, pa in ma._trainable())
+    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+    for (k, pa), (_, pb) in zip(ma._trainable(), mb._trainable()):
+        assert max_abs(pa.detach().cpu(), pb.detach().cpu()) <= 4 * 2e-3 + 1e-6, k
+    assert la[-1] < la[0]
+
+
 def test_native_step_loss_matches_reference_loss():
     """The fused loss kernel (value + both gradients) against the ORACLE's step_loss (oracle/step_oracle.py, pinned to the
     reference's step_loss / masked_mae by tests/test_oracle_golden.py), evaluated on the CPU."""

@@ -177,7 +177,7 @@ def test_h12_mae_parity(mode):
     minibatches and Gumbel noise) on N=64 nodes x 168 tokens, batch 4, then an eval-mode forward on 64 held-out windows.
     The oracle side (its own fp32 TSFormer states) was run in the build container six times with round-off sized input
     perturbations (tools/make_n1_golden.py -> tests/golden/n1_oracle.npz): horizon-12 masked MAE 38.79 +- 0.53 %, all
-    horizons 38.38 +- 0.16 %.  The native module must land within 1.5 % (horizon 12) / 1 % (all horizons) of the oracle's mean."""
+    horizons 38.38 +- 0.16 %.  The native module must land within 1 % (horizon 12 and all horizons) of the oracle's mean."""
     z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "n1_oracle.npz"))
     N, L, T_train, steps, B, k = [int(x) for x in z["cfg"]]
     runs = z["runs"]
@@ -219,7 +219,72 @@ def test_h12_mae_parity(mode):
     assert losses[0] == pytest.approx(float(z["first_loss"]), rel=5e-3)
     assert tail < 0.6 * losses[0]                                   # it trains
     assert tail == pytest.approx(o_tail, rel=2e-2)
-    assert h12 == pytest.approx(o_h12, rel=1.5e-2)          # (+-2 % until round 4; measured -0.50 .. +1.07 % over the rounds' commits, oracle's own spread 0.53 %)
+    assert h12 == pytest.approx(o_h12, rel=1e-2)            # SURVEY 8c's +-1 % (+-2 % until round 4, 1.5 % in round 5; measured -0.38 / +0.47 %; oracle's own spread 0.53 %)
+    assert mae == pytest.approx(o_mae, rel=1e-2)
+
+
+# ------------------------------------------------------------- horizon-12 MAE at the METRIC'S OWN SHAPE (PEMS04: N=307, L=4032)
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_h12_mae_parity_pems04_shape(mode):
+    """N1 at the shape BASELINE.json's metric is quoted on ("training windows/sec on PEMS04, horizon-12 MAE parity"): N = 307 nodes,
+    long history 4032 (336 tokens), 13 599 training rows behind the graph learner, batch 2, 80 free-running optimizer steps with
+    the reference's settings (step/STEP_PEMS04.py:90-106; MultiStepLR milestones scaled to steps 48 / 64), then the eval-mode
+    held-out horizon-12 masked MAE the reference's test loop reports (base_tsf_runner.py:277-318, mae.py:5-28).  The oracle side
+    -- its OWN fp32 TSFormer states -- was run in the build container five times with round-off sized input perturbations
+    (tools/make_n1_pems04_golden.py -> tests/golden/n1_pems04.npz); the native module (f32 and the timed bf16 mode, device
+    encoder) must land within 1 % of the oracle's mean for horizon 12 and for all horizons."""
+    import os
+    from tools.make_n1_pems04_golden import CFG
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "n1_pems04.npz"))
+    N, L, T_train, steps, B, k, T_all, n_train, n_eval, m0, m1 = [int(x) for x in z["cfg"]]
+    assert (N, L, T_train) == (307, 4032, 13599) and [CFG[q] for q in ("steps", "B", "k", "T_all", "n_train", "n_eval", "m0", "m1")] == [steps, B, k, T_all, n_train, n_eval, m0, m1]
+    runs = z["runs"]
+    assert len(runs) >= 4
+    o_h12, o_mae, o_tail = runs[:, 1].mean(), runs[:, 2].mean(), runs[:, 3].mean()
+    prob = TPb.Problem(N, L, T_train, n_train=n_train, n_eval=n_eval, T_all=T_all)
+    model = TPb.build_native(N, L, T_train, prob.series, k=k).cuda()
+    model.train()
+    model.matmul_precision = mode
+    model.backend.dropout = 0.0
+    model.tsformer.dropout_p = 0.0
+    params = [q for q in model.parameters() if q.requires_grad]
+    opt = torch.optim.Adam(params, lr=TPb.LR0, weight_decay=1e-5, eps=1e-8)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[m0, m1], gamma=TPb.LR_GAMMA)
+    schedule, noises = prob.schedule(steps, B), prob.noises(steps, B)
+    losses = []
+    for it, ts in enumerate(schedule):
+        assert opt.param_groups[0]["lr"] == pytest.approx(TPb.lr_at(it, True, (m0, m1)))
+        hist, longh, fut = [x.cuda() for x in prob.batch(ts)]
+        model._noise_override = noises[it]
+        opt.zero_grad(set_to_none=True)
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=it, epoch=1)
+        loss = O.step_loss(O.rescale(pred[..., [0]], prob.mean, prob.std), O.rescale(fut[..., [0]], prob.mean, prob.std), theta, knn, coef)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 3.0)
+        opt.step()
+        sched.step()
+        losses.append(float(loss.detach()))
+    model.eval()
+    u_eval = torch.rand(len(prob.eval_t), N * N, 2, generator=torch.Generator().manual_seed(999))
+    preds, futs = [], []
+    with torch.no_grad():
+        for i in range(0, len(prob.eval_t), 4):           # (24 windows x 307 x 4032 x 3 floats: in slices of four)
+            hist, longh, fut = [x.cuda() for x in prob.batch(prob.eval_t[i:i + 4])]
+            model._noise_override = u_eval[i:i + 4]
+            pred, _, _, _ = model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=0, epoch=None)
+            preds.append(pred[..., [0]].cpu())
+            futs.append(fut[..., [0]].cpu())
+    pr, fu = O.rescale(torch.cat(preds), prob.mean, prob.std), O.rescale(torch.cat(futs), prob.mean, prob.std)
+    h12, mae = float(O.masked_mae(pr[:, 11], fu[:, 11], 0.0)), float(O.masked_mae(pr, fu, 0.0))
+    tail = float(np.mean(losses[-10:]))
+    print(f"N1 at PEMS04 shape [{mode}] {steps} steps, N={N} P={L // 12} T_train={T_train} B={B}: training loss {losses[0]:.3f} -> {tail:.3f} "
+          f"(oracle {float(z['first_loss']):.3f} -> {o_tail:.3f}); held-out horizon-12 MAE native {h12:.4f} vs oracle {o_h12:.4f} +- "
+          f"{100 * runs[:, 1].std() / o_h12:.2f} % ({(h12 / o_h12 - 1) * 100:+.2f} %), all horizons {mae:.4f} vs {o_mae:.4f} +- "
+          f"{100 * runs[:, 2].std() / o_mae:.2f} % ({(mae / o_mae - 1) * 100:+.2f} %)")
+    assert losses[0] == pytest.approx(float(z["first_loss"]), rel=5e-3)
+    assert tail < 0.6 * losses[0]                                   # it trains
+    assert tail == pytest.approx(o_tail, rel=2e-2)
+    assert h12 == pytest.approx(o_h12, rel=1e-2)
     assert mae == pytest.approx(o_mae, rel=1e-2)
 
 

@@ -41,9 +41,9 @@ def build_native(N, L, T_train, series, k=10, seed=0):
 
 
 class Problem:
-    def __init__(self, N=64, L=2016, T_train=1200, n_train=64, n_eval=64, seed=0):
+    def __init__(self, N=64, L=2016, T_train=1200, n_train=64, n_eval=64, seed=0, T_all=None):
         self.N, self.L, self.T_train = N, L, T_train
-        self.series = make_series(N, L + 1500, seed)
+        self.series = make_series(N, L + 1500 if T_all is None else T_all, seed)
         self.data = torch.from_numpy(self.series)
         rng = np.random.default_rng(seed + 1)
         ts = list(range(L, self.series.shape[0] - 12, 5))
@@ -117,11 +117,11 @@ def oracle_eval(prob, p, hidden, u, k):
 LR0, LR_MILESTONES, LR_GAMMA = 2e-3, (120, 160), 0.25     # MultiStepLR like the reference configs (STEP_PEMS04.py:98-102), in steps
 
 
-def lr_at(it, decay=True):
-    return LR0 * LR_GAMMA ** sum(it >= m for m in LR_MILESTONES) if decay else LR0
+def lr_at(it, decay=True, milestones=LR_MILESTONES):
+    return LR0 * LR_GAMMA ** sum(it >= m for m in milestones) if decay else LR0
 
 
-def oracle_train(prob, sd, hidden, schedule, noises, k=10, perturb=0.0, lr_decay=False):
+def oracle_train(prob, sd, hidden, schedule, noises, k=10, perturb=0.0, lr_decay=False, milestones=LR_MILESTONES, progress=None):
     """K free-running optimizer steps; returns (losses, final parameter dict).  perturb: relative Gaussian perturbation of the
     hidden states per step (the oracle's own sensitivity to round-off sized input changes)."""
     p = trainable(sd)
@@ -130,7 +130,7 @@ def oracle_train(prob, sd, hidden, schedule, noises, k=10, perturb=0.0, lr_decay
     losses = []
     for it, ts in enumerate(schedule):
         for grp in opt.param_groups:
-            grp["lr"] = lr_at(it, lr_decay)
+            grp["lr"] = lr_at(it, lr_decay, milestones)
         hid = hidden
         if perturb:
             g = torch.Generator().manual_seed(1000 + it)
@@ -141,4 +141,6 @@ def oracle_train(prob, sd, hidden, schedule, noises, k=10, perturb=0.0, lr_decay
         opt.step()
         update_running_stats(p, stats)
         losses.append(float(loss.detach()))
+        if progress is not None:
+            progress(it, losses[-1])
     return losses, p
