@@ -207,6 +207,26 @@ def graph_replay_figure(config, B, ckpt, args, steps=30, timeout=240):
         return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
+def runner_feed_figure(timeout=300):
+    """The same config driven by the REFERENCE's own training loop (tools/runner_feed_bench.py: the reference's unmodified config file, STEPRunner,
+    train_iters and scaler registry from the staged sources, tests/_shims for easytorch) with `CFG.RUNNER = step_amd.runner.native_runner(STEPRunner)`,
+    `CFG.DATASET_CLS = step_amd.runner.DeviceForecastingDataset`, in child processes: what a maintainer gets from the three config lines of
+    INTEGRATION.md, and -- 24 iterations -- the reference's runner and host dataset as they are around the same module."""
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "runner_feed_bench.py")
+    out = {}
+    for name, extra in (("native_runner_device_dataset", ["--runner", "native", "--dataset", "device", "--loss", "native", "--iters", "60"]),
+                        ("native_runner_device_dataset_reference_loss", ["--runner", "native", "--dataset", "device", "--iters", "60"]),
+                        ("reference_runner_host_dataset", ["--runner", "reference", "--dataset", "host", "--iters", "24"])):
+        try:
+            r = subprocess.run([sys.executable, tool] + extra, timeout=timeout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+            out[name] = next((json.loads(l) for l in reversed(r.strip().splitlines()) if l.startswith("{")), {"error": "no output"})
+        except Exception as ex:          # noqa: BLE001 -- an optional figure must not take the headline line with it
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    out["what"] = ("runner.train() of the reference around step_amd.STEP at this config (batch 8, bf16 mode, dropout on, shuffled windows over the whole "
+                   "training split): windows/s and ms per iteration, host side included")
+    return out
+
+
 def pmc_child(args):
     """Child of live_pmc_traffic: three training-mode encoder launches at the config's size, nothing else."""
     from step_amd import TSFormer
@@ -815,6 +835,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the reference config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loader-figure", action="store_true", help="skip the second timed loop through the device-resident window loader")
+    ap.add_argument("--no-runner-figure", action="store_true", help="skip the child runs that drive the config through the reference's runner loop")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no random-init / no-prefetch / other-config figures, no counter run")
     ap.add_argument("--other-configs", default=None, help="comma list of further configs measured after the headline (default: the three "
                     "north-star configs at N=1, none at N>1; '-' = none)")
@@ -1081,6 +1102,8 @@ def main():
             out["random_init"] = random_init
         if loader_fig is not None:
             out["other_input_feed"] = loader_fig
+        if world == 1 and extras and not args.forward_only and args.config == "STEP_PEMS04" and not args.no_runner_figure:
+            out.setdefault("other_input_feed", {})["reference_runner_loop"] = runner_feed_figure()
         if graph_fig is not None:
             out["graph_replay"] = graph_fig
         if comm is not None:

@@ -254,7 +254,9 @@ int step_gwnet_forward(const float* hist, int B, int N, int Cin, const float* hi
  * the encoder is busy: phase 1 = supports + the 8 WaveNet layers (hidden_last / pred unused), phase 2 = head (hist / adj
  * unused; same saved / work buffers, after phase 1 in stream order), phase 0 = both.  The head in two: phase 3 = the fc_his branch
  * (needs hidden_last only: it can be queued behind the encoder before phase 1 has finished elsewhere), phase 4 = the rest of the
- * head (after phases 1 and 3; needs pred). */
+ * head (after phases 1 and 3; needs pred).  Phase 1 in two (ABI 10): phase 5 = its part that does not read `adj` (start convolution,
+ * adaptive support, weight packing, layer 0's gated TCN: model.py:143-155,165,183-189; adj may be NULL) -- it can run next to the graph
+ * learner that produces adj -- and phase 6 = the rest of phase 1 (after phase 5 in stream / event order; hist unused). */
 int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                              const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                              float* saved, float* work, float* pred, int phase, void* stream);
@@ -433,6 +435,12 @@ int step_loss_fwd_bwd(const float* pred, const float* real, long n_pred, const f
 int step_loss_scaled_fwd_bwd(const float* pred, const float* real, long n_pred, long real_stride, float scale, float shift,
                              const float* theta, const float* prior, long n_adj, float null_val, float coef, double* work, float* loss,
                              float* dpred, float* dtheta, void* stream);
+/* The runner's three training metrics in one launch (ABI 10): out = [masked MAE, masked RMSE, masked MAPE] of `pred` against `real`
+ * with the semantics of basicts/metrics/{mae,rmse,mape}.py (mask = |real - null_val| > 5e-5; MAPE zeroes |real| < 1e-4 and masks 0),
+ * evaluated every iteration by base_tsf_runner.py:252-254 (~30 element-wise torch launches).  Element i of pred / real sits at
+ * i * stride floats.  work: 6 doubles, zero before the FIRST call; the kernel leaves them zero again. */
+int step_masked_metrics(const float* pred, long pred_stride, const float* real, long real_stride, long n, float null_val, double* work,
+                        float* out, void* stream);
 /* out_a = a * *g, out_b = b * *g with g a device scalar (autograd's incoming gradient of the loss applied to both gradients). */
 int step_scale2(const float* a, long na, const float* b, long nb, const float* g, float* out_a, float* out_b, void* stream);
 

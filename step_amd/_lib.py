@@ -136,6 +136,7 @@ _SIGS = {
     "step_loss_fwd_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "step_loss_scaled_fwd_bwd": (_i, [_vp, _vp, _l, _l, _f, _f, _vp, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "step_scale2": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp]),
+    "step_masked_metrics": (_i, [_vp, _l, _vp, _l, _l, _f, _vp, _vp, _vp]),
     "step_adam_work_floats": (_l, []),
     "step_adam_clip": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     "step_adam_clip_sharded": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 #define STEP_ERR_HIP 2
 
 void step_set_error(const char* fmt, ...);
+int step_raise_lds_once(const void* kernel, int bytes, const char* what);      // errors.cpp: once per (kernel, device), thread-safe
 
 #define STEP_REQUIRE(cond, ...)                 \
     do {                                        \

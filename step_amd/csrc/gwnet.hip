@@ -946,11 +946,14 @@ extern "C" long step_gwnet_saved_offset(int B, int N, int dropout, int item, int
     return p ? (long)(p - (float*)16) : -1;
 }
 
+// first_tcn_only: layer 0's gated TCN and nothing else (it reads the start convolution's output, not the adjacency: phase 5);
+// skip_first_tcn: everything but that launch (phase 6)
 template <bool BF16>
 static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const Work& W, int B, int N, bool training, float drop_p,
-                                uint64_t seed, float momentum, bool dead_bn7, const StepDynState* dyn, hipStream_t st) {
+                                uint64_t seed, float momentum, bool dead_bn7, const StepDynState* dyn, hipStream_t st,
+                                bool first_tcn_only = false, bool skip_first_tcn = false) {
     const long BN = (long)B * N;
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < (first_tcn_only ? 1 : NL); ++i) {
         const int Tin = TIN[i], Tout = TOUT[i], dil = DIL[i];
         const long npos = BN * Tout;
         // statistics of BatchNorm_{i-1} (sums left by mix_fwd of the previous layer), finalised by this layer's first kernel
@@ -959,9 +962,12 @@ static int gwnet_layers_forward(const StepGwnetParams* p, const Saved& S, const 
             bn.gamma = p->bn_w[i - 1]; bn.beta = p->bn_b[i - 1]; bn.rm = p->bn_rm[i - 1]; bn.rv = p->bn_rv[i - 1];
             bn.stat = S.bnstat[i - 1]; bn.sums = W.acc64 + (long)(i - 1) * NCOPY * 64;
         }
-        tcn_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(i == 0 ? S.x0 : S.y[i - 1], bn, npos, Tin, Tout, dil, W.wcat + i * 4096,
-                                                                        W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
-        STEP_LAUNCH_CHECK("tcn_fwd");
+        if (!(i == 0 && skip_first_tcn)) {
+            tcn_fwd_kernel<BF16><<<(unsigned)cdiv(npos, 128), 256, 0, st>>>(i == 0 ? S.x0 : S.y[i - 1], bn, npos, Tin, Tout, dil, W.wcat + i * 4096,
+                                                                            W.bcat + i * 64, S.tf[i], S.sg[i], S.cat[i], S.zlast, i);
+            STEP_LAUNCH_CHECK("tcn_fwd");
+        }
+        if (first_tcn_only) break;
         if (i == NL - 1 && !(dead_bn7 && training)) break;
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 0, 0, 1, B, N, Tout, BF16, W.xT, st));      // slots 1,3,5 = P_s z
         STEP_TRY(nconv_fwd3(S.Pstk, S.PT16, S.cat[i], 1, 2, 2, B, N, Tout, BF16, W.xT, st));      // slots 2,4,6 = P_s (P_s z)
@@ -1009,9 +1015,13 @@ extern "C" int step_gwnet_forward_phase(const float* hist, int B, int N, int Cin
 extern "C" int step_gwnet_forward_phase_dyn(const float* hist, int B, int N, int Cin, const float* hidden_last, const float* adj,
                                             const StepGwnetParams* p, int training, float dropout_p, uint64_t seed, float momentum,
                                             float* saved, float* work, float* pred, int phase, const StepDynState* dyn, void* stream) {
-    STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 4, "gwnet_forward: null argument / bad phase");
-    const bool do_layers = phase == 0 || phase == 1, do_his = phase == 0 || phase == 2 || phase == 3, do_head = phase == 0 || phase == 2 || phase == 4;
-    STEP_REQUIRE(!do_layers || (hist && adj), "gwnet_forward: the layer phase needs hist and adj");
+    STEP_REQUIRE(p && saved && work && phase >= 0 && phase <= 6, "gwnet_forward: null argument / bad phase");
+    // phase 1 in two: 5 = what does not read the sampled adjacency (start convolution, adaptive support, weight packing, layer 0's gated
+    // TCN), 6 = the rest (random-walk supports, bf16 stacks, hops and mixes of all layers) -- the caller can run 5 next to the graph learner
+    const bool do_prep = phase == 0 || phase == 1 || phase == 5, do_layers = phase == 0 || phase == 1 || phase == 6;
+    const bool do_his = phase == 0 || phase == 2 || phase == 3, do_head = phase == 0 || phase == 2 || phase == 4;
+    STEP_REQUIRE(!do_prep || hist, "gwnet_forward: the layer phase needs hist");
+    STEP_REQUIRE(!do_layers || adj, "gwnet_forward: the layer phase needs adj");
     STEP_REQUIRE(!do_his || hidden_last, "gwnet_forward: the fc_his phase needs hidden_last");
     STEP_REQUIRE(!do_head || pred, "gwnet_forward: the head phase needs pred");
     STEP_REQUIRE(B > 0 && N > 0 && Cin >= 2, "gwnet_forward: bad sizes B=%d N=%d C=%d", B, N, Cin);
@@ -1023,42 +1033,45 @@ extern "C" int step_gwnet_forward_phase_dyn(const float* hist, int B, int N, int
     const long BN = (long)B * N;
     const int allbf16 = p->gemm_bf16;      // bf16 mode: every contraction of this file on the bf16 matrix cores (the K=10 / dpred-transposed ones stay f32)
 
-    if (do_layers) {
-    STEP_TRY(zero((float*)W.acc64, 2L * NL * NCOPY * 64, st));
-    start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
-    STEP_LAUNCH_CHECK("start_conv");
-    // supports (model.py:160-166)
-    row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs, S.cs);
-    {
-        int slices = cdiv(512, cdiv(N, 64) * B);          // ~2 blocks per compute unit
-        if (slices > cdiv(N, 64)) slices = cdiv(N, 64);
-        if (slices < 1) slices = 1;
-        col_sums_kernel<<<dim3(cdiv(N, 64), slices, B), 256, 0, st>>>(adj, N, S.cs);
-    }
     const long NN = (long)N * N;
-    rw_build_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(adj, N, S.rs, S.cs, S.Pstk, S.Pstk + B * NN, S.PTstk,
-                                                                       S.PTstk + B * NN);
-    STEP_LAUNCH_CHECK("rw_build");
-    {
-        StepGemm g = gemm_desc(N, N, 10, p->nodevec1, 10, 1, p->nodevec2, N, 1, S.Madp, N);
-        STEP_TRY(step_gemm_launch(g, st));
-        softmax_relu_rows_kernel<<<N, 256, 0, st>>>(S.Madp, N, S.Pa);
-        replicate_adp_kernel<<<g1(NN), 256, 0, st>>>(S.Pa, N, B, S.Pstk + 2 * B * NN, S.PTstk + 2 * B * NN);
-        STEP_LAUNCH_CHECK("adp_softmax");
-    }
-    if (p->gemm_bf16) {
-        const long rows = 3L * B * N;
-        stacks_to_bf16_kernel<<<dim3((unsigned)cdiv(rows * (n8(N) / 2), 256), 2), 256, 0, st>>>(S.Pstk, S.PTstk, rows, N, n8(N), S.P16,
-                                                                                               S.PT16);
-        STEP_LAUNCH_CHECK("stacks_to_bf16");
-    }
-    STEP_TRY(pack_weights(p, W, st));
-
-    // 8 layers: gated TCN (one kernel), two diffusion hops (the three supports per launch), gcn mix + dropout + residual + BatchNorm
-    // statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
     const bool dead_bn7 = (training & 2) != 0;
-    if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st));
-    else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st));
+    if (do_prep) {
+        STEP_TRY(zero((float*)W.acc64, 2L * NL * NCOPY * 64, st));
+        start_conv_kernel<<<g1(BN * 13 * C), 256, 0, st>>>(hist, B, N, Cin, p->start_w, p->start_b, S.x0);
+        STEP_LAUNCH_CHECK("start_conv");
+        {   // adaptive support softmax(relu(E1 E2)) (model.py:165), replicated per sample into stack slot 2
+            StepGemm g = gemm_desc(N, N, 10, p->nodevec1, 10, 1, p->nodevec2, N, 1, S.Madp, N);
+            STEP_TRY(step_gemm_launch(g, st));
+            softmax_relu_rows_kernel<<<N, 256, 0, st>>>(S.Madp, N, S.Pa);
+            replicate_adp_kernel<<<g1(NN), 256, 0, st>>>(S.Pa, N, B, S.Pstk + 2 * B * NN, S.PTstk + 2 * B * NN);
+            STEP_LAUNCH_CHECK("adp_softmax");
+        }
+        STEP_TRY(pack_weights(p, W, st));
+        if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st, true, false));
+        else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st, true, false));
+    }
+    if (do_layers) {
+        // random-walk supports of the sampled adjacency (model.py:160-166)
+        row_sums_kernel<<<(unsigned)BN, 256, 0, st>>>(adj, N, S.rs, S.cs);
+        {
+            int slices = cdiv(512, cdiv(N, 64) * B);          // ~2 blocks per compute unit
+            if (slices > cdiv(N, 64)) slices = cdiv(N, 64);
+            if (slices < 1) slices = 1;
+            col_sums_kernel<<<dim3(cdiv(N, 64), slices, B), 256, 0, st>>>(adj, N, S.cs);
+        }
+        rw_build_kernel<<<dim3(cdiv(N, 32), cdiv(N, 32), B), 256, 0, st>>>(adj, N, S.rs, S.cs, S.Pstk, S.Pstk + B * NN, S.PTstk,
+                                                                           S.PTstk + B * NN);
+        STEP_LAUNCH_CHECK("rw_build");
+        if (p->gemm_bf16) {
+            const long rows = 3L * B * N;
+            stacks_to_bf16_kernel<<<dim3((unsigned)cdiv(rows * (n8(N) / 2), 256), 2), 256, 0, st>>>(S.Pstk, S.PTstk, rows, N, n8(N), S.P16,
+                                                                                                   S.PT16);
+            STEP_LAUNCH_CHECK("stacks_to_bf16");
+        }
+        // 8 layers: gated TCN (one kernel; layer 0's ran with the preparation), two diffusion hops (the three supports per launch), gcn mix +
+        // dropout + residual + BatchNorm statistics (one kernel); the BatchNorm transform itself is applied by the next layer's reads
+        if (allbf16) STEP_TRY(gwnet_layers_forward<true>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st, false, true));
+        else STEP_TRY(gwnet_layers_forward<false>(p, S, W, B, N, train, use_drop ? dropout_p : 0.f, seed, momentum, dead_bn7, dyn, st, false, true));
     }
 
     // head (model.py:215-220).  fc_his (phase 3) is the only part that needs the TSFormer's hidden state, and needs nothing else: the

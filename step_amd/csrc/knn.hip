@@ -204,11 +204,202 @@ __global__ __launch_bounds__(TK_THREADS) void tk_mask_kernel(const float* __rest
 static long tk_slices(int N) { return ((long)N * N + TK_SLICE - 1) / TK_SLICE; }
 
 static long tk_bytes(int B, int N) { return (long)B * (3 * TK_BINS + tk_slices(N) + 2) * (long)sizeof(uint32_t); }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Symmetric Gram product for graphs of up to 320 nodes (METR-LA, PEMS04, PEMS08 of the reference's datasets): raw[b] = H[b] H[b]^T, H bf16 [N][F].
+// The staged GEMM computes the full square from 128 x 128 tiles, each of which streams its two 128-row operand panels over the whole
+// feature axis: 6 x the 158 MB of H through L2 at PEMS04, 181 us alone and 250 us next to the encoder -- for 48.6 GFLOP (19 us of matrix
+// time).  Here ONE workgroup of 16 waves owns the WHOLE (padded) output for a slice of the feature axis: a 64-feature slab of all N rows
+// is staged once in LDS (double buffered) and every wave multiplies the row panels of its 64 x 64 block (2 x 2 MFMA tiles: four fragment
+// reads for four products) -- only the <= 15 blocks on or above the diagonal exist, one per wave (64 accumulator registers).  H is read exactly once; the partial blocks of the feature
+// slices go to a workspace in accumulator order (coalesced), and gram_finish_kernel adds them, applies the cosine normalisation
+// (similarity.py:8-14) and writes both triangles.
+constexpr int GS_KS = 64, GS_PITCH = GS_KS * 2 + 8;          // slab of 64 features; LDS row = 128 B + 8 (conflict-free 16-byte fragment reads)
+__host__ __device__ constexpr int gs_blocks(int nb) { return nb * (nb + 1) / 2; }
+// block p (0 .. NB(NB+1)/2 - 1) -> (bi <= bj), row-major over the upper triangle
+__device__ __forceinline__ void gs_block_of(int p, int NB, int& bi, int& bj) {
+    bi = 0;
+    while (p >= NB - bi) { p -= NB - bi; ++bi; }
+    bj = bi + p;
+}
+__global__ __launch_bounds__(1024) void gram_sym_kernel(const uint16_t* __restrict__ H, int N, int F, int NB, int slabs_per_split,
+                                                        float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const int rows = NB * 64;                                   // padded row count (zero rows beyond N)
+    const int buf_bytes = rows * GS_PITCH;
+    const uint16_t* Hb = H + (long)b * N * F;
+    const int k_begin = s * slabs_per_split * GS_KS;
+    const int k_end = min(F, (s + 1) * slabs_per_split * GS_KS);
+    // zero both buffers once: rows >= N (and the pad bytes) are never written again
+    for (int i = tid; i < 2 * buf_bytes / 16; i += 1024) ((uint4*)gs_lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int nblk = gs_blocks(NB);
+    constexpr int Q = 1;                                        // blocks per wave (NB <= 5: 15 blocks for 16 waves)
+    int bi[Q], bj[Q];
+    bool own[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int p = wave + 16 * q;
+        own[q] = p < nblk;
+        gs_block_of(own[q] ? p : 0, NB, bi[q], bj[q]);
+    }
+    f32x16 acc[Q][4];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][t][e] = 0.f;
+    // staging: chunk c = (row, 16-byte piece) of the slab; up to 3 chunks per thread (384 rows x 8 pieces / 1024 threads)
+    const int nchunk = N * (GS_KS / 8);
+    uint4 st[3];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = tid + u * 1024;
+            st[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nchunk) {
+                const int row = c >> 3, k = k0 + (c & 7) * 8;
+                if (k < k_end) st[u] = *(const uint4*)(Hb + (long)row * F + k);          // (F % 8 == 0 and slices end on slab boundaries or at F: whole pieces)
+            }
+        }
+    };
+    auto commit = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int c = tid + u * 1024;
+            if (c < nchunk) {
+                char* d = buf + (c >> 3) * GS_PITCH + (c & 7) * 16;
+                *(uint2*)d = make_uint2(st[u].x, st[u].y);
+                *(uint2*)(d + 8) = make_uint2(st[u].z, st[u].w);
+            }
+        }
+    };
+    __syncthreads();
+    if (k_begin < k_end) {
+        fetch(k_begin);
+        commit(gs_lds);
+        __syncthreads();
+        int cur = 0;
+        const int r = lane & 31, h = lane >> 5;
+        for (int k0 = k_begin; k0 < k_end; k0 += GS_KS) {
+            const bool more = k0 + GS_KS < k_end;
+            if (more) fetch(k0 + GS_KS);
+            const char* buf = gs_lds + cur * buf_bytes;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (!own[q]) continue;
+                const char* pa = buf + (bi[q] * 64 + r) * GS_PITCH + h * 16;
+                const char* pb = buf + (bj[q] * 64 + r) * GS_PITCH + h * 16;
+                const bool diag = bi[q] == bj[q];
+#pragma unroll
+                for (int ks = 0; ks < GS_KS / 16; ++ks) {
+                    auto frag = [&](const char* p) -> bf16x8 {
+                        const uint2 lo = *(const uint2*)(p + ks * 32), hi = *(const uint2*)(p + ks * 32 + 8);
+                        return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    };
+                    const bf16x8 a0 = frag(pa), a1 = frag(pa + 32 * GS_PITCH);
+                    const bf16x8 b0 = diag ? a0 : frag(pb), b1 = diag ? a1 : frag(pb + 32 * GS_PITCH);
+                    acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[q][0], 0, 0, 0);
+                    acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[q][1], 0, 0, 0);
+                    if (!diag) acc[q][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[q][2], 0, 0, 0);
+                    acc[q][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[q][3], 0, 0, 0);
+                }
+            }
+            if (more) commit(gs_lds + (cur ^ 1) * buf_bytes);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // partial blocks -> workspace [split][sample][block][tile 0..3][accumulator register e][lane]: 256-byte runs per store instruction
+    float* out = ws + ((long)(s * gridDim.y + b) * nblk) * 4096;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (!own[q]) continue;
+        float* o = out + (long)(wave + 16 * q) * 4096 + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t == 2 && bi[q] == bj[q]) continue;               // the lower tile of a diagonal block is the transpose of tile 1
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t * 1024 + e * 64] = acc[q][t][e];
+        }
+    }
+    (void)S;
+}
+// sum of the feature slices, cosine normalisation, both triangles.  grid (blocks of the upper triangle, B), 256 threads; every thread owns
+// accumulator elements (t, e, lane) with lane = tid & 63, e = 4 (tid >> 6) .. + 3 of all four tiles.
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ ws, int S, int N, int NB, const float* __restrict__ sqn_part,
+                                                          float* __restrict__ sim) {
+    __shared__ float tile[64][65];
+    __shared__ float nrm[128];
+    const int b = blockIdx.y, Bn = gridDim.y, nblk = gs_blocks(NB);
+    int bi, bj;
+    gs_block_of(blockIdx.x, NB, bi, bj);
+    const int tid = threadIdx.x, lane = tid & 63, eg = tid >> 6;
+    if (tid < 128) {           // norms of the block's 64 rows and 64 columns (similarity.py:8-14: |F| + 1e-7)
+        const int n = (tid < 64 ? bi * 64 : bj * 64 - 64) + tid;
+        float sum = 0.f;
+        if (n < N) {
+            const float* p = sqn_part + ((long)b * N + n) * 16;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) sum += p[w];
+        }
+        nrm[tid] = sqrtf(fmaxf(sum, 0.f)) + 1e-7f;
+    }
+    const bool diag = bi == bj;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t == 2 && diag) continue;
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = eg * 4 + ee;
+            float v = 0.f;
+            for (int sp = 0; sp < S; ++sp) v += ws[((long)(sp * Bn + b) * nblk + blockIdx.x) * 4096 + t * 1024 + e * 64 + lane];
+            // accumulator element (e, lane) of a 32 x 32 product: row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31
+            const int rr = (t >> 1) * 32 + 8 * (e >> 2) + (e & 3) + 4 * (lane >> 5), cc = (t & 1) * 32 + (lane & 31);
+            tile[rr][cc] = v;
+            if (diag && t == 1) tile[cc][rr] = v;                   // (the skipped lower tile)
+        }
+    }
+    __syncthreads();
+    // rows of the block (and, off the diagonal, of its transpose) in 256-byte runs
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        const int gi = bi * 64 + rr, gj = bj * 64 + cc;
+        if (gi < N && gj < N) sim[((long)b * N + gi) * N + gj] = tile[rr][cc] / (nrm[rr] * nrm[64 + cc]);
+    }
+    if (!diag) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int cc = i >> 6, rr = i & 63;                      // element (gj, gi) of the output = tile[rr][cc]
+            const int gi = bi * 64 + rr, gj = bj * 64 + cc;
+            if (gi < N && gj < N) sim[((long)b * N + gj) * N + gi] = tile[rr][cc] / (nrm[rr] * nrm[64 + cc]);
+        }
+    }
+}
+// feature slices per sample: enough workgroups for about half the chip (the product runs next to other kernels), at least 2 slabs each
+static int gram_sym_splits(int B, int F) {
+    static const int forced = []() { const char* e = getenv("STEP_GRAM_SPLITS"); return e ? atoi(e) : 0; }();
+    const int slabs = (F + GS_KS - 1) / GS_KS;
+    int S = forced > 0 ? forced : (128 + B - 1) / B;
+    if (S > slabs / 2) S = slabs / 2;
+    return S < 1 ? 1 : S;
+}
+static bool gram_sym_ok(int N) {
+    static const bool off = []() { const char* e = getenv("STEP_GRAM_SYM"); return e && e[0] == '0'; }();
+    return !off && N <= 320;
+}
+static long gram_sym_ws_floats(int B, int N, int F) {
+    const int NB = (N + 63) / 64;
+    return (long)gram_sym_splits(B, F) * B * gs_blocks(NB) * 4096;
+}
+
 // F > 0 (step_knn_graph): the selection state, then -- 256-byte aligned -- the partial tiles of the split-K Gram product
 // (StepGemm.splitk_ws: 33 MB at PEMS04, where 11 splits x 8 x 307^2 f32 atomics were most of the launch)
 static long gram_ws_floats(int B, int N, int F) {
     const int splits = step_gemm_auto_splitk(N, N, F, B);
-    return splits > 1 ? (long)splits * B * N * N : 0;
+    const long staged = splits > 1 ? (long)splits * B * N * N : 0;
+    const long sym = gram_sym_ok(N) ? gram_sym_ws_floats(B, N, F) : 0;
+    return staged > sym ? staged : sym;
 }
 extern "C" long step_knn_workspace_bytes(int B, int N, int F) {
     const long base = tk_bytes(B, N);
@@ -248,11 +439,23 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
                               float* sim, float* adj, void* work, long work_bytes, void* stream) {
     STEP_REQUIRE(hidden && sim && adj && B > 0 && N > 0 && F > 0 && k_total > 0, "knn_graph: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    STEP_REQUIRE(F % 8 == 0, "knn_graph: feature length %d must be a multiple of 8", F);
+    if (gram_sym_ok(N) && sqnorm_part && work && work_bytes >= step_knn_workspace_bytes(B, N, F) && (((uintptr_t)hidden) & 15) == 0) {
+        // small graphs: the whole output per workgroup, H read once (gram_sym_kernel), normalisation in the reduction of the slices
+        const int NB = (N + 63) / 64, S = gram_sym_splits(B, F), slabs = (F + GS_KS - 1) / GS_KS;
+        float* ws = (float*)((char*)work + ((tk_bytes(B, N) + 255) & ~255L));
+        const int lds = 2 * NB * 64 * GS_PITCH;
+        STEP_TRY(step_raise_lds_once((const void*)gram_sym_kernel, 160 * 1024, "knn_graph"));
+        gram_sym_kernel<<<dim3(S, B), 1024, lds, st>>>(hidden, N, F, NB, (slabs + S - 1) / S, ws);
+        STEP_LAUNCH_CHECK("gram_sym");
+        gram_finish_kernel<<<dim3(gs_blocks(NB), B), 256, 0, st>>>(ws, S, N, NB, sqnorm_part, sim);
+        STEP_LAUNCH_CHECK("gram_finish");
+        return step_topk_mask(sim, B, N, k_total, adj, work, work_bytes, stream);
+    }
     if (hipMemsetAsync(sim, 0, (size_t)B * N * N * sizeof(float), st) != hipSuccess) {
         step_set_error("knn_graph: memset failed");
         return STEP_ERR_HIP;
     }
-    STEP_REQUIRE(F % 8 == 0, "knn_graph: feature length %d must be a multiple of 8", F);
     {
         // raw[b] = H[b] H[b]^T on the bf16 matrix cores: the staged GEMM (k-contiguous bf16 rows on both sides, 128x128
         // tiles, split-K with f32 atomics into the zeroed output).  The full square is computed: the symmetric half would

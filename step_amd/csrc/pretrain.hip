@@ -929,19 +929,15 @@ extern "C" int step_pt_layernorm_bwd(const float* dy, const float* x, long R, co
     STEP_LAUNCH_CHECK("pt_layernorm_bwd");
     return STEP_OK;
 }
-static void attn_attrs() {
-    static bool attr = false;
-    if (!attr) {
-        // (a failure shows up as a launch error of the first call that needs more than the default limit)
-        (void)hipFuncSetAttribute((const void*)attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+static int attn_attrs() {
+    STEP_TRY(step_raise_lds_once((const void*)attn_kernel<true>, 160 * 1024, "pt_attention"));
+    STEP_TRY(step_raise_lds_once((const void*)attn_kernel<false>, 160 * 1024, "pt_attention"));
+    return STEP_OK;
 }
 extern "C" int step_pt_attention_fwd(const float* qkv, long S, int T, float p, uint64_t seed, uint32_t site, float* out, float* stats,
                                      void* stream) {
     STEP_REQUIRE(qkv && out && stats && S > 0 && T > 0 && T <= 336, "pt_attention_fwd: bad arguments (T=%d; at most 336 tokens, the limit of the backward)", T);
-    attn_attrs();
+    STEP_TRY(attn_attrs());
     size_t lds = (size_t)(3 * T * DH) * sizeof(float);
     attn_kernel<false><<<(unsigned)(S * H), 256, lds, (hipStream_t)stream>>>(qkv, S, T, p, SEED_LO(seed), SEED_HI(seed), site, out, stats,
                                                                             nullptr, nullptr);
@@ -952,7 +948,7 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
                                      uint64_t seed, uint32_t site, float* dqkv, void* stream) {
     STEP_REQUIRE(qkv && out && dout && stats && dqkv && S > 0 && T > 0 && T <= 336, "pt_attention_bwd: bad arguments (T=%d)", T);
     size_t lds = (size_t)(4 * T * DH + 3 * T) * sizeof(float);
-    attn_attrs();
+    STEP_TRY(attn_attrs());
     attn_kernel<true><<<(unsigned)(S * H), 256, lds, (hipStream_t)stream>>>(qkv, S, T, p, SEED_LO(seed), SEED_HI(seed), site,
                                                                            const_cast<float*>(out), const_cast<float*>(stats), dout, dqkv);
     STEP_LAUNCH_CHECK("pt_attention_bwd");
@@ -974,10 +970,7 @@ extern "C" int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, fl
                      "pt_attention_fwd_bf16: pool of %ld words is not a power of two in [4096, 2^30]", pool_words);
     }
     const int Tp = (T + 31) & ~31;
-    if (hipFuncSetAttribute((const void*)attn_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-        step_set_error("pt_attention_fwd_bf16: cannot raise the dynamic LDS limit");
-        return STEP_ERR_HIP;
-    }
+    STEP_TRY(step_raise_lds_once((const void*)attn_mfma_fwd_kernel, 160 * 1024, "pt_attention_fwd_bf16"));
     attn_mfma_fwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_fwd_lds(Tp), (hipStream_t)stream>>>(qkv, T, Tp, p, SEED_LO(seed), SEED_HI(seed),
                                                                                                     site, out, stats, keepbits,
                                                                                                     pool && p > 0.f ? (const uint32_t*)pool : nullptr,
@@ -992,10 +985,7 @@ extern "C" int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* o
                  "pt_attention_bwd_bf16: bad arguments (T=%d; at most 352 tokens, 16-byte aligned bf16 tensors)", T);
     const int Tp = (T + 31) & ~31;
     STEP_REQUIRE(ma_bwd_lds(Tp) <= 160 * 1024, "pt_attention_bwd_bf16: %d tokens do not fit the LDS", T);
-    if (hipFuncSetAttribute((const void*)attn_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-        step_set_error("pt_attention_bwd_bf16: cannot raise the dynamic LDS limit");
-        return STEP_ERR_HIP;
-    }
+    STEP_TRY(step_raise_lds_once((const void*)attn_mfma_bwd_kernel, 160 * 1024, "pt_attention_bwd_bf16"));
     attn_mfma_bwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_bwd_lds(Tp), (hipStream_t)stream>>>(qkv, out, dout, stats, T, Tp, p, SEED_LO(seed),
                                                                                                     SEED_HI(seed), site, dqkv, keepbits);
     STEP_LAUNCH_CHECK("pt_attention_bwd_bf16");

@@ -1080,27 +1080,15 @@ FfnArgs make_args(const float* h1, const float* df2, float* out, long R, const v
 
 constexpr int FR_WAVES = 8;
 
-// the dynamic-LDS limit of a kernel is a per-device attribute: raised once per (kernel, device), not on every launch (a launch inside a stream
-// capture then stays a plain kernel node).  `done` is the caller's fast path for device 0.
+// the dynamic-LDS limit of a kernel is a per-(kernel, device) attribute: step_raise_lds_once (errors.cpp) sets it once per pair under a lock;
+// `done` is the caller's lock-free fast path, valid for the device that set it (done = device index + 1)
 template <typename K>
-int raise_lds(K kernel, int bytes, bool& done) {
+int raise_lds(K kernel, int bytes, int& done) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev == 0 && __atomic_load_n(&done, __ATOMIC_ACQUIRE)) return STEP_OK;
-    // first launches may come from two host threads at once (the autograd worker and the main thread): the list below is shared
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    static const void* seen[128];
-    static int seen_dev[128], nseen = 0;
-    const void* kp = (const void*)kernel;
-    for (int i = 0; i < nseen; ++i)
-        if (seen[i] == kp && seen_dev[i] == dev) return STEP_OK;
-    if (hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
-        step_set_error("pretrain_fused: cannot raise the dynamic LDS limit to %d bytes", bytes);
-        return STEP_ERR_HIP;
-    }
-    if (nseen < 128) { seen[nseen] = kp; seen_dev[nseen] = dev; ++nseen; }
-    if (dev == 0) __atomic_store_n(&done, true, __ATOMIC_RELEASE);
+    if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) == dev + 1) return STEP_OK;
+    STEP_TRY(step_raise_lds_once((const void*)kernel, bytes, "pretrain_fused"));
+    __atomic_store_n(&done, dev + 1, __ATOMIC_RELEASE);
     return STEP_OK;
 }
 
@@ -1116,7 +1104,7 @@ int fwd_waves() {
 }
 template <bool LN>
 int launch_rows_fwd4(const FfnArgs& a, hipStream_t st) {       // four waves per workgroup, two workgroups per compute unit (A/B variant)
-    static bool raised[2] = {false, false};
+    static int raised[2] = {};
     const int lds = 2 * FF_BLOCK_F + 4 * STG_IN;
     const long npass = (a.R + 127) / 128;
     const int grid = (int)(npass < 512 ? npass : 512);
@@ -1130,7 +1118,7 @@ int launch_rows_fwd4(const FfnArgs& a, hipStream_t st) {       // four waves per
     return STEP_OK;
 }
 int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
+    static int raised[4] = {};
     if (fwd_waves() == 4) return launch_rows_fwd4<true>(a, st);
     const long npass = (a.R + 32 * FR_WAVES - 1) / (32 * FR_WAVES);
     const int grid = (int)(npass < 512 ? npass : 512);
@@ -1158,7 +1146,7 @@ int launch_rows_ln(const FfnArgs& a, hipStream_t st) {
 
 template <bool BWD>
 int launch_rows(const FfnArgs& a, hipStream_t st) {
-    static bool raised[4] = {false, false, false, false};
+    static int raised[4] = {};
     if constexpr (!BWD) {
         if (fwd_waves() == 4) return launch_rows_fwd4<false>(a, st);
     }
@@ -1189,7 +1177,7 @@ int launch_rows(const FfnArgs& a, hipStream_t st) {
 
 template <bool W1K>
 int launch_wgrad(const FfnArgs& a, int grid, hipStream_t st) {
-    static bool raised[2] = {false, false};
+    static int raised[2] = {};
     const int lds = 2 * FwLayout<W1K>::STAGE;
     if (a.pool) {
         STEP_TRY(raise_lds(ffn_wgrad_kernel<W1K, true>, lds, raised[1]));
@@ -1270,7 +1258,7 @@ extern "C" int step_pt_rows_linear_pack(const float* w, long swo, long swi, int 
 namespace {
 template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
 int launch_lin(const LinArgs& a, hipStream_t st) {
-    static bool raised = false;
+    static int raised = 0;
     const int wbytes = NOG * 3 * NKC * 6 * FF_FRAG + NOG * 96 * 4;
     const int lds = ((wbytes + 1023) & ~1023) + 8 * STG_WAVE;
     STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN>, lds, raised));
@@ -1322,7 +1310,7 @@ extern "C" int step_pt_proj_wgrad(const float* x, const uint16_t* dqkv, const fl
                                   float* dwo, void* stream) {
     STEP_REQUIRE(x && dqkv && dov && a && ws && dwi && dbi && dwo && R > 0 && R < (1L << 36), "pt_proj_wgrad: bad arguments");
     STEP_REQUIRE((((uintptr_t)x | (uintptr_t)dqkv | (uintptr_t)dov | (uintptr_t)a) & 15) == 0, "pt_proj_wgrad: 16-byte aligned tensors expected");
-    static bool raised = false;
+    static int raised = 0;
     STEP_TRY(raise_lds(proj_wgrad_kernel, 2 * PW_TILE, raised));
     const hipStream_t st = (hipStream_t)stream;
     const long ntile = (R + 31) / 32;

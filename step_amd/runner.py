@@ -21,8 +21,10 @@ implementation and only changes WHERE the data lives and WHEN the host reads num
   ``LookaheadLoader``: it holds one batch ahead, puts that batch on the device (pinned memory + an asynchronous copy on its own stream
   for host batches; one gather launch for index batches) and calls ``model.prefetch(next long history)`` BEFORE it hands out the
   current batch -- the frozen TSFormer + kNN prior of batch i + 1 then run next to the whole of step i ("Step schedule").
-* the epoch meters are fed from device-side sums once per epoch (when ``print_epoch_meters`` needs them) instead of ``.item()`` per
-  iteration; the printed averages are the same numbers.
+* the epoch meters are fed once per epoch (when ``print_epoch_meters`` needs them) from values that stayed on the device instead of
+  ``.item()`` per iteration, and the three metrics of ``basicts/metrics`` come from one launch (``step_masked_metrics``) instead of
+  ~30 element-wise ones; the printed averages are the same numbers.  The feature selections of ``step_runner.py:25-26,39-40`` become
+  slices where the feature list is a contiguous range (advanced indexing copies an index tensor to the device: a blocking copy).
 * ``init_training`` swaps the ``torch.optim.Adam`` + ``clip_grad_norm_`` pair the config asks for (``STEP_PEMS04.py:89-106``) for
   ``step_amd.optim.FusedAdamClip`` with the same hyper-parameters (one pass over the flat buffers); any other optimizer is left alone.
 
@@ -122,8 +124,9 @@ class LookaheadLoader:
         with torch.cuda.stream(self._copy_stream):
             for t in batch:
                 if torch.is_tensor(t) and not t.is_cuda:
-                    t = t if t.is_pinned() else t.pin_memory()          # (the reference's loader pins already: PIN_MEMORY = True, STEP_PEMS04.py:122)
-                    d = t.to(dev, non_blocking=True)
+                    # pinned batches (the reference's loader pins: PIN_MEMORY = True, STEP_PEMS04.py:122) are copied asynchronously; a pageable
+                    # one goes as it is -- pinning it here would be one more pass over 119 MB of long history on the host
+                    d = t.to(dev, non_blocking=t.is_pinned())
                     d.record_stream(main)
                     out.append(d)
                 else:
@@ -171,7 +174,7 @@ class _Deferred:
         return self
 
 
-def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, encoder_workgroups=None):
+def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, encoder_workgroups=None, native_metrics=True):
     """-> subclass of ``base`` (the reference's ``STEPRunner``, or any ``BaseTimeSeriesForecastingRunner``) for ``CFG.RUNNER``.
     ``encoder_workgroups``: compute units of the persistent encoder launch next to the step (None: 160 at 307 nodes / 336 tokens, the
     measured optimum of config C2; 0: one workgroup per sequence) -- only used while batches are prefetched."""
@@ -182,7 +185,8 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
         def __init__(self, cfg):
             super().__init__(cfg)
             self._deferring = False
-            self._pending = {}          # meter name -> [device sum, count]
+            self._pending = {}          # meter name -> [(device value, n), ...] since the last flush
+            self._metric_cache = None
 
         # ---------------------------------------------------------------- loaders
         def _lookahead(self, loader, on):
@@ -204,9 +208,29 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
         def build_test_data_loader(self, cfg):
             return self._lookahead(super().build_test_data_loader(cfg), False)
 
+        # ---------------------------------------------------------------- feature selection without a host-device synchronisation
+        # ``data[:, :, :, [0, 1, 2]]`` (step_runner.py:25-26,39-40) builds an index tensor on the host and copies it to the device: a blocking
+        # copy behind everything queued on the stream, twice per iteration.  For the feature lists the STEP configs use -- contiguous
+        # ranges -- a slice selects the same values as a VIEW: no index tensor, no copy, and forward() sees the very tensor the loader
+        # announced to STEP.prefetch.  Any other list goes through the reference's indexing (and ``alias_batch``).
+        @staticmethod
+        def _range_of(features):
+            if features is None:
+                return None
+            f = [int(i) for i in features]
+            return (f[0], f[0] + len(f)) if f and f == list(range(f[0], f[0] + len(f))) else None
+
         def select_input_features(self, data):
-            out = super().select_input_features(data)
             ff = getattr(self, "forward_features", None)
+            if isinstance(data, LongHistoryRef):
+                return data if ff is None else data[:, :, :, list(ff)]
+            r = self._range_of(ff)
+            if r is not None and torch.is_tensor(data) and data.dim() == 4 and r[1] <= data.shape[3]:
+                out = data[:, :, :, r[0]:r[1]]
+                if r[0] != 0 and data.is_cuda and isinstance(_unwrap(self.model), STEP):
+                    _unwrap(self.model).alias_batch(data, out, channel=r[0])          # (a view that starts at another channel: another address)
+                return out
+            out = super().select_input_features(data)
             if out is not data and torch.is_tensor(out) and torch.is_tensor(data) and data.is_cuda:
                 model = _unwrap(self.model)
                 if isinstance(model, STEP):
@@ -214,6 +238,12 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
                     # channel the TSFormer reads), so that forward() finds the prefetched branch
                     model.alias_batch(data, out, channel=0 if ff is None else int(ff[0]))
             return out
+
+        def select_target_features(self, data):
+            r = self._range_of(getattr(self, "target_features", None))
+            if r is not None and torch.is_tensor(data) and data.dim() == 4 and r[1] <= data.shape[3]:
+                return data[:, :, :, r[0]:r[1]]
+            return super().select_target_features(data)
 
         # ---------------------------------------------------------------- optimizer
         def init_training(self, cfg):
@@ -240,13 +270,27 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
 
         # ---------------------------------------------------------------- meters without a device synchronisation per iteration
         def train_iters(self, epoch, iter_index, data):
-            self._deferring = defer_meters
+            self._deferring, self._metric_cache = defer_meters, None
             try:
                 return super().train_iters(epoch, iter_index, data)
             finally:
-                self._deferring = False
+                self._deferring, self._metric_cache = False, None
+
+        _NATIVE_METRICS = {"masked_mae": 0, "masked_rmse": 1, "masked_mape": 2}
 
         def metric_forward(self, metric_func, args):
+            if self._deferring and metric_func is not self.loss and native_metrics:
+                # the three metrics of basicts/metrics the runner evaluates per iteration (base_tsf_runner.py:252-254), from one launch
+                k = self._NATIVE_METRICS.get(getattr(metric_func, "__name__", None))
+                nv = getattr(self, "null_val", 0.0)
+                if (k is not None and str(getattr(metric_func, "__module__", "")).startswith("basicts.metrics") and len(args) == 2
+                        and torch.is_tensor(args[0]) and args[0].is_cuda and args[0].dtype == torch.float32 and torch.is_tensor(args[1])
+                        and args[1].dtype == torch.float32 and args[0].shape == args[1].shape and nv == nv):
+                    c = self._metric_cache
+                    if c is None or c[0] is not args[0] or c[1] is not args[1]:
+                        from .step_loss import masked_metrics_native
+                        c = self._metric_cache = (args[0], args[1], masked_metrics_native(args[0], args[1], float(nv)))
+                    return _Deferred(c[2][k])
             out = super().metric_forward(metric_func, args)
             if self._deferring and metric_func is not self.loss and torch.is_tensor(out) and out.is_cuda:
                 return _Deferred(out.detach())
@@ -254,22 +298,22 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
 
         def update_epoch_meter(self, name, value, n=1):
             if isinstance(value, _Deferred):
-                p = self._pending.get(name)
-                if p is None:
-                    self._pending[name] = [value.value.float() * n, n]
-                else:
-                    p[0] += value.value * n
-                    p[1] += n
+                self._pending.setdefault(name, []).append((value.value, n))          # kept on the device: nothing is launched, nothing waited for
                 return
             super().update_epoch_meter(name, value, n)
 
         def flush_meters(self):
-            """feed the deferred sums to the epoch meters (one device synchronisation for all of them)"""
+            """feed the deferred values to the epoch meters (one device synchronisation for all of them)"""
             pending, self._pending = self._pending, {}
             if pending:
-                sums = torch.stack([p[0] for p in pending.values()]).cpu().tolist()
-                for (name, (_, n)), s in zip(pending.items(), sums):
-                    super().update_epoch_meter(name, s / n, n)
+                means, counts = [], []
+                for name, items in pending.items():
+                    vals = torch.stack([v.float().reshape(()) for v, _ in items])
+                    ns = torch.tensor([float(n) for _, n in items], device=vals.device)
+                    means.append((vals * ns).sum() / ns.sum())
+                    counts.append(sum(n for _, n in items))
+                for name, m, c in zip(pending, torch.stack(means).cpu().tolist(), counts):
+                    super().update_epoch_meter(name, m, c)
 
         def print_epoch_meters(self, meter_type):
             self.flush_meters()

@@ -141,6 +141,20 @@ class _StepFunction(torch.autograd.Function):
             ready = torch.cuda.Event()
             ready.record(main)              # inputs, weights (the previous optimizer step) and the noise are ordered before this point
         P = Lh // 12
+        # What the WaveNet needs before its first diffusion hop and that does not read the sampled adjacency -- start convolution, adaptive
+        # support, weight packing, layer 0's gated TCN (phase 5, ~60 us of small dependent kernels) -- runs on a third stream NEXT TO the
+        # graph learner instead of behind it; the layers (phase 6) wait for both
+        prep_done = None
+        if side is not None and model.split_wavenet_prep and model._dyn is None:
+            prep = model._side_stream(dev, "aux")
+            prep.wait_event(ready)
+            with torch.cuda.stream(prep):
+                hist.record_stream(prep)
+                L.call("step_gwnet_forward_phase_dyn", L.ptr(hist), B, N, Cin, None, None, ctypes.byref(bstruct),
+                       int(training) | (2 if (training and model.track_dead_bn7) else 0),
+                       float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 5, None, L.stream())
+                prep_done = torch.cuda.Event()
+                prep_done.record(prep)
 
         def graph_and_layers(sst):
             if sh is None:
@@ -159,9 +173,11 @@ class _StepFunction(torch.autograd.Function):
                         model._sum_over_ranks(exchange[phase])
             L.call("step_dgl_edges_forward_dyn", L.ptr(g), N, B, ctypes.byref(dstruct), L.ptr(u) if u is not None else None, seed,
                    TEMPERATURE, L.ptr(esaved), L.ptr(theta), L.ptr(adj), L.ptr(model._dyn), sst)
+            if prep_done is not None:
+                torch.cuda.current_stream().wait_event(prep_done)
             L.call("step_gwnet_forward_phase_dyn", L.ptr(hist), B, N, Cin, None, L.ptr(adj), ctypes.byref(bstruct),
                    int(training) | (2 if (training and model.track_dead_bn7) else 0),
-                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 1, L.ptr(model._dyn), sst)
+                   float(drop), seed_gw, BN_MOMENTUM, L.ptr(wsaved), L.ptr(wwork), None, 6 if prep_done is not None else 1, L.ptr(model._dyn), sst)
             if training:
                 with torch.no_grad():
                     # the BatchNorm step counters: one multi-tensor launch instead of ten scalar ones, on this (the second) stream -- on the
@@ -417,7 +433,14 @@ class STEP(nn.Module):
         self._flat_grad = None
         self._backward_count = 0
         self.overlap_streams = os.environ.get("STEP_NO_OVERLAP", "0") != "1"      # graph learner + WaveNet layers next to the encoder
+        # the adjacency-independent start of the WaveNet (library phases 5 / 6) on a third stream next to the graph learner: measured, no gain
+        # (3.496 / 3.495 vs 3.476 / 3.491 ms at PEMS04, profiles/r06_e_*: the step is bound by the prefetched branch, not by this chain) -- off
+        self.split_wavenet_prep = os.environ.get("STEP_PREP_SPLIT", "0") == "1"
+        # prefetch(): the kNN prior (Gram product + top-k, ~0.35 ms at PEMS04) of the announced batch on a stream of its own instead of behind
+        # its encoder on the prefetch stream -- only the loss needs it, half a step later
+        self.prefetch_knn_stream = os.environ.get("STEP_PREFETCH_KNN_STREAM", "1") == "1"
         self._prefetched = None             # FIFO (list) of the frozen branches queued by prefetch() for upcoming batches
+        self._precision_override = None
         self._alias = {}                    # batch key of a derived tensor -> key of the announced batch it was made from (alias_batch)
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
@@ -475,6 +498,8 @@ class STEP(nn.Module):
             enc_done.record()
             knn_stream.wait_event(enc_done)
             with torch.cuda.stream(knn_stream):
+                for t in (enc["hidden_bf16"], enc["sqnorm"], sim, adj_knn, kwork):
+                    t.record_stream(knn_stream)
                 L.call("step_knn_graph", L.ptr(enc["hidden_bf16"]), L.ptr(enc["sqnorm"]), B, N, P * 96, self.discrete_graph_learning.k * N,
                        L.ptr(sim), L.ptr(adj_knn), L.ptr(kwork), kwork.numel(), L.stream())
                 knn_done = torch.cuda.Event()
@@ -525,9 +550,10 @@ class STEP(nn.Module):
         ready.record(main)                  # the batch (a gather on the main stream) and any inline encoder launch come first
         ps.wait_event(ready)
         mode = self.training
+        ks = self._side_stream(dev, "knn") if self.prefetch_knn_stream else None
         with torch.cuda.stream(ps):
-            rec = self._frozen_branch(long_history_data, B, N, channel=channel)
-            rec["done"] = torch.cuda.Event()
+            rec = self._frozen_branch(long_history_data, B, N, knn_stream=ks, channel=channel)
+            rec["done"] = torch.cuda.Event()          # (with a kNN stream: the encoder; the prior graph has its own event, knn_done)
             rec["done"].record(ps)
         # everything the branch allocated is consumed on the main stream after the `done` event
         for t in (rec["enc"]["hidden_bf16"], rec["enc"]["last"], rec["enc"]["sqnorm"], rec["sim"], rec["adj_knn"]):
@@ -539,8 +565,7 @@ class STEP(nn.Module):
         q = self._prefetched if isinstance(self._prefetched, list) else []
         q.append(rec)
         while len(q) > 2:                    # nobody came for the oldest: keep the stream order, drop the record
-            old = q.pop(0)
-            main.wait_event(old["done"])
+            self._wait_record(main, q.pop(0))
         self._prefetched = q
 
     def cancel_prefetch(self):
@@ -550,8 +575,14 @@ class STEP(nn.Module):
         refill the pool under a running kernel (that would make the dropout masks irreproducible)."""
         q, self._prefetched = self._prefetched, None
         for rec in (q or []):
-            if rec.get("done") is not None:
-                torch.cuda.current_stream().wait_event(rec["done"])
+            self._wait_record(torch.cuda.current_stream(), rec)
+
+    @staticmethod
+    def _wait_record(stream, rec):
+        """order `stream` behind everything a queued frozen branch launched (its encoder and, on its own stream, its kNN prior)"""
+        for k in ("done", "knn_done"):
+            if rec.get(k) is not None:
+                stream.wait_event(rec[k])
 
     def _take_prefetched(self, long_hist):
         q = self._prefetched
@@ -567,7 +598,7 @@ class STEP(nn.Module):
             # queued in the other mode (a branch announced at the end of a training epoch, then validation): it would pin its encoder
             # output and kNN buffers (160 MB and more each at PEMS04) and add an event wait to every forward of the whole eval loop
             for rec in stale:
-                main.wait_event(rec["done"])
+                self._wait_record(main, rec)
             q[:] = [rec for rec in q if rec["training"] == self.training]
             if not q:
                 self._prefetched = None
@@ -575,7 +606,7 @@ class STEP(nn.Module):
         for idx, rec in enumerate(q):
             if rec["key"] == key and rec["training"] == self.training:
                 for skipped in q[:idx]:              # announced but never consumed: keep the stream order, drop them
-                    main.wait_event(skipped["done"])
+                    self._wait_record(main, skipped)
                 del q[:idx + 1]
                 if not q:
                     self._prefetched = None
@@ -583,7 +614,7 @@ class STEP(nn.Module):
         # not an announced batch (e.g. the very first step): the inline encoder launch refills the shared keep-mask pool, so it is ordered
         # behind the queued branches -- which stay queued for the batches they were announced for
         for rec in q:
-            main.wait_event(rec["done"])
+            self._wait_record(main, rec)
         return None
 
     def _prefetch_stream(self, dev):
@@ -607,6 +638,9 @@ class STEP(nn.Module):
         FusedAdamClip calls) their addresses do not move, so the structs are kept and re-checked against a few addresses per call --
         .to() / .cuda() / load of another flat buffer drop them (_apply, flatten_parameters)."""
         dgl, be = self.discrete_graph_learning, self.backend
+        ov = self._precision_override          # tools/precision_split.py: {"dgl": 0 | 1, "backend": 0 | 1} (which half of the step rounds its operands)
+        if ov is not None:
+            return fill_dgl_struct(dgl.native_tensors(full=full), ov.get("dgl", bf)), fill_gwnet_struct(be.native_tensors(), ov.get("backend", bf))
         if self._flat_param is None:
             return fill_dgl_struct(dgl.native_tensors(full=full), bf), fill_gwnet_struct(be.native_tensors(), bf)
         fcw = dgl.fc.weight if (dgl._shard is None or full) else dgl.fc_weight_slice

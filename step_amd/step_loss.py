@@ -112,3 +112,28 @@ def masked_mae_native(preds, labels, null_val=0.0, rescale=None):
     if d is None:      # the graph term of step_loss with coefficient 0: one edge with theta = prior = 1/2
         d = _DUMMY[dev] = (torch.full((1, 1, 1), 0.5, device=dev), torch.full((1, 1, 1), 0.5, device=dev))
     return step_loss_native(preds, labels, d[0], d[1], 0.0, null_val=null_val, rescale=rescale)
+
+
+_METRIC_WORK = {}
+
+
+def masked_metrics_native(preds, labels, null_val=0.0):
+    """-> f32 cuda tensor [3] = (masked_mae, masked_rmse, masked_mape) of ``basicts/metrics/{mae,rmse,mape}.py`` for a finite ``null_val``
+    (MAPE's own null value is 0, mape.py:21), from ONE launch of libstep_hip instead of ~30 element-wise ones -- the three numbers the
+    reference's runner evaluates every training iteration (base_tsf_runner.py:252-254).  No gradient (they feed the epoch meters)."""
+    from . import _lib
+    p, r = preds.detach(), labels.detach()
+    if p.dtype != torch.float32 or r.dtype != torch.float32 or not p.is_cuda or p.numel() != r.numel():
+        raise ValueError("masked_metrics_native: f32 cuda tensors of one size")
+    ps, rs = _flat_stride(p), _flat_stride(r)
+    if ps is None:
+        p, ps = p.contiguous(), 1
+    if rs is None:
+        r, rs = r.contiguous(), 1
+    work = _METRIC_WORK.get(p.device)
+    if work is None:
+        work = _METRIC_WORK[p.device] = torch.zeros(6, dtype=torch.float64, device=p.device)
+    out = torch.empty(3, dtype=torch.float32, device=p.device)
+    _lib.call("step_masked_metrics", ctypes.c_void_p(p.data_ptr()), ps, ctypes.c_void_p(r.data_ptr()), rs, p.numel(), float(null_val),
+              _lib.ptr(work), _lib.ptr(out), _lib.stream())
+    return out

@@ -104,13 +104,13 @@ class Runner:
             for it, data in enumerate(self.train_data_loader):
                 loss = self.train_iters(epoch, it, data)
                 self.backward(loss)
-                losses.append(float(loss.detach()))
+                losses.append(loss.detach())          # (easytorch does not read the loss back per iteration either)
                 done += 1
                 if max_iters is not None and done >= max_iters:
-                    return losses
+                    return [float(l) for l in losses]
             if self.scheduler is not None:
                 self.scheduler.step()
-        return losses
+        return [float(l) for l in losses]
 
 
 def launch_training(cfg, devices=None, node_rank=0):

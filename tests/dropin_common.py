@@ -10,6 +10,7 @@ reference reads with cwd-relative paths --
 has no /root/reference, can build the same module.  Everything is synthetic and seeded."""
 import os
 import pickle
+import sys
 
 import numpy as np
 import torch
@@ -78,3 +79,49 @@ def make_workspace(root, ds="METR-LA", seed=0, n_train=6, full_history_only=True
     a = dict(model_param(ds)["tsformer_args"], mode="pre-train")
     torch.save({"model_state_dict": TSFormer(**a).state_dict()}, os.path.join(root, "tsformer_ckpt", f"TSFormer_{ds}.pt"))
     return series
+
+
+PKGS = ("step", "basicts", "easytorch", "easydict", "timm", "setproctitle")
+
+
+class Workspace:
+    """a scratch cwd holding the files the reference reads + the reference and the easytorch stand-ins on sys.path, for the duration of a
+    `with` block; `config()` imports the reference's own config file and points CFG.MODEL.ARCH at step_amd.STEP"""
+    def __init__(self, root, ds, **kw):
+        self.root, self.ds = root, ds
+        self.series = make_workspace(root, ds, **kw)
+
+    def __enter__(self):
+        self.old = os.getcwd()
+        os.chdir(self.root)
+        from oracle.reference_loader import reference_root
+        self.added = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shims"), reference_root()]
+        for p in self.added:
+            sys.path.insert(0, p)
+        self.saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in PKGS}
+        for k in self.saved:
+            del sys.modules[k]
+        return self
+
+    def __exit__(self, *exc):
+        os.chdir(self.old)
+        for p in self.added:
+            sys.path.remove(p)
+        for k in [k for k in sys.modules if k.split(".")[0] in PKGS]:
+            del sys.modules[k]
+        sys.modules.update(self.saved)
+
+    def config(self, batch, dropout=False):
+        import importlib
+        cfg = importlib.import_module("step.STEP_" + self.ds).CFG          # the reference's config file
+        from step_amd import STEP
+        cfg.MODEL.ARCH = STEP
+        if not dropout:
+            cfg.MODEL.PARAM["tsformer_args"]["dropout"] = 0.0
+            cfg.MODEL.PARAM["backend_args"]["dropout"] = 0.0
+        cfg.TRAIN.DATA.BATCH_SIZE = batch
+        cfg.TRAIN.DATA.SHUFFLE = False
+        cfg["_DEVICE"] = "cuda"
+        return cfg
+
+

@@ -381,6 +381,40 @@ def test_knn_graph(L, Bn, N, F, k):
     assert bool((((flat < kth_d[:, None]) | eye) <= (a2 == 0)).all())
 
 
+@pytest.mark.parametrize("Bn,N,F,k", [(2, 20, 768, 3), (3, 37, 2304, 4), (1, 307, 4032, 10), (8, 307, 32256, 10), (2, 320, 1032, 5), (2, 65, 16128, 3),
+                                       (1, 207, 16128, 10), (2, 321, 2304, 4)])
+def test_knn_graph_with_encoder_norms(L, Bn, N, F, k):
+    """step_knn_graph as the step calls it -- squared norms supplied by the encoder's epilogue ([S, 16] partial sums): up to 320 nodes the
+    symmetric Gram kernel (one workgroup owns the whole output of a feature slice, H read once; gram_sym_kernel / gram_finish_kernel),
+    beyond that the staged GEMM.  Shapes: every graph size class (one block, ragged last block, exactly 320, just above), a feature axis that
+    is not a multiple of the 64-feature slab, the PEMS04 launch itself."""
+    g = torch.Generator().manual_seed(N + F)
+    base = torch.randn(Bn, 1, F, generator=g)
+    H = (base + 0.7 * torch.randn(Bn, N, F, generator=g)).to(torch.bfloat16)
+    want, sim_want = O.cosine_knn_graph(H.float(), k * N)
+    Hd = H.cuda()
+    sq = torch.zeros(Bn * N, 16)
+    parts = H.float().pow(2).view(Bn * N, -1)
+    for w in range(4):                                   # partial sums spread over a few of the 16 slots, like the encoder's waves
+        sq[:, w] = parts[:, w::4].sum(1)
+    sim = torch.full((Bn, N, N), float("nan"), device="cuda")
+    adj = torch.empty(Bn, N, N, device="cuda")
+    work = torch.empty(L.lib().step_knn_workspace_bytes(Bn, N, F), dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                   # (twice: nothing depends on a cleared workspace)
+        L.call("step_knn_graph", L.ptr(Hd), L.ptr(sq.cuda()), Bn, N, F, k * N, L.ptr(sim), L.ptr(adj), L.ptr(work), work.numel(), L.stream())
+    torch.cuda.synchronize()
+    s_ = sim.cpu()
+    assert bool(torch.isfinite(s_).all()) and torch.equal(s_, s_.transpose(1, 2)) if N <= 320 else bool(torch.isfinite(s_).all())
+    assert max_abs(s_, sim_want) < 2e-5
+    a = adj.cpu()
+    assert a.sum(dim=(1, 2)).tolist() == want.sum(dim=(1, 2)).tolist()
+    diff = (a != want).nonzero()
+    kth = torch.topk(sim_want.reshape(Bn, -1), k * N, -1).values[:, -1]
+    assert diff.shape[0] <= 4 * Bn, diff.shape          # entries within round-off of the k-th value; they flip in symmetric pairs (i, j) / (j, i)
+    for b, i, j in diff.tolist():
+        assert abs(float(sim_want[b, i, j] - kth[b])) < 1e-4
+
+
 def test_gemm_slot_remap_and_kscale(L):
     """Index remaps used by the GraphWaveNet gcn buffer and the per-channel affine used by the DGL fc."""
     g = torch.Generator().manual_seed(9)

@@ -23,44 +23,9 @@ from tests import dropin_common as DC
 REF = reference_root()
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(REF is None, reason="needs the reference sources (tools/stage_reference.sh stages them for the GPU box)")]
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "runner_metr_la.json")
-PKGS = ("step", "basicts", "easytorch", "easydict", "timm", "setproctitle")
 
 
-class Workspace:
-    def __init__(self, root, ds, **kw):
-        self.root, self.ds = root, ds
-        self.series = DC.make_workspace(root, ds, **kw)
-
-    def __enter__(self):
-        self.old = os.getcwd()
-        os.chdir(self.root)
-        self.added = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shims"), REF]
-        for p in self.added:
-            sys.path.insert(0, p)
-        self.saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in PKGS}
-        for k in self.saved:
-            del sys.modules[k]
-        return self
-
-    def __exit__(self, *exc):
-        os.chdir(self.old)
-        for p in self.added:
-            sys.path.remove(p)
-        for k in [k for k in sys.modules if k.split(".")[0] in PKGS]:
-            del sys.modules[k]
-        sys.modules.update(self.saved)
-
-    def config(self, batch, dropout=False):
-        cfg = importlib.import_module("step.STEP_" + self.ds).CFG          # the reference's config file
-        from step_amd import STEP
-        cfg.MODEL.ARCH = STEP
-        if not dropout:
-            cfg.MODEL.PARAM["tsformer_args"]["dropout"] = 0.0
-            cfg.MODEL.PARAM["backend_args"]["dropout"] = 0.0
-        cfg.TRAIN.DATA.BATCH_SIZE = batch
-        cfg.TRAIN.DATA.SHUFFLE = False
-        cfg["_DEVICE"] = "cuda"
-        return cfg
+Workspace = DC.Workspace
 
 
 def _record_gumbel(native, gold, N, seen):
@@ -106,7 +71,7 @@ def test_native_runner_reproduces_the_recorded_losses(tmp_path, dataset):
         assert isinstance(runner.optim, FusedAdamClip) and runner.clip_grad_param is None
         assert runner.optim.max_norm == cfg.TRAIN.CLIP_GRAD_PARAM["max_norm"] and runner.optim.param_groups[0]["lr"] == cfg.TRAIN.OPTIM.PARAM["lr"]
         # the meters: nothing was read back per iteration, the epoch averages appear when they are printed
-        assert runner.meters["train_MAE"].n == 0 and len(runner._pending) == 3
+        assert runner.meters["train_MAE"].n == 0 and sorted(runner._pending) == ["train_MAE", "train_MAPE", "train_RMSE"] and len(runner._pending["train_MAE"]) == 3
         runner.print_epoch_meters("train")
         assert runner.meters["train_MAE"].n == 3 and runner.meters["train_RMSE"].n == 3 and runner.meters["train_MAPE"].n == 3
         assert runner.meters["train_MAE"].avg > 0 and not runner._pending

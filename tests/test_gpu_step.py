@@ -377,6 +377,69 @@ def test_native_step_loss_matches_reference_loss():
             assert float(nt_.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_wavenet_phase_5_plus_6_is_phase_1(mode):
+    """step_gwnet_forward_phase: the adjacency-independent start of the WaveNet (phase 5, on a third stream next to the graph learner) +
+    the rest (phase 6) give bit-identical predictions, edge probabilities and gradients to the single layer phase (1)."""
+    g = load_golden("step_small")
+    mean, std = [float(x) for x in g["meta.scaler"]]
+    hist, long_hist, fut = inputs_of(g)
+    outs = []
+    for split in (False, True):
+        torch.manual_seed(0)
+        model = build_native(g)
+        model.train()
+        model.matmul_precision = mode
+        model.backend.dropout = 0.0
+        model.tsformer.dropout_p = 0.0
+        model._noise_override = g["in.u"]
+        model.split_wavenet_prep = split
+        pred, theta, knn, coef = model(history_data=hist, long_history_data=long_hist, future_data=None, batch_seen=0, epoch=1)
+        O.step_loss(O.rescale(pred[..., [0]], mean, std), O.rescale(fut[..., [0]], mean, std), theta, knn, coef).backward()
+        torch.cuda.synchronize()
+        outs.append((pred.detach().clone(), theta.detach().clone(), {k: v.grad.detach().clone() for k, v in model._trainable() if v.grad is not None}))
+    if mode == "bf16":          # (f32 mode: the graph learner's fc product adds its split-K pieces with atomics -- two runs differ in the last bits anyway)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_l2(outs[1][0].cpu(), outs[0][0].cpu()) < 1e-5 and max_abs(outs[1][1].cpu(), outs[0][1].cpu()) < 1e-6
+    for k, a in outs[0][2].items():
+        if k.startswith("be.") and ("gate" in k or "filter" in k or "skip" in k or "gconv" in k or "bn" in k):
+            continue          # (weight gradients of split-K / atomic reductions: equal up to the order of the atomics)
+        assert rel_l2(outs[1][2][k].cpu(), a.cpu()) < 1e-5, k
+
+
+def test_native_masked_metrics_match_the_reference_definitions():
+    """step_masked_metrics: MAE / RMSE / MAPE of basicts/metrics/{mae,rmse,mape}.py (restated below line by line) from one launch,
+    including null values, labels below 1e-4 (MAPE zeroes and masks them), a strided label view and an all-masked batch."""
+    from step_amd.step_loss import masked_metrics_native
+
+    def ref(p, y, null):
+        def mask_of(lab, nv):
+            m = (~torch.isclose(lab, torch.tensor(nv).expand_as(lab), atol=5e-5, rtol=0.)).float()
+            m = m / m.mean()
+            return torch.where(torch.isnan(m), torch.zeros_like(m), m)
+        m = mask_of(y, null)
+        mae = torch.nan_to_num(torch.abs(p - y) * m, nan=0.0).mean()
+        mse = torch.nan_to_num((p - y) ** 2 * m, nan=0.0).mean()
+        y0 = torch.where(torch.abs(y) < 1e-4, torch.zeros_like(y), y)
+        m0 = mask_of(y0, 0.0)
+        ape = torch.abs(torch.abs(p - y0) / y0) * m0
+        mape = torch.where(torch.isnan(ape), torch.zeros_like(ape), ape).mean()
+        return torch.stack([mae, torch.sqrt(mse), mape])
+    gen = torch.Generator().manual_seed(3)
+    for shape, null in (((8, 12, 307, 1), 0.0), ((3, 12, 37, 1), 0.0), ((2, 12, 20, 1), -1.0)):
+        y3 = torch.randn(*shape[:3], 3, generator=gen) * 50 + 100
+        y3[..., 0][torch.rand(shape[:3], generator=gen) < 0.2] = null
+        y3[..., 0][torch.rand(shape[:3], generator=gen) < 0.05] = 3e-5
+        p = y3[..., :1] + torch.randn(*shape, generator=gen) * 10
+        want = ref(p, y3[..., :1].contiguous(), null)
+        got = masked_metrics_native(p.cuda(), y3.cuda()[..., :1], null).cpu()          # labels: a strided view of the batch tensor
+        again = masked_metrics_native(p.cuda(), y3.cuda()[..., :1].contiguous(), null).cpu()          # (the work buffer was left clean)
+        print("metrics", shape, null, got.tolist(), want.tolist())
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-6) and torch.equal(got, again)
+    y = torch.zeros(2, 12, 5, 1)
+    assert masked_metrics_native(torch.ones(2, 12, 5, 1).cuda(), y.cuda(), 0.0).cpu().tolist() == [0.0, 0.0, 0.0]
+
+
 def test_native_step_loss_with_inverse_scaling_inside():
     """step_loss_native(..., rescale=(mean, std)): the runner's inverse scaling (base_tsf_runner.py:240-250) folded into the loss
     kernels, the target read in place as feature 0 of the [B, 12, N, C] batch tensor -- against the oracle's step_loss on the rescaled
