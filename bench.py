@@ -591,6 +591,8 @@ class StepBench:
         elif getattr(args, "encoder_workgroups", None):
             self.enc_wgs = int(args.encoder_workgroups)
         self.model.tsformer.encoder_workgroups = self.enc_wgs
+        if os.environ.get("STEP_PREFETCH_KNN_STREAM") is None:          # the announced batch's kNN prior on its own stream: with the early announcement only
+            self.model.prefetch_knn_stream = bool(self.prefetch and self.prefetch_early)
         if args.eval_dropout_off:
             self.model.backend.dropout = 0.0
             self.model.tsformer.dropout_p = 0.0
@@ -802,10 +804,22 @@ class StepBench:
         iso = e0.elapsed_time(e1) / reps
         exposed = float(np.mean(self.reduce_waits)) if self.reduce_waits else float("nan")
         small = self.small
-        t_ex = torch.tensor([iso, exposed], device=dev, dtype=torch.float64)
+        # proof of the group the step's collectives ran in: a one summed over the ranks through the SAME transport (RCCL's C API when the step
+        # uses it), and what every rank's communicator says about itself
+        probe = torch.ones(1, device=dev)
+        if nc is not None:
+            nc.allreduce_(probe, average=False)
+        else:
+            dist.all_reduce(probe)
+        seen = float(probe.item())
+        step_bytes = float((fo if self.sharded else lay["total"]) * 4)          # the flat gradient (the time slices' small sums are listed in small_collectives)
+        t_ex = torch.tensor([iso, exposed, seen, float(nc.world if nc is not None else dist.get_world_size()),
+                             float(nc.rank if nc is not None else dist.get_rank()), step_bytes], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(t_ex) for _ in range(world)]
         dist.all_gather(gathered, t_ex)
         return {"allreduce_bytes": int((fo if self.sharded else lay["total"]) * 4),
+                "per_rank": [{"rank": int(g[4]), "communicator_world_size": int(g[3]), "ranks_summed_by_a_probe_allreduce": int(round(float(g[2]))),
+                              "bytes_allreduced_per_step": int(g[5])} for g in gathered],
                 "chunks": [int(fo * 4)] if self.sharded else [int(fn * 4), int(fo * 4)],
                 "graph_learner_time_slices": bool(self.sharded),
                 "per_rank_allreduce_ms_isolated": [float(g[0]) for g in gathered],

@@ -685,41 +685,50 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(StepGemm g, FastArgs fa)
             // channels-last bf16 activations (dgl_conv_mfma.hip): column n belongs to channel n % C, the result and the BatchNorm input
             // are bf16.  Stored: x > 0 ? v - kc (m1 + (x - mean) rstd m2) : 0 with v = alpha A.B (the BatchNorm scale kc is already in B).
             // A thread's 4 columns (and channels) are the same for all of its pieces: the coefficients live in registers.
-            const int C = fu.channels, cb = (n0 + (tid % (BN / 4)) * 4) % C;
-            float km1[4], km2[4], mu4[4];
+            // A thread's piece: EIGHT consecutive columns of one row (16 bytes of bf16 in, 16 bytes out; host-checked: channels % 8 == 0).
+            // All pieces of a thread are requested before the first store: 128 bytes in flight per thread -- with 4-column pieces
+            // (8-byte loads, round 4) the launch moved 2.5-2.8 TB/s, Little's law on 64 bytes per thread.
+            const int C = fu.channels, cb = (n0 + (tid % (BN / 8)) * 8) % C;
+            float km1[8], km2[8], mu8[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 const int c = cb + i;
                 km1[i] = fu.bncoef[2 * C + c] * fu.bncoef[c];
                 km2[i] = fu.bncoef[2 * C + c] * fu.bncoef[C + c] * fu.bnstat[3 * C + c];
-                mu4[i] = fu.bnstat[2 * C + c];
+                mu8[i] = fu.bnstat[2 * C + c];
             }
             uint16_t* Ch = (uint16_t*)Cb;
             const uint16_t* xh = (const uint16_t*)fu.bnx;
-            for (int pb = 0; pb < NPC; pb += NB) {
-                uint2 x2[NB];
-                long off[NB];
-                bool ok[NB];
+            constexpr int PIECES8 = BM * BN / 8, NPC8 = PIECES8 / 256, NB8 = NPC8 < 8 ? NPC8 : 8;
+            static_assert(PIECES8 % 256 == 0 && NPC8 % NB8 == 0, "piece loop shape (8-column pieces)");
+            for (int pb = 0; pb < NPC8; pb += NB8) {
+                uint4 x4[NB8];
+                long off[NB8];
+                bool ok[NB8];
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
+                for (int u = 0; u < NB8; ++u) {
                     const int pc = tid + (pb + u) * 256;
-                    const int gm = m0 + pc / (BN / 4), gn = n0 + (pc % (BN / 4)) * 4;
-                    ok[u] = gm < g.M && gn < g.N;
+                    const int gm = m0 + pc / (BN / 8), gn = n0 + (pc % (BN / 8)) * 8;
+                    ok[u] = gm < g.M && gn < g.N;                       // (N % 8 == 0: a piece is inside or outside as a whole)
                     off[u] = ok[u] ? (long)gm * g.ldc + gn : 0;
-                    x2[u] = *(const uint2*)(xh + off[u]);
+                    x4[u] = *(const uint4*)(xh + off[u]);
                 }
 #pragma unroll
-                for (int u = 0; u < NB; ++u) {
+                for (int u = 0; u < NB8; ++u) {
                     if (!ok[u]) continue;
                     const int pc = tid + (pb + u) * 256;
-                    const float4 t4 = *(const float4*)(tile + (pc / (BN / 4)) * TP + (pc % (BN / 4)) * 4);
-                    const float v[4] = {t4.x, t4.y, t4.z, t4.w};
-                    const float x[4] = {__uint_as_float(x2[u].x << 16), __uint_as_float(x2[u].x & 0xffff0000u),
-                                        __uint_as_float(x2[u].y << 16), __uint_as_float(x2[u].y & 0xffff0000u)};
-                    float o[4];
+                    const float* tp = tile + (pc / (BN / 8)) * TP + (pc % (BN / 8)) * 8;
+                    const float4 t0 = *(const float4*)tp, t1 = *(const float4*)(tp + 4);
+                    const float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    const uint32_t xw[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+                    float o[8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = x[i] > 0.f ? v[i] - km1[i] - (x[i] - mu4[i]) * km2[i] : 0.f;
-                    *(uint2*)(Ch + off[u]) = pack4(o[0], o[1], o[2], o[3]);
+                    for (int i = 0; i < 8; ++i) {
+                        const float x = __uint_as_float((i & 1) ? (xw[i >> 1] & 0xffff0000u) : (xw[i >> 1] << 16));
+                        o[i] = x > 0.f ? v[i] - km1[i] - (x - mu8[i]) * km2[i] : 0.f;
+                    }
+                    const uint2 lo = pack4(o[0], o[1], o[2], o[3]), hi = pack4(o[4], o[5], o[6], o[7]);
+                    *(uint4*)(Ch + off[u]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
             return;
@@ -986,7 +995,8 @@ int step_gemm_bf16_launch(StepGemm g, hipStream_t st, const GemmFused* fused) {
     fa.wide_store = wide_store_ok(g, fused != nullptr);
     if (fused) STEP_REQUIRE(fast && fa.wide_store && !g.bias && !g.relu && g.batch == 1 && g.splitk <= 1 &&
                             ((fused->flags & (GEMM_FUSED_FFN_FWD | GEMM_FUSED_MASKNZ | GEMM_FUSED_BF16OUT)) ? (g.accumulate == 0 && !fused->dotw && !fused->bnx && !g.c_nscale) :
-                             (fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && !fused->dotw) : fused->period >= 128),
+                             (fused->flags & GEMM_FUSED_INTERLEAVED) ? (128 % fused->channels == 0 && fused->channels % 8 == 0 && g.N % 8 == 0 && g.ldc % 8 == 0 &&
+                                                                       ((((uintptr_t)fused->bnx) | ((uintptr_t)g.C)) & 15) == 0 && !fused->dotw) : fused->period >= 128),
                             "step_gemm: the fused DGL epilogues need the staged path with a wide-store result (aligned dense C, period >= 128)");
     if (g.splitk < 0) {
         STEP_REQUIRE(g.accumulate == 2, "step_gemm: automatic split-K needs accumulate==2");

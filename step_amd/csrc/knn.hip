@@ -213,7 +213,7 @@ static long tk_bytes(int B, int N) { return (long)B * (3 * TK_BINS + tk_slices(N
 // reads for four products) -- only the <= 15 blocks on or above the diagonal exist, one per wave (64 accumulator registers).  H is read exactly once; the partial blocks of the feature
 // slices go to a workspace in accumulator order (coalesced), and gram_finish_kernel adds them, applies the cosine normalisation
 // (similarity.py:8-14) and writes both triangles.
-constexpr int GS_KS = 64, GS_PITCH = GS_KS * 2 + 8;          // slab of 64 features; LDS row = 128 B + 8 (conflict-free 16-byte fragment reads)
+constexpr int GS_KS = 64, GS_ROWB = GS_KS * 2;               // slab of 64 features = 128 bytes per row, 8 pieces of 16 bytes
 __host__ __device__ constexpr int gs_blocks(int nb) { return nb * (nb + 1) / 2; }
 // block p (0 .. NB(NB+1)/2 - 1) -> (bi <= bj), row-major over the upper triangle
 __device__ __forceinline__ void gs_block_of(int p, int NB, int& bi, int& bj) {
@@ -221,110 +221,101 @@ __device__ __forceinline__ void gs_block_of(int p, int NB, int& bi, int& bj) {
     while (p >= NB - bi) { p -= NB - bi; ++bi; }
     bj = bi + p;
 }
-__global__ __launch_bounds__(1024) void gram_sym_kernel(const uint16_t* __restrict__ H, int N, int F, int NB, int slabs_per_split,
-                                                        float* __restrict__ ws) {
+// lane i's 16 bytes land at lds_dst + 16 i (lds_dst wave-uniform): global_load_lds_dwordx4, no registers in between
+__device__ __forceinline__ void gs_dma_1k(const void* gsrc_lane, uint32_t lds_dst) {
+    uint32_t keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+// Staging: a slab of all 64 NB (padded) rows goes from global memory straight into one of three LDS buffers by DMA -- NB instructions of 1 KB
+// (8 rows) from each of waves 0..7, two slabs ahead of the matrix work.  A row's 8 pieces are stored XOR-swizzled (piece c of row r in slot
+// c ^ (r & 7): the DMA fixes where a lane's data lands, not what it loads), so the 16-byte fragment reads of 8 consecutive rows hit all 32
+// banks.  Rows beyond N repeat row N - 1: they only feed outputs that are never stored.  LDS moves 1 KB per matrix product here (four
+// fragments for the four products of a 64 x 64 block): 2048 cycles per slab on the LDS port against 2048 on the matrix pipe -- with two-way
+// bank conflicts (the first version: padded rows, 8-byte reads) the kernel ran at the LDS port's pace, 67 us instead of ~30.
+template <int NB>
+__global__ __launch_bounds__(1024) void gram_sym_kernel(const uint16_t* __restrict__ H, int N, int F, int slabs_per_split, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
-    const int rows = NB * 64;                                   // padded row count (zero rows beyond N)
-    const int buf_bytes = rows * GS_PITCH;
+    constexpr int ROWS = NB * 64, BUF = ROWS * GS_ROWB, NBLK = gs_blocks(NB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x, b = blockIdx.y;
     const uint16_t* Hb = H + (long)b * N * F;
-    const int k_begin = s * slabs_per_split * GS_KS;
-    const int k_end = min(F, (s + 1) * slabs_per_split * GS_KS);
-    // zero both buffers once: rows >= N (and the pad bytes) are never written again
-    for (int i = tid; i < 2 * buf_bytes / 16; i += 1024) ((uint4*)gs_lds)[i] = make_uint4(0u, 0u, 0u, 0u);
-    const int nblk = gs_blocks(NB);
-    constexpr int Q = 1;                                        // blocks per wave (NB <= 5: 15 blocks for 16 waves)
-    int bi[Q], bj[Q];
-    bool own[Q];
+    const int nslab_all = F / GS_KS;
+    const int slab0 = s * slabs_per_split;
+    const int nslab = min(nslab_all - slab0, slabs_per_split);
+    int bi, bj;
+    const bool own = wave < NBLK;
+    gs_block_of(own ? wave : 0, NB, bi, bj);
+    f32x16 acc[4];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int p = wave + 16 * q;
-        own[q] = p < nblk;
-        gs_block_of(own[q] ? p : 0, NB, bi[q], bj[q]);
-    }
-    f32x16 acc[Q][4];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)gs_lds;
+    auto issue = [&](int slab, int buf) {              // waves 0..7: NB groups of 8 rows each
+        if (wave < 8) {
+            const long k0 = (long)(slab0 + slab) * GS_KS;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[q][t][e] = 0.f;
-    // staging: chunk c = (row, 16-byte piece) of the slab; up to 3 chunks per thread (384 rows x 8 pieces / 1024 threads)
-    const int nchunk = N * (GS_KS / 8);
-    uint4 st[3];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int c = tid + u * 1024;
-            st[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (c < nchunk) {
-                const int row = c >> 3, k = k0 + (c & 7) * 8;
-                if (k < k_end) st[u] = *(const uint4*)(Hb + (long)row * F + k);          // (F % 8 == 0 and slices end on slab boundaries or at F: whole pieces)
+            for (int j = 0; j < NB; ++j) {
+                const int g = wave * NB + j;
+                int row = g * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (row & 7);
+                row = row < N ? row : N - 1;
+                gs_dma_1k(Hb + (long)row * F + k0 + c * 8, lds0 + (uint32_t)(buf * BUF + g * 1024));
             }
         }
     };
-    auto commit = [&](char* buf) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int c = tid + u * 1024;
-            if (c < nchunk) {
-                char* d = buf + (c >> 3) * GS_PITCH + (c & 7) * 16;
-                *(uint2*)d = make_uint2(st[u].x, st[u].y);
-                *(uint2*)(d + 8) = make_uint2(st[u].z, st[u].w);
-            }
-        }
-    };
-    __syncthreads();
-    if (k_begin < k_end) {
-        fetch(k_begin);
-        commit(gs_lds);
-        __syncthreads();
-        int cur = 0;
+    if (nslab > 0) {
         const int r = lane & 31, h = lane >> 5;
-        for (int k0 = k_begin; k0 < k_end; k0 += GS_KS) {
-            const bool more = k0 + GS_KS < k_end;
-            if (more) fetch(k0 + GS_KS);
-            const char* buf = gs_lds + cur * buf_bytes;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (!own[q]) continue;
-                const char* pa = buf + (bi[q] * 64 + r) * GS_PITCH + h * 16;
-                const char* pb = buf + (bj[q] * 64 + r) * GS_PITCH + h * 16;
-                const bool diag = bi[q] == bj[q];
+        issue(0, 0);
+        if (nslab > 1) issue(1, 1);
+        for (int i = 0; i < nslab; ++i) {
+            // slab i has landed: this wave's DMAs of slab i + 1 (NB of them, if requested) may still be in flight
+            if (i + 1 < nslab) {
+                if constexpr (NB == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if constexpr (NB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                                   // everybody's pieces of slab i are there; everybody is done with slab i - 1
+            if (i + 2 < nslab) issue(i + 2, (i + 2) % 3);      // ... whose buffer is refilled
+            if (own) {
+                const char* buf = gs_lds + (i % 3) * BUF;
+                const int ra = bi * 64 + r, rb = bj * 64 + r;
+                const char* pa0 = buf + ra * GS_ROWB;
+                const char* pa1 = pa0 + 32 * GS_ROWB;
+                const char* pb0 = buf + rb * GS_ROWB;
+                const char* pb1 = pb0 + 32 * GS_ROWB;
+                const bool diag = bi == bj;
 #pragma unroll
                 for (int ks = 0; ks < GS_KS / 16; ++ks) {
-                    auto frag = [&](const char* p) -> bf16x8 {
-                        const uint2 lo = *(const uint2*)(p + ks * 32), hi = *(const uint2*)(p + ks * 32 + 8);
-                        return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                    };
-                    const bf16x8 a0 = frag(pa), a1 = frag(pa + 32 * GS_PITCH);
-                    const bf16x8 b0 = diag ? a0 : frag(pb), b1 = diag ? a1 : frag(pb + 32 * GS_PITCH);
-                    acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[q][0], 0, 0, 0);
-                    acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[q][1], 0, 0, 0);
-                    if (!diag) acc[q][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[q][2], 0, 0, 0);
-                    acc[q][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[q][3], 0, 0, 0);
+                    const int sl = (((ks * 2 + h) ^ (r & 7)) << 4);        // rows ra, ra + 32, rb, rb + 32 share r & 7
+                    const bf16x8 a0 = *(const bf16x8*)(pa0 + sl), a1 = *(const bf16x8*)(pa1 + sl);
+                    const bf16x8 b0 = diag ? a0 : *(const bf16x8*)(pb0 + sl), b1 = diag ? a1 : *(const bf16x8*)(pb1 + sl);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);
+                    if (!diag) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
                 }
             }
-            if (more) commit(gs_lds + (cur ^ 1) * buf_bytes);
-            __syncthreads();
-            cur ^= 1;
         }
     }
     // partial blocks -> workspace [split][sample][block][tile 0..3][accumulator register e][lane]: 256-byte runs per store instruction
-    float* out = ws + ((long)(s * gridDim.y + b) * nblk) * 4096;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        if (!own[q]) continue;
-        float* o = out + (long)(wave + 16 * q) * 4096 + lane;
+    if (own) {
+        float* o = ws + ((long)(s * gridDim.y + b) * NBLK + wave) * 4096 + lane;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (t == 2 && bi[q] == bj[q]) continue;               // the lower tile of a diagonal block is the transpose of tile 1
+            if (t == 2 && bi == bj) continue;                  // the lower tile of a diagonal block is the transpose of tile 1
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[t * 1024 + e * 64] = acc[q][t][e];
+            for (int e = 0; e < 16; ++e) o[t * 1024 + e * 64] = acc[t][e];
         }
     }
-    (void)S;
 }
 // sum of the feature slices, cosine normalisation, both triangles.  grid (blocks of the upper triangle, B), 256 threads; every thread owns
 // accumulator elements (t, e, lane) with lane = tid & 63, e = 4 (tid >> 6) .. + 3 of all four tiles.
@@ -353,8 +344,16 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
             const int e = eg * 4 + ee;
-            float v = 0.f;
-            for (int sp = 0; sp < S; ++sp) v += ws[((long)(sp * Bn + b) * nblk + blockIdx.x) * 4096 + t * 1024 + e * 64 + lane];
+            // (four independent chains: the loads of four slices are in flight together)
+            const float* src = ws + ((long)b * nblk + blockIdx.x) * 4096 + t * 1024 + e * 64 + lane;
+            const long sstr = (long)Bn * nblk * 4096;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int sp = 0;
+            for (; sp + 4 <= S; sp += 4) {
+                v0 += src[(long)sp * sstr]; v1 += src[(long)(sp + 1) * sstr]; v2 += src[(long)(sp + 2) * sstr]; v3 += src[(long)(sp + 3) * sstr];
+            }
+            for (; sp < S; ++sp) v0 += src[(long)sp * sstr];
+            const float v = (v0 + v1) + (v2 + v3);
             // accumulator element (e, lane) of a 32 x 32 product: row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31
             const int rr = (t >> 1) * 32 + 8 * (e >> 2) + (e & 3) + 4 * (lane >> 5), cc = (t & 1) * 32 + (lane & 31);
             tile[rr][cc] = v;
@@ -376,7 +375,8 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
         }
     }
 }
-// feature slices per sample: enough workgroups for about half the chip (the product runs next to other kernels), at least 2 slabs each
+// feature slices per sample: ~128 workgroups, at least 2 slabs each (inside the step, next to the encoder's persistent launch, 4 / 8 / 16
+// slices per sample give the same step time at PEMS04: 3.411 / 3.404 / 3.399 ms, profiles/r06_h_gram_sweep.log; alone, more slices are faster)
 static int gram_sym_splits(int B, int F) {
     static const int forced = []() { const char* e = getenv("STEP_GRAM_SPLITS"); return e ? atoi(e) : 0; }();
     const int slabs = (F + GS_KS - 1) / GS_KS;
@@ -440,15 +440,25 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
     STEP_REQUIRE(hidden && sim && adj && B > 0 && N > 0 && F > 0 && k_total > 0, "knn_graph: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     STEP_REQUIRE(F % 8 == 0, "knn_graph: feature length %d must be a multiple of 8", F);
-    if (gram_sym_ok(N) && sqnorm_part && work && work_bytes >= step_knn_workspace_bytes(B, N, F) && (((uintptr_t)hidden) & 15) == 0) {
+    if (gram_sym_ok(N) && F % GS_KS == 0 && sqnorm_part && work && work_bytes >= step_knn_workspace_bytes(B, N, F) && (((uintptr_t)hidden) & 15) == 0) {
         // small graphs: the whole output per workgroup, H read once (gram_sym_kernel), normalisation in the reduction of the slices
-        const int NB = (N + 63) / 64, S = gram_sym_splits(B, F), slabs = (F + GS_KS - 1) / GS_KS;
+        const int NB = (N + 63) / 64, S = gram_sym_splits(B, F), slabs = F / GS_KS, per = (slabs + S - 1) / S;
         float* ws = (float*)((char*)work + ((tk_bytes(B, N) + 255) & ~255L));
-        const int lds = 2 * NB * 64 * GS_PITCH;
-        STEP_TRY(step_raise_lds_once((const void*)gram_sym_kernel, 160 * 1024, "knn_graph"));
-        gram_sym_kernel<<<dim3(S, B), 1024, lds, st>>>(hidden, N, F, NB, (slabs + S - 1) / S, ws);
+        const int lds = 3 * NB * 64 * GS_ROWB;
+        const dim3 grid((slabs + per - 1) / per, B);
+#define GS_LAUNCH(nb)                                                                                            \
+        case nb:                                                                                                 \
+            STEP_TRY(step_raise_lds_once((const void*)gram_sym_kernel<nb>, 160 * 1024, "knn_graph"));            \
+            gram_sym_kernel<nb><<<grid, 1024, lds, st>>>(hidden, N, F, per, ws);                                 \
+            break;
+        switch (NB) {
+            GS_LAUNCH(1) GS_LAUNCH(2) GS_LAUNCH(3) GS_LAUNCH(4) GS_LAUNCH(5)
+            default: STEP_REQUIRE(false, "knn_graph: %d nodes in the symmetric Gram path", N);
+        }
+#undef GS_LAUNCH
         STEP_LAUNCH_CHECK("gram_sym");
-        gram_finish_kernel<<<dim3(gs_blocks(NB), B), 256, 0, st>>>(ws, S, N, NB, sqnorm_part, sim);
+        const int S_used = (int)grid.x;
+        gram_finish_kernel<<<dim3(gs_blocks(NB), B), 256, 0, st>>>(ws, S_used, N, NB, sqnorm_part, sim);
         STEP_LAUNCH_CHECK("gram_finish");
         return step_topk_mask(sim, B, N, k_total, adj, work, work_bytes, stream);
     }

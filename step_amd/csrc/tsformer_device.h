@@ -23,7 +23,7 @@ struct EncArgs {
     unsigned int* fallback;                  // optional 64 counters (summed by the caller): (wave, head) pairs that ran the re-shifting softmax loop; NULL = not counted
     bool f16;          // operand fragments of wpack are float16 (else bfloat16)
     bool always_rescale;                     // test hook: take the softmax re-shift path on every key tile
-    bool range_flag;                         // STEP_ENC_RANGE_FLAG: fallback[64] |= 1 when a wave's output is not finite (float16 operand overflow)
+    unsigned int* range_word;                // STEP_ENC_RANGE_FLAG: fallback_count + 64, OR-ed with 1 when a wave's output is not finite (float16 operand overflow); else NULL
     int grid_limit;                          // > 0: persistent launch of at most this many workgroups (each loops over sequences)
 };
 

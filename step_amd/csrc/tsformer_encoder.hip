@@ -1056,14 +1056,15 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 sq += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
             }
     }
-    if (A.sqn || A.range_flag) {
-        sq = wave_sum_swz(sq);
-        // float16 operands overflow at 65 504 (round-to-nearest packs give inf, the matrix cores carry it into the residual stream, the
-        // final LayerNorm turns it into NaN): the squared norm this wave just formed says so for free -- one compare per wave
-        if (A.range_flag && lane_e == 0 && !(sq <= 3.0e38f)) atomicOr(A.fallback + 64, 1u);
-    }
     if (A.sqn) {
-        if (lane_e == 0) A.sqn[(long)seq * 16 + wave] = sq;
+        sq = wave_sum_swz(sq);
+        if (lane_e == 0) {
+            A.sqn[(long)seq * 16 + wave] = sq;
+            // float16 operands overflow at 65 504 (round-to-nearest packs give inf, the matrix cores carry it into the residual stream, the
+            // final LayerNorm turns it into NaN): the squared norm this wave just formed says so for free -- one compare per wave
+            // (STEP_ENC_RANGE_FLAG; the host passes sqnorm_part whenever it asks for the flag)
+            if (A.range_word && !(sq <= 3.0e38f)) atomicOr(A.range_word, 1u);
+        }
         if (wave == 0 && lane_e >= nkt && lane_e < 16) A.sqn[(long)seq * 16 + lane_e] = 0.f;
     }
     }   // sequences of this workgroup
@@ -1230,7 +1231,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
                  wpack_bytes, (long)TSF_TOTAL_BYTES(depth, P));
     STEP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "tsformer_encode: bad dropout %f", dropout_p);
     STEP_REQUIRE((flags & ~(7 | (0xffff << 8))) == 0, "tsformer_encode: unknown flag bits 0x%x", flags);
-    STEP_REQUIRE(!(flags & STEP_ENC_RANGE_FLAG) || fallback_count, "tsformer_encode: STEP_ENC_RANGE_FLAG needs fallback_count (uint32 [65])");
+    STEP_REQUIRE(!(flags & STEP_ENC_RANGE_FLAG) || (fallback_count && sqnorm_part), "tsformer_encode: STEP_ENC_RANGE_FLAG needs fallback_count (uint32 [65]) and sqnorm_part");
     const bool dr = dropout_p > 0.f;
     EncArgs a;
     a.series = series; a.S = S; a.L = L; a.P = P; a.depth = depth; a.nkt = (P + 31) / 32;
@@ -1248,7 +1249,7 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.fallback = fallback_count;
     a.f16 = (flags & STEP_ENC_F16) != 0;
     a.always_rescale = (flags & STEP_ENC_ALWAYS_RESHIFT) != 0;
-    a.range_flag = (flags & STEP_ENC_RANGE_FLAG) != 0;
+    a.range_word = (flags & STEP_ENC_RANGE_FLAG) ? fallback_count + 64 : nullptr;
     a.grid_limit = (flags >> 8) & 0xffff;               // STEP_ENC_WORKGROUPS(n): persistent launch of at most n workgroups
     hipStream_t st = (hipStream_t)stream;
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)

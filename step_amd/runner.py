@@ -200,6 +200,7 @@ def native_runner(base, prefetch=True, defer_meters=True, fused_optimizer=True, 
                 if n is None:
                     n = 160 if (model.backend.num_nodes, int(model.tsformer.num_token)) == (307, 336) else 0
                 model.tsformer.encoder_workgroups = int(n)
+                model.prefetch_knn_stream = int(n) > 0          # (the look-ahead loader announces at the start of the step: bench.py's policy)
             return loader
 
         def build_val_data_loader(self, cfg):

@@ -436,9 +436,11 @@ class STEP(nn.Module):
         # the adjacency-independent start of the WaveNet (library phases 5 / 6) on a third stream next to the graph learner: measured, no gain
         # (3.496 / 3.495 vs 3.476 / 3.491 ms at PEMS04, profiles/r06_e_*: the step is bound by the prefetched branch, not by this chain) -- off
         self.split_wavenet_prep = os.environ.get("STEP_PREP_SPLIT", "0") == "1"
-        # prefetch(): the kNN prior (Gram product + top-k, ~0.35 ms at PEMS04) of the announced batch on a stream of its own instead of behind
-        # its encoder on the prefetch stream -- only the loss needs it, half a step later
-        self.prefetch_knn_stream = os.environ.get("STEP_PREFETCH_KNN_STREAM", "1") == "1"
+        # prefetch(): the kNN prior (Gram product + top-k) of the announced batch on a stream of its own instead of behind its encoder on the
+        # prefetch stream -- only the loss needs it, half a step later.  Pays where the branch is announced at the START of the step
+        # (PEMS04: 3.66 -> 3.55 ms on one box) and costs where it is announced late and the prior is large (PEMS07, 883 nodes: 5.57 -> 6.68 ms,
+        # profiles/r06_j_knn_stream_C4.log): off here, bench.py and step_amd.runner switch it on with the early announcement
+        self.prefetch_knn_stream = os.environ.get("STEP_PREFETCH_KNN_STREAM", "0") == "1"
         self._prefetched = None             # FIFO (list) of the frozen branches queued by prefetch() for upcoming batches
         self._precision_override = None
         self._alias = {}                    # batch key of a derived tensor -> key of the announced batch it was made from (alias_batch)

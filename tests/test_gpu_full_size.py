@@ -95,13 +95,18 @@ def test_full_size_training_step_parity(case, mode):
     if tight:
         assert max(errs.values()) < 2e-2, worst
     else:
-        # bf16 mode, per tensor.  The graph learner's small tensors in front of / behind a train-mode BatchNorm
-        # (conv / fc biases, BatchNorm affines, conv weights) are masked parts of sums that cancel exactly in f32, and the adaptive adjacency's
-        # node embeddings (K = 10 products of softmax gradients): 6-13 % measured.  Everything else -- every GraphWaveNet weight, the fc
-        # weight (98 % of the gradient bytes), the edge MLP -- within 5 %.
+        # bf16 mode, per tensor.  Every GraphWaveNet weight, the fc weight (98 % of the gradient bytes) and the edge MLP: within 5 %.  The
+        # graph learner's small tensors in front of / behind a train-mode BatchNorm (conv / fc biases, BatchNorm affines, conv weights) and the
+        # adaptive adjacency's node embeddings are sums whose terms cancel almost completely in exact arithmetic -- fc_b, for one, is minus the
+        # sum of a zero-sum vector over the rows the ReLU switched off -- so the 2^-9 operand rounding of the FORWARD contractions (which moves
+        # BatchNorm statistics and flips ReLU masks near zero) shows up amplified: 6-13 % measured.  tools/precision_split.py (round 6,
+        # profiles/r06_d_precision_split.log, r06_e_precision_split_f32_storage.log) runs the step with bf16 operands in one half at a time
+        # against the exact-f32 step: the graph learner's own contractions alone give conv2_b 10.6 %, conv1_b 9.3 %, bn1_b 8.9 %, bn2_b 8.3 %,
+        # fc_b 7.3 %; with f32-STORED activations and bf16 operands 9.3 / 5.5 / 8.9 / 6.8 / 6.3 % -- it is the operand format of the products,
+        # not sums over bf16-stored values (round 5's guess): nothing short of wider operands (float16 activations, split bf16) removes it.
         loose = ("dgl.conv1_", "dgl.conv2_", "dgl.bn1_", "dgl.bn2_", "dgl.bn3_", "dgl.fc_b", "be.nodevec")
         for kname, e in errs.items():
-            bound = 0.2 if kname.startswith(loose) else 0.05
+            bound = 0.16 if kname.startswith(loose) else 0.05
             assert e < bound, (kname, e, bound, worst)
     num = sum(float(((dict(model._trainable())[a].grad.cpu() - p[ref_name(a)].grad) ** 2).sum()) for a in errs)
     den = sum(float((p[ref_name(a)].grad ** 2).sum()) for a in errs)
@@ -215,13 +220,18 @@ def test_full_size_c5_4096_nodes_parity(mode):
     if tight:
         assert max(errs.values()) < 2e-2, worst
     else:
-        # bf16 mode, per tensor.  The graph learner's small tensors in front of / behind a train-mode BatchNorm
-        # (conv / fc biases, BatchNorm affines, conv weights) are masked parts of sums that cancel exactly in f32, and the adaptive adjacency's
-        # node embeddings (K = 10 products of softmax gradients): 6-13 % measured.  Everything else -- every GraphWaveNet weight, the fc
-        # weight (98 % of the gradient bytes), the edge MLP -- within 5 %.
+        # bf16 mode, per tensor.  Every GraphWaveNet weight, the fc weight (98 % of the gradient bytes) and the edge MLP: within 5 %.  The
+        # graph learner's small tensors in front of / behind a train-mode BatchNorm (conv / fc biases, BatchNorm affines, conv weights) and the
+        # adaptive adjacency's node embeddings are sums whose terms cancel almost completely in exact arithmetic -- fc_b, for one, is minus the
+        # sum of a zero-sum vector over the rows the ReLU switched off -- so the 2^-9 operand rounding of the FORWARD contractions (which moves
+        # BatchNorm statistics and flips ReLU masks near zero) shows up amplified: 6-13 % measured.  tools/precision_split.py (round 6,
+        # profiles/r06_d_precision_split.log, r06_e_precision_split_f32_storage.log) runs the step with bf16 operands in one half at a time
+        # against the exact-f32 step: the graph learner's own contractions alone give conv2_b 10.6 %, conv1_b 9.3 %, bn1_b 8.9 %, bn2_b 8.3 %,
+        # fc_b 7.3 %; with f32-STORED activations and bf16 operands 9.3 / 5.5 / 8.9 / 6.8 / 6.3 % -- it is the operand format of the products,
+        # not sums over bf16-stored values (round 5's guess): nothing short of wider operands (float16 activations, split bf16) removes it.
         loose = ("dgl.conv1_", "dgl.conv2_", "dgl.bn1_", "dgl.bn2_", "dgl.bn3_", "dgl.fc_b", "be.nodevec")
         for kname, e in errs.items():
-            bound = 0.2 if kname.startswith(loose) else 0.05
+            bound = 0.16 if kname.startswith(loose) else 0.05
             assert e < bound, (kname, e, bound, worst)
     assert whole < (5e-3 if tight else 5e-2)
     assert e_pred < (2e-3 if tight else 1e-2)
