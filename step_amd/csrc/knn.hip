@@ -317,18 +317,21 @@ __global__ __launch_bounds__(1024) void gram_sym_kernel(const uint16_t* __restri
         }
     }
 }
-// sum of the feature slices, cosine normalisation, both triangles.  grid (blocks of the upper triangle, B), 256 threads; every thread owns
-// accumulator elements (t, e, lane) with lane = tid & 63, e = 4 (tid >> 6) .. + 3 of all four tiles.
+// sum of the feature slices, cosine normalisation, both triangles.  grid (4 x blocks of the upper triangle, B): one 32 x 32 MFMA tile per
+// workgroup of 256 threads (thread: accumulator elements e = 4 (tid >> 6) .. + 3 of lane tid & 63).
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ ws, int S, int N, int NB, const float* __restrict__ sqn_part,
                                                           float* __restrict__ sim) {
-    __shared__ float tile[64][65];
-    __shared__ float nrm[128];
-    const int b = blockIdx.y, Bn = gridDim.y, nblk = gs_blocks(NB);
+    __shared__ float tile[32][33];
+    __shared__ float nrm[64];
+    const int b = blockIdx.y, Bn = gridDim.y, nblk = gs_blocks(NB), blk = blockIdx.x >> 2, t = blockIdx.x & 3;
     int bi, bj;
-    gs_block_of(blockIdx.x, NB, bi, bj);
+    gs_block_of(blk, NB, bi, bj);
+    const bool diag = bi == bj;
+    if (diag && t == 2) return;                                    // (never stored: the transpose of tile 1, written by that tile's workgroup)
+    const int row0 = bi * 64 + (t >> 1) * 32, col0 = bj * 64 + (t & 1) * 32;
     const int tid = threadIdx.x, lane = tid & 63, eg = tid >> 6;
-    if (tid < 128) {           // norms of the block's 64 rows and 64 columns (similarity.py:8-14: |F| + 1e-7)
-        const int n = (tid < 64 ? bi * 64 : bj * 64 - 64) + tid;
+    if (tid < 64) {           // norms of the tile's 32 rows and 32 columns (similarity.py:8-14: |F| + 1e-7)
+        const int n = tid < 32 ? row0 + tid : col0 + tid - 32;
         float sum = 0.f;
         if (n < N) {
             const float* p = sqn_part + ((long)b * N + n) * 16;
@@ -337,41 +340,30 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
         }
         nrm[tid] = sqrtf(fmaxf(sum, 0.f)) + 1e-7f;
     }
-    const bool diag = bi == bj;
+    const long sstr = (long)Bn * nblk * 4096;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t == 2 && diag) continue;
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const int e = eg * 4 + ee;
-            // (four independent chains: the loads of four slices are in flight together)
-            const float* src = ws + ((long)b * nblk + blockIdx.x) * 4096 + t * 1024 + e * 64 + lane;
-            const long sstr = (long)Bn * nblk * 4096;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-            int sp = 0;
-            for (; sp + 4 <= S; sp += 4) {
-                v0 += src[(long)sp * sstr]; v1 += src[(long)(sp + 1) * sstr]; v2 += src[(long)(sp + 2) * sstr]; v3 += src[(long)(sp + 3) * sstr];
-            }
-            for (; sp < S; ++sp) v0 += src[(long)sp * sstr];
-            const float v = (v0 + v1) + (v2 + v3);
-            // accumulator element (e, lane) of a 32 x 32 product: row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31
-            const int rr = (t >> 1) * 32 + 8 * (e >> 2) + (e & 3) + 4 * (lane >> 5), cc = (t & 1) * 32 + (lane & 31);
-            tile[rr][cc] = v;
-            if (diag && t == 1) tile[cc][rr] = v;                   // (the skipped lower tile)
+    for (int ee = 0; ee < 4; ++ee) {
+        const int e = eg * 4 + ee;
+        // (four independent chains: the loads of four slices are in flight together)
+        const float* src = ws + ((long)b * nblk + blk) * 4096 + t * 1024 + e * 64 + lane;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= S; sp += 4) {
+            v0 += src[(long)sp * sstr]; v1 += src[(long)(sp + 1) * sstr]; v2 += src[(long)(sp + 2) * sstr]; v3 += src[(long)(sp + 3) * sstr];
         }
+        for (; sp < S; ++sp) v0 += src[(long)sp * sstr];
+        // accumulator element (e, lane) of a 32 x 32 product: row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31
+        tile[8 * (e >> 2) + (e & 3) + 4 * (lane >> 5)][lane & 31] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
-    // rows of the block (and, off the diagonal, of its transpose) in 256-byte runs
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int rr = i >> 6, cc = i & 63;
-        const int gi = bi * 64 + rr, gj = bj * 64 + cc;
-        if (gi < N && gj < N) sim[((long)b * N + gi) * N + gj] = tile[rr][cc] / (nrm[rr] * nrm[64 + cc]);
+    for (int i = tid; i < 32 * 32; i += 256) {                        // rows of the tile in 128-byte runs
+        const int rr = i >> 5, cc = i & 31, gi = row0 + rr, gj = col0 + cc;
+        if (gi < N && gj < N) sim[((long)b * N + gi) * N + gj] = tile[rr][cc] / (nrm[rr] * nrm[32 + cc]);
     }
-    if (!diag) {
-        for (int i = tid; i < 64 * 64; i += 256) {
-            const int cc = i >> 6, rr = i & 63;                      // element (gj, gi) of the output = tile[rr][cc]
-            const int gi = bi * 64 + rr, gj = bj * 64 + cc;
-            if (gi < N && gj < N) sim[((long)b * N + gj) * N + gi] = tile[rr][cc] / (nrm[rr] * nrm[64 + cc]);
+    if (!(diag && (t == 0 || t == 3))) {                              // ... and of its transpose (tiles on the diagonal hold both triangles already)
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int cc = i >> 5, rr = i & 31, gi = row0 + rr, gj = col0 + cc;          // element (gj, gi) of the output = tile[rr][cc]
+            if (gi < N && gj < N) sim[((long)b * N + gj) * N + gi] = tile[rr][cc] / (nrm[rr] * nrm[32 + cc]);
         }
     }
 }
@@ -381,6 +373,7 @@ static int gram_sym_splits(int B, int F) {
     static const int forced = []() { const char* e = getenv("STEP_GRAM_SPLITS"); return e ? atoi(e) : 0; }();
     const int slabs = (F + GS_KS - 1) / GS_KS;
     int S = forced > 0 ? forced : (128 + B - 1) / B;
+    if (forced <= 0 && S > 16) S = 16;          // (few samples: more slices only lengthen the reduction -- 64 slices at METR-LA's B = 2 made it 89 us)
     if (S > slabs / 2) S = slabs / 2;
     return S < 1 ? 1 : S;
 }
@@ -458,7 +451,7 @@ extern "C" int step_knn_graph(const uint16_t* hidden, const float* sqnorm_part, 
 #undef GS_LAUNCH
         STEP_LAUNCH_CHECK("gram_sym");
         const int S_used = (int)grid.x;
-        gram_finish_kernel<<<dim3(gs_blocks(NB), B), 256, 0, st>>>(ws, S_used, N, NB, sqnorm_part, sim);
+        gram_finish_kernel<<<dim3(4 * gs_blocks(NB), B), 256, 0, st>>>(ws, S_used, N, NB, sqnorm_part, sim);
         STEP_LAUNCH_CHECK("gram_finish");
         return step_topk_mask(sim, B, N, k_total, adj, work, work_bytes, stream);
     }

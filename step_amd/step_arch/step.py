@@ -552,7 +552,11 @@ class STEP(nn.Module):
         ready.record(main)                  # the batch (a gather on the main stream) and any inline encoder launch come first
         ps.wait_event(ready)
         mode = self.training
-        ks = self._side_stream(dev, "knn") if self.prefetch_knn_stream else None
+        # (never under a process group: RCCL's and the communicator's streams already compete for the four hardware queues, and a fifth stream
+        #  of the step then shares a queue with one that must not wait -- 4.89 instead of 3.57 ms at PEMS04, profiles/r06_l_knn_stream_process_group.log)
+        import torch.distributed as dist
+        grouped = self._process_group is not None or (dist.is_available() and dist.is_initialized())
+        ks = self._side_stream(dev, "knn") if (self.prefetch_knn_stream and not grouped) else None
         with torch.cuda.stream(ps):
             rec = self._frozen_branch(long_history_data, B, N, knn_stream=ks, channel=channel)
             rec["done"] = torch.cuda.Event()          # (with a kNN stream: the encoder; the prior graph has its own event, knn_done)

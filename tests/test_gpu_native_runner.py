@@ -106,6 +106,81 @@ def test_deferred_meters_equal_the_reference_meters(tmp_path):
         assert res["native"][k] == pytest.approx(res["reference"][k], rel=1e-4)
 
 
+def _metrics(pred, real, null=0.0):
+    """masked MAE / RMSE / MAPE as basicts/metrics/{mae,rmse,mape}.py define them (restated)"""
+    def mask_of(lab, nv):
+        m = (~torch.isclose(lab, torch.tensor(nv).expand_as(lab), atol=5e-5, rtol=0.)).float()
+        m = m / m.mean()
+        return torch.where(torch.isnan(m), torch.zeros_like(m), m)
+    m = mask_of(real, null)
+    mae = torch.nan_to_num((pred - real).abs() * m, nan=0.0).mean()
+    rmse = torch.sqrt(torch.nan_to_num((pred - real) ** 2 * m, nan=0.0).mean())
+    y0 = torch.where(real.abs() < 1e-4, torch.zeros_like(real), real)
+    ape = ((pred - y0).abs() / y0).abs() * mask_of(y0, 0.0)
+    return float(mae), float(rmse), float(torch.where(torch.isnan(ape), torch.zeros_like(ape), ape).mean())
+
+
+@pytest.mark.parametrize("kind", ["reference_runner", "native_runner"])
+def test_reference_test_loop_reports_the_oracles_per_horizon_metrics(tmp_path, kind):
+    """`runner.test_process()` -- the reference's own test loop (base_runner.py:156-185, base_tsf_runner.py:277-318: eval-mode forward over the
+    test loader, inverse scaling, masked MAE / RMSE / MAPE per horizon and overall, logged and fed to the test meters) -- around the HIP
+    module: every logged per-horizon number and the three test meters equal what the CPU oracle (its OWN fp32 TSFormer) gives for the same
+    weights, windows and Gumbel noise ("missing" 5)."""
+    import logging
+    import re
+    from oracle import step_oracle as O
+    from step_amd.runner import native_runner
+    with open(GOLDEN) as f:
+        gold = json.load(f)
+    with Workspace(str(tmp_path), "METR-LA") as ws:
+        cfg = ws.config(batch=2)
+        cfg.TEST.DATA.BATCH_SIZE = 2
+        if kind == "native_runner":
+            cfg.RUNNER = native_runner(cfg.RUNNER)
+        torch.manual_seed(gold["init_seed"])
+        runner = cfg.RUNNER(cfg)
+        native = runner.model
+        N, _, L = DC.DATASETS["METR-LA"]
+        u = torch.rand(2, N * N, 2, generator=torch.Generator().manual_seed(77))
+        native.register_forward_pre_hook(lambda m, a, k: setattr(m, "_noise_override", u), with_kwargs=True)
+        lines = []
+
+        class Grab(logging.Handler):
+            def emit(self, record):
+                lines.append(record.getMessage())
+        runner.logger.addHandler(Grab())
+        runner.logger.setLevel(logging.INFO)
+        runner.test_process(cfg)
+        torch.cuda.synchronize()
+        assert not native.training
+        # the oracle on the same two test windows
+        idx = __import__("pickle").load(open(os.path.join("datasets", "METR-LA", "index_in12_out12.pkl"), "rb"))["test"]
+        d = torch.from_numpy(ws.series)
+        hist = torch.stack([d[a:b] for a, b, c in idx]); fut = torch.stack([d[b:c] for a, b, c in idx]); longh = torch.stack([d[b - L:b] for a, b, c in idx])
+        p = {k: v.detach().float().cpu() for k, v in native.state_dict().items()}
+        with torch.no_grad():
+            pred, _, _, _ = O.step_forward(hist, longh[..., [0]], native.discrete_graph_learning.node_feats.cpu(), p, u, native.discrete_graph_learning.k, None,
+                                           training=False)
+        pr, re_ = O.rescale(pred, DC.MEAN, DC.STD), O.rescale(fut[..., [0]], DC.MEAN, DC.STD)
+        got = {}
+        for ln in lines:
+            m = re.search(r"horizon (\d+), Test MAE: ([0-9.eE+-]+), Test RMSE: ([0-9.eE+-]+), Test MAPE: ([0-9.eE+-]+)", ln)
+            if m:
+                got[int(m.group(1))] = (float(m.group(2)), float(m.group(3)), float(m.group(4)))
+        assert sorted(got) == list(range(1, 13)), lines
+        worst = 0.0
+        for h in range(1, 13):
+            want = _metrics(pr[:, h - 1], re_[:, h - 1])
+            for a, b in zip(got[h], want):
+                worst = max(worst, abs(a - b) / abs(b))
+                assert a == pytest.approx(b, rel=2e-2, abs=2e-4), (h, got[h], want)          # (logged with 4 decimals; 16-bit encoder operands)
+        overall = _metrics(pr, re_)
+        print(f"{kind}: reference test loop around the HIP module, 12 horizons x 3 metrics: worst relative deviation from the oracle {worst:.2e}; "
+              f"overall MAE / RMSE / MAPE {[runner.meters['test_' + k].avg for k in ('MAE', 'RMSE', 'MAPE')]} vs oracle {list(overall)}")
+        for k, b in zip(("MAE", "RMSE", "MAPE"), overall):
+            assert runner.meters["test_" + k].n == 1 and runner.meters["test_" + k].avg == pytest.approx(b, rel=1e-2)
+
+
 def test_runner_driven_loop_timed_at_config_c2(tmp_path):
     """>= 50 timed ``runner.train`` iterations at PEMS04 shape, batch 8, bf16 mode, dropout on: (a) the native runner over the
     device-resident dataset -- the bench.py schedule reached from the reference's loop; (b) the native runner over the reference's

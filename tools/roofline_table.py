@@ -32,7 +32,14 @@ def rows_of(N, T, B, P, L):
     hop_key = ("gemm_fast_kernelILi128ELi64ELi1ELi2ELb0", "gemm_fast_kernelILi64ELi64ELi1ELi2ELb0")
     return [
         ("tsformer_encoder_kernel", f"fused TSFormer encoder ({S} sequences x {P} tokens)", "mfma", S * L * 4 + S * P * 96 * 2, S * P * (4 * (221184 + 384 * P) + 2304)),
-        ("gemm_fast_kernelILi128ELi128ELi1ELi1ELb0", f"cosine Gram ({B} x {N}^2 x {P * 96}) and DGL fc forward (bf16 rows x bf16 weight copy), averaged", "hbm/L2", (S * P * 96 * 2 + B * N * N * 4 + a2h + wp) / 2, (2.0 * B * N * N * P * 96 + 2.0 * N * EMB * K) / 2),
+        # (graphs of up to 320 nodes: the cosine Gram is gram_sym_kernel + gram_finish_kernel since round 6, and this instantiation is the fc forward alone)
+        (("gemm_fast_kernelILi128ELi128ELi1ELi1ELb0",) if N > 320 else ("gemm_fast_kernelILi128ELi128ELi1ELi1ELb0",),
+         (f"cosine Gram ({B} x {N}^2 x {P * 96}) and DGL fc forward (bf16 rows x bf16 weight copy), averaged" if N > 320 else
+          "DGL fc forward (bf16 rows x bf16 weight copy, split-K through a workspace)"), "hbm/L2",
+         (S * P * 96 * 2 + B * N * N * 4 + a2h + wp) / 2 if N > 320 else a2h + wp, (2.0 * B * N * N * P * 96 + 2.0 * N * EMB * K) / 2 if N > 320 else 2.0 * N * EMB * K),
+        ("gram_sym_kernel", f"symmetric cosine Gram ({B} x {N}^2 x {P * 96}): the whole output per workgroup, H read once, blocks on / above the diagonal", "mfma/lds",
+         S * P * 96 * 2 + B * N * N * 4, 2.0 * B * N * N * P * 96),
+        ("gram_finish_kernel", "sum of the Gram product's feature slices + cosine normalisation, both triangles", "hbm", 16 * B * ((N + 63) // 64) * ((N + 63) // 64 + 1) // 2 * 16384 + B * N * N * 4, None),
         ("gemm_fast_kernelILi128ELi128ELi2ELi3ELb0", "DGL fc weight gradient G = dgpre^T a2 (n-contiguous bf16 loader)", "hbm", a2h + fcw, 2.0 * N * EMB * K),
         ("fc_unpermute_kernel", "G -> fc.weight layout, BN2 affine, stored into the gradient, BN2 backward sums", "hbm", 3 * fcw, None),
         ("fc_prep_kernel", "per-step bf16 (t,c)-ordered copy of fc.weight with BN2's scale", "hbm", fcw + wp, None),
