@@ -69,6 +69,11 @@ class DeviceForecastingDataset(Dataset):
             raise ValueError("DeviceForecastingDataset gathers history and future windows of one length (the STEP configs: 12 -> 12)")
         self._loaders = {}
 
+    def __getstate__(self):          # DataLoader workers get the index and the host series, never the device copies
+        d = dict(self.__dict__)
+        d["_loaders"] = {}
+        return d
+
     def __getitem__(self, index):
         idx = self.index[index]
         if idx[1] - idx[0] != self.history_len or idx[2] - idx[1] != self.future_len:

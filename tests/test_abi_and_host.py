@@ -558,6 +558,13 @@ def test_device_forecasting_dataset_reads_the_reference_files(tmp_path):
     assert (ds.history_len, ds.future_len, ds.seq_len) == (12, 12, 96) and ds.index_only
     batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=3)))
     assert batch.tolist() == [12, 50, 200] and batch.dtype == torch.int64
+    # through worker processes, as the reference's configs ask for (NUM_WORKERS = 2, PIN_MEMORY = True: STEP_PEMS04.py:121-122); the device
+    # copies of the series never travel to a worker
+    ds._loaders[("cuda", 0)] = object()
+    import pickle as _p
+    assert _p.loads(_p.dumps(ds))._loaders == {}
+    del ds._loaders[("cuda", 0)]
+    assert [b.tolist() for b in torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2)] == [[12, 50], [200]]
     with pytest.raises(FileNotFoundError):
         DeviceForecastingDataset(str(tmp_path / "nope.pkl"), str(tmp_path / "index.pkl"), "train", 96)
     with pytest.raises(AssertionError):
