@@ -106,6 +106,42 @@ def test_deferred_meters_equal_the_reference_meters(tmp_path):
         assert res["native"][k] == pytest.approx(res["reference"][k], rel=1e-4)
 
 
+def test_device_dataset_batches_equal_the_reference_datasets(tmp_path):
+    """`DeviceForecastingDataset` + `LookaheadLoader` hand the runner the same VALUES as the reference's `ForecastingDataset` + default
+    collate (step/step_data/forecasting_dataset.py:52-71), window by window -- including windows whose long history would start before the
+    series does (all-zero history there, :66-67) -- and the long-history reference answers the runner's `.to()`, `.shape` and feature
+    selection like the tensor it stands for."""
+    from step_amd import LongHistoryRef
+    from step_amd.runner import DeviceForecastingDataset, LookaheadLoader
+    with Workspace(str(tmp_path), "METR-LA", n_train=7, full_history_only=False) as ws:
+        from step.step_data import ForecastingDataset          # the reference's class
+        N, _, L = DC.DATASETS["METR-LA"]
+        d = os.path.join("datasets", "METR-LA")
+        args = (os.path.join(d, "data_in12_out12.pkl"), os.path.join(d, "index_in12_out12.pkl"), "train", L)
+        ref_ds, dev_ds = ForecastingDataset(*args), DeviceForecastingDataset(*args)
+        assert len(ref_ds) == len(dev_ds) == 7
+        zero_hist = [i for i in range(7) if ref_ds.index[i][1] - L < 0]
+        assert zero_hist and len(zero_hist) < 7, "the sample should mix windows with and without a full long history"
+
+        class R:          # what LookaheadLoader needs of a runner: the model (for its device) and the feature list
+            model = torch.nn.Linear(1, 1).cuda()
+            forward_features = [0, 1, 2]
+        ref_batches = list(torch.utils.data.DataLoader(ref_ds, batch_size=3, shuffle=False))
+        dev_batches = list(LookaheadLoader(torch.utils.data.DataLoader(dev_ds, batch_size=3, shuffle=False), R(), prefetch=False))
+        assert len(ref_batches) == len(dev_batches) == 3
+        from step_amd import _lib
+        for (rf, rh, rl), (df, dh, dl) in zip(ref_batches, dev_batches):
+            assert torch.equal(df.cpu(), rf) and torch.equal(dh.cpu(), rh)
+            assert isinstance(dl, LongHistoryRef) and tuple(dl.shape) == tuple(rl.shape) and dl.to("cuda") is dl and dl.cuda() is dl
+            sel = dl[:, :, :, [0, 1, 2]]
+            assert isinstance(sel, LongHistoryRef) and sel.channels == [0, 1, 2] and dl[:, :, :, [2]].channels == [2]
+            B = rl.shape[0]
+            series = torch.empty(B * N, L, device="cuda")          # what the model gathers from the reference: channel 0 as [B * N, L]
+            _lib.call("step_gather_windows", _lib.ptr(dl.data), dl.data.shape[0], N, 3, 0, _lib.ptr(dl.t0), B, L, 12, _lib.ptr(series), None, None,
+                      _lib.stream())
+            assert torch.equal(series.cpu().view(B, N, L), rl[..., 0].permute(0, 2, 1))
+
+
 def _metrics(pred, real, null=0.0):
     """masked MAE / RMSE / MAPE as basicts/metrics/{mae,rmse,mape}.py define them (restated)"""
     def mask_of(lab, nv):
