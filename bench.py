@@ -591,6 +591,8 @@ class StepBench:
         elif getattr(args, "encoder_workgroups", None):
             self.enc_wgs = int(args.encoder_workgroups)
         self.model.tsformer.encoder_workgroups = self.enc_wgs
+        self.prefetch_ahead = max(1, int(getattr(args, "prefetch_ahead", 1) or 1))
+        self.model.prefetch_fifo = 1 + self.prefetch_ahead
         if os.environ.get("STEP_PREFETCH_KNN_STREAM") is None:          # the announced batch's kNN prior on its own stream: with the early announcement only
             self.model.prefetch_knn_stream = bool(self.prefetch and self.prefetch_early)
         if args.eval_dropout_off:
@@ -626,6 +628,7 @@ class StepBench:
         self.loader = DeviceWindowLoader(self.dser, Lh)
         self.n_train = int((cfg["T_all"] - 23) * cfg.get("train_ratio", 0.6))
         self._staged = None
+        self._announced = None
         self._pin = None
 
     def barrier(self):
@@ -657,22 +660,31 @@ class StepBench:
     def batch(self, i):
         if not self.use_loader:
             return self.batches[i % len(self.batches)]
-        if self._staged is not None and self._staged[0] == i:
-            return self._staged[1]
+        if isinstance(self._staged, dict) and i in self._staged:
+            return self._staged.pop(i)
         return self.loader.batch(self.origins(i))
 
     def stage(self, i):
-        """the loader is one batch ahead: gather batch i now (during step i - 1)"""
+        """the loader runs ahead of the step: gather batch i now (one or two steps early); kept until step i takes it"""
         if not self.use_loader:
             return self.batches[i % len(self.batches)]
-        self._staged = (i, self.loader.batch(self.origins(i)))
-        return self._staged[1]
+        if not isinstance(self._staged, dict):
+            self._staged = {}
+        if i not in self._staged:
+            for old in [k for k in self._staged if k < i - 3]:
+                del self._staged[old]
+            self._staged[i] = self.loader.batch(self.origins(i))
+        return self._staged[i]
 
     def train_step(self, i, epoch=1):
         hist, longh, fut = self.batch(i)
         early = self.prefetch and self.prefetch_early
         if early:                         # the next batch's frozen branch (TSFormer + kNN prior) runs next to the whole of this step
-            self.model.prefetch(self.stage(i + 1)[1])
+            ahead = self.prefetch_ahead
+            if ahead > 1 and not getattr(self, "_announced", None) == i:          # first step of a loop: batch i + 1 was not announced a step ago
+                self.model.prefetch(self.stage(i + 1)[1])
+            self.model.prefetch(self.stage(i + ahead)[1])
+            self._announced = i + 1
         self.opt.zero_grad(set_to_none=True)
         pred, theta, knn, coef = self.model(history_data=hist, long_history_data=longh, future_data=None, batch_seen=i, epoch=epoch)
         if not early:
@@ -730,6 +742,7 @@ class StepBench:
         m.overlap_streams, self.prefetch, m.tsformer.encoder_workgroups = False, False, 0       # one workgroup per sequence: the whole chip
         m.cancel_prefetch()
         self._staged = None
+        self._announced = None
         m.tsformer._events = []
         for i in range(6):
             self.step(start + i)
@@ -745,10 +758,12 @@ class StepBench:
         keep = (self.prefetch, m.tsformer.encoder_workgroups, self.use_loader)
         m.cancel_prefetch()
         self._staged = None
+        self._announced = None
         self.prefetch, m.tsformer.encoder_workgroups, self.use_loader = prefetch, enc_wgs, loader
         r = self.run(3, steps, start)
         m.cancel_prefetch()
         self._staged = None
+        self._announced = None
         self.prefetch, m.tsformer.encoder_workgroups, self.use_loader = keep
         torch.cuda.synchronize()
         return {"value": r["value"], "unit": "windows/s", "ms_per_step": r["ms_per_step"], "steps": steps, "encoder_ms_per_launch": r["enc_ms"],
@@ -862,6 +877,7 @@ def main():
     ap.add_argument("--prefetch-early", action="store_true", help="queue the next batch's frozen branch at the start of the step (default at PEMS04)")
     ap.add_argument("--prefetch-late", action="store_true", help="queue the next batch's frozen branch behind this batch's forward (before its backward) "
                     "instead of at the start of the step")
+    ap.add_argument("--prefetch-ahead", type=int, default=1, help="announce the frozen branch of batch i + k at the start of step i (2: the encoders of successive batches run back to back)")
     ap.add_argument("--pageable-origins", action="store_true", help="(A/B) copy the forecast origins from pageable host memory: the copy then blocks the host every step")
     ap.add_argument("--resident-batches", action="store_true", help="cycle eight resident input batches instead of the index-only device loader")
     ap.add_argument("--eval-dropout-off", action="store_true", help="disable dropout (parity runs)")

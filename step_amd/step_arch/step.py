@@ -443,6 +443,9 @@ class STEP(nn.Module):
         self.prefetch_knn_stream = os.environ.get("STEP_PREFETCH_KNN_STREAM", "0") == "1"
         self._prefetched = None             # FIFO (list) of the frozen branches queued by prefetch() for upcoming batches
         self._precision_override = None
+        # announced branches kept at once: 2 = batch i + 1 announced before forward(i) consumed batch i's; 3 = batch i + 2 announced at the
+        # start of step i -- the encoders of successive batches then run back to back on the prefetch stream (see bench.py --prefetch-ahead)
+        self.prefetch_fifo = 2
         self._alias = {}                    # batch key of a derived tensor -> key of the announced batch it was made from (alias_batch)
         self.prefetch_enabled = os.environ.get("STEP_NO_PREFETCH", "0") != "1"
         self._reduce_wait_ms = None         # bench.py: list that collect_reduce_waits() fills
@@ -570,7 +573,7 @@ class STEP(nn.Module):
         # next to the WHOLE of step i, not only its backward)
         q = self._prefetched if isinstance(self._prefetched, list) else []
         q.append(rec)
-        while len(q) > 2:                    # nobody came for the oldest: keep the stream order, drop the record
+        while len(q) > self.prefetch_fifo:   # nobody came for the oldest: keep the stream order, drop the record
             self._wait_record(main, q.pop(0))
         self._prefetched = q
 
