@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstep_hip.so")
 SOURCES = ["errors.cpp", "comm.cpp", "gemm.hip", "gemm_bf16.hip", "tsformer_encoder.hip", "knn.hip", "selftest.hip",
-           "dgl.hip", "dgl_conv_mfma.hip", "gwnet.hip", "optim.hip", "pretrain.hip", "pretrain_fused.hip"]
+           "dgl.hip", "dgl_conv_mfma.hip", "gwnet.hip", "optim.hip", "pretrain.hip", "pretrain_fused.hip", "pretrain_attn2.hip"]
 
 
 def _newer(target, deps):

@@ -955,6 +955,16 @@ extern "C" int step_pt_attention_bwd(const float* qkv, const float* out, const f
     return STEP_OK;
 }
 // the same attention on the matrix cores (bf16 operands, f32 accumulation) -- what TSFormer(mode="pre-train") uses with matmul_precision = "bf16"
+// second version of the two kernels (pretrain_attn2.hip): keep decisions from the step's pool (or no dropout); STEP_PT_ATTN_V1=1 keeps the first one (A/B runs)
+bool step_attn2_fits(int T);
+int step_attn2_fwd(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats, uint32_t* keepbits,
+                   const uint64_t* pool, long pool_words, hipStream_t st);
+int step_attn2_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* stats, long S, int T, float p, uint16_t* dqkv,
+                   const uint32_t* keepbits, hipStream_t st);
+static bool attn_v1_forced() {
+    static const bool v1 = [] { const char* e = getenv("STEP_PT_ATTN_V1"); return e && e[0] == '1'; }();
+    return v1;
+}
 static size_t ma_fwd_lds(int Tp) {      // operands, re-used by the f32 staging tile of the output
     const size_t ops = (size_t)(2 * Tp * MA_RP + 32 * (Tp + 8)) * 2, stage = (size_t)Tp * MA_SP * 4;
     return ops > stage ? ops : stage;
@@ -970,6 +980,8 @@ extern "C" int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, fl
                      "pt_attention_fwd_bf16: pool of %ld words is not a power of two in [4096, 2^30]", pool_words);
     }
     const int Tp = (T + 31) & ~31;
+    if (!attn_v1_forced() && step_attn2_fits(T) && (p == 0.f || pool))
+        return step_attn2_fwd(qkv, S, T, p, SEED_LO(seed), site, out, stats, keepbits, pool, pool_words, (hipStream_t)stream);
     STEP_TRY(step_raise_lds_once((const void*)attn_mfma_fwd_kernel, 160 * 1024, "pt_attention_fwd_bf16"));
     attn_mfma_fwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_fwd_lds(Tp), (hipStream_t)stream>>>(qkv, T, Tp, p, SEED_LO(seed), SEED_HI(seed),
                                                                                                     site, out, stats, keepbits,
@@ -984,6 +996,8 @@ extern "C" int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* o
                  ((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0,
                  "pt_attention_bwd_bf16: bad arguments (T=%d; at most 352 tokens, 16-byte aligned bf16 tensors)", T);
     const int Tp = (T + 31) & ~31;
+    if (!attn_v1_forced() && step_attn2_fits(T) && (p == 0.f || keepbits))
+        return step_attn2_bwd(qkv, out, dout, stats, S, T, p, dqkv, keepbits, (hipStream_t)stream);
     STEP_REQUIRE(ma_bwd_lds(Tp) <= 160 * 1024, "pt_attention_bwd_bf16: %d tokens do not fit the LDS", T);
     STEP_TRY(step_raise_lds_once((const void*)attn_mfma_bwd_kernel, 160 * 1024, "pt_attention_bwd_bf16"));
     attn_mfma_bwd_kernel<<<(unsigned)(S * H), 64 * (Tp / 32), ma_bwd_lds(Tp), (hipStream_t)stream>>>(qkv, out, dout, stats, T, Tp, p, SEED_LO(seed),
