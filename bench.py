@@ -44,7 +44,9 @@ import time
 # (profiles/r05_j_dp_one_rank.log).  (b) With the next batch's frozen branch prefetched (the default where ENC_SPLIT has an entry) FOUR
 # streams carry work -- main, side / aux, and the prefetch stream with the persistent encoder -- and need a queue each: 3.73 ms with four
 # queues against 5.4 with two and 5.6 with three (profiles/r05_k_persist_prefetch.log, r05_l_*).  Real multi-rank runs keep the default.
-ENC_SPLIT = {"STEP_PEMS04": 160, "STEP_PEMS07": 416}      # config -> workgroups of the persistent encoder launch when the frozen branch is prefetched
+ENC_SPLIT = {"STEP_PEMS04": 160, "STEP_PEMS07": 256}      # config -> one-sequence workgroups of the persistent encoder launch when the frozen branch is prefetched
+# (PEMS07, round 6: at 168 tokens the encoder now puts TWO sequences into a twelve-wave workgroup -- 1.7 -> 1.1 ms alone -- so 256 units = 128
+#  workgroups = 128 compute units; 416 before.  profiles/r06_za_C4_split_sweep.log)
 # ... and WHEN the next batch's frozen branch is queued: at the start of the step (next to the whole step: 3.73 -> 3.48 ms at PEMS04, where the
 # encoder is then done before the bandwidth-bound backward of the graph learner starts) or behind the forward (next to the backward only: better
 # at PEMS07, 5.57 vs 5.97 ms: there the graph learner's forward wants the whole chip too) -- profiles/r05_w_prefetch_early_sweep.log

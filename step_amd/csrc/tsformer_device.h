@@ -24,6 +24,7 @@ struct EncArgs {
     bool f16;          // operand fragments of wpack are float16 (else bfloat16)
     bool always_rescale;                     // test hook: take the softmax re-shift path on every key tile
     unsigned int* range_word;                // STEP_ENC_RANGE_FLAG: fallback_count + 64, OR-ed with 1 when a wave's output is not finite (float16 operand overflow); else NULL
+    int nseq;                                // sequences per workgroup: 1, or 2 (each half of the waves owns one; P <= 192)
     int grid_limit;                          // > 0: persistent launch of at most this many workgroups (each loops over sequences)
 };
 

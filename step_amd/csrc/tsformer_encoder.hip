@@ -163,7 +163,15 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int P = A.P, nkt = A.nkt;
-    const int tok = wave * 32 + c;
+    // Two sequences per workgroup (A.nseq == 2, round 6: P <= 192, six token tiles each): waves 0 .. nkt - 1 own sequence 2 b, the next nkt waves
+    // sequence 2 b + 1; they share the weight ring, its barriers and the DMA issue, and each half has its own K / V fragment area.  At 168
+    // tokens a six-wave workgroup left the compute unit at 1.4 waves per SIMD (the second workgroup the register / LDS budget admits only fits
+    // when its two-wave SIMDs happen to be the other's one-wave SIMDs; profiles/r06_y_encoder_occupancy.txt), and one wave alone issues a vector
+    // instruction every ~7.5 cycles; twelve waves are three per SIMD by construction.  wsq / wv: this wave's sequence slot and its tile in it.
+    const int nw = nkt * A.nseq;
+    const int wsq = (A.nseq == 2 && wave >= nkt) ? 1 : 0;
+    const int wv = wave - wsq * nkt;
+    const int tok = wv * 32 + c;
     const bool tok_ok = tok < P;
     const int tokc = tok_ok ? tok : 0;
     const char* W = A.wpack;
@@ -177,9 +185,9 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     auto h48 = [&]() -> int { return (fresh_lane_id() >> 5) * 48; };
 
     // LDS: [K frags nkt*2 KB][V frags nkt*2 KB][weight ring: 2 stage blocks of 25 KB]
-    char* kbuf = smem;
-    char* vbuf = smem + nkt * 2 * TSF_FRAG;
-    char* ring = smem + nkt * 4 * TSF_FRAG;
+    char* kbuf = smem + wsq * (nkt * 4 * TSF_FRAG);
+    char* vbuf = kbuf + nkt * 2 * TSF_FRAG;
+    char* ring = smem + nw * 4 * TSF_FRAG;
     // Ring of NSLOT stage blocks.  With four slots (where the LDS budget allows: the 9..12 tile variant without the parked
     // operand copy) the six feed-forward blocks are consumed in PAIRS -- one barrier per two blocks, fills issued two blocks ahead.
     constexpr int NSLOT = ring_slots<MAXW, PARK>();
@@ -199,13 +207,13 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // only the four first-dispatched waves (one per SIMD) request the pieces: they are the ones that reach every barrier early and wait
             // there (49 % of their time, profiles/r05_a_encoder_phase_table.md), while a piece costs the last-arriving wave 100+ cycles of the
             // workgroup's critical path behind every stage boundary
-            int nf = nkt < 4 ? nkt : 4;                  // (workgroups of fewer than four waves: all of them)
+            int nf = nw < 4 ? nw : 4;                    // (workgroups of fewer than four waves: all of them)
             asm volatile("" : "+s"(nf));                 // (compared at every call: hoisted, `wave < nf` is kept as a 0 / 1 vector register in scratch memory)
             if (wave < nf)
                 for (int pc = wave; pc < 25; pc += nf) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
             return;
         }
-        for (int pc = wave; pc < 25; pc += nkt) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
+        for (int pc = wave; pc < 25; pc += nw) dma_1k(src + pc * TSF_FRAG, dst + (uint32_t)pc * TSF_FRAG);
     };
     // Stage boundary: my DMA pieces of every block requested so far have landed (vmcnt), everybody's have (barrier), and
     // everybody is done with the blocks before g -- whose slots are then refilled, up to `ahead` blocks beyond g (block b lands
@@ -218,14 +226,17 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         return slot_of(g);
     };
 
-    if (TSF_STATIC_PRIO == 1 && wave * 2 >= nkt) __builtin_amdgcn_s_setprio(1);
+    if (TSF_STATIC_PRIO == 1 && wave * 2 >= nw) __builtin_amdgcn_s_setprio(1);
     if (TSF_STATIC_PRIO == 2) {               // (A/B builds) the later a wave was dispatched onto its SIMD, the higher its priority: reverses the age order
         if (wave >= 8) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
     bool first_block_requested = false;       // (persistent launch) block 0 of this sequence was requested during the previous one
 #pragma unroll 1
-    for (int seq = blockIdx.x; seq < A.S; seq += gridDim.x) {          // one iteration unless the launch is persistent (grid_limit)
+    for (int seq0 = blockIdx.x * A.nseq; seq0 < A.S; seq0 += gridDim.x * A.nseq) {          // one iteration unless the launch is persistent (grid_limit)
+    // (an odd number of sequences: the second half of the last workgroup computes its partner's sequence again and stores nothing)
+    const bool seq_ok = seq0 + wsq < A.S;
+    const int seq = seq_ok ? seq0 + wsq : seq0;
     // no barrier between sequences: the first stage_begin() of a sequence is one, and ring slot 0 was released two stages before the end
     if (!first_block_requested) issue_fill(0);
     issued = 1;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         float xin[12];
         // (per-lane addresses of this block are derived from a fresh lane id: as loop invariants of the persistent variant they
         //  would be kept alive -- in scratch memory -- across the whole sequence)
-        const int lane_p = fresh_lane_id(), h_p = lane_p >> 5, tok_p = wave * 32 + (lane_p & 31);
+        const int lane_p = fresh_lane_id(), h_p = lane_p >> 5, tok_p = wv * 32 + (lane_p & 31);
         const bool tok_ok_p = tok_p < P;
         const int tokc_p = tok_ok_p ? tok_p : 0;
         const float4* src = (const float4*)(A.series + (long)seq * A.L + (long)tokc_p * TSF_PATCH);
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         if constexpr (drop) {            // positional_encoding.py:32; the survivor scale rides on sqrt(d)
             const uint32_t chunk = drop_chunk_base(A.seed, (uint32_t)seq, (uint32_t)A.depth, pmask);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) keep16(xT[t], mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + t) * 16u));
+            for (int t = 0; t < 3; ++t) keep16(xT[t], mask_words(chunk, dl.d1 + (uint32_t)(wv * 3 + t) * 16u));
             sc *= fresh_uniform(inv_keep);
         }
 #pragma unroll
@@ -360,14 +371,14 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (i == 14) {
-                        if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
-                        *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
-                        *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                        if (h == 0) { kk[13] = 1.0f; kk[14] = (wv * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                        *(op8*)(kbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                        *(op8*)(kbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
-                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
+                *(bf16x8*)(vbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
 #elif TSF_QKV_PIPE == 2
             {
@@ -407,11 +418,11 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) vv = mfma16<F16>(xb[k], wA[k], vv);
-                if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
-                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
-                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
-                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
-                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
+                if (h == 0) { kk[13] = 1.0f; kk[14] = (wv * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                *(op8*)(kbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                *(op8*)(kbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                *(bf16x8*)(vbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
 #else
             {
@@ -463,14 +474,14 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 for (int i = 0; i < 16; ++i) vv[i] = bv;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) vv = mfma16<F16>(xb[k], wa[k], vv);
-                if (h == 0) { kk[13] = 1.0f; kk[14] = (wave * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
-                *(op8*)(kbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
-                *(op8*)(kbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
+                if (h == 0) { kk[13] = 1.0f; kk[14] = (wv * 32 + (fresh_lane_id() & 31) < P) ? 0.0f : 1.0f; }     // slots 25 / 26 of this key (rows 25, 26)
+                *(op8*)(kbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 0);
+                *(op8*)(kbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<F16>(kk, 1);
                 fence();
 #pragma unroll
                 for (int k = 0; k < 3; ++k) vv = mfma16<F16>(xb[3 + k], wb[k], vv);
-                *(bf16x8*)(vbuf + (wave * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
-                *(bf16x8*)(vbuf + (wave * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
+                *(bf16x8*)(vbuf + (wv * 2 + 0) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 0);
+                *(bf16x8*)(vbuf + (wv * 2 + 1) * TSF_FRAG + lane * 16) = pack_half<false>(vv, 1);
             }
 #endif
             TSF_PRIO_CHAIN(0);
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             // test hook: re-shift whenever a tile holds a new running maximum (classic online softmax) instead of only
             // when the head room is used up
             const float thr = A.always_rescale ? -TSF_BIAS : TSF_THR;
-            const uint32_t att_off = (uint32_t)((hd * nkt + wave) * nkt) * 16u;
+            const uint32_t att_off = (uint32_t)((hd * nkt + wv) * nkt) * 16u;
 
             // Is a re-shift due?  (wave-uniform answer.)  tmax: this lane's largest score of the tile.
             auto tile_max = [&](const f32x16& sc) -> float {          // two interleaved v_max3_f32 chains (dependency depth 5)
@@ -834,8 +845,8 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
 #pragma unroll
                 for (int f = 6 - NPARK; f < 6; ++f) xb[f] = lfrag<F16>(xpark, f - (6 - NPARK), lane);
             }
-            const mask_ptr w1[3] = {mask_words(chunk, dl.d1 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 1) * 16u),
-                                    mask_words(chunk, dl.d1 + (uint32_t)(wave * 3 + 2) * 16u)};
+            const mask_ptr w1[3] = {mask_words(chunk, dl.d1 + (uint32_t)(wv * 3) * 16u), mask_words(chunk, dl.d1 + (uint32_t)(wv * 3 + 1) * 16u),
+                                    mask_words(chunk, dl.d1 + (uint32_t)(wv * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w1, inv_keep);
         }
         layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
@@ -869,7 +880,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 TSF_STAMP(21 + 2 * j);
                 blk = stage_begin(g, PAIR ? 3 : 1);
                 TSF_STAMP(22 + 2 * j);
-                if (PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                if (PAIR && j == 4 && layer == A.depth - 1 && seq0 + (int)gridDim.x * A.nseq < A.S) {
                     issue_fill(0);
                     first_block_requested = true;
                 }
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
             };
             auto load_mw = [&](int q) {
                 if constexpr (drop) {
-                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + q) * 16u);
+                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wv * 12 + j * 2 + q) * 16u);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) mw[i] = mp[i];
                 }
@@ -956,7 +967,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 blk = (PAIR && (j & 1)) ? slot_of(g) : stage_begin(g, PAIR ? 3 : 1);      // PAIR: odd blocks arrived with their predecessor
                 if (!(PAIR && (j & 1))) TSF_STAMP(22 + 2 * j);
                 tail = (const float*)(blk + TSF_TAIL);
-                if (PAIR && j == 4 && layer == A.depth - 1 && seq + (int)gridDim.x < A.S) {
+                if (PAIR && j == 4 && layer == A.depth - 1 && seq0 + (int)gridDim.x * A.nseq < A.S) {
                     issue_fill(0);            // slot 0 (block g - 2) is free since this stage's barrier: the next sequence's first block
                     first_block_requested = true;
                 }
@@ -977,7 +988,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 for (int f = 0; f < 6; ++f) wd[f] = lfrag<F16>(blk, cc * 12 + 6 + f, lane);
                 unsigned long long mw[16];
                 if constexpr (drop) {
-                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wave * 12 + j * 2 + cc) * 16u);
+                    const mask_ptr mp = mask_words(chunk, dl.ffn + (uint32_t)(wv * 12 + j * 2 + cc) * 16u);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) mw[i] = mp[i];
                 }
@@ -1016,8 +1027,8 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
         if (TSF_PROGRESS_PRIO) __builtin_amdgcn_s_setprio(0);
         TSF_STAMP(34);
         if constexpr (drop) {
-            const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wave * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 1) * 16u),
-                                    mask_words(chunk, dl.d2 + (uint32_t)(wave * 3 + 2) * 16u)};
+            const mask_ptr w2[3] = {mask_words(chunk, dl.d2 + (uint32_t)(wv * 3) * 16u), mask_words(chunk, dl.d2 + (uint32_t)(wv * 3 + 1) * 16u),
+                                    mask_words(chunk, dl.d2 + (uint32_t)(wv * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
         }
         layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
@@ -1027,17 +1038,17 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     }  // layers
 
     // one atomic per wave that took the slow path at all, spread over 64 counters (100 000 adds to one address cost 0.1 ms)
-    if (A.fallback != nullptr && slow_units > 0 && fresh_lane_id() == 0) atomicAdd(A.fallback + (blockIdx.x & 63), (unsigned)slow_units);
+    if (A.fallback != nullptr && slow_units > 0 && seq_ok && fresh_lane_id() == 0) atomicAdd(A.fallback + (blockIdx.x & 63), (unsigned)slow_units);
 
     // ------------------------------------------------------------------ encoder_norm + outputs
     // Lane-derived indices are re-derived here from a fresh lane id: kept alive from the kernel's start they sit in scratch memory
     // for its whole duration (64 bytes per lane and wave of HBM write-back for nothing).
     const int lane_e = fresh_lane_id();
     const int h_e = lane_e >> 5;
-    const int tok_e = wave * 32 + (lane_e & 31);
+    const int tok_e = wv * 32 + (lane_e & 31);
     layer_norm96(xT, (const float*)(W + TSF_G_NORM_G) + h_e * 48, (const float*)(W + TSF_G_NORM_B) + h_e * 48);
     float sq = 0.f;
-    if (tok_e < P) {
+    if (tok_e < P && seq_ok) {
         const long row = ((long)seq * P + tok_e) * TSF_D;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -1056,16 +1067,16 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                 sq += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
             }
     }
-    if (A.sqn) {
+    if (A.sqn && seq_ok) {
         sq = wave_sum_swz(sq);
         if (lane_e == 0) {
-            A.sqn[(long)seq * 16 + wave] = sq;
+            A.sqn[(long)seq * 16 + wv] = sq;
             // float16 operands overflow at 65 504 (round-to-nearest packs give inf, the matrix cores carry it into the residual stream, the
             // final LayerNorm turns it into NaN): the squared norm this wave just formed says so for free -- one compare per wave
             // (STEP_ENC_RANGE_FLAG; the host passes sqnorm_part whenever it asks for the flag)
             if (A.range_word && !(sq <= 3.0e38f)) atomicOr(A.range_word, 1u);
         }
-        if (wave == 0 && lane_e >= nkt && lane_e < 16) A.sqn[(long)seq * 16 + lane_e] = 0.f;
+        if (wv == 0 && lane_e >= nkt && lane_e < 16) A.sqn[(long)seq * 16 + lane_e] = 0.f;
     }
     }   // sequences of this workgroup
 }
@@ -1129,7 +1140,8 @@ __global__ void gather_short_windows_kernel(const float* __restrict__ data, int 
 
 template <int MAXW, bool DROP, bool PARK, bool F16, int TG>
 int launch_enc_tg(const EncArgs& a, hipStream_t st) {
-    size_t lds = (size_t)a.nkt * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (size_t)a.nkt * parked_frags<MAXW, PARK>() * TSF_FRAG;
+    const int nw = a.nkt * a.nseq;
+    size_t lds = (size_t)nw * 4 * TSF_FRAG + (size_t)ring_slots<MAXW, PARK>() * TSF_BLOCK + (size_t)nw * parked_frags<MAXW, PARK>() * TSF_FRAG;
     // once per device and instantiation (the attribute is per device): not on every launch, so that a launch inside a stream capture
     // (step_amd.GraphedTrainStep, after its eager warm-up steps) is a plain kernel node
     static bool raised[16] = {};
@@ -1144,8 +1156,9 @@ int launch_enc_tg(const EncArgs& a, hipStream_t st) {
         }
         __atomic_store_n(&raised[dev & 15], true, __ATOMIC_RELEASE);
     }
-    const int grid = (a.grid_limit > 0 && a.S > a.grid_limit) ? a.grid_limit : a.S;
-    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, a.nkt * 64, lds, st>>>(a);
+    const int units = (a.S + a.nseq - 1) / a.nseq, limit = (a.grid_limit + a.nseq - 1) / a.nseq;      // (the limit counts one-sequence workgroups)
+    const int grid = (a.grid_limit > 0 && units > limit) ? limit : units;
+    tsformer_encoder_kernel<MAXW, DROP, PARK, F16, TSF_PIPE, TG><<<grid, nw * 64, lds, st>>>(a);
     STEP_LAUNCH_CHECK("step_tsformer_encode");
     return STEP_OK;
 }
@@ -1155,6 +1168,9 @@ template <int MAXW, bool DROP, bool PARK, bool F16>
 int launch_enc_t(const EncArgs& a, hipStream_t st) {
     constexpr int TGX = !TSF_TAIL_GROUPS ? 4 : MAXW == 8 ? 1 : MAXW == 12 ? 2 : 4;
     const int tail_keys = a.P - (a.nkt - 1) * 32;
+    if constexpr (MAXW == 12 && !PARK && TSF_TAIL_GROUPS) {         // two sequences of <= 192 tokens per workgroup: P = 168 ends on 8 keys
+        if (a.nseq == 2 && tail_keys == 8) return launch_enc_tg<MAXW, DROP, PARK, F16, 1>(a, st);
+    }
     if (TGX != 4 && tail_keys == 8 * TGX) return launch_enc_tg<MAXW, DROP, PARK, F16, TGX>(a, st);
     return launch_enc_tg<MAXW, DROP, PARK, F16, 4>(a, st);
 }
@@ -1251,7 +1267,17 @@ extern "C" int step_tsformer_encode(const float* series, int S, int L, const voi
     a.always_rescale = (flags & STEP_ENC_ALWAYS_RESHIFT) != 0;
     a.range_word = (flags & STEP_ENC_RANGE_FLAG) ? fallback_count + 64 : nullptr;
     a.grid_limit = (flags >> 8) & 0xffff;               // STEP_ENC_WORKGROUPS(n): persistent launch of at most n workgroups
+    a.nseq = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (a.nkt >= 5 && a.nkt <= 6 && S >= 2) {
+        // 5 / 6 token tiles (P = 168: METR-LA, PEMS-BAY, PEMS07): two sequences per twelve-wave workgroup, three waves per SIMD (see the kernel's
+        // prologue).  STEP_ENC_NSEQ=1 keeps one sequence per workgroup (A/B measurements).
+        static const bool one = [] { const char* e = getenv("STEP_ENC_NSEQ"); return e && e[0] == '1'; }();
+        if (!one) {
+            a.nseq = 2;
+            return dr ? launch_enc<12, true, false>(a, st) : launch_enc<12, false, false>(a, st);
+        }
+    }
     // parking the operand copy needs nkt * 10 KB + 50 KB of LDS (<= 160 KB up to 11 token tiles = 352 tokens)
     if (a.nkt <= 4) return dr ? launch_enc<4, true, true>(a, st) : launch_enc<4, false, true>(a, st);
     if (a.nkt <= 8) {

@@ -602,3 +602,46 @@ def test_timed_encoder_on_the_benchmark_checkpoint_matches_oracle(L, steps):
           f"softmax units on the re-shifting path {slow1} (dropout on) / {slow0} (off) of {S * 4 * 4 * 11}")
     assert torch.isfinite(h1).all()
     assert e1 < 1e-2 and e0 < 1e-2
+
+
+@pytest.mark.gpu
+def test_encoder_two_sequences_per_workgroup_is_bit_identical():
+    """At <= 192 tokens (P = 168: METR-LA, PEMS-BAY, PEMS07) the encoder puts TWO sequences into one twelve-wave workgroup (round 6:
+    three waves per SIMD instead of 1.4).  Every wave does the arithmetic it did before, in the same order, on its own sequence:
+    the hidden states, last-patch states and squared norms are bit-identical to the one-sequence launch (STEP_ENC_NSEQ=1, read once
+    per process: two child processes), with dropout on (same keep-mask pool) and with an ODD number of sequences (the second half of
+    the last workgroup computes its partner's sequence again and stores nothing)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from step_amd import TSFormer
+torch.manual_seed(3)
+m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=168, mask_ratio=0.75,
+             encoder_depth=4, decoder_depth=1, mode="forecasting").cuda()
+out = {}
+for tag, S in (("odd", 7), ("even", 64)):
+    x = torch.randn(S, 2016, generator=torch.Generator().manual_seed(S)).cuda()
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        torch.manual_seed(11)
+        r = m.encode_series(x)
+        out[tag + "_" + mode] = np.concatenate([r["hidden_bf16"].float().cpu().numpy().reshape(S, -1), r["last"].cpu().numpy(), r["sqnorm"].cpu().numpy()], axis=1)
+np.savez(sys.argv[1], **out)
+""" % root
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for nseq in ("1", "2"):
+            path = os.path.join(d, f"enc_{nseq}.npz")
+            env = dict(os.environ, STEP_ENC_NSEQ=nseq)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root)
+            res[nseq] = dict(np.load(path))
+    assert set(res["1"]) == set(res["2"]) and len(res["1"]) == 4
+    for k in res["1"]:
+        a, b = res["1"][k], res["2"][k]
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))

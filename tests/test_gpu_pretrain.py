@@ -439,7 +439,7 @@ def test_fused_feed_forward_block_matches_reference(R, p):
     assert max(errs.values()) < 6e-3
 
 
-@pytest.mark.parametrize("T", [42, 168])
+@pytest.mark.parametrize("T", [42, 77, 168, 336])
 def test_matrix_core_attention_with_pool_drawn_keep_words(T):
     """step_pt_attention_fwd_bf16 with a keep-mask pool (what the pre-training step passes in the bf16 mode): the keep word of every
     (query, key tile) is the pool's 32-bit word at the (sequence, head)'s hashed offset -- rebuilt here on the host --, it reaches the
