@@ -748,16 +748,20 @@ __device__ __forceinline__ void tile_out_bf16(uint16_t* __restrict__ y, long row
     lds_order();
 }
 
-template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
-__global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
+// NW waves per workgroup (round 6: 12 = three per SIMD, what 150-170 registers admit; 8 before, and still for the LayerNorm output stage's 217).  A wave's staging area is ONE 6 KB tile: the operand fragments of the input
+// tile are in registers before the first product, so the f32 output blocks go through the same bytes (the first version kept a second 4 KB
+// area and, with 134 KB per eight waves, one workgroup = two waves per SIMD per compute unit; a wave of these kernels waits for its own
+// loads, then for its own stores: what hides that is other waves).
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false, int NW = 12>
+__global__ __launch_bounds__(NW * 64) void rows_linear_kernel(LinArgs A) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int NW = 8, NFRAG = NOG * 3 * NKC * 6, WBYTES = NFRAG * FF_FRAG + NOG * 96 * 4;
+    constexpr int NFRAG = NOG * 3 * NKC * 6, WBYTES = NFRAG * FF_FRAG + NOG * 96 * 4;
     static_assert(NKC * NOG <= 3 && !(IN_BF16 && NKC == 1 && false), "fragment set must fit the LDS");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     for (int i = threadIdx.x; i < WBYTES / 16; i += NW * 64) ((uint4*)smem)[i] = ((const uint4*)A.pack)[i];
     __syncthreads();
     const float* bias = (const float*)(smem + NFRAG * FF_FRAG);
-    char* stg = smem + ((WBYTES + 1023) & ~1023) + wave * STG_WAVE;
+    char* stg = smem + ((WBYTES + 1023) & ~1023) + wave * STG_IN;
     const long ntile = (A.R + 31) / 32;
 #pragma unroll 1
     for (long tile = (long)blockIdx.x * NW + wave; tile < ntile; tile += (long)gridDim.x * NW) {
@@ -785,9 +789,9 @@ __global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) acc[t] = mma(mfrag(smem, (og * 3 + t) * 6 + ks, lane), xb[ks], acc[t]);
-                if constexpr (LN) tile_out_ln(A.ln, row0, A.R, stg + STG_IN, lane, acc);
+                if constexpr (LN) tile_out_ln(A.ln, row0, A.R, stg, lane, acc);
                 else if constexpr (OUT_BF16) tile_out_bf16((uint16_t*)A.y, row0, A.R, A.ldy, og * 96, stg, lane, acc);
-                else tile_out<ACCUM>((float*)A.y + og * 96, row0, A.R, stg + STG_IN, lane, acc);
+                else tile_out<ACCUM>((float*)A.y + og * 96, row0, A.R, stg, lane, acc);
             }
         } else {
             static_assert(NKC == 1 || (IN_BF16 && NOG == 1 && !OUT_BF16), "the K = 288 form reads bf16 and writes f32");
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(512) void rows_linear_kernel(LinArgs A) {
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) acc[t] = mma(mfrag(smem, (t * NKC + kc) * 6 + ks, lane), xb[ks], acc[t]);
             }
-            tile_out<ACCUM>((float*)A.y, row0, A.R, stg + STG_IN, lane, acc);
+            tile_out<ACCUM>((float*)A.y, row0, A.R, stg, lane, acc);
         }
     }
 }
@@ -1256,15 +1260,24 @@ extern "C" int step_pt_rows_linear_pack(const float* w, long swo, long swi, int 
 }
 
 namespace {
-template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
-int launch_lin(const LinArgs& a, hipStream_t st) {
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN, int NW>
+int launch_lin_nw(const LinArgs& a, hipStream_t st) {
     static int raised = 0;
     const int wbytes = NOG * 3 * NKC * 6 * FF_FRAG + NOG * 96 * 4;
-    const int lds = ((wbytes + 1023) & ~1023) + 8 * STG_WAVE;
-    STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN>, lds, raised));
-    const long ntile = (a.R + 31) / 32, nwg = (ntile + 7) / 8;
-    rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN><<<(int)(nwg < 256 ? nwg : 256), 512, lds, st>>>(a);
+    const int lds = ((wbytes + 1023) & ~1023) + NW * STG_IN;
+    STEP_TRY(raise_lds(rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN, NW>, lds, raised));
+    const long ntile = (a.R + 31) / 32, nwg = (ntile + NW - 1) / NW;
+    rows_linear_kernel<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN, NW><<<(int)(nwg < 256 ? nwg : 256), NW * 64, lds, st>>>(a);
     return STEP_OK;
+}
+template <int NKC, int NOG, bool IN_BF16, bool OUT_BF16, bool ACCUM, bool LN = false>
+int launch_lin(const LinArgs& a, hipStream_t st) {
+    static const int nw = [] { const char* e = getenv("STEP_PT_LIN_WAVES"); return e ? atoi(e) : 12; }();      // (A/B measurements: 8 = the first version's occupancy)
+    if constexpr (LN) return launch_lin_nw<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN, 8>(a, st);
+    else {
+        if (nw == 8) return launch_lin_nw<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN, 8>(a, st);
+        return launch_lin_nw<NKC, NOG, IN_BF16, OUT_BF16, ACCUM, LN, 12>(a, st);
+    }
 }
 }  // namespace
 
