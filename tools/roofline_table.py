@@ -69,12 +69,12 @@ def rows_of_pretrain(N, B, P, Pu=None):
     att = lambda k: (4 * S * 4 * Pu * Pu + S * 4 * P * P) / 5.0 * 2.0 * 24 * k      # k products of T x T x 24 per (sequence, head)
     f32, b16 = 96 * 4, 96 * 2
     return [
-        ("attn_mfma_bwd_kernel", "attention backward on the matrix cores (dQ, dK, dV; scores recomputed in both orientations)", "valu/lds",
+        (("attn2_bwd_kernel", "attn_mfma_bwd_kernel"), "attention backward on the matrix cores (dQ, dK, dV; scores recomputed in both orientations; round 6: pretrain_attn2.hip)", "valu issue / hbm",
          lay * (2 * 3 * b16 + 2 * b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(5)),
         ("ln_bwd_drop_kernel", "LayerNorm backward + dropout of the continuing gradient + parameter / bias gradient sums", "hbm", ln * 4 * f32 * (10.0 / 12) + ln * 3 * f32 * (2.0 / 12), None),
         ("add_ln_fwd_kernel", "LayerNorm forward of the two final norms (the layers' residual + dropout + LayerNorm steps are output stages of row kernels)", "hbm", (Re + Rd) / 2.0 * 2 * f32, None),
         ("ffn_rows_kernelILi8ELb1", "fused feed-forward, input gradient (hidden layer recomputed; reads h1, d f2, read-modify-writes d h1)", "hbm", lay * 4 * f32, lay * 3 * 2.0 * 96 * 384),
-        ("attn_mfma_fwd_kernel", "attention forward on the matrix cores", "valu/lds", lay * (3 * b16 + b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(2)),
+        (("attn2_fwd_kernel", "attn_mfma_fwd_kernel"), "attention forward on the matrix cores (round 6: pretrain_attn2.hip)", "valu issue / hbm", lay * (3 * b16 + b16 + 4 * 8 + 4 * 4 * ((P + 31) // 32)), att(2)),
         ("ffn_wgrad_kernelILb1", "fused feed-forward, d W1 and d b1 (hidden layer and its gradient recomputed)", "lds", lay * 2 * f32, lay * 3 * 2.0 * 96 * 384),
         ("ffn_rows_kernelILi8ELb0", "fused feed-forward, forward (hidden layer in registers) + residual + dropout + LayerNorm 2 as its output stage", "hbm", lay * 3 * f32, lay * 2 * 2.0 * 96 * 384),
         ("rows_linear_kernelILi3ELi1ELb1ELb0ELb1", "d x += d qkv . Wi (row kernel, LDS-resident weights)", "hbm", lay * (3 * b16 + 2 * f32), lay * 2.0 * 96 * 288),
