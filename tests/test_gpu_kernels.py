@@ -645,3 +645,31 @@ np.savez(sys.argv[1], **out)
         a, b = res["1"][k], res["2"][k]
         assert a.shape == b.shape and np.isfinite(a).all()
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens", [168, 336])
+def test_persistent_encoder_launch_is_bit_identical(tokens):
+    """`TSFormer.encoder_workgroups = n` (what the timed schedule runs: the frozen branch of the next batch as a persistent launch on a
+    share of the chip, every workgroup walking the sequences blockIdx.x, + n, ...) computes what the one-workgroup-per-sequence launch
+    computes, bit for bit: eval and training mode (same keep-mask pool), n that does and does not divide the number of sequences, an odd
+    number of sequences (at 168 tokens a workgroup holds two sequences and n counts one-sequence units)."""
+    from step_amd import TSFormer
+    torch.manual_seed(5)
+    m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=tokens, mask_ratio=0.75,
+                 encoder_depth=4, decoder_depth=1, mode="forecasting").cuda()
+    for S in (23, 48):
+        x = torch.randn(S, tokens * 12, generator=torch.Generator().manual_seed(S)).cuda()
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            outs = []
+            for n in (0, 5, 8, 16):
+                m.encoder_workgroups = n
+                m._seed_counter = 0
+                torch.manual_seed(11)
+                r = m.encode_series(x)
+                outs.append(torch.cat([r["hidden_bf16"].float().reshape(S, -1), r["last"], r["sqnorm"]], dim=1).cpu())
+            assert torch.isfinite(outs[0]).all()
+            for n, o in zip((5, 8, 16), outs[1:]):
+                assert torch.equal(o, outs[0]), (tokens, S, mode, n, float((o - outs[0]).abs().max()))
+    m.encoder_workgroups = 0
