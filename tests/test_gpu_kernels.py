@@ -621,16 +621,17 @@ import sys, torch, numpy as np
 sys.path.insert(0, %r)
 from step_amd import TSFormer
 torch.manual_seed(3)
-m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=168, mask_ratio=0.75,
-             encoder_depth=4, decoder_depth=1, mode="forecasting").cuda()
 out = {}
-for tag, S in (("odd", 7), ("even", 64)):
-    x = torch.randn(S, 2016, generator=torch.Generator().manual_seed(S)).cuda()
-    for mode in ("eval", "train"):
-        m.train(mode == "train")
-        torch.manual_seed(11)
-        r = m.encode_series(x)
-        out[tag + "_" + mode] = np.concatenate([r["hidden_bf16"].float().cpu().numpy().reshape(S, -1), r["last"].cpu().numpy(), r["sqnorm"].cpu().numpy()], axis=1)
+for P in (168, 150):          # six tiles ending on 8 keys (the reference's L = 2016); five tiles ending on 22 keys (the generic last step)
+    m = TSFormer(patch_size=12, in_channel=1, embed_dim=96, num_heads=4, mlp_ratio=4, dropout=0.1, num_token=P, mask_ratio=0.75,
+                 encoder_depth=4, decoder_depth=1, mode="forecasting").cuda()
+    for tag, S in (("odd", 7), ("even", 64)):
+        x = torch.randn(S, 12 * P, generator=torch.Generator().manual_seed(S)).cuda()
+        for mode in ("eval", "train"):
+            m.train(mode == "train")
+            torch.manual_seed(11)
+            r = m.encode_series(x)
+            out[f"{P}_{tag}_{mode}"] = np.concatenate([r["hidden_bf16"].float().cpu().numpy().reshape(S, -1), r["last"].cpu().numpy(), r["sqnorm"].cpu().numpy()], axis=1)
 np.savez(sys.argv[1], **out)
 """ % root
     res = {}
@@ -640,7 +641,7 @@ np.savez(sys.argv[1], **out)
             env = dict(os.environ, STEP_ENC_NSEQ=nseq)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root)
             res[nseq] = dict(np.load(path))
-    assert set(res["1"]) == set(res["2"]) and len(res["1"]) == 4
+    assert set(res["1"]) == set(res["2"]) and len(res["1"]) == 8
     for k in res["1"]:
         a, b = res["1"][k], res["2"][k]
         assert a.shape == b.shape and np.isfinite(a).all()
