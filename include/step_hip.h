@@ -394,7 +394,11 @@ int step_pt_attention_bwd(const float* qkv, const float* out, const float* dout,
  * given the same buffer reads them instead of regenerating the Philox stream.
  * pool (nullable; needs keepbits): the forward takes the keep word of every (query, key tile) from the step's Bernoulli pool
  * (step_dropout_pool_fill; pool_words a power of two >= 4096; a (sequence, head) reads T * ceil(T/32) consecutive 32-bit words at a
- * hashed offset) instead of running Philox -- 0.73 -> 0.4 ms at config C3's decoder layer. */
+ * hashed offset) instead of running Philox -- 0.73 -> 0.4 ms at config C3's decoder layer.
+ * Round 6: with the pool (or p == 0) both entry points run the second-version kernels of csrc/pretrain_attn2.hip -- same tensors, same
+ * statistics, same keep words, rebuilt for occupancy (<= 128 / 88 registers: two / three workgroups per compute unit): forward 620 -> 434 us,
+ * backward 1497 -> 883 us at 168 tokens; the kernels of csrc/pretrain.hip remain the path of Philox-drawn keep decisions
+ * (STEP_PT_ATTN_V1=1 in the environment forces them). */
 int step_pt_attention_fwd_bf16(const uint16_t* qkv, long S, int T, float p, uint64_t seed, uint32_t site, uint16_t* out, float* stats,
                                uint32_t* keepbits, const uint64_t* pool, long pool_words, void* stream);
 int step_pt_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* stats, long S, int T, float p,
