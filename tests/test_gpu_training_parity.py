@@ -178,7 +178,7 @@ def test_h12_mae_parity(mode):
     The oracle side (its own fp32 TSFormer states) was run in the build container six times with round-off sized input
     perturbations (tools/make_n1_golden.py -> tests/golden/n1_oracle.npz): horizon-12 masked MAE 38.79 +- 0.53 %, all
     horizons 38.38 +- 0.16 %.  The native module must land within 1 % (horizon 12 and all horizons) of the oracle's mean.
-    Round 6: the native side is the mean of THREE runs (the second and third start from parameters perturbed by 1e-7 relative, and the
+    Round 6: the native side is the mean of THREE (f32) / FIVE (bf16) runs (all but the first start from parameters perturbed by 1e-7 relative, and the
     atomic additions of the reductions reorder anyway): one run against the mean of six is a +-1.75 sigma band at the oracle's own 0.53 % --
     single runs of this test measured -0.38 / +0.47 / +0.76 / +1.003 % over the rounds, the last one a failure of the band, not of the module."""
     z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "n1_oracle.npz"))
@@ -223,7 +223,9 @@ def test_h12_mae_parity(mode):
         pr, fu = O.rescale(pred[..., [0]].cpu(), prob.mean, prob.std), O.rescale(fut[..., [0]].cpu(), prob.mean, prob.std)
         return float(O.masked_mae(pr[:, 11], fu[:, 11], 0.0)), float(O.masked_mae(pr, fu, 0.0)), losses
 
-    results = [one_run(rep) for rep in range(3)]
+    # (bf16 mode: five runs -- its single runs spread -0.4 .. +1.2 % around a mean of about +0.45 % over the rounds' records; the mean of five
+    #  has sigma 0.22 %)
+    results = [one_run(rep) for rep in range(5 if mode == "bf16" else 3)]
     losses = results[0][2]
     h12, mae = float(np.mean([r[0] for r in results])), float(np.mean([r[1] for r in results]))
     tail = float(np.mean([np.mean(r[2][-20:]) for r in results]))
