@@ -238,10 +238,24 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(const float* __restric
     const bool on = q < D / 4;
     const float4 g4 = on ? ((const float4*)g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ac[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long row = (long)blockIdx.x * 8 + w; row < R; row += (long)gridDim.x * 8) {
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    // the NEXT row's operands are requested before this row is worked on (round 6): a half wave had one row = 2 x 16 bytes per lane in flight
+    // and then two dependent 5-step reductions; with ~19 waves per unit that is ~40 KB in flight per unit = 4.9 TB/s (Little), now twice that
+    const long stride = (long)gridDim.x * 8;
+    long row = (long)blockIdx.x * 8 + w;
+    float4 nxv = make_float4(0.f, 0.f, 0.f, 0.f), nyv = nxv;
+    float2 nst = make_float2(0.f, 1.f);
+    if (row < R) {
+        const long k0 = row * (D / 4) + (on ? q : 0);
+        nxv = ((const float4*)x)[k0]; nyv = ((const float4*)dy)[k0]; nst = *(const float2*)(stats + row * 2);
+    }
+    for (; row < R; row += stride) {
+        const float mean = nst.x, rstd = nst.y;
         const long k = row * (D / 4) + (on ? q : 0);
-        float4 xv = ((const float4*)x)[k], yv = ((const float4*)dy)[k];
+        float4 xv = nxv, yv = nyv;
+        if (row + stride < R) {
+            const long kn = (row + stride) * (D / 4) + (on ? q : 0);
+            nxv = ((const float4*)x)[kn]; nyv = ((const float4*)dy)[kn]; nst = *(const float2*)(stats + (row + stride) * 2);
+        }
         if (!on) { xv = make_float4(mean, mean, mean, mean); yv = make_float4(0.f, 0.f, 0.f, 0.f); }
         const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
         const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
