@@ -184,10 +184,16 @@ __device__ __forceinline__ float wave_sum_swz(float v) {
 #ifndef TSF_ABLATE
 #define TSF_ABLATE 0
 #endif
+#ifndef TSF_LN_TWO_FMA
+#define TSF_LN_TWO_FMA 0     // 1: LayerNorm's last step as two fmas per element (A/B builds: encoder alone 2.00-2.02 -> 1.96-1.98 ms, C2 3.377 -> 3.364 ms,
+                             // profiles/r06_zl_encoder_ln_two_fma.log).  Not the default: the unparked eight-tile variants without dropout then need 20 bytes of
+                             // scratch per lane, and leaving only those on the old form breaks the bit-identity of one vs two sequences per workgroup
+#endif
 #ifndef TSF_LN_PACKED
 #define TSF_LN_PACKED 1      // 0: the scalar reduction chains of the first version (A/B builds)
 #endif
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+template <bool TWO_FMA = (TSF_LN_TWO_FMA != 0)>
 __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, const float* bb) {
     if (TSF_ABLATE & 128) return;
     float s, q;
@@ -241,10 +247,20 @@ __device__ __forceinline__ void layer_norm96(f32x16 (&a)[3], const float* gg, co
         q = lo + hi;
     }
     const float rstd = rsqrtf(q * (1.0f / 96.0f) + 1e-5f);
+    if constexpr (TWO_FMA) {
+    // two fused multiply-adds per element ((a rstd - mean rstd) g + b: packed f32 fmas, 4.6 cycles per pair each) instead of subtract, multiply
+    // and one fma (2.9 + 2.3 + 2.3 per element)
+    const float nm = -mean * rstd;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[t][i] = __builtin_fmaf(__builtin_fmaf(a[t][i], rstd, nm), gg[t * 16 + i], bb[t * 16 + i]);
+    } else {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[t][i] = (a[t][i] - mean) * rstd * gg[t * 16 + i] + bb[t * 16 + i];
+    }
 }
 
 // One 1 KB piece global -> LDS by the DMA path (no VGPR round trip, invisible to hipcc's waitcnt

@@ -157,6 +157,9 @@ template <int MAXW, bool DROP, bool PARK, bool F16, int PIPE, int TG>
 __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void tsformer_encoder_kernel(EncArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool drop = DROP;
+    // LayerNorm's last step as two fmas (tsformer_device.h) -- except in the unparked eight-tile variants without dropout, where the form costs
+    // the allocation 20 bytes of scratch per lane
+    constexpr bool LN2F = TSF_LN_TWO_FMA && !(MAXW == 8 && !DROP && !PARK);
     typedef typename Opnd<F16>::v8 op8;            // one MFMA operand: 8 x bfloat16 or 8 x float16
     typedef typename Opnd<F16>::elem ope;
     const int lane = threadIdx.x & 63;
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                                     mask_words(chunk, dl.d1 + (uint32_t)(wv * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w1, inv_keep);
         }
-        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
+        layer_norm96<LN2F>(acc, tail + 64 + h48(), tail + 160 + h48());      // LN1 params ride in head 3's block
 
         // ---- FFN 96 -> 384 -> 96: 6 stages of two 32-unit chunks, hidden units never leave registers
         TSF_STAMP(21);
@@ -1031,7 +1034,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
                                     mask_words(chunk, dl.d2 + (uint32_t)(wv * 3 + 2) * 16u)};
             add_residual_op<F16>(acc, xb, w2, A.inv_keep2);
         }
-        layer_norm96(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
+        layer_norm96<LN2F>(acc, tail + 64 + h48(), tail + 160 + h48());      // LN2 params ride in the last ffn block
         TSF_STAMP(35);
 #pragma unroll
         for (int t = 0; t < 3; ++t) xT[t] = acc[t];
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(MAXW * 64, (min_waves_per_simd<MAXW, PARK>())) void
     const int lane_e = fresh_lane_id();
     const int h_e = lane_e >> 5;
     const int tok_e = wv * 32 + (lane_e & 31);
-    layer_norm96(xT, (const float*)(W + TSF_G_NORM_G) + h_e * 48, (const float*)(W + TSF_G_NORM_B) + h_e * 48);
+    layer_norm96<LN2F>(xT, (const float*)(W + TSF_G_NORM_G) + h_e * 48, (const float*)(W + TSF_G_NORM_B) + h_e * 48);
     float sq = 0.f;
     if (tok_e < P && seq_ok) {
         const long row = ((long)seq * P + tok_e) * TSF_D;
