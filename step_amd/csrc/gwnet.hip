@@ -773,7 +773,9 @@ static inline int n8(int N) { return (N + 7) & ~7; }
 // graphs from this many nodes on feed the diffusion hops a transposed bf16 copy of their source slots (see slots_to_bf16T_kernel);
 // STEP_HOP_XT_MIN_N overrides the threshold (A/B measurements: a huge value = always the in-place f32 operand)
 static inline bool hop_transposed_operand(int N) {
-    static const int min_n = []() { const char* e = getenv("STEP_HOP_XT_MIN_N"); return e ? atoi(e) : 1024; }();
+    // (768 since the end of round 6: at 883 nodes the copy pays too, 5.35 / 5.32 -> 5.32 / 5.30 ms per step; at 307 it costs, 3.39 -> 3.47:
+    //  profiles/r06_zm_hop_xt.log)
+    static const int min_n = []() { const char* e = getenv("STEP_HOP_XT_MIN_N"); return e ? atoi(e) : 768; }();
     return N >= min_n;
 }
 
